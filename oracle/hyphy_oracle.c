@@ -1,0 +1,349 @@
+/*
+ * TEST INFRASTRUCTURE — NOT PART OF THE PRODUCT PATH.
+ *
+ * CPU restatement (plain C, scalar, single thread) of the reference's likelihood hot path,
+ * used only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the
+ * checker for the HIP implementation.  The product (hyphy_amd/csrc) never links, imports
+ * or calls anything in this file.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function below against
+ * golden vectors produced by the real reference binary (oracle/_ref/hyphy, built from the
+ * sources under /root/reference by oracle/Makefile.ref) via oracle/make_golden.py:
+ * scalar logL at fixed parameters, per-site log-likelihoods, Exp(Q) matrices, a deep-tree
+ * case that forces rescaling, an ambiguity/gap case and a 3-class rate-category case.
+ *
+ * Each function cites the reference code it restates (paths relative to /root/reference).
+ * The arithmetic is the reference's algorithm, not its SIMD schedule: dot products are
+ * summed in plain ascending order where the reference uses 4x4-blocked AVX/FMA kernels
+ * (tree_evaluator.cpp:2083-2251, matrix_mult.cpp:3616), so results agree with the
+ * reference to rounding (<= 1e-12 relative on logL), not bit-for-bit.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* tree.cpp:126-129 */
+static const double LF_SCALER_UP = 18446744073709551616.0;          /* 2^64  _lfScalerUpwards */
+static const double LF_SCALER_THRESHOLD = 1.0 / 18446744073709551616.0; /* 2^-64 _lfScalingFactorThreshold */
+#define LOG_LF_SCALER (64.0 * 0.69314718055994530942)               /* _logLFScaler */
+
+static double lf_max_scaler(void) { return sqrt(DBL_MAX * 1.e-10); } /* _lfMaxScaler */
+static double lf_min_scaler(void) { return 1.0 / lf_max_scaler(); }  /* _lfMinScaler */
+
+double hy_oracle_log_scaler(void) { return LOG_LF_SCALER; }
+
+/* ------------------------------------------------------------------------------------ */
+/* _Matrix::Exponentiate(scale_to, check_transition=true)  matrix.cpp:5537-5951          */
+/* helpers: RowAndColumnMax :4901, MinElement :5075 (doAbs=1), IsMaxElement :4984,       */
+/*          Sqr :6952, diag_populator :5837-5852, transition_verifier :5820-5835         */
+/* sparse_hint: 1 when the reference would hold Q in sparse storage (theIndex != nil:    */
+/* codon models in the LF path) -> scale 2*sqrt(m) and MinElement over stored entries;   */
+/* 0 for dense storage (nucleotide/protein models, HBL Exp() of a dense literal) ->       */
+/* 8*sqrt(m), MinElement over all entries.                                               */
+/* Returns number of restarts (>=0) or -1 on failure (NaN / ill-conditioned).            */
+/* ------------------------------------------------------------------------------------ */
+static void matmul(long D, const double *A, const double *B, double *C) {
+  for (long i = 0; i < D; i++) {
+    for (long j = 0; j < D; j++) {
+      double s = 0.0;
+      for (long k = 0; k < D; k++) s += A[i * D + k] * B[k * D + j];
+      C[i * D + j] = s;
+    }
+  }
+}
+
+static int exp_once(long D, const double *A, int sparse_hint, double scale_to, double *R,
+                    long *n_taylor, long *n_square) {
+  const long N = D * D;
+  double *rowS = (double *)calloc((size_t)(2 * D), sizeof(double)), *colS = rowS + D;
+  double minabs = DBL_MAX;
+  for (long i = 0; i < D; i++)
+    for (long j = 0; j < D; j++) {
+      double v = A[i * D + j], a = fabs(v);
+      rowS[i] += a;
+      colS[j] += a;
+      if (sparse_hint ? (v != 0.0) : 1) {
+        if (a < minabs) minabs = a;
+      }
+    }
+  double r = 0., c = 0.;
+  for (long i = 0; i < D; i++) {
+    if (rowS[i] > r) r = rowS[i];
+    if (colS[i] > c) c = colS[i];
+  }
+  free(rowS);
+  double max = r * c, mmax = 1.0;
+  long power2 = 0;
+  if (max > .1) {
+    max = scale_to * (sparse_hint ? 2. : 8.) * sqrt(max);
+    power2 = (long)(log(max) / log(2.0)) + 1L;
+    max = exp(power2 * log(2.0));
+    mmax = max;
+  } else {
+    power2 = 0;
+    mmax = 1.;
+  }
+  /* result = I + A/max (power2>0) or I + A */
+  if (power2 > 0 && max > 0.0) {
+    for (long k = 0; k < N; k++) R[k] = A[k] * (1.0 / max);
+    for (long d = 0; d < D; d++) R[d * D + d] += 1.;
+  } else {
+    memset(R, 0, sizeof(double) * (size_t)N);
+    for (long d = 0; d < D; d++) R[d * D + d] = 1.;
+    if (max == 0.0) return 0;
+    for (long k = 0; k < N; k++) R[k] += A[k];
+  }
+  double tMax = minabs * sqrt((double)D);
+  if (minabs == DBL_MAX) tMax = 0.0;
+  if (tMax < 1e-16) tMax = 1e-16;
+  double *T = (double *)malloc(sizeof(double) * (size_t)N), *T2 = (double *)malloc(sizeof(double) * (size_t)N);
+  memcpy(T, A, sizeof(double) * (size_t)N);
+  long i = 2;
+  int more;
+  do {
+    matmul(D, T, A, T2);
+    { double *sw = T; T = T2; T2 = sw; }
+    double f = (i > 2) ? 1.0 / (mmax * i) : 0.5 / (mmax * mmax);
+    for (long k = 0; k < N; k++) { T[k] *= f; R[k] += T[k]; }
+    i++;
+    (*n_taylor)++;
+    double bench = tMax * 1e-16 * i;
+    more = 0;
+    for (long k = 0; k < N; k++) if (T[k] > bench || T[k] < -bench) { more = 1; break; }
+    if (i > 1000) break;
+  } while (more);
+  free(T2);
+  /* check_transition */
+  int status = 0;
+  for (long d = 0; d < D; d++) if (R[d * D + d] > 1.) status = 1;
+  if (!status) {
+    for (long rr = 0; rr < D; rr++) {
+      double sum = 0.;
+      for (long cc = 0; cc < D; cc++) sum += R[rr * D + cc];
+      R[rr * D + rr] += 1. - sum;
+      if (isnan(sum)) status = -1;
+    }
+  }
+  if (status) { free(T); return status; }
+  double last_diff = 0.;
+  for (long s = 0; s < power2; s++) {
+    matmul(D, R, R, T);
+    double diff = 0.;
+    for (long k = 0; k < N; k++) { double d = fabs(R[k] - T[k]); if (d > diff) diff = d; }
+    memcpy(R, T, sizeof(double) * (size_t)N);
+    (*n_square)++;
+    if (diff < DBL_EPSILON * 1.e3 || (s >= 10 && diff > last_diff * 100.)) break;
+    last_diff = diff;
+  }
+  free(T);
+  if (power2) {
+    for (long d = 0; d < D; d++) if (R[d * D + d] > 1.) return 1;
+    for (long rr = 0; rr < D; rr++) {
+      double sum = 0.;
+      for (long cc = 0; cc < D; cc++) sum += R[rr * D + cc];
+      R[rr * D + rr] += 1. - sum;
+      if (isnan(sum)) return -1;
+    }
+  }
+  return 0;
+}
+
+int hy_oracle_expm(long D, const double *A, int sparse_hint, double *P, long *n_taylor, long *n_square) {
+  double scale_to = 1.0;
+  int restarts = 0;
+  long nt = 0, ns = 0;
+  for (;;) {
+    int st = exp_once(D, A, sparse_hint, scale_to, P, &nt, &ns);
+    if (st == 0) break;
+    if (st < 0) return -1;
+    if (scale_to < 1.e100) { scale_to *= 100.; restarts++; continue; }   /* matrix.cpp:5854-5864 */
+    return -1;
+  }
+  if (n_taylor) *n_taylor = nt;
+  if (n_square) *n_square = ns;
+  return restarts;
+}
+
+int hy_oracle_expm_batch(long D, long n, const double *Q, int sparse_hint, double *P) {
+  for (long b = 0; b < n; b++) {
+    if (hy_oracle_expm(D, Q + b * D * D, sparse_hint, P + b * D * D, 0, 0) < 0) return -1;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* _TheTree::ComputeTreeBlockByBranch   tree_evaluator.cpp:3556-4171  (tcc == nil,      */
+/* setBranch == -1, identity siteOrdering: a device implementation works in pattern-id   */
+/* space).  State that persists between evaluations is owned by the caller:  */
+/*   iNodeCache[I*S*D]          conditional likelihoods (site-major, state-minor)        */
+/*   scalingAdjustments[I*S]    sticky per-(node,site) factors, initialised to 1         */
+/*   *overallScaler             cumulative scaler count (only touched when !storageVec)  */
+/* P: transition matrices indexed by node code, P[n*D*D + i*D + j] = Pr(i -> j | branch n)*/
+/* ------------------------------------------------------------------------------------ */
+double hy_oracle_tree_block(long D, long S, long L, long I, const long *flat_parents,
+                            const long *update_nodes, long n_update, const double *P,
+                            const long *leaf_codes, const double *ambig,
+                            const long *pattern_freq, const double *root_freqs,
+                            double *iNodeCache, double *scalingAdjustments,
+                            long *overallScaler, long siteFrom, long siteTo,
+                            double *storageVec, long *siteCorrectionCounts) {
+  long *tagged = (long *)calloc((size_t)I, sizeof(long));
+  double *mvs = (double *)malloc(sizeof(double) * (size_t)D);
+  long localScalerChange = 0;
+  if (siteTo > S) siteTo = S;
+  const double maxS = lf_max_scaler(), minS = lf_min_scaler();
+
+  for (long nodeID = 0; nodeID < n_update; nodeID++) {
+    long nodeCode = update_nodes[nodeID], parentCode = flat_parents[nodeCode];
+    int isLeaf = nodeCode < L;
+    const double *tMatrix = P + nodeCode * D * D;
+    long inode = nodeCode - L;
+    double *parentBase = iNodeCache + (parentCode * S) * D;
+
+    if (!tagged[parentCode]) { /* first touch: fill with sticky factors, :3618-3664 + :584-605 */
+      tagged[parentCode] = 1;
+      for (long s = siteFrom; s < siteTo; s++) {
+        double f = scalingAdjustments[parentCode * S + s];
+        for (long k = 0; k < D; k++) parentBase[s * D + k] = f;
+      }
+    }
+    for (long s = siteFrom; s < siteTo; s++) {
+      double *pc = parentBase + s * D;
+      const double *childVector;
+      double sum = 0.0;
+      long didScale = 0;
+      if (isLeaf) { /* __ll_handle_conditional_array_initialization :161-260 */
+        long siteState = leaf_codes[nodeCode * S + s];
+        if (siteState >= 0) {
+          for (long k = 0; k < D; k++) pc[k] *= tMatrix[siteState + D * k];
+          continue; /* no rescale check after a resolved-leaf column gather */
+        }
+        childVector = ambig + (-siteState - 1) * D;
+      } else {
+        childVector = iNodeCache + (inode * S + s) * D;
+      }
+      /* _hy_mvp_blocked + _hy_vvmult_sum  :2083, :2351 */
+      for (long i = 0; i < D; i++) {
+        double a = 0.0;
+        for (long j = 0; j < D; j++) a += tMatrix[i * D + j] * childVector[j];
+        mvs[i] = a;
+      }
+      for (long k = 0; k < D; k++) { pc[k] *= mvs[k]; sum += pc[k]; }
+      /* __ll_loop_handle_scaling<D,true>  :410-525 ; helpers tree.cpp:160-202 */
+      double *adj = scalingAdjustments + parentCode * S + s;
+      if (sum < LF_SCALER_THRESHOLD && sum > 0.0) {
+        double cur = *adj * LF_SCALER_UP;
+        if (cur < maxS) {
+          didScale = 1;
+          double sm = sum * LF_SCALER_UP, try2 = cur * LF_SCALER_UP, scaler = LF_SCALER_UP;
+          while (sm < LF_SCALER_THRESHOLD && try2 < maxS) {
+            sm *= LF_SCALER_UP; try2 *= LF_SCALER_UP; scaler *= LF_SCALER_UP; didScale++;
+          }
+          for (long k = 0; k < D; k++) pc[k] *= scaler;
+          localScalerChange += didScale * pattern_freq[s];
+          *adj *= scaler;
+        }
+      } else if (sum > LF_SCALER_UP && sum < HUGE_VAL) {
+        double cur = *adj * LF_SCALER_THRESHOLD;
+        if (cur > minS) {
+          didScale = -1;
+          double sm = sum * LF_SCALER_THRESHOLD, try2 = cur * LF_SCALER_THRESHOLD, scaler = LF_SCALER_THRESHOLD;
+          while (sm > LF_SCALER_UP && try2 > minS) {
+            sm *= LF_SCALER_THRESHOLD; try2 *= LF_SCALER_THRESHOLD; scaler *= LF_SCALER_THRESHOLD; didScale--;
+          }
+          for (long k = 0; k < D; k++) pc[k] *= scaler;
+          localScalerChange += didScale * pattern_freq[s];
+          *adj *= scaler;
+        }
+      }
+      if (didScale && siteCorrectionCounts) siteCorrectionCounts[s] += didScale; /* __ll_loop_epilogue :83-87 */
+    }
+  }
+  /* root: :4046-4150 */
+  const double *rootC = iNodeCache + D * ((I - 1) * S);
+  double result = 0.0, correction = 0.0;
+  for (long s = siteFrom; s < siteTo; s++) {
+    double acc = 0.;
+    for (long p = 0; p < D; p++) acc += rootC[s * D + p] * root_freqs[p];
+    if (storageVec) {
+      storageVec[s] = acc;
+    } else {
+      if (acc <= 0.0) { result = -INFINITY; break; }
+      if (!isnan(acc)) {
+        long f = pattern_freq[s];
+        double term = (f > 1) ? log(acc) * f - correction : log(acc) - correction;
+        double t = result + term; /* Kahan */
+        correction = (t - result) - term;
+        result = t;
+      } else {
+        result = NAN; break;
+      }
+    }
+  }
+  if (!storageVec && localScalerChange) *overallScaler += localScalerChange; /* :4165-4168 */
+  free(tagged);
+  free(mvs);
+  return result;
+}
+
+/* _LikelihoodFunction::ComputeBlock, scalar mode, np blocks  likefunc.cpp:10995-11123:  */
+/* pruning over np contiguous pattern blocks, Neumaier combine, minus logU*overallScaler */
+double hy_oracle_compute_block(long D, long S, long L, long I, const long *flat_parents,
+                               const long *update_nodes, long n_update, const double *P,
+                               const long *leaf_codes, const double *ambig,
+                               const long *pattern_freq, const double *root_freqs,
+                               double *iNodeCache, double *scalingAdjustments,
+                               long *overallScaler, long np) {
+  if (np < 1) np = 1;
+  long sitesPerP = S;
+  if (np > S) { np = S; sitesPerP = 1; } else sitesPerP = S / np + 1;
+  double sum = 0., corr = 0.;
+  for (long b = 0; b < np; b++) {
+    double r = hy_oracle_tree_block(D, S, L, I, flat_parents, update_nodes, n_update, P, leaf_codes,
+                                    ambig, pattern_freq, root_freqs, iNodeCache, scalingAdjustments,
+                                    overallScaler, b * sitesPerP, (b + 1) * sitesPerP, 0, 0);
+    if (np == 1) { sum = r; break; }
+    if (r == -INFINITY) { sum = -INFINITY; break; }
+    double t = sum + r;
+    if (sum < r) corr += (sum - t) + r; else corr += (r - t) + sum;
+    sum = t;
+  }
+  if (np > 1 && sum != -INFINITY) sum += corr;
+  return sum - LOG_LF_SCALER * (double)(*overallScaler);
+}
+
+/* Category mixing: PopulateConditionalProbabilities, weighted-sum mode                   */
+/* likefunc2.cpp:820-853, then SumUpSiteLikelihoods likefunc2.cpp:1484-1506 with          */
+/* myLog/addScaler likefunc.cpp:644-661 and acquireScalerMultiplier tree.cpp:205-219.     */
+/* site_lik[c*S+s], site_scalers[c*S+s] are the per-class outputs of per-site ComputeBlock.*/
+double hy_oracle_mix_categories(long S, long C, const double *weights, const double *site_lik,
+                                const long *site_scalers, const long *pattern_freq,
+                                double *mixed_out, long *scalers_out) {
+  double *buf = (double *)malloc(sizeof(double) * (size_t)S);
+  long *sc = (long *)malloc(sizeof(long) * (size_t)S);
+  for (long c = 0; c < C; c++) {
+    double w = weights[c];
+    for (long s = 0; s < S; s++) {
+      long scv = site_scalers[c * S + s];
+      double v = site_lik[c * S + s];
+      if (c == 0) { buf[s] = w * v; sc[s] = scv; }
+      else if (scv < sc[s]) { buf[s] = w * v + buf[s] * exp(-LOG_LF_SCALER * (double)(sc[s] - scv)); sc[s] = scv; }
+      else if (scv > sc[s]) { buf[s] += w * v * exp(-LOG_LF_SCALER * (double)(scv - sc[s])); }
+      else buf[s] += w * v;
+    }
+  }
+  double logL = 0.;
+  long cumulative = 0;
+  for (long s = 0; s < S; s++) {
+    long f = pattern_freq[s];
+    double lg = buf[s] > 0.0 ? log(buf[s]) : -1000000.;
+    if (f == 1) logL += lg; else logL += lg * (double)f;
+    if (buf[s] > 0.0) cumulative += sc[s] * f;
+  }
+  if (mixed_out) memcpy(mixed_out, buf, sizeof(double) * (size_t)S);
+  if (scalers_out) memcpy(scalers_out, sc, sizeof(long) * (size_t)S);
+  free(buf);
+  free(sc);
+  return cumulative == 0 ? logL : logL - (double)cumulative * LOG_LF_SCALER;
+}

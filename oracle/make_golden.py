@@ -1,0 +1,136 @@
+"""TEST INFRASTRUCTURE — generates the golden fixtures under ``tests/golden/`` by running the
+REAL reference binary (``oracle/_ref/hyphy``; build it with ``make -f oracle/Makefile.ref``)
+on deterministic synthetic inputs.  Run in the build container only (needs
+/root/reference for the build); the fixtures it writes are plain data (inputs + expected
+outputs) and travel with the repo.
+
+    python -m oracle.make_golden            # regenerate everything
+
+Cases (SURVEY §8c "Fixtures to commit"):
+  codon_small   8 taxa x 40 codons, MG94xREV, logL + per-site logL
+  codon_ambig   same tree, 5% gaps / N / partial ambiguities
+  codon_deep    120-taxon ladder tree, longer branches -> forces 2^64 rescaling
+  codon_cat3    3 discrete rate classes (weights .7/.25/.05, rates .1/1/5) -> category mixing
+  nuc_small     HKY85, 8 taxa x 300 sites (pattern compression, freq > 1)
+  nuc_ambig     GTR with ambiguities
+  nuc_deep      300-taxon ladder, rescaling in the 4-state path
+  expm_*        P = Exp(Q) through _Matrix::Exponentiate for 4/20/61-state Q at several scales
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from hyphy_amd import data, models, tree  # noqa: E402
+from oracle import hbl  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+POS_FREQS = np.array([[0.30, 0.20, 0.25, 0.25], [0.20, 0.30, 0.30, 0.20], [0.25, 0.25, 0.20, 0.30]])
+REV = dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4)
+NUC_FREQS = np.array([0.35, 0.15, 0.2, 0.3])
+
+
+def branch_lengths(flat, seed, lo, hi):
+    rng = np.random.default_rng(seed)
+    return {n: float(rng.uniform(lo, hi)) for n in flat.branch_names()}
+
+
+def codon_case(name, n_taxa, n_codons, seed, *, ladder=False, missing=0.0, tlo=0.02, thi=0.12,
+               omega=0.3, category=None, p_change=0.04):
+    tr = tree.caterpillar_tree(n_taxa) if ladder else None
+    syn = data.evolve(n_taxa, n_codons, 3, seed=seed, p_change=p_change, tree=tr)
+    seqs = syn.seqs
+    if missing > 0:
+        seqs = data.inject_missing(seqs, 3, missing, seed + 1000)
+    flat = syn.flat
+    bt = branch_lengths(flat, seed + 7, tlo, thi)
+    tmpl = models.mg94rev_template(POS_FREQS)
+    pi = models.f3x4_codon_freqs(POS_FREQS)
+    g = dict(R=omega, **REV)
+    rate_expr = "t" if category is None else f"{category['name']}*t"
+    res = hbl.evaluate(names=flat.leaf_names, seqs=seqs, newick=tree.to_newick(syn.tree), unit=3,
+                       model_block=hbl.codon_model_block(tmpl, pi, rate_expr=rate_expr), model_name="MGM",
+                       globals_=g, branch_t=bt, category=category)
+    pd = data.compress(seqs, 3)
+    fx = dict(kind="codon", D=61, L=flat.L, flat_parents=flat.flat_parents, leaf_codes=pd.leaf_codes,
+              ambig=pd.ambig, pattern_freq=pd.pattern_freq, site_to_pattern=pd.site_to_pattern,
+              t=np.array([bt[n] for n in flat.branch_names()]), omega=omega,
+              rev=np.array([REV[k] for k in ("AC", "AT", "CG", "CT", "GT")]), pos_freqs=POS_FREQS,
+              root_freqs=pi, logl=res["logl"], site_logl=res["site_logl"])
+    if category:
+        fx["cat_weights"] = np.array(category["weights"])
+        fx["cat_values"] = np.array(category["values"])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(f"{name}: logL = {res['logl']!r}  S = {pd.S}  n_ambig = {len(pd.ambig)}")
+
+
+def nuc_case(name, n_taxa, n_sites, seed, *, ladder=False, missing=0.0, rev=None, tlo=0.02, thi=0.2, p_change=0.04):
+    tr = tree.caterpillar_tree(n_taxa) if ladder else None
+    syn = data.evolve(n_taxa, n_sites, 1, seed=seed, tree=tr, p_change=p_change)
+    seqs = syn.seqs
+    if missing > 0:
+        seqs = data.inject_missing(seqs, 1, missing, seed + 1000)
+    flat = syn.flat
+    bt = branch_lengths(flat, seed + 7, tlo, thi)
+    rev = rev or models.hky85_rev(0.35)
+    g = {k: v for k, v in rev.items()}
+    res = hbl.evaluate(names=flat.leaf_names, seqs=seqs, newick=tree.to_newick(syn.tree), unit=1,
+                       model_block=hbl.nuc_model_block(NUC_FREQS), model_name="NM", globals_=g, branch_t=bt)
+    pd = data.compress(seqs, 1)
+    fx = dict(kind="nuc", D=4, L=flat.L, flat_parents=flat.flat_parents, leaf_codes=pd.leaf_codes,
+              ambig=pd.ambig, pattern_freq=pd.pattern_freq, site_to_pattern=pd.site_to_pattern,
+              t=np.array([bt[n] for n in flat.branch_names()]),
+              rev=np.array([rev[k] for k in ("AC", "AT", "CG", "CT", "GT")]),
+              root_freqs=NUC_FREQS, logl=res["logl"], site_logl=res["site_logl"])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(f"{name}: logL = {res['logl']!r}  S = {pd.S}  n_ambig = {len(pd.ambig)}")
+
+
+def expm_cases():
+    rng = np.random.default_rng(5)
+    Qs, Ps, names = [], [], []
+    for t in (0.001, 0.05, 0.7, 6.0):
+        Q = models.mg94rev_Q(t, 0.45, REV, POS_FREQS)
+        Qs.append(Q); names.append(f"mg94_t{t}")
+    for t in (0.01, 0.5, 20.0):
+        Q = models.nuc_rev_Q(t, models.hky85_rev(0.3), NUC_FREQS)
+        Qs.append(Q); names.append(f"hky_t{t}")
+    for t in (0.02, 1.5):   # 20-state random reversible
+        pi = rng.dirichlet(np.ones(20) * 5)
+        Sx = rng.uniform(0.1, 2.0, size=(20, 20)); Sx = (Sx + Sx.T) / 2
+        Q = Sx * pi[None, :] * t
+        np.fill_diagonal(Q, 0.0)
+        Q = models.finish_rate_matrix(Q)
+        Qs.append(Q); names.append(f"aa_t{t}")
+    out = {}
+    for n, Q in zip(names, Qs):
+        P = hbl.expm_via_reference(Q)
+        out["Q_" + n] = Q
+        out["P_" + n] = P
+        print(f"expm {n}: row-sum err {abs(P.sum(1) - 1).max():.2e}")
+    np.savez_compressed(os.path.join(OUT, "expm.npz"), **out)
+
+
+def main():
+    if not hbl.have_reference():
+        raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
+    os.makedirs(OUT, exist_ok=True)
+    codon_case("codon_small", 8, 40, seed=11)
+    codon_case("codon_ambig", 8, 60, seed=12, missing=0.05)
+    codon_case("codon_deep", 120, 12, seed=13, ladder=True, tlo=0.2, thi=0.6, p_change=0.3)
+    codon_case("codon_cat3", 10, 50, seed=14,
+               category=dict(name="rc", weights=[0.7, 0.25, 0.05], values=[0.1, 1.0, 5.0]))
+    nuc_case("nuc_small", 8, 300, seed=21)
+    nuc_case("nuc_ambig", 12, 200, seed=22, missing=0.05, rev=dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4))
+    nuc_case("nuc_deep", 300, 40, seed=23, ladder=True, tlo=0.1, thi=0.5, p_change=0.25)
+    expm_cases()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""Pins the CPU restatement (oracle/hyphy_oracle.c) against golden vectors produced by the
+REAL reference binary (oracle/make_golden.py).  CPU-only."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import common
+
+CASES = ["codon_small", "codon_ambig", "codon_deep", "nuc_small", "nuc_ambig", "nuc_deep"]
+
+
+def _partition(fx, C=1):
+    return oracle.OraclePartition(int(fx["D"]), fx["flat_parents"], int(fx["L"]), fx["leaf_codes"], fx["ambig"],
+                                  fx["pattern_freq"], C)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_logl_matches_reference(name):
+    fx = common.load(name)
+    part = _partition(fx)
+    Q = common.fixture_Q(fx)
+    P = oracle.expm(Q, sparse_hint=(str(fx["kind"]) == "codon"))
+    part.set_P(common.all_nodes(fx), P)
+    ll = part.compute_block(common.all_nodes(fx), fx["root_freqs"])
+    assert abs(ll - float(fx["logl"])) <= 1e-11 * abs(float(fx["logl"]))
+    # thread-block split (np blocks + Neumaier combine) gives the same value
+    part2 = _partition(fx)
+    part2.set_P(common.all_nodes(fx), P)
+    ll2 = part2.compute_block(common.all_nodes(fx), fx["root_freqs"], np_blocks=3)
+    assert abs(ll2 - ll) <= 1e-12 * abs(ll)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_site_logl_matches_reference(name):
+    fx = common.load(name)
+    part = _partition(fx)
+    P = oracle.expm(common.fixture_Q(fx), sparse_hint=(str(fx["kind"]) == "codon"))
+    part.set_P(common.all_nodes(fx), P)
+    sl = part.site_log_likelihoods(common.all_nodes(fx), fx["root_freqs"])
+    ref = fx["site_logl"]
+    got = sl[fx["site_to_pattern"]]
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref) / np.abs(ref)) < 1e-11
+
+
+def test_deep_cases_really_rescale():
+    for name in ("codon_deep", "nuc_deep"):
+        fx = common.load(name)
+        part = _partition(fx)
+        P = oracle.expm(common.fixture_Q(fx), sparse_hint=(str(fx["kind"]) == "codon"))
+        part.set_P(common.all_nodes(fx), P)
+        part.compute_block(common.all_nodes(fx), fx["root_freqs"])
+        assert part.overall[0][0] > 0, name
+
+
+def test_category_mixing_matches_reference():
+    fx = common.load("codon_cat3")
+    C = len(fx["cat_weights"])
+    part = _partition(fx, C)
+    liks, scs = [], []
+    for c in range(C):
+        P = oracle.expm(common.fixture_Q(fx, float(fx["cat_values"][c])), sparse_hint=True)
+        part.set_P(common.all_nodes(fx), P, cat=c)
+        lik, sc = part.site_block(common.all_nodes(fx), fx["root_freqs"], cat=c)
+        liks.append(lik)
+        scs.append(sc)
+    ll, mixed, sc = oracle.mix_categories(fx["cat_weights"], np.array(liks), np.array(scs), fx["pattern_freq"])
+    assert abs(ll - float(fx["logl"])) <= 1e-11 * abs(float(fx["logl"]))
+    site = (np.log(mixed) - sc * 64 * np.log(2.0))[fx["site_to_pattern"]]
+    assert np.max(np.abs(site - fx["site_logl"]) / np.abs(fx["site_logl"])) < 1e-11
+
+
+def test_expm_matches_reference():
+    z = common.load("expm")
+    for k in z:
+        if not k.startswith("Q_"):
+            continue
+        Q, Pref = z[k], z["P_" + k[2:]]
+        P = oracle.expm(Q, sparse_hint=False)   # HBL Exp() of a dense literal -> dense path
+        assert np.max(np.abs(P - Pref)) < 2e-14, k
+        assert np.max(np.abs(P.sum(1) - 1)) < 1e-14
+
+
+def test_partial_update_equals_full():
+    """Change one branch, re-evaluate only the DetermineNodesForUpdate path: same logL as a
+    fresh full evaluation (sticky scaling state carried over)."""
+    from hyphy_amd import tree
+    fx = common.load("codon_deep")
+    L = int(fx["L"])
+    flat = tree.flat_from_parents(fx["flat_parents"], L)
+    part = _partition(fx)
+    Q = common.fixture_Q(fx)
+    P = oracle.expm(Q, True)
+    part.set_P(common.all_nodes(fx), P)
+    part.compute_block(common.all_nodes(fx), fx["root_freqs"])
+    node = 5
+    Q2 = Q.copy()
+    Q2[node] *= 3.0
+    P2 = oracle.expm(Q2[node], True)
+    part.set_P([node], P2[None])
+    ll_partial = part.compute_block(flat.path_update_nodes(node), fx["root_freqs"])
+    fresh = _partition(fx)
+    Pall = P.copy()
+    Pall[node] = P2
+    fresh.set_P(common.all_nodes(fx), Pall)
+    ll_full = fresh.compute_block(common.all_nodes(fx), fx["root_freqs"])
+    assert abs(ll_partial - ll_full) <= 1e-12 * abs(ll_full)
