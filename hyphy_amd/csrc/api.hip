@@ -1,0 +1,725 @@
+// C-ABI of libhyphy_hip.so (include/hyphy_hip.h): partition state, post-order schedule
+// construction, pattern sharding over devices, kernel sequencing.  Host-side bookkeeping only —
+// all arithmetic of the hot path happens in expm.hip / prune.hip.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <set>
+
+#include "../../include/hyphy_hip.h"
+#include "common.h"
+
+using namespace hyhip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(const std::string &msg) {
+  g_last_error = msg;
+  return -1;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+    }                                                                                             \
+  } while (0)
+
+struct Shard {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t s0 = 0, S = 0;  // pattern range [s0, s0+S) of the partition
+  int S_pad = 0, ntiles = 0, T = 1;
+  int16_t *codes = nullptr;
+  double *freq = nullptr;
+  double *ambig = nullptr;
+  double *partials = nullptr;  // [C] x per-class block
+  int32_t *counts = nullptr;   // [C][I][S_pad]
+  double *site_lik = nullptr;  // [C][S_pad]
+  int32_t *site_cnt = nullptr;
+  double *mixed_lik = nullptr;
+  int32_t *mixed_cnt = nullptr;
+  double *Pfrag = nullptr, *PTg = nullptr, *Prow = nullptr;  // [C][B]...
+  double *qbuf = nullptr;                                   // [C*B*D*D]
+  int32_t *slots = nullptr;                                 // [C*B]
+  int4 *ops = nullptr;
+  double *pi = nullptr;       // [DP]
+  double *out = nullptr;      // [2]
+  int32_t *status = nullptr;  // [1]
+  double *weights = nullptr;  // [C]
+  double *templates = nullptr;
+  double *coeffs = nullptr;
+  // pinned host staging
+  int4 *h_ops = nullptr;
+  double *h_out = nullptr;
+  int32_t *h_status = nullptr;
+  int32_t *h_slots = nullptr;
+  double *h_small = nullptr;  // pi / weights / coeffs staging
+  size_t h_small_cap = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t partial_stride = 0;  // doubles per class
+};
+
+}  // namespace
+
+struct hyphy_hip_partition {
+  int64_t D = 0, S = 0, L = 0, I = 0, C = 1, B = 0;
+  int DP = 0, NW = 0;
+  bool nuc = false;
+  std::vector<int64_t> parents;              // [L+I]
+  std::vector<std::vector<int>> children;    // per internal node, ascending node codes
+  std::vector<Shard> shards;
+  std::vector<char> initialized;             // per class: a full evaluation has populated the caches
+  std::vector<int4> ops_host;
+  std::vector<int64_t> cached_update;        // update list the device schedule was built for
+  bool cached_full = false;
+  int cached_valid = 0;
+  std::vector<double> cached_pi;             // root frequencies currently on the device
+  std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
+  int64_t K = 0;                             // Q templates
+  double timings[3] = {0, 0, 0};
+};
+
+namespace {
+
+size_t ops_capacity(const hyphy_hip_partition *p) { return (size_t)(p->L + p->I); }
+
+void free_shard(Shard &s) {
+  hipSetDevice(s.device);
+  if (s.stream) hipStreamSynchronize(s.stream);
+  void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
+                 s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
+                 s.weights, s.templates, s.coeffs};
+  for (void *d : dev)
+    if (d) hipFree(d);
+  void *host[] = {s.h_ops, s.h_out, s.h_status, s.h_slots, s.h_small};
+  for (void *h : host)
+    if (h) hipHostFree(h);
+  for (auto &e : s.ev)
+    if (e) hipEventDestroy(e);
+  if (s.stream) hipStreamDestroy(s.stream);
+  s = Shard();
+}
+
+// Build the post-order schedule for the nodes the host marked dirty.  update_nodes comes from
+// DetermineNodesForUpdate (tree.cpp:3117-3331): dirty nodes, their ancestors and the direct
+// children of every touched internal node.  We recompute every internal node that is the parent
+// of a listed node (plus ancestors, defensively) from ALL its children; children whose
+// conditionals were not recomputed in this call are read back from the persisted device copy.
+void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, bool full) {
+  const int L = (int)p->L, I = (int)p->I;
+  std::vector<char> touched(I, 0);
+  if (full) {
+    std::fill(touched.begin(), touched.end(), 1);
+  } else {
+    for (int64_t k = 0; k < n_update; k++) {
+      int64_t n = update_nodes[k];
+      if (n < 0 || n >= L + I) continue;
+      int64_t par = p->parents[n];
+      while (par >= 0 && !touched[par]) {
+        touched[par] = 1;
+        par = p->parents[L + par];
+      }
+    }
+  }
+  p->ops_host.clear();
+  int last_final = -1;  // internal index of the node finalised by the previous op
+  for (int par = 0; par < I; par++) {
+    if (!touched[par]) continue;
+    const std::vector<int> &ch = p->children[par];
+    // order: [node still in registers] -> leaves -> remaining internal children (ascending)
+    std::vector<int> order;
+    int inreg = -1;
+    for (int c : ch)
+      if (c >= L && c - L == last_final) inreg = c;
+    if (inreg >= 0) order.push_back(inreg);
+    for (int c : ch)
+      if (c != inreg) order.push_back(c);
+    for (size_t k = 0; k < order.size(); k++) {
+      const int c = order[k];
+      int flags = 0;
+      if (k == 0) flags |= OP_FIRST;
+      if (k + 1 == order.size()) flags |= OP_LAST;
+      if (c < L) flags |= OP_LEAF;
+      if (c == inreg) flags |= OP_INREGS;
+      int4 op;
+      op.x = c;
+      op.y = par;
+      op.z = flags;
+      op.w = c >= L ? c - L : -1;
+      p->ops_host.push_back(op);
+    }
+    last_final = par;
+  }
+}
+
+int upload_small(Shard &s, const double *src, size_t n, double *dst) {
+  if (n > s.h_small_cap) return fail("internal: staging buffer too small");
+  HIPCHK(hipStreamSynchronize(s.stream));  // staging buffer reuse
+  memcpy(s.h_small, src, n * sizeof(double));
+  HIPCHK(hipMemcpyAsync(dst, s.h_small, n * sizeof(double), hipMemcpyHostToDevice, s.stream));
+  return 0;
+}
+
+// Enqueue everything for one rate class on one shard.  q may be a host or device pointer.
+int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, bool pi_changed, bool slots_changed,
+                 const int64_t *q_nodes, int64_t n_q,
+                 const double *q, bool q_on_device, int q_is_prob, const double *root_freqs, double *d_logl_out,
+                 bool reduce, bool floor_log) {
+  HIPCHK(hipSetDevice(s.device));
+  const int64_t D = p->D, B = p->B;
+  const int DP = p->DP;
+  if (sched_changed && !p->ops_host.empty()) {
+    HIPCHK(hipStreamSynchronize(s.stream));
+    memcpy(s.h_ops, p->ops_host.data(), p->ops_host.size() * sizeof(int4));
+    HIPCHK(hipMemcpyAsync(s.ops, s.h_ops, p->ops_host.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+  }
+  // root frequencies, zero padded (uploaded only when they change)
+  if (pi_changed) {
+    std::vector<double> pi(p->nuc ? 4 : DP, 0.0);
+    for (int64_t k = 0; k < D; k++) pi[k] = root_freqs[k];
+    if (upload_small(s, pi.data(), pi.size(), s.pi)) return -1;
+  }
+  HIPCHK(hipEventRecord(s.ev[0], s.stream));
+  if (n_q > 0) {
+    int32_t *h_slots = s.h_slots + (size_t)cat * B, *d_slots = s.slots + (size_t)cat * B;
+    if (slots_changed) {
+      HIPCHK(hipStreamSynchronize(s.stream));
+      for (int64_t k = 0; k < n_q; k++) {
+        if (q_nodes[k] < 0 || q_nodes[k] >= B) return fail("q_nodes entry out of range");
+        h_slots[k] = (int32_t)q_nodes[k];
+      }
+      HIPCHK(hipMemcpyAsync(d_slots, h_slots, n_q * sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
+    }
+    const double *dq = q;
+    if (!q_on_device) {
+      HIPCHK(hipMemcpyAsync(s.qbuf, q, (size_t)n_q * D * D * sizeof(double), hipMemcpyHostToDevice, s.stream));
+      dq = s.qbuf;
+    }
+    ExpmArgs ea;
+    ea.Q = dq;
+    ea.slots = d_slots;
+    ea.n = (int)n_q;
+    ea.D = (int)D;
+    ea.is_prob = q_is_prob;
+    ea.status = s.status;
+    if (p->nuc) {
+      ea.Prow = s.Prow + (size_t)cat * B * 16;
+      ea.Pfrag = nullptr;
+      ea.PTg = nullptr;
+    } else {
+      ea.Prow = nullptr;
+      ea.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
+      ea.PTg = s.PTg + (size_t)cat * B * DP * DP;
+    }
+    launch_expm(ea, s.stream);
+  }
+  HIPCHK(hipEventRecord(s.ev[1], s.stream));
+  const int n_ops = (int)p->ops_host.size();
+  double *site_lik = s.site_lik + (size_t)cat * s.S_pad;
+  int32_t *site_cnt = s.site_cnt + (size_t)cat * s.S_pad;
+  if (p->nuc) {
+    NucArgs na;
+    na.ops = s.ops;
+    na.n_ops = n_ops;
+    na.S_pad = s.S_pad;
+    na.root_inode = (int)p->I - 1;
+    na.P = s.Prow + (size_t)cat * B * 16;
+    na.codes = s.codes;
+    na.ambig = s.ambig;
+    na.partials = s.partials + (size_t)cat * s.partial_stride;
+    na.counts = s.counts + (size_t)cat * p->I * s.S_pad;
+    na.pi = s.pi;
+    na.site_lik = site_lik;
+    na.site_cnt = site_cnt;
+    launch_prune_nuc(na, s.stream);
+  } else {
+    PruneArgs pa;
+    pa.ops = s.ops;
+    pa.n_ops = n_ops;
+    pa.NW = p->NW;
+    pa.T = s.T;
+    pa.S_pad = s.S_pad;
+    pa.ntiles = s.ntiles;
+    pa.root_inode = (int)p->I - 1;
+    pa.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
+    pa.PTg = s.PTg + (size_t)cat * B * DP * DP;
+    pa.codes = s.codes;
+    pa.ambig = s.ambig;
+    pa.partials = s.partials + (size_t)cat * s.partial_stride;
+    pa.counts = s.counts + (size_t)cat * p->I * s.S_pad;
+    pa.pi = s.pi;
+    pa.site_lik = site_lik;
+    pa.site_cnt = site_cnt;
+    launch_prune_mfma(pa, s.stream);
+  }
+  HIPCHK(hipEventRecord(s.ev[2], s.stream));
+  if (reduce)
+    launch_site_reduce(site_lik, site_cnt, s.freq, s.S_pad, floor_log ? 1 : 0, d_logl_out ? d_logl_out : s.out,
+                       s.out + 1, s.stream);
+  HIPCHK(hipEventRecord(s.ev[3], s.stream));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+bool same_update(const hyphy_hip_partition *p, const int64_t *u, int64_t n, bool full) {
+  if (!p->cached_valid) return false;
+  if (full && p->cached_full) return true;
+  if (full != p->cached_full) return false;
+  if ((int64_t)p->cached_update.size() != n) return false;
+  return n == 0 || memcmp(p->cached_update.data(), u, n * sizeof(int64_t)) == 0;
+}
+
+int prepare_schedule(hyphy_hip_partition *p, int cat, const int64_t *update_nodes, int64_t n_update, bool *changed) {
+  bool full = !p->initialized[cat];
+  if (!full && n_update >= p->B) full = true;
+  if (same_update(p, update_nodes, n_update, full)) {
+    *changed = false;
+    return 0;
+  }
+  build_schedule(p, update_nodes, n_update, full);
+  if (p->ops_host.size() > ops_capacity(p)) return fail("internal: schedule overflow");
+  p->cached_update.assign(update_nodes, update_nodes + (full ? 0 : n_update));
+  p->cached_full = full;
+  p->cached_valid = 1;
+  *changed = true;
+  return 0;
+}
+
+int collect_status(hyphy_hip_partition *p) {
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipMemcpyAsync(s.h_status, s.status, sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+  }
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    if (*s.h_status) {
+      hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream);
+      return fail("Failed to compute a valid transition matrix; this is usually caused by ill-conditioned rate "
+                  "matrices (e.g. very large rate values)");
+    }
+  }
+  return 0;
+}
+
+void record_timings(hyphy_hip_partition *p) {
+  Shard &s = p->shards[0];
+  float t;
+  for (int k = 0; k < 3; k++) {
+    t = 0.f;
+    if (hipEventElapsedTime(&t, s.ev[k], s.ev[k + 1]) == hipSuccess) p->timings[k] = t;
+  }
+}
+
+// sum of shard partials exactly as ComputeBlock combines its thread blocks (Neumaier,
+// likefunc.cpp:11046-11093)
+double combine(const std::vector<double> &parts) {
+  if (parts.size() == 1) return parts[0];
+  double sum = 0., corr = 0.;
+  for (double r : parts) {
+    if (r != r) return r;
+    if (r == -INFINITY) return -INFINITY;
+    double t = sum + r;
+    if (sum < r) corr += (sum - t) + r;
+    else corr += (r - t) + sum;
+    sum = t;
+  }
+  return sum + corr;
+}
+
+int gather_sites(hyphy_hip_partition *p, int cat, double *site_lik_out, int64_t *site_scaler_out, bool mixed) {
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    const double *lik = mixed ? s.mixed_lik : s.site_lik + (size_t)cat * s.S_pad;
+    const int32_t *cn = mixed ? s.mixed_cnt : s.site_cnt + (size_t)cat * s.S_pad;
+    if (site_lik_out)
+      HIPCHK(hipMemcpyAsync(site_lik_out + s.s0, lik, s.S * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    if (site_scaler_out) {
+      std::vector<int32_t> tmp(s.S);
+      HIPCHK(hipMemcpyAsync(tmp.data(), cn, s.S * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+      HIPCHK(hipStreamSynchronize(s.stream));
+      for (int64_t k = 0; k < s.S; k++) site_scaler_out[s.s0 + k] = tmp[k];
+    }
+    HIPCHK(hipStreamSynchronize(s.stream));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hyphy_hip_last_error(void) { return g_last_error.c_str(); }
+const char *hyphy_hip_version(void) { return "hyphy_hip 0.1 (gfx950, FP64 MFMA)"; }
+
+int hyphy_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void hyphy_hip_destroy(hyphy_hip_partition *p) {
+  if (!p) return;
+  for (Shard &s : p->shards) free_shard(s);
+  delete p;
+}
+
+int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L, int64_t I, int64_t C,
+                     const int64_t *flat_parents, const int64_t *leaf_codes, const double *ambig, int64_t n_ambig,
+                     const int64_t *pattern_freq, int device_first, int device_count) {
+  if (!out) return fail("out == NULL");
+  *out = nullptr;
+  if (D < 2 || D > 64) {
+    g_last_error = "unsupported state count (this version: 2 <= D <= 64)";
+    return 1;
+  }
+  if (S < 1 || L < 2 || I < 1 || C < 1 || !flat_parents || !leaf_codes || !pattern_freq)
+    return fail("invalid partition dimensions / null input");
+  if (n_ambig > 32767) {
+    g_last_error = "too many distinct ambiguity vectors for the packed leaf table";
+    return 1;
+  }
+  int ndev = hyphy_hip_device_count();
+  if (ndev <= 0) return fail("no HIP device available (this library has no CPU fallback)");
+  int force = 0;
+  if (const char *e = getenv("HYPHY_HIP_FORCE_SHARDS")) force = atoi(e);
+  if (device_count < 1) device_count = 1;
+  if (!force && (device_first < 0 || device_first + device_count > ndev)) return fail("device range out of bounds");
+  if (force > 0 && device_first >= ndev) return fail("device out of bounds");
+  int nshards = force > 0 ? force : device_count;
+  if ((int64_t)nshards > S) nshards = (int)S;
+
+  hyphy_hip_partition *p = new hyphy_hip_partition();
+  p->D = D; p->S = S; p->L = L; p->I = I; p->C = C; p->B = L + I - 1;
+  p->nuc = (D == 4);
+  p->NW = (int)((D + 15) / 16);
+  p->DP = 16 * p->NW;
+  p->parents.assign(flat_parents, flat_parents + L + I);
+  p->children.assign(I, std::vector<int>());
+  int roots = 0;
+  for (int64_t n = 0; n < L + I; n++) {
+    int64_t par = flat_parents[n];
+    if (par < 0) { roots++; continue; }
+    if (par >= I || (n >= L && par <= n - L)) { delete p; return fail("flat_parents is not a post-order tree"); }
+    p->children[par].push_back((int)n);
+  }
+  if (roots != 1 || flat_parents[L + I - 1] != -1) { delete p; return fail("root must be the last internal node"); }
+  for (int64_t k = 0; k < L * S; k++)
+    if (leaf_codes[k] >= D || leaf_codes[k] < -n_ambig) { delete p; return fail("leaf code out of range"); }
+  p->initialized.assign(C, 0);
+
+  const int DP = p->DP;
+  const int64_t B = p->B;
+  int tiles_override = 0;
+  if (const char *e = getenv("HYPHY_HIP_TILES")) tiles_override = atoi(e);
+
+  int64_t base = S / nshards, rem = S % nshards, s0 = 0;
+  for (int k = 0; k < nshards; k++) {
+    Shard s;
+    s.device = force > 0 ? device_first : device_first + k;
+    s.s0 = s0;
+    s.S = base + (k < rem ? 1 : 0);
+    s0 += s.S;
+    p->shards.push_back(s);
+  }
+  for (Shard &s : p->shards) {
+    if (hipSetDevice(s.device) != hipSuccess) { hyphy_hip_destroy(p); return fail("hipSetDevice failed"); }
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, s.device);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      hyphy_hip_destroy(p);
+      return fail(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    }
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int64_t tiles = (s.S + 15) / 16;
+    int T = 1;
+    if (!p->nuc) {
+      T = (int)std::min<int64_t>(4, std::max<int64_t>(1, (tiles + cus - 1) / cus));
+      if (tiles_override >= 1 && tiles_override <= 4) T = tiles_override;
+    }
+    s.T = T;
+    if (p->nuc) {
+      s.S_pad = (int)((s.S + 63) / 64 * 64);
+      s.ntiles = 0;
+      s.partial_stride = (size_t)I * 4 * s.S_pad;
+    } else {
+      s.ntiles = (int)((tiles + T - 1) / T * T);
+      s.S_pad = s.ntiles * 16;
+      s.partial_stride = (size_t)I * s.ntiles * 16 * DP;
+    }
+#define A_(ptr, n) if (hipMalloc((void **)&(ptr), (n)) != hipSuccess) { hyphy_hip_destroy(p); return fail("hipMalloc failed (" #ptr ")"); }
+    hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    for (auto &e : s.ev) hipEventCreate(&e);
+    A_(s.codes, (size_t)L * s.S_pad * sizeof(int16_t));
+    A_(s.freq, (size_t)s.S_pad * sizeof(double));
+    A_(s.ambig, (size_t)std::max<int64_t>(1, n_ambig) * DP * sizeof(double));
+    A_(s.partials, (size_t)C * s.partial_stride * sizeof(double));
+    A_(s.counts, (size_t)C * I * s.S_pad * sizeof(int32_t));
+    A_(s.site_lik, (size_t)C * s.S_pad * sizeof(double));
+    A_(s.site_cnt, (size_t)C * s.S_pad * sizeof(int32_t));
+    A_(s.mixed_lik, (size_t)s.S_pad * sizeof(double));
+    A_(s.mixed_cnt, (size_t)s.S_pad * sizeof(int32_t));
+    if (p->nuc) {
+      A_(s.Prow, (size_t)C * B * 16 * sizeof(double));
+    } else {
+      A_(s.Pfrag, (size_t)C * B * DP * DP * sizeof(double));
+      A_(s.PTg, (size_t)C * B * DP * DP * sizeof(double));
+    }
+    A_(s.qbuf, (size_t)C * B * D * D * sizeof(double));
+    A_(s.slots, (size_t)C * B * sizeof(int32_t));
+    A_(s.ops, ops_capacity(p) * sizeof(int4));
+    A_(s.pi, (size_t)DP * sizeof(double));
+    A_(s.out, 2 * sizeof(double));
+    A_(s.status, sizeof(int32_t));
+    A_(s.weights, (size_t)C * sizeof(double));
+#undef A_
+    s.h_small_cap = (size_t)std::max<int64_t>(std::max<int64_t>(DP, C), 64);
+    if (hipHostMalloc((void **)&s.h_ops, ops_capacity(p) * sizeof(int4)) != hipSuccess ||
+        hipHostMalloc((void **)&s.h_out, 2 * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void **)&s.h_status, sizeof(int32_t)) != hipSuccess ||
+        hipHostMalloc((void **)&s.h_slots, (size_t)C * B * sizeof(int32_t)) != hipSuccess ||
+        hipHostMalloc((void **)&s.h_small, s.h_small_cap * sizeof(double)) != hipSuccess) {
+      hyphy_hip_destroy(p);
+      return fail("hipHostMalloc failed");
+    }
+    hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream);
+    hipMemsetAsync(s.partials, 0, (size_t)C * s.partial_stride * sizeof(double), s.stream);
+    hipMemsetAsync(s.counts, 0, (size_t)C * I * s.S_pad * sizeof(int32_t), s.stream);
+    hipMemsetAsync(s.site_lik, 0, (size_t)C * s.S_pad * sizeof(double), s.stream);
+    hipMemsetAsync(s.site_cnt, 0, (size_t)C * s.S_pad * sizeof(int32_t), s.stream);
+    // leaf table: int64 pattern-indexed -> packed int16 [L][S_pad]; padding patterns use state 0, weight 0
+    std::vector<int16_t> codes((size_t)L * s.S_pad, 0);
+    for (int64_t l = 0; l < L; l++)
+      for (int64_t k = 0; k < s.S; k++) codes[(size_t)l * s.S_pad + k] = (int16_t)leaf_codes[l * S + s.s0 + k];
+    std::vector<double> fr(s.S_pad, 0.0);
+    for (int64_t k = 0; k < s.S; k++) fr[k] = (double)pattern_freq[s.s0 + k];
+    std::vector<double> amb((size_t)std::max<int64_t>(1, n_ambig) * DP, 0.0);
+    const int astride = p->nuc ? 4 : DP;
+    for (int64_t a = 0; a < n_ambig; a++)
+      for (int64_t k = 0; k < D; k++) amb[a * astride + k] = ambig[a * D + k];
+    hipMemcpy(s.codes, codes.data(), codes.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+    hipMemcpy(s.freq, fr.data(), fr.size() * sizeof(double), hipMemcpyHostToDevice);
+    hipMemcpy(s.ambig, amb.data(), amb.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (hipStreamSynchronize(s.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+      hyphy_hip_destroy(p);
+      return fail("device initialisation failed");
+    }
+  }
+  *out = p;
+  return 0;
+}
+
+static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                       const int64_t *q_nodes, int64_t n_q, const double *q, bool q_on_device, int q_is_probability,
+                       const double *root_freqs, double *d_logl_out, bool reduce, bool floor_log) {
+  if (!p) return fail("partition == NULL");
+  if (cat < 0) cat = 0;
+  if (cat >= p->C) return fail("rate class out of range");
+  if (!root_freqs) return fail("root_freqs == NULL");
+  if ((n_update > 0 && !update_nodes) || (n_q > 0 && (!q_nodes || !q))) return fail("null node / matrix list");
+  if (n_q > p->B) return fail("more matrices than branches");
+  if (!p->initialized[cat] && n_q < p->B)
+    return fail("first evaluation of a rate class must supply all L+I-1 transition matrices");
+  bool changed = false;
+  if (prepare_schedule(p, (int)cat, update_nodes, n_update, &changed)) return -1;
+  bool pi_changed = p->cached_pi.size() != (size_t)p->D || memcmp(p->cached_pi.data(), root_freqs, p->D * sizeof(double));
+  if (pi_changed) p->cached_pi.assign(root_freqs, root_freqs + p->D);
+  if (p->cached_slots.size() != (size_t)p->C) p->cached_slots.assign(p->C, std::vector<int64_t>());
+  std::vector<int64_t> &cs = p->cached_slots[cat];
+  bool slots_changed = cs.size() != (size_t)n_q || (n_q > 0 && memcmp(cs.data(), q_nodes, n_q * sizeof(int64_t)));
+  if (slots_changed) cs.assign(q_nodes, q_nodes + n_q);
+  for (Shard &s : p->shards)
+    if (enqueue_eval(p, s, (int)cat, changed, pi_changed, slots_changed, q_nodes, n_q, q, q_on_device,
+                     q_is_probability, root_freqs, d_logl_out, reduce, floor_log))
+      return -1;
+  p->initialized[cat] = 1;
+  return 0;
+}
+
+int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                       const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
+                       const double *root_freqs, double *logl_out, double *site_lik_out, int64_t *site_scaler_out) {
+  if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, q_dense, false, q_is_probability, root_freqs, nullptr,
+                  true, false))
+    return -1;
+  std::vector<double> parts;
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipMemcpyAsync(s.h_out, s.out, 2 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  }
+  if (collect_status(p)) return -1;
+  for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
+  record_timings(p);
+  if (logl_out) *logl_out = combine(parts);
+  if (site_lik_out || site_scaler_out)
+    return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
+  return 0;
+}
+
+int hyphy_hip_evaluate_device(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                              const int64_t *q_nodes, int64_t n_q, const double *d_q, int q_is_probability,
+                              const double *root_freqs, double *d_logl_out) {
+  if (!p) return fail("partition == NULL");
+  if (p->shards.size() != 1) return fail("evaluate_device needs a single-device partition");
+  return eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, d_q, true, q_is_probability, root_freqs, d_logl_out,
+                     true, false);
+}
+
+int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update,
+                                  const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
+                                  const double *weights, const double *root_freqs, double *logl_out,
+                                  double *site_lik_out, int64_t *site_scaler_out) {
+  if (!p) return fail("partition == NULL");
+  if (!weights) return fail("weights == NULL");
+  const int64_t D = p->D;
+  for (int64_t c = 0; c < p->C; c++) {
+    // every class shares the dirty set; schedule cache is keyed on the update list only
+    if (!p->initialized[c]) p->cached_valid = 0;
+    if (eval_common(p, c, update_nodes, n_update, q_nodes, n_q, q_dense ? q_dense + (size_t)c * n_q * D * D : nullptr,
+                    false, q_is_probability, root_freqs, nullptr, false, true))
+      return -1;
+  }
+  std::vector<double> parts;
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    if (upload_small(s, weights, (size_t)p->C, s.weights)) return -1;
+    launch_mix_categories(s.site_lik, s.site_cnt, s.weights, (int)p->C, s.S_pad, s.mixed_lik, s.mixed_cnt, s.stream);
+    launch_site_reduce(s.mixed_lik, s.mixed_cnt, s.freq, s.S_pad, 1, s.out, s.out + 1, s.stream);
+    HIPCHK(hipMemcpyAsync(s.h_out, s.out, 2 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  }
+  if (collect_status(p)) return -1;
+  for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
+  if (logl_out) *logl_out = combine(parts);
+  if (site_lik_out || site_scaler_out) return gather_sites(p, 0, site_lik_out, site_scaler_out, true);
+  return 0;
+}
+
+int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *inode_cache, int64_t *scaler_counts) {
+  if (!p) return fail("partition == NULL");
+  if (cat < 0) cat = 0;
+  if (cat >= p->C) return fail("rate class out of range");
+  const int64_t D = p->D, I = p->I, S = p->S;
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    if (inode_cache) {
+      if (p->nuc) {
+        std::vector<double> tmp((size_t)I * 4 * s.S_pad);
+        HIPCHK(hipMemcpy(tmp.data(), s.partials + (size_t)cat * s.partial_stride, tmp.size() * sizeof(double),
+                         hipMemcpyDeviceToHost));
+        for (int64_t n = 0; n < I; n++)
+          for (int64_t k = 0; k < s.S; k++)
+            for (int j = 0; j < 4; j++)
+              inode_cache[(n * S + s.s0 + k) * 4 + j] = tmp[((size_t)n * 4 + j) * s.S_pad + k];
+      } else {
+        double *dtmp = nullptr;
+        HIPCHK(hipMalloc((void **)&dtmp, (size_t)I * s.S * D * sizeof(double)));
+        launch_unpack_partials_mfma(s.partials + (size_t)cat * s.partial_stride, (int)I, s.ntiles, p->NW, (int)D,
+                                    (int)s.S, s.s0, S, dtmp, s.stream);
+        hipError_t e = hipMemcpy2DAsync(inode_cache + s.s0 * D, (size_t)S * D * sizeof(double), dtmp,
+                                        (size_t)s.S * D * sizeof(double), (size_t)s.S * D * sizeof(double), (size_t)I,
+                                        hipMemcpyDeviceToHost, s.stream);
+        hipStreamSynchronize(s.stream);
+        hipFree(dtmp);
+        if (e != hipSuccess) return fail(std::string("download_partials: ") + hipGetErrorString(e));
+      }
+    }
+    if (scaler_counts) {
+      std::vector<int32_t> tmp((size_t)I * s.S_pad);
+      HIPCHK(hipMemcpy(tmp.data(), s.counts + (size_t)cat * I * s.S_pad, tmp.size() * sizeof(int32_t),
+                       hipMemcpyDeviceToHost));
+      for (int64_t n = 0; n < I; n++)
+        for (int64_t k = 0; k < s.S; k++) scaler_counts[n * S + s.s0 + k] = tmp[(size_t)n * s.S_pad + k];
+    }
+  }
+  return 0;
+}
+
+int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_out) {
+  if (D < 2 || D > 64) {
+    g_last_error = "unsupported state count (this version: 2 <= D <= 64)";
+    return 1;
+  }
+  if (n <= 0) return 0;
+  if (!q_dense || !p_out) return fail("null matrix pointer");
+  if (hyphy_hip_device_count() <= 0) return fail("no HIP device available (this library has no CPU fallback)");
+  double *dq = nullptr, *dp = nullptr;
+  int32_t *st = nullptr;
+  const size_t bytes = (size_t)n * D * D * sizeof(double);
+  HIPCHK(hipMalloc((void **)&dq, bytes));
+  HIPCHK(hipMalloc((void **)&dp, bytes));
+  HIPCHK(hipMalloc((void **)&st, sizeof(int32_t)));
+  HIPCHK(hipMemset(st, 0, sizeof(int32_t)));
+  HIPCHK(hipMemcpy(dq, q_dense, bytes, hipMemcpyHostToDevice));
+  ExpmArgs ea;
+  ea.Q = dq; ea.slots = nullptr; ea.n = (int)n; ea.D = (int)D; ea.is_prob = 0;
+  ea.Prow = dp; ea.Pfrag = nullptr; ea.PTg = nullptr; ea.status = st;
+  launch_expm(ea, nullptr);
+  int32_t hst = 0;
+  hipError_t e1 = hipMemcpy(p_out, dp, bytes, hipMemcpyDeviceToHost);
+  hipError_t e2 = hipMemcpy(&hst, st, sizeof(int32_t), hipMemcpyDeviceToHost);
+  hipFree(dq); hipFree(dp); hipFree(st);
+  if (e1 != hipSuccess || e2 != hipSuccess) return fail("expm_batch: device copy failed");
+  if (hst) return fail("Failed to compute a valid transition matrix; this is usually caused by ill-conditioned rate "
+                       "matrices (e.g. very large rate values)");
+  return 0;
+}
+
+int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *templates) {
+  if (!p || K < 1 || !templates) return fail("invalid templates");
+  const int64_t D = p->D;
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    if (s.templates) hipFree(s.templates);
+    if (s.coeffs) hipFree(s.coeffs);
+    s.templates = s.coeffs = nullptr;
+    HIPCHK(hipMalloc((void **)&s.templates, (size_t)K * D * D * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&s.coeffs, (size_t)p->C * p->B * K * sizeof(double)));
+    HIPCHK(hipMemcpy(s.templates, templates, (size_t)K * D * D * sizeof(double), hipMemcpyHostToDevice));
+  }
+  p->K = K;
+  return 0;
+}
+
+int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs) {
+  if (!p || !p->K) return fail("build_q: templates not set");
+  if (n < 0 || n > p->C * p->B || !coeffs) return fail("build_q: bad arguments");
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipMemcpyAsync(s.coeffs, coeffs, (size_t)n * p->K * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    launch_build_q(s.templates, s.coeffs, (int)n, (int)p->K, (int)p->D, s.qbuf, s.stream);
+  }
+  return 0;
+}
+
+double *hyphy_hip_q_buffer(hyphy_hip_partition *p) { return p && !p->shards.empty() ? p->shards[0].qbuf : nullptr; }
+
+int hyphy_hip_synchronize(hyphy_hip_partition *p) {
+  if (!p) return fail("partition == NULL");
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipStreamSynchronize(s.stream));
+  }
+  return 0;
+}
+
+void *hyphy_hip_stream(hyphy_hip_partition *p) { return p && !p->shards.empty() ? (void *)p->shards[0].stream : nullptr; }
+
+int hyphy_hip_last_timings(hyphy_hip_partition *p, double out[3]) {
+  if (!p || !out) return fail("null argument");
+  if (hipSetDevice(p->shards[0].device) != hipSuccess) return fail("hipSetDevice failed");
+  hipStreamSynchronize(p->shards[0].stream);
+  record_timings(p);
+  for (int k = 0; k < 3; k++) out[k] = p->timings[k];
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// Internal definitions shared by the HIP translation units of libhyphy_hip.so.
+// gfx950 (MI355X / CDNA4) only: wave64, v_mfma_f64_16x16x4_f64, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace hyhip {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// Rescaling constants of the reference (src/core/tree.cpp:126-129).
+constexpr double kScalerUp = 18446744073709551616.0;            // 2^64   _lfScalerUpwards
+constexpr double kScalerThreshold = 1.0 / 18446744073709551616.0;  // 2^-64  _lfScalingFactorThreshold
+constexpr double kLogScaler = 64.0 * 0.69314718055994530942;    // _logLFScaler
+
+// ---------------------------------------------------------------------------------------
+// Device-private "fragment" layout of one tile of 16 site patterns x DP states
+// (DP = 16*NW, NKK = DP/4 k-steps of v_mfma_f64_16x16x4_f64).
+//
+//   element (state j, site s) lives with lane = (j & 3) * 16 + s, k-step kk = j >> 2
+//   at double index FRAG(kk, lane) = ((kk >> 1) * 64 + lane) * 2 + (kk & 1)
+//
+// i.e. exactly the B-operand register image of the MFMA (lane l holds B[k = l>>4][n = l&15]
+// for each k-step), stored so that one 16-byte access per lane fetches two k-steps and a
+// wave's access is one contiguous 1 KiB line.  The MFMA's C/D image (row = 4*r + (l>>4),
+// col = l&15 for accumulator register r of row-block w) is the SAME map with kk = 4*w + r,
+// so a node's freshly computed conditionals feed its parent's product with no data movement.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1) * 64 + lane) << 1) + (kk & 1); }
+
+// Schedule entry: one child edge.  x = child node code, y = parent internal index, z = flags.
+enum : int {
+  OP_FIRST = 1,   // first child of this parent: initialise the running product to 1
+  OP_LAST = 2,    // last child: finalise (exchange, rescale, persist) the parent
+  OP_LEAF = 4,    // child is a leaf (column gather / ambiguity vector)
+  OP_INREGS = 8,  // child is the node finalised by the previous op: conditionals still in registers
+};
+
+struct PruneArgs {
+  const int4 *ops;
+  int n_ops;
+  int NW;                    // row blocks (waves per workgroup) = DP/16
+  int T;                     // 16-pattern tiles per workgroup
+  int S_pad;                 // patterns padded to 16*T
+  int ntiles;                // S_pad / 16
+  int root_inode;            // I - 1
+  const double *Pfrag;       // [B][NW][NKK*64]      A-operand images of the transition matrices
+  const double *PTg;         // [B][DP][NW][4][4]    column-gather images (leaf edges)
+  const int16_t *codes;      // [L][S_pad]           >= 0 state, < 0 -> -(k+1) ambiguity row
+  const double *ambig;       // [n_ambig][DP]
+  double *partials;          // [I][ntiles][NKK*64]  conditionals, fragment layout
+  int32_t *counts;           // [I][S_pad]           cumulative 2^64-exponent of the subtree
+  const double *pi;          // [DP] root frequencies (zero padded)
+  double *site_lik;          // [S_pad]
+  int32_t *site_cnt;         // [S_pad]
+};
+
+struct NucArgs {
+  const int4 *ops;
+  int n_ops;
+  int S_pad;
+  int root_inode;
+  const double *P;           // [B][16] row-major 4x4
+  const int16_t *codes;      // [L][S_pad]
+  const double *ambig;       // [n_ambig][4]
+  double *partials;          // [I][4][S_pad]  state-major planes (coalesced per state)
+  int32_t *counts;           // [I][S_pad]
+  const double *pi;          // [4]
+  double *site_lik;
+  int32_t *site_cnt;
+};
+
+struct ExpmArgs {
+  const double *Q;           // [n][D*D] row-major (rate matrices, or probabilities if is_prob)
+  const int32_t *slots;      // [n] destination branch slot (node code) or nullptr -> identity
+  int n;
+  int D;
+  int is_prob;
+  double *Prow;              // optional [.][D*D] row-major output (slot-indexed)
+  double *Pfrag;             // optional [.][NW][NKK*64]
+  double *PTg;               // optional [.][DP][NW][16]
+  int32_t *status;           // [1] set to nonzero if any matrix failed (NaN / ill-conditioned)
+};
+
+// launchers (defined in the .hip files)
+void launch_expm(const ExpmArgs &a, hipStream_t stream);
+void launch_prune_mfma(const PruneArgs &a, hipStream_t stream);
+void launch_prune_nuc(const NucArgs &a, hipStream_t stream);
+void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,
+                        double *out_logl, double *out_cnt, hipStream_t stream);
+void launch_mix_categories(const double *site_lik /*[C][S_pad]*/, const int32_t *site_cnt, const double *weights_dev,
+                           int C, int S_pad, double *mixed_lik, int32_t *mixed_cnt, hipStream_t stream);
+void launch_build_q(const double *templates, const double *coeffs, int n, int K, int D, double *Q, hipStream_t stream);
+void launch_unpack_partials_mfma(const double *partials, int I, int ntiles, int NW, int D, int S, int64_t s0,
+                                 int64_t S_total, double *out /* device [I*S*D] shard-local */, hipStream_t stream);
+
+}  // namespace hyhip

@@ -1,0 +1,436 @@
+// Batched matrix exponential P = exp(Q) on gfx950 — the device counterpart of the OpenMP loop
+// in _TheTree::ExponentiateMatrices (src/core/tree.cpp:3011-3037), each iteration of which is
+// _Matrix::Exponentiate(1., true, storage) (src/core/matrix.cpp:5537-5951).
+//
+// Same numerical contract as the reference (scaling by a power of two, Taylor series,
+// diag_populator forcing row sums to 1 before AND after the squarings, restart with a 100x
+// larger scale when a diagonal exceeds 1, early exit from the squarings), re-designed for the
+// matrix cores: one workgroup per matrix, everything resident in LDS/registers, every product a
+// DPxDP FP64 MFMA GEMM (v_mfma_f64_16x16x4_f64).  The degree-12 Taylor polynomial is evaluated
+// by Paterson-Stockmeyer in 5 products instead of the reference's one sparse product per term
+// (matrix.cpp:5703-5721): on the GPU a dense 64^3 MFMA product is cheaper than CSR bookkeeping
+// (SURVEY §2.1 K10).  With ||Q/2^p|| <= 1/4 the truncation error is < 2.5e-18.
+#include "common.h"
+
+namespace hyhip {
+
+namespace {
+
+__device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// 1/k!
+__constant__ double kInvFact[13] = {1.0,
+                                    1.0,
+                                    0.5,
+                                    1.0 / 6.0,
+                                    1.0 / 24.0,
+                                    1.0 / 120.0,
+                                    1.0 / 720.0,
+                                    1.0 / 5040.0,
+                                    1.0 / 40320.0,
+                                    1.0 / 362880.0,
+                                    1.0 / 3628800.0,
+                                    1.0 / 39916800.0,
+                                    1.0 / 479001600.0};
+
+template <int NT>
+struct Frag {
+  f64x4 t[NT];  // C/D image of this wave's 16-row block: t[c][r] = M[16w + 4r + g][16c + sl]
+};
+
+template <int NT>
+__device__ __forceinline__ Frag<NT> mm(const double *__restrict__ Lm, const double *__restrict__ Rm, int w, int g,
+                                       int sl) {
+  constexpr int DP = 16 * NT, LD = DP + 2, NKK = DP / 4;
+  Frag<NT> d;
+#pragma unroll
+  for (int c = 0; c < NT; c++) d.t[c] = (f64x4){0., 0., 0., 0.};
+#pragma unroll 4
+  for (int kk = 0; kk < NKK; kk++) {
+    const double av = Lm[(16 * w + sl) * LD + 4 * kk + g];
+#pragma unroll
+    for (int c = 0; c < NT; c++) {
+      const double bv = Rm[(4 * kk + g) * LD + 16 * c + sl];
+      d.t[c] = mfma(av, bv, d.t[c]);
+    }
+  }
+  return d;
+}
+
+template <int NT>
+__device__ __forceinline__ void store_frag(double *__restrict__ M, const Frag<NT> &f, int w, int g, int sl) {
+  constexpr int DP = 16 * NT, LD = DP + 2;
+#pragma unroll
+  for (int c = 0; c < NT; c++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) M[(16 * w + 4 * r + g) * LD + 16 * c + sl] = f.t[c][r];
+}
+
+// Row sums -> R_ii += 1 - sum (diag_populator, matrix.cpp:5837-5852); reports a diagonal > 1
+// (transition_verifier, :5820-5835) or a NaN through `bad` (workgroup-wide OR via LDS).
+template <int NT>
+__device__ __forceinline__ bool diag_fix(Frag<NT> &R, int w, int g, int sl, int *flag) {
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    double s = 0.;
+#pragma unroll
+    for (int c = 0; c < NT; c++) s += R.t[c][r];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    if (s != s) bad = true;
+    if (sl == 4 * r + g) {  // this lane holds the diagonal of row 16w + 4r + g (column tile c == w)
+#pragma unroll
+      for (int c = 0; c < NT; c++)
+        if (c == w) {
+          if (R.t[c][r] > 1.) bad = true;
+          R.t[c][r] += 1. - s;
+        }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *flag = 0;
+  __syncthreads();
+  if (bad) atomicOr(flag, 1);
+  __syncthreads();
+  return *flag == 0;
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void expm_mfma_kernel(ExpmArgs a) {
+  constexpr int DP = 16 * NT, LD = DP + 2, NKK = DP / 4, MS = DP * LD, NW = NT;
+  extern __shared__ __align__(16) double sm[];
+  double *Xs = sm, *Ys = sm + MS, *Zs = sm + 2 * MS, *red = sm + 3 * MS;  // red: 2*DP + 8 doubles
+  int *flag = reinterpret_cast<int *>(red + 2 * DP + 4);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, sl = lane & 15;
+  const int D = a.D;
+  const int m = blockIdx.x;
+  const int slot = a.slots ? a.slots[m] : m;
+  const double *Q = a.Q + (size_t)m * D * D;
+
+  for (int idx = tid; idx < DP * DP; idx += 64 * NT) {
+    const int r = idx / DP, c = idx - r * DP;
+    Xs[r * LD + c] = (r < D && c < D) ? Q[r * D + c] : 0.0;
+  }
+  __syncthreads();
+
+  if (!a.is_prob) {
+    // max row / column absolute sums (RowAndColumnMax, matrix.cpp:4901)
+    if (tid < DP) {
+      double rs = 0., cs = 0.;
+      for (int k = 0; k < DP; k++) {
+        rs += fabs(Xs[tid * LD + k]);
+        cs += fabs(Xs[k * LD + tid]);
+      }
+      red[tid] = rs;
+      red[DP + tid] = cs;
+    }
+    __syncthreads();
+    double rmax = 0., cmax = 0.;
+    bool nan_in = false;
+    for (int k = 0; k < DP; k++) {
+      const double rv = red[k], cv = red[DP + k];
+      if (rv != rv) nan_in = true;
+      rmax = fmax(rmax, rv);
+      cmax = fmax(cmax, cv);
+    }
+    const double mnorm = rmax * cmax;
+    int p = 0;
+    if (mnorm > 0.) {
+      const double s = 4. * sqrt(mnorm);  // ||Q / 2^p|| <= 1/4  (||.||_2 <= sqrt(||.||_1 ||.||_inf))
+      if (s > 1.) p = ilogb(s) + 1;
+    }
+    // original Q in registers (C/D image) so that a restart can rescale it
+    Frag<NT> Qr;
+#pragma unroll
+    for (int c = 0; c < NT; c++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) Qr.t[c][r] = Xs[(16 * w + 4 * r + g) * LD + 16 * c + sl];
+    __syncthreads();
+
+    Frag<NT> R;
+    bool done = false, failed = nan_in || !(mnorm < 1e300);
+    for (int attempt = 0; attempt < 48 && !done && !failed; attempt++) {
+      const double scale = ldexp(1.0, -p);
+      Frag<NT> Xr;
+#pragma unroll
+      for (int c = 0; c < NT; c++) Xr.t[c] = Qr.t[c] * scale;
+      store_frag<NT>(Xs, Xr, w, g, sl);
+      __syncthreads();
+      Frag<NT> X2 = mm<NT>(Xs, Xs, w, g, sl);
+      store_frag<NT>(Ys, X2, w, g, sl);
+      __syncthreads();
+      Frag<NT> X3 = mm<NT>(Xs, Ys, w, g, sl);
+      store_frag<NT>(Zs, X3, w, g, sl);
+      // Paterson-Stockmeyer, s = 3:  p(X) = B0 + X3 (B1 + X3 (B2 + X3 (B3 + c12 X3)))
+      Frag<NT> acc;
+#pragma unroll
+      for (int c = 0; c < NT; c++) {
+        acc.t[c] = kInvFact[10] * Xr.t[c] + kInvFact[11] * X2.t[c] + kInvFact[12] * X3.t[c];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (c == w && sl == 4 * r + g) acc.t[c][r] += kInvFact[9];
+      }
+#pragma unroll 1
+      for (int blk = 2; blk >= 0; blk--) {
+        __syncthreads();  // previous readers of Ys are done (and Zs is complete on the first pass)
+        store_frag<NT>(Ys, acc, w, g, sl);
+        __syncthreads();
+        acc = mm<NT>(Zs, Ys, w, g, sl);
+        const double c0 = kInvFact[3 * blk], c1 = kInvFact[3 * blk + 1], c2 = kInvFact[3 * blk + 2];
+#pragma unroll
+        for (int c = 0; c < NT; c++) {
+          acc.t[c] += c1 * Xr.t[c] + c2 * X2.t[c];
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (c == w && sl == 4 * r + g) acc.t[c][r] += c0;
+        }
+      }
+      R = acc;
+      if (!diag_fix<NT>(R, w, g, sl, flag)) {  // matrix.cpp:5854-5864: restart, scale_to *= 100
+        p += 7;
+        if (p > 900) failed = true;
+        continue;
+      }
+      double last_diff = 0.;
+      for (int s = 0; s < p; s++) {  // matrix.cpp:5873-5920
+        __syncthreads();
+        store_frag<NT>(Xs, R, w, g, sl);
+        __syncthreads();
+        Frag<NT> Rn = mm<NT>(Xs, Xs, w, g, sl);
+        double diff = 0.;
+#pragma unroll
+        for (int c = 0; c < NT; c++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) diff = fmax(diff, fabs(Rn.t[c][r] - R.t[c][r]));
+        R = Rn;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) diff = fmax(diff, __shfl_xor(diff, off));
+        if (lane == 0) red[w] = diff;
+        __syncthreads();
+        diff = red[0];
+#pragma unroll
+        for (int k = 1; k < NW; k++) diff = fmax(diff, red[k]);
+        if (diff < 2.220446049250313e-16 * 1.e3 || (s >= 10 && diff > last_diff * 100.)) break;
+        last_diff = diff;
+      }
+      if (p > 0 && !diag_fix<NT>(R, w, g, sl, flag)) {
+        p += 7;
+        if (p > 900) failed = true;
+        continue;
+      }
+      done = true;
+    }
+    if (!done) {
+      if (tid == 0) atomicOr(a.status, 1);
+      return;
+    }
+    __syncthreads();
+    store_frag<NT>(Xs, R, w, g, sl);
+    __syncthreads();
+  }
+
+  // ---- outputs: row-major, A-operand image, column-gather image ----
+  if (a.Prow) {
+    double *out = a.Prow + (size_t)slot * D * D;
+    for (int idx = tid; idx < D * D; idx += 64 * NT) {
+      const int r = idx / D, c = idx - r * D;
+      out[idx] = Xs[r * LD + c];
+    }
+  }
+  if (a.Pfrag) {
+    // wave wb, k-step kk, lane l  <-  P[16 wb + (l & 15)][4 kk + (l >> 4)]
+    double *out = a.Pfrag + (size_t)slot * DP * DP;
+    for (int idx = tid; idx < DP * DP; idx += 64 * NT) {
+      const int wb = idx / (NKK * 64), rem = idx - wb * (NKK * 64);
+      const int kk2 = rem >> 7, l = (rem >> 1) & 63, kb = rem & 1, kk = 2 * kk2 + kb;
+      const int rr = 16 * wb + (l & 15), cc = 4 * kk + (l >> 4);
+      out[idx] = (rr < D && cc < D) ? Xs[rr * LD + cc] : 0.0;  // padded states carry exact zeros
+    }
+  }
+  if (a.PTg) {
+    // [code][wb][gg][r]  <-  P[16 wb + 4 r + gg][code]
+    double *out = a.PTg + (size_t)slot * DP * DP;
+    for (int idx = tid; idx < DP * DP; idx += 64 * NT) {
+      const int code = idx / (NW * 16), rem = idx - code * (NW * 16);
+      const int wb = rem >> 4, gg = (rem >> 2) & 3, r = rem & 3;
+      const int rr = 16 * wb + 4 * r + gg;
+      out[idx] = (rr < D && code < D) ? Xs[rr * LD + code] : 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4-state specialisation: one thread per matrix, everything in registers.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mm4(const double *A, const double *B, double *C) {
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double s = 0.;
+#pragma unroll
+      for (int k = 0; k < 4; k++) s = fma(A[4 * i + k], B[4 * k + j], s);
+      C[4 * i + j] = s;
+    }
+}
+
+__device__ __forceinline__ bool diag_fix4(double *R) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const double s = (R[4 * i] + R[4 * i + 1]) + (R[4 * i + 2] + R[4 * i + 3]);
+    if (s != s || R[5 * i] > 1.) ok = false;
+    R[5 * i] += 1. - s;
+  }
+  return ok;
+}
+
+__global__ void expm_nuc_kernel(ExpmArgs a) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= a.n) return;
+  const int slot = a.slots ? a.slots[m] : m;
+  double Q[16], R[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) Q[k] = a.Q[(size_t)m * 16 + k];
+  if (a.is_prob) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) R[k] = Q[k];
+  } else {
+    double rmax = 0., cmax = 0.;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      double rs = 0., cs = 0.;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        rs += fabs(Q[4 * i + j]);
+        cs += fabs(Q[4 * j + i]);
+      }
+      rmax = fmax(rmax, rs);
+      cmax = fmax(cmax, cs);
+    }
+    const double mnorm = rmax * cmax;
+    int p = 0;
+    if (mnorm > 0.) {
+      const double s = 4. * sqrt(mnorm);
+      if (s > 1.) p = ilogb(s) + 1;
+    }
+    bool done = false, failed = !(mnorm < 1e300);
+    for (int attempt = 0; attempt < 48 && !done && !failed; attempt++) {
+      const double scale = ldexp(1.0, -p);
+      double X[16], T[16], T2[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) X[k] = Q[k] * scale;
+      // Horner: R = I + X (I + X/2 (I + X/3 (... (I + X/12))))
+#pragma unroll
+      for (int k = 0; k < 16; k++) T[k] = X[k] * (1.0 / 12.0);
+#pragma unroll
+      for (int d = 0; d < 4; d++) T[5 * d] += 1.0;
+      for (int k = 11; k >= 1; k--) {
+        mm4(X, T, T2);
+        const double f = 1.0 / (double)k;
+#pragma unroll
+        for (int e = 0; e < 16; e++) T[e] = T2[e] * f;
+#pragma unroll
+        for (int d = 0; d < 4; d++) T[5 * d] += 1.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++) R[k] = T[k];
+      if (!diag_fix4(R)) {
+        p += 7;
+        if (p > 900) failed = true;
+        continue;
+      }
+      double last_diff = 0.;
+      for (int s = 0; s < p; s++) {
+        mm4(R, R, T);
+        double diff = 0.;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          diff = fmax(diff, fabs(T[k] - R[k]));
+          R[k] = T[k];
+        }
+        if (diff < 2.220446049250313e-16 * 1.e3 || (s >= 10 && diff > last_diff * 100.)) break;
+        last_diff = diff;
+      }
+      if (p > 0 && !diag_fix4(R)) {
+        p += 7;
+        if (p > 900) failed = true;
+        continue;
+      }
+      done = true;
+    }
+    if (!done) {
+      atomicOr(a.status, 1);
+      return;
+    }
+  }
+  if (a.Prow) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) a.Prow[(size_t)slot * 16 + k] = R[k];
+  }
+}
+
+// Q_b = sum_k coeff[b][k] T_k off-diagonal, diagonal = -(row sum)   
+__global__ void build_q_kernel(const double *__restrict__ templates, const double *__restrict__ coeffs, int K, int D,
+                               double *__restrict__ Q) {
+  const int b = blockIdx.x;
+  extern __shared__ double rowsum[];
+  double *out = Q + (size_t)b * D * D;
+  for (int r = threadIdx.x; r < D; r += blockDim.x) rowsum[r] = 0.;
+  __syncthreads();
+  // one thread per row keeps the column-order subtraction of MultByFreqs (matrix.cpp:1664-1674)
+  for (int r = threadIdx.x; r < D; r += blockDim.x) {
+    double d = 0.;
+    for (int c = 0; c < D; c++) {
+      if (c == r) continue;
+      double v = 0.;
+      for (int k = 0; k < K; k++) v += coeffs[(size_t)b * K + k] * templates[((size_t)k * D + r) * D + c];
+      out[r * D + c] = v;
+      d -= v;
+    }
+    out[r * D + r] = d;
+  }
+}
+
+}  // namespace
+
+void launch_expm(const ExpmArgs &a, hipStream_t stream) {
+  if (a.n <= 0) return;
+  if (a.D == 4 && !a.Pfrag && !a.PTg) {
+    hipLaunchKernelGGL(expm_nuc_kernel, dim3((a.n + 63) / 64), dim3(64), 0, stream, a);
+    return;
+  }
+  const int NT = (a.D + 15) / 16;
+  const int DP = 16 * NT, LD = DP + 2;
+  const size_t lds = (size_t)(3 * DP * LD + 2 * DP + 8) * sizeof(double);
+  switch (NT) {
+    case 1:
+      hipLaunchKernelGGL(expm_mfma_kernel<1>, dim3(a.n), dim3(64), lds, stream, a);
+      break;
+    case 2:
+      hipLaunchKernelGGL(expm_mfma_kernel<2>, dim3(a.n), dim3(128), lds, stream, a);
+      break;
+    case 3:
+      hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<3>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(expm_mfma_kernel<3>, dim3(a.n), dim3(192), lds, stream, a);
+      break;
+    default:
+      hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<4>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(expm_mfma_kernel<4>, dim3(a.n), dim3(256), lds, stream, a);
+      break;
+  }
+}
+
+void launch_build_q(const double *templates, const double *coeffs, int n, int K, int D, double *Q, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(build_q_kernel, dim3(n), dim3(64), D * sizeof(double), stream, templates, coeffs, K, D, Q);
+}
+
+}  // namespace hyhip

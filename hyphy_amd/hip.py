@@ -1,0 +1,216 @@
+"""ctypes binding of the C-ABI in ``include/hyphy_hip.h`` (``hyphy_amd/lib/libhyphy_hip.so``).
+
+This is the only way Python reaches the device code: there is no PyTorch/numpy/CPU fallback —
+if the shared library is missing or no MI355X is visible, construction raises.  The class
+mirrors the reference-side lifetime: ``HipPartition(...)`` ≙ the hook in
+``_LikelihoodFunction::SetupLFCaches`` (``likefunc.cpp:4313-4316``), ``evaluate`` ≙ the call
+from ``ComputeBlock`` (``likefunc.cpp:10978-11123``), ``close`` ≙ ``DeleteCaches``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libhyphy_hip.so")
+
+EXPORTS = [
+    "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
+    "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
+    "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
+    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
+    "hyphy_hip_version",
+]
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class HipUnsupported(HipError):
+    """The library answered "> 0": use the CPU path of the host application."""
+
+
+def load():
+    """Load libhyphy_hip.so; raise loudly if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipError(f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    dp, lp, vp = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p
+    lib.hyphy_hip_device_count.restype = C.c_int
+    lib.hyphy_hip_create.restype = C.c_int
+    lib.hyphy_hip_create.argtypes = [C.POINTER(vp)] + [C.c_int64] * 5 + [lp, lp, dp, C.c_int64, lp, C.c_int, C.c_int]
+    lib.hyphy_hip_destroy.restype = None
+    lib.hyphy_hip_destroy.argtypes = [vp]
+    lib.hyphy_hip_evaluate.restype = C.c_int
+    lib.hyphy_hip_evaluate.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp, dp, dp, lp]
+    lib.hyphy_hip_evaluate_device.restype = C.c_int
+    lib.hyphy_hip_evaluate_device.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, vp, C.c_int, dp, vp]
+    lib.hyphy_hip_evaluate_categories.restype = C.c_int
+    lib.hyphy_hip_evaluate_categories.argtypes = [vp, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp, dp, dp, dp, lp]
+    lib.hyphy_hip_download_partials.restype = C.c_int
+    lib.hyphy_hip_download_partials.argtypes = [vp, C.c_int64, dp, lp]
+    lib.hyphy_hip_expm_batch.restype = C.c_int
+    lib.hyphy_hip_expm_batch.argtypes = [C.c_int64, C.c_int64, dp, dp]
+    lib.hyphy_hip_set_q_templates.restype = C.c_int
+    lib.hyphy_hip_set_q_templates.argtypes = [vp, C.c_int64, dp]
+    lib.hyphy_hip_build_q.restype = C.c_int
+    lib.hyphy_hip_build_q.argtypes = [vp, C.c_int64, dp]
+    lib.hyphy_hip_q_buffer.restype = vp
+    lib.hyphy_hip_q_buffer.argtypes = [vp]
+    lib.hyphy_hip_synchronize.restype = C.c_int
+    lib.hyphy_hip_synchronize.argtypes = [vp]
+    lib.hyphy_hip_stream.restype = vp
+    lib.hyphy_hip_stream.argtypes = [vp]
+    lib.hyphy_hip_last_timings.restype = C.c_int
+    lib.hyphy_hip_last_timings.argtypes = [vp, dp]
+    lib.hyphy_hip_last_error.restype = C.c_char_p
+    lib.hyphy_hip_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc == 0:
+        return
+    msg = load().hyphy_hip_last_error().decode()
+    if rc > 0:
+        raise HipUnsupported(msg)
+    raise HipError(msg)
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _l(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64)) if a is not None else None
+
+
+def device_count() -> int:
+    return int(load().hyphy_hip_device_count())
+
+
+def expm_batch(Q: np.ndarray) -> np.ndarray:
+    """Batched P = exp(Q) on the device (drop-in for the loop at ``tree.cpp:3011-3037``)."""
+    Q = np.ascontiguousarray(Q, dtype=np.float64)
+    single = Q.ndim == 2
+    Qb = Q[None] if single else Q
+    P = np.empty_like(Qb)
+    _check(load().hyphy_hip_expm_batch(Qb.shape[1], Qb.shape[0], _d(Qb), _d(P)))
+    return P[0] if single else P
+
+
+class HipPartition:
+    """Device-resident state of one (filter, tree) partition."""
+
+    def __init__(self, D: int, flat_parents, L: int, leaf_codes, ambig, pattern_freq, C_cat: int = 1,
+                 device_first: int = 0, device_count: int = 1):
+        lib = load()
+        self.D, self.L = int(D), int(L)
+        fp = np.ascontiguousarray(flat_parents, dtype=np.int64)
+        self.I = len(fp) - self.L
+        codes = np.ascontiguousarray(leaf_codes, dtype=np.int64)
+        self.S = int(codes.shape[1])
+        self.C = int(C_cat)
+        self.B = self.L + self.I - 1
+        amb = np.ascontiguousarray(ambig, dtype=np.float64) if ambig is not None and len(ambig) else None
+        freq = np.ascontiguousarray(pattern_freq, dtype=np.int64)
+        h = C.c_void_p()
+        _check(lib.hyphy_hip_create(C.byref(h), self.D, self.S, self.L, self.I, self.C, _l(fp), _l(codes),
+                                    _d(amb), 0 if amb is None else amb.shape[0], _l(freq), device_first, device_count))
+        self._h = h
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hyphy_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- evaluation -------------------------------------------------------------------------
+    def evaluate(self, update_nodes, q_nodes, q_dense, root_freqs, cat: int = -1, q_is_probability: bool = False,
+                 per_site: bool = False):
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        q = np.ascontiguousarray(q_dense, dtype=np.float64) if len(qn) else None
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        out = C.c_double(0.0)
+        sl = np.zeros(self.S) if per_site else None
+        sc = np.zeros(self.S, dtype=np.int64) if per_site else None
+        _check(self._lib.hyphy_hip_evaluate(self._h, cat, _l(un), len(un), _l(qn), len(qn), _d(q),
+                                            int(q_is_probability), _d(rf), C.byref(out), _d(sl), _l(sc)))
+        return (out.value, sl, sc) if per_site else out.value
+
+    def evaluate_device(self, update_nodes, q_nodes, d_q_ptr: int, root_freqs, d_logl_ptr: int, cat: int = -1,
+                        q_is_probability: bool = False):
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        _check(self._lib.hyphy_hip_evaluate_device(self._h, cat, _l(un), len(un), _l(qn), len(qn),
+                                                   C.c_void_p(d_q_ptr), int(q_is_probability), _d(rf),
+                                                   C.c_void_p(d_logl_ptr)))
+
+    def evaluate_categories(self, update_nodes, q_nodes, q_dense, weights, root_freqs, q_is_probability: bool = False,
+                            per_site: bool = False):
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        q = np.ascontiguousarray(q_dense, dtype=np.float64) if len(qn) else None
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        out = C.c_double(0.0)
+        sl = np.zeros(self.S) if per_site else None
+        sc = np.zeros(self.S, dtype=np.int64) if per_site else None
+        _check(self._lib.hyphy_hip_evaluate_categories(self._h, _l(un), len(un), _l(qn), len(qn), _d(q),
+                                                       int(q_is_probability), _d(w), _d(rf), C.byref(out), _d(sl),
+                                                       _l(sc)))
+        return (out.value, sl, sc) if per_site else out.value
+
+    def download_partials(self, cat: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        cache = np.zeros((self.I, self.S, self.D))
+        counts = np.zeros((self.I, self.S), dtype=np.int64)
+        _check(self._lib.hyphy_hip_download_partials(self._h, cat, _d(cache), _l(counts)))
+        return cache, counts
+
+    # -- device-side Q construction -------------------------------------------------------------
+    def set_q_templates(self, templates: np.ndarray):
+        t = np.ascontiguousarray(templates, dtype=np.float64)
+        _check(self._lib.hyphy_hip_set_q_templates(self._h, t.shape[0], _d(t)))
+
+    def build_q(self, coeffs: np.ndarray):
+        c = np.ascontiguousarray(coeffs, dtype=np.float64)
+        _check(self._lib.hyphy_hip_build_q(self._h, c.shape[0], _d(c)))
+
+    def q_buffer(self) -> int:
+        return int(self._lib.hyphy_hip_q_buffer(self._h))
+
+    def synchronize(self):
+        _check(self._lib.hyphy_hip_synchronize(self._h))
+
+    def stream(self) -> int:
+        return int(self._lib.hyphy_hip_stream(self._h) or 0)
+
+    def last_timings(self) -> np.ndarray:
+        out = np.zeros(3)
+        _check(self._lib.hyphy_hip_last_timings(self._h, _d(out)))
+        return out

@@ -1,0 +1,175 @@
+/*
+ * hyphy_hip.h — C-ABI of the MI355X-native phylogenetic likelihood core.
+ *
+ * This is the drop-in boundary for the ONE hot path of veg/hyphy that this repository
+ * replaces:
+ *
+ *   _LikelihoodFunction::ComputeBlock            src/core/likefunc.cpp:10783-11289
+ *     -> _TheTree::ExponentiateMatrices          src/core/tree.cpp:2932-3113
+ *          -> _Matrix::Exponentiate              src/core/matrix.cpp:5537-5951
+ *     -> _TheTree::ComputeTreeBlockByBranch      src/core/tree_evaluator.cpp:3556-4171
+ *     -> Neumaier combine, - logU * scalers      src/core/likefunc.cpp:11046-11123
+ *
+ * The reference has no plug-in/FFI interface; its (dead) OpenCL hook shows the seam:
+ * construct per partition in SetupLFCaches (likefunc.cpp:4182-4183, 4313-4316), destroy in
+ * DeleteCaches/Cleanup (likefunc.cpp:10546-10551, 10594-10599) and one call from ComputeBlock
+ * (historically launchmdsocl(...), likefuncocl.cpp:1043-1053).  The entry points below are
+ * exactly what a HyPhy host adapter binds at those three touch-points (INTEGRATION.md shows
+ * the patch).  Plain C: opaque handle, pointers and sizes only — no C++ or torch types.
+ *
+ * Conventions
+ *   - all sizes int64_t, all reals double (hyFloat, include/hy_types.h:57)
+ *   - return 0 = ok; > 0 = "unsupported here, use the CPU path" (no state change);
+ *     < 0 = hard error, text in hyphy_hip_last_error() (adapter -> HandleApplicationError,
+ *     likefunc.cpp:11284)
+ *   - host arrays are borrowed for the duration of the call only
+ *   - node codes: n < L is leaf n, n >= L is internal node n-L; both in post-order, root
+ *     last (tree.cpp:722-766).  P[i*D+j] = Pr(parent state i -> child state j)
+ *   - never called concurrently for one partition (ComputeBlock is entered from the HBL
+ *     interpreter's single thread; the library replaces the OpenMP region inside it)
+ *   - there is NO CPU fallback inside the library: without a usable MI355X every compute
+ *     entry point returns < 0.
+ */
+#ifndef HYPHY_HIP_H
+#define HYPHY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hyphy_hip_partition hyphy_hip_partition; /* device-side state of ONE (filter, tree) partition */
+
+/* Number of usable gfx950 devices (0 if none / no HIP runtime). */
+int hyphy_hip_device_count(void);
+
+/*
+ * Replaces the allocation half of _LikelihoodFunction::SetupLFCaches (likefunc.cpp:4163-4319)
+ * for one partition: conditional-likelihood caches (conditionalInternalNodeLikelihoodCaches,
+ * :4220-4223), scaling state (siteScalingFactors :4232, siteCorrections :4238-4246), the leaf
+ * state table (conditionalTerminalNodeStateFlag :4235-4236, :4305) and the ambiguity vectors
+ * (conditionalTerminalNodeLikelihoodCaches :4263-4311) all live on the device afterwards.
+ *
+ *   D,S,L,I,C       GetDimension, GetPatternCount, GetLeafCount, GetINodeCount, categoryCount
+ *   flat_parents    [L+I] parent as internal index, root = -1            (tree.cpp:746-757)
+ *   leaf_codes      [L*S] pattern-indexed; >= 0 state, < 0 -> -(k+1) = ambiguity vector k
+ *   ambig           [n_ambig*D]
+ *   pattern_freq    [S] theFrequencies
+ *   device_first, device_count
+ *                   patterns are sharded in contiguous ranges over devices
+ *                   device_first .. device_first+device_count-1 of THIS process (the
+ *                   reference's OpenMP site blocks, likefunc.cpp:10995-11044).  One rank per
+ *                   GPU (torch.distributed / HYPHYMPI) passes device_count = 1 and its own
+ *                   shard of the patterns.
+ * Returns > 0 (unsupported) for D > 64 or D < 2 in this version.
+ */
+int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L, int64_t I, int64_t C,
+                     const int64_t *flat_parents, const int64_t *leaf_codes, const double *ambig,
+                     int64_t n_ambig, const int64_t *pattern_freq, int device_first, int device_count);
+
+/* Replaces DeleteCaches (likefunc.cpp:10556-10600) for the partition. NULL is a no-op. */
+void hyphy_hip_destroy(hyphy_hip_partition *p);
+
+/*
+ * One likelihood evaluation of rate class `cat` (-1 == 0 when C == 1): replaces, inside
+ * ComputeBlock, ExponentiateMatrices (likefunc.cpp:10978-10980) AND the OpenMP pruning loop
+ * + combine (likefunc.cpp:10995-11123).
+ *
+ *   update_nodes    node codes from _TheTree::DetermineNodesForUpdate (tree.cpp:3117-3331),
+ *                   ascending; on the first evaluation after create: all L+I-1 branches
+ *                   (likefunc.cpp:10965-10967).  The library recomputes every internal node
+ *                   that is the parent of a listed node, from ALL of that node's children.
+ *   q_nodes/q_dense node codes whose transition matrix changed and their numeric rate
+ *                   matrices [n_q*D*D], already multiplied by the branch length, MultByFreqs
+ *                   applied (what _CalcNode::RecomputeMatrix hands to SetCompExp,
+ *                   calcnode.cpp:526-735).  q_is_probability = 1: q_dense already holds
+ *                   P = exp(Q) (host did the exponential, e.g. explicit-form mixtures
+ *                   P = sum_k w_k exp(Q_k), tree.cpp:3047-3090).
+ *   root_freqs      [D] theProbs (InitializeTreeFrequencies, tree.cpp:2436-2451)
+ *   logl_out        sum_s f_s log L_s - 64 ln2 * scalers — the value ComputeBlock returns
+ *                   (likefunc.cpp:11123).  -INFINITY if a pattern has likelihood 0
+ *                   (tree_evaluator.cpp:4094-4112); NaN propagates (adapter then calls
+ *                   _TerminateAndDump as tree_evaluator.cpp:4142 does).
+ *   site_lik_out    optional [S], pattern-indexed == storageVec (tree_evaluator.cpp:4080):
+ *                   per-pattern likelihood l_s (NOT log), scaled so that the true value is
+ *                   l_s * 2^(-64*c_s)
+ *   site_scaler_out optional [S] == the siteCorrections slice: c_s.  Only differences of c_s
+ *                   between rate classes and sum_s f_s c_s are observable upstream
+ *                   (likefunc2.cpp:736-770, 828-853, 1484-1506).
+ */
+int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                       const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
+                       const double *root_freqs, double *logl_out, double *site_lik_out,
+                       int64_t *site_scaler_out);
+
+/*
+ * Same evaluation with device-resident inputs/outputs, enqueued asynchronously on the
+ * partition's stream (device_count must be 1): d_q is a DEVICE pointer [n_q*D*D];
+ * d_logl_out a DEVICE pointer to one double that receives this shard's partial
+ * log-likelihood (ready for an RCCL all-reduce across site-sharded ranks).  Call
+ * hyphy_hip_synchronize() (or synchronise the stream) before reading it.
+ */
+int hyphy_hip_evaluate_device(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                              const int64_t *q_nodes, int64_t n_q, const double *d_q, int q_is_probability,
+                              const double *root_freqs, double *d_logl_out);
+
+/*
+ * Rate-category batch (config "BUSTED 3-rate-class"): evaluates ALL C classes in one
+ * schedule (classes are an extra batch dimension on the device) and mixes them exactly as
+ * PopulateConditionalProbabilities' weighted-sum mode + SumUpSiteLikelihoods do
+ * (likefunc2.cpp:820-853, 1484-1506).  q_dense is [C][n_q][D*D]; weights [C].
+ */
+int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update,
+                                  const int64_t *q_nodes, int64_t n_q, const double *q_dense,
+                                  int q_is_probability, const double *weights, const double *root_freqs,
+                                  double *logl_out, double *site_lik_out, int64_t *site_scaler_out);
+
+/*
+ * Copies device partials back in the reference's host layout for code that reads the caches
+ * directly (ReconstructAncestors likefunc2.cpp:416-449, FillInConditionals tree.cpp:3335-3371):
+ *   inode_cache [I*S*D]  iNodeCache[(node*S + pattern)*D + state] (tree_evaluator.cpp:3608-3617)
+ *   scaler_counts [I*S]  cumulative 2^64-exponent of the subtree below (node, pattern): the
+ *                        stored vector times 2^(-64*count) is the unscaled conditional.
+ */
+int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *inode_cache, int64_t *scaler_counts);
+
+/*
+ * Stand-alone batched matrix exponential: drop-in for the OpenMP loop in ExponentiateMatrices
+ * (tree.cpp:3011-3037, each iteration = _Matrix::Exponentiate(1., true, storage)).
+ * q_dense, p_out: host [n*D*D].  Rows of P sum to 1 (diag_populator, matrix.cpp:5837-5852).
+ */
+int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_out);
+
+/*
+ * Device-side rate-matrix construction for template models: every branch's
+ * numeric Q is a linear combination of K fixed D x D templates,
+ *       Q_b = sum_k coeff[b][k] * T_k   (off-diagonal),   Q_b[i][i] = -sum_{j != i} Q_b[i][j]
+ * e.g. MG94xREV with fixed nucleotide biases: T_0 = synonymous part, T_1 = non-synonymous part,
+ * coeff[b] = (t_b, omega * t_b).  Templates are uploaded once; per evaluation only the
+ * n*K coefficients cross PCIe.  Replaces the serial RecomputeMatrix + MultByFreqs loop
+ * (tree.cpp:2944-2969, matrix.cpp:1546-1677) for such models.  Output goes to the partition's
+ * device Q buffer which hyphy_hip_evaluate_device() accepts as d_q
+ * (hyphy_hip_q_buffer()).
+ */
+int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *templates /* [K*D*D] */);
+int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs /* host [n*K] */);
+double *hyphy_hip_q_buffer(hyphy_hip_partition *p); /* device pointer, capacity (L+I-1)*C*D*D doubles */
+
+/* Blocks until all work enqueued for the partition has finished. */
+int hyphy_hip_synchronize(hyphy_hip_partition *p);
+
+/* The HIP stream (hipStream_t) work is enqueued on for shard 0 — for event timing. */
+void *hyphy_hip_stream(hyphy_hip_partition *p);
+
+/* Per-call device timers of the last evaluation, milliseconds (SURVEY §5 tracing row):
+ * out[0] = expm kernel(s), out[1] = pruning kernel, out[2] = root/site reduction. */
+int hyphy_hip_last_timings(hyphy_hip_partition *p, double out[3]);
+
+const char *hyphy_hip_last_error(void);
+const char *hyphy_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPHY_HIP_H */
