@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py — full-tree log-L evaluations / second of the MI355X likelihood core.
+
+One "step" = one full-tree log-likelihood evaluation after a GLOBAL parameter change (omega is
+swept 0.3 + 0.001 k), i.e. per step: device-side rate-matrix build for every branch,
+batched matrix exponential of all L+I-1 branches, one full Felsenstein pruning pass, root
+reduction, (N > 1: one RCCL all-reduce of the partition log-likelihood), log-L back on the host.
+That is exactly what the reference's timing loop `R = ...; LFCompute (lf, res);` does per
+iteration.  Inputs (alignment, tree, rate-matrix templates) are resident in HBM
+before the timed region starts; each step is synchronous (the value is needed by the caller).
+
+Workloads:  mg94_64x10k (default; BASELINE.json metric: 61-state MG94 codon, 64 taxa x 10k codons)
+            mg94_32x5k (configs[1]),  mg94_128x100k (configs[3]),  hky_8x1k (configs[0])
+
+Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+                   --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+Patterns are sharded contiguously over the ranks (one process per GPU, device-resident partial
+log-L, torch.distributed all_reduce == RCCL over xGMI).  Total work is fixed -> "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hyphy_amd import data, hip, models  # noqa: E402
+
+POS_FREQS = np.array([[0.30, 0.20, 0.25, 0.25], [0.20, 0.30, 0.30, 0.20], [0.25, 0.25, 0.20, 0.30]])
+REV = dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4)
+NUC_FREQS = np.array([0.35, 0.15, 0.2, 0.3])
+WORKLOADS = {
+    "mg94_64x10k": dict(taxa=64, sites=10000, unit=3, seed=3),
+    "mg94_32x5k": dict(taxa=32, sites=5000, unit=3, seed=2),
+    "mg94_128x100k": dict(taxa=128, sites=100000, unit=3, seed=4),
+    "hky_8x1k": dict(taxa=8, sites=1000, unit=1, seed=1),
+}
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (== vector) peak, AMD datasheet; see DESIGN.md §roofline
+HBM_PEAK_GBS = 8000.0
+
+
+def templates_for(unit):
+    """Q_b = t_b * T0 + (t_b * omega) * T1  (off-diagonal); device builds the diagonal."""
+    if unit == 3:
+        T = np.zeros((2, 61, 61))
+        rv = dict(REV, AG=1.0)
+        for (i, j, name, ns, pf) in models.mg94rev_template(POS_FREQS):
+            T[1 if ns else 0, i, j] = rv[name] * pf
+        return T, models.f3x4_codon_freqs(POS_FREQS)
+    T = np.zeros((2, 4, 4))
+    rv = dict(models.hky85_rev(0.35), AG=1.0)
+    for i in range(4):
+        for j in range(4):
+            if i != j:
+                T[0, i, j] = rv[models.REV_NAMES[(min(i, j), max(i, j))]] * NUC_FREQS[j]
+    return T, NUC_FREQS
+
+
+def alg_work(D, S, L, I):
+    """SURVEY §8d algorithmic work of one pruning pass (per full-tree evaluation)."""
+    flops = S * ((I - 1) * (2 * D * D + 2 * D) + L * D + 2 * D)
+    bytes_ = S * ((2 * (I - 1) + 1) * 8 * D + L)
+    return flops, bytes_
+
+
+def cpu_baseline(wl, syn, omega0, t_branch, n_threads, budget_s=25.0):
+    """Reference CPU path timed on this host: the real hyphy binary (oracle/_ref) when present,
+    else the scalar C restatement.  Bounded sample of the same workload."""
+    from oracle import hbl
+    from hyphy_amd import tree as htree
+    if hbl.have_reference() and wl["unit"] == 3:
+        tmpl = models.mg94rev_template(POS_FREQS)
+        pi = models.f3x4_codon_freqs(POS_FREQS)
+        g = dict(R=omega0, **REV)
+        bt = {n: t_branch for n in syn.flat.branch_names()}
+        # ~0.36 s / eval / thread at 64 x 10k; scale to the budget
+        per_eval = 0.36 * (syn.flat.L / 64.0) * (syn.states.shape[1] / 10000.0) / max(1, min(n_threads, 8)) * 1.6
+        n = int(max(4, min(400, budget_s / max(per_eval, 1e-3))))
+        res = hbl.evaluate(names=syn.flat.leaf_names, seqs=syn.seqs, newick=htree.to_newick(syn.tree), unit=3,
+                           model_block=hbl.codon_model_block(tmpl, pi), model_name="MGM", globals_=g, branch_t=bt,
+                           sweep=dict(param="R", start=omega0, step=0.001, n=n), threads=n_threads, per_site=False,
+                           timeout=900.0)
+        secs = max(res.get("sweep_seconds", 0.0), 1.0)   # Time(1) has 1 s resolution
+        return dict(value=n / secs, unit="evals/s", cores=n_threads, kind="reference",
+                    sample=f"{n} LFCompute calls with R swept (HBL Time(1), 1 s resolution) on the same alignment/tree, "
+                           f"reference hyphy 2.5.100 built by oracle/Makefile.ref, NUMBER_THREADS={n_threads}"), \
+            res["logl"], res.get("sweep_last")
+    return None, None, None
+
+
+def cpu_port_baseline(pd, flat, Q, pi, sparse):
+    from oracle import oracle
+    t0 = time.time()
+    P = oracle.expm(Q, sparse)
+    op = oracle.OraclePartition(pd.D, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq)
+    nodes = np.arange(flat.n_branches, dtype=np.int64)
+    op.set_P(nodes, P)
+    ll = op.compute_block(nodes, pi)
+    dt = time.time() - t0
+    return dict(value=1.0 / dt, unit="evals/s", cores=1, kind="port",
+                sample="1 full evaluation (expm of every branch + full pruning pass) by oracle/hyphy_oracle.c, scalar C"), ll
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="mg94_64x10k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--pipelined", action="store_true", help="also report throughput with no per-step host sync")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    N = args.gpus
+    dist = None
+    if N > 1:
+        if world != N:
+            raise SystemExit(f"--gpus {N} needs WORLD_SIZE={N} (launch with torch.distributed.run)")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")   # == RCCL on ROCm
+    import torch
+    torch.cuda.set_device(local if N > 1 else 0)
+
+    wl = WORKLOADS[args.workload]
+    syn = data.evolve(wl["taxa"], wl["sites"], wl["unit"], seed=wl["seed"])
+    D = 61 if wl["unit"] == 3 else 4
+    pd_all = data.from_states(syn.states, D)
+    flat = syn.flat
+    S_all, L, I, B = pd_all.S, flat.L, flat.I, flat.n_branches
+    # contiguous pattern shard of this rank (the reference's OpenMP site blocks, likefunc.cpp:10995-11044)
+    lo = (S_all * rank) // N
+    hi = (S_all * (rank + 1)) // N
+    codes = np.ascontiguousarray(pd_all.leaf_codes[:, lo:hi])
+    freq = np.ascontiguousarray(pd_all.pattern_freq[lo:hi])
+
+    T, pi = templates_for(wl["unit"])
+    t_branch = 0.05
+    tb = np.full(B, t_branch)
+    nodes = np.arange(B, dtype=np.int64)
+    omega0 = 0.3
+
+    part = hip.HipPartition(D, flat.flat_parents, L, codes, None, freq, device_first=(local if N > 1 else 0))
+    part.set_q_templates(T)
+    stream = torch.cuda.Stream()             # everything (kernels, RCCL, the .item() copy) in ONE stream
+    torch.cuda.set_stream(stream)
+    part.set_stream(stream.cuda_stream)
+    d_logl = torch.zeros(2, dtype=torch.float64, device="cuda")
+    coeffs = np.empty((B, 2))
+    coeffs[:, 0] = tb
+    enqueue = part.prepare_device_step(nodes, nodes, pi, d_logl.data_ptr(), coeffs)
+
+    def step(k, sync=True):
+        omega = omega0 + 0.001 * k
+        coeffs[:, 1] = tb * omega
+        enqueue()      # device-side Q for every branch, then expm + pruning + reduction (C-ABI calls)
+        if N > 1:
+            dist.all_reduce(d_logl[:1])                        # one RCCL all-reduce per evaluation
+        if sync:
+            return float(d_logl[0].item())                     # log-L back on the host (synchronises)
+        return None
+
+    ll0 = step(0)
+    for k in range(args.warmup):
+        step(k + 1)
+    t_exp = t_prune = t_red = 0.0
+    if N > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for k in range(args.steps):
+        last = step(k + 1)
+        tm = part.last_timings()      # HIP events recorded by the library around each kernel on ITS stream
+        t_exp += tm[0]; t_prune += tm[1]; t_red += tm[2]
+    if N > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if N > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    pipelined = None
+    if args.pipelined:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step(k + 1, sync=False)
+        torch.cuda.synchronize()
+        pipelined = args.steps / (time.perf_counter() - t1)
+
+    if rank == 0:
+        S_rank = hi - lo
+        flops, bytes_ = alg_work(D, S_rank, L, I)
+        prune_ms = t_prune / args.steps
+        bound = "mfma" if D > 4 else "hbm"
+        if bound == "mfma":
+            ach = flops / (prune_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=ach / FP64_MFMA_PEAK_TFLOPS, traffic=None)
+        else:
+            ach = bytes_ / (prune_ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
+        roof["kernel"] = "prune_mfma_kernel" if D > 4 else "prune_nuc_kernel"
+        roof["kernel_ms"] = prune_ms
+        roof["expm_ms"] = t_exp / args.steps
+        roof["reduce_ms"] = t_red / args.steps
+        roof["alg_flops_per_launch"] = flops
+        roof["alg_bytes_per_launch"] = bytes_
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                roof["traffic"] = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        out = {
+            "metric": "full-tree log-L evals/sec, 61-state MG94 codon, 64 taxa x 10k codons",
+            "value": args.steps / dt, "unit": "evals/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "states": D, "taxa": L, "codons" if D > 4 else "sites": wl["sites"],
+                       "unique_patterns": int(S_all), "branches": int(B), "rate_classes": 1,
+                       "parallelism": f"site-shard x{N}" if N > 1 else "single GPU",
+                       "step": "device Q build + expm of all branches + full pruning pass + reduction" +
+                               (" + RCCL all-reduce" if N > 1 else "") + ", log-L returned to host every step"},
+            "logl_first": ll0, "logl_last": last,
+            "roofline": roof,
+        }
+        if pipelined:
+            out["value_pipelined_no_host_sync"] = pipelined
+        if not args.no_cpu_baseline and N == 1:
+            nthr = args.cpu_threads or min(os.cpu_count() or 1, 32)
+            cb = None
+            try:
+                cb, ref_ll, _ = cpu_baseline(wl, syn, omega0, t_branch, nthr)
+            except Exception as e:  # reference binary missing / failed: fall back to the C restatement
+                sys.stderr.write(f"[bench] reference baseline unavailable: {e}\n")
+            if cb is None:
+                Q0 = (models.mg94rev_Q_batch(tb, omega0, REV, POS_FREQS) if D > 4 else
+                      np.stack([models.nuc_rev_Q(t_branch, models.hky85_rev(0.35), NUC_FREQS)] * B))
+                cb, ref_ll = cpu_port_baseline(pd_all, flat, Q0, pi, D > 4)
+            out["cpu_baseline"] = cb
+            out["parity"] = {"logl_gpu": ll0, "logl_cpu": ref_ll, "rel_err": abs(ll0 - ref_ll) / abs(ref_ll),
+                             "tolerance": 1e-6}
+        print(json.dumps(out))
+    part.close()
+    if N > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <set>
@@ -23,6 +24,26 @@ int fail(const std::string &msg) {
   return -1;
 }
 
+struct Trace {
+  bool on;
+  double t0;
+  const char *what;
+  static double now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+  }
+  explicit Trace(const char *w) : on(getenv("HYPHY_HIP_TRACE") != nullptr), t0(0), what(w) {
+    if (on) t0 = now();
+  }
+  void lap(const char *stage) {
+    if (!on) return;
+    double t = now();
+    fprintf(stderr, "[hyphy_hip trace] %s/%s %.1f us\n", what, stage, t - t0);
+    t0 = t;
+  }
+};
+
 #define HIPCHK(expr)                                                                              \
   do {                                                                                            \
     hipError_t e_ = (expr);                                                                       \
@@ -33,7 +54,8 @@ int fail(const std::string &msg) {
 
 struct Shard {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // stream in use
+  hipStream_t own_stream = nullptr;  // stream created (and destroyed) by the library
   int64_t s0 = 0, S = 0;  // pattern range [s0, s0+S) of the partition
   int S_pad = 0, ntiles = 0, T = 1;
   int16_t *codes = nullptr;
@@ -51,6 +73,10 @@ struct Shard {
   int4 *ops = nullptr;
   double *pi = nullptr;       // [DP]
   double *out = nullptr;      // [2]
+  double *wg_sum = nullptr;   // per-workgroup partial sums of the pruning kernel
+  long long *wg_cnt = nullptr;
+  int *wg_flag = nullptr;
+  int wg_cap = 0;
   int32_t *status = nullptr;  // [1]
   double *weights = nullptr;  // [C]
   double *templates = nullptr;
@@ -95,7 +121,7 @@ void free_shard(Shard &s) {
   if (s.stream) hipStreamSynchronize(s.stream);
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
-                 s.weights, s.templates, s.coeffs};
+                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag};
   for (void *d : dev)
     if (d) hipFree(d);
   void *host[] = {s.h_ops, s.h_out, s.h_status, s.h_slots, s.h_small};
@@ -103,7 +129,7 @@ void free_shard(Shard &s) {
     if (h) hipHostFree(h);
   for (auto &e : s.ev)
     if (e) hipEventDestroy(e);
-  if (s.stream) hipStreamDestroy(s.stream);
+  if (s.own_stream) hipStreamDestroy(s.own_stream);
   s = Shard();
 }
 
@@ -129,32 +155,81 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
     }
   }
   p->ops_host.clear();
-  int last_final = -1;  // internal index of the node finalised by the previous op
-  for (int par = 0; par < I; par++) {
-    if (!touched[par]) continue;
+  const int T = p->shards.empty() ? 1 : p->shards[0].T;
+  const int G = p->nuc ? 1 : (T == 1 ? 4 : (T == 2 ? 2 : 1));  // leaves per leaf-group entry (prune.hip)
+  // which touched node is consumed by which later entry: a finished node whose parent is the next
+  // touched node stays in registers; otherwise it is parked in an LDS slot (1..lds_slots(T)-1) until its
+  // parent comes up, or — when the slots run out — re-read from the persisted copy in HBM.
+  std::vector<int> touched_list;
+  for (int par = 0; par < I; par++)
+    if (touched[par]) touched_list.push_back(par);
+  std::vector<int> slot_of(I, -1);      // LDS slot currently caching internal node i
+  std::vector<char> recomputed(I, 0);   // finalised earlier in this schedule
+  const int n_slots = lds_slots(T);
+  std::vector<char> slot_busy(n_slots, 0);
+  int last_final = -1;  // internal index of the node finalised by the previous entry
+  for (size_t ti = 0; ti < touched_list.size(); ti++) {
+    const int par = touched_list[ti];
     const std::vector<int> &ch = p->children[par];
-    // order: [node still in registers] -> leaves -> remaining internal children (ascending)
-    std::vector<int> order;
+    // order: [node still in registers] -> leaves (grouped) -> remaining internal children (ascending)
+    std::vector<int4> entries;
+    std::vector<int> release_after;
     int inreg = -1;
     for (int c : ch)
       if (c >= L && c - L == last_final) inreg = c;
-    if (inreg >= 0) order.push_back(inreg);
-    for (int c : ch)
-      if (c != inreg) order.push_back(c);
-    for (size_t k = 0; k < order.size(); k++) {
-      const int c = order[k];
-      int flags = 0;
-      if (k == 0) flags |= OP_FIRST;
-      if (k + 1 == order.size()) flags |= OP_LAST;
-      if (c < L) flags |= OP_LEAF;
-      if (c == inreg) flags |= OP_INREGS;
+    auto internal_entry = [&](int c, int extra) {
+      int src = 0xff;
+      if (!(extra & OP_INREGS) && slot_of[c - L] > 0) {
+        src = slot_of[c - L];
+        release_after.push_back(src);  // reusable only after this parent's finalisation barriers
+        slot_of[c - L] = -1;
+      } else if (!(extra & OP_INREGS) && recomputed[c - L]) {
+        extra |= OP_GSYNC;  // slots ran out: the persisted copy was written earlier in this launch
+      }
       int4 op;
-      op.x = c;
+      op.x = extra | (src << 24);
       op.y = par;
-      op.z = flags;
-      op.w = c >= L ? c - L : -1;
-      p->ops_host.push_back(op);
+      op.z = c;
+      op.w = c - L;
+      entries.push_back(op);
+    };
+    if (inreg >= 0) internal_entry(inreg, OP_INREGS);
+    std::vector<int> leaves;
+    for (int c : ch)
+      if (c < L) leaves.push_back(c);
+    for (size_t k = 0; k < leaves.size(); k += G) {
+      const int nl = (int)std::min<size_t>(G, leaves.size() - k);
+      unsigned pk[4] = {0, 0, 0, 0};
+      for (int i = 0; i < nl; i++) pk[i] = (unsigned)leaves[k + i];
+      int4 op;
+      op.x = OP_LEAF | (nl << 8) | (0xff << 24);
+      op.y = par;
+      op.z = (int)(pk[0] | (pk[1] << 16));
+      op.w = (int)(pk[2] | (pk[3] << 16));
+      entries.push_back(op);
     }
+    for (int c : ch)
+      if (c >= L && c != inreg) internal_entry(c, 0);
+    entries.front().x |= OP_FIRST;
+    // destination slot of the finished node
+    int dst = 0, keep = 0;
+    const bool next_consumes = ti + 1 < touched_list.size() && p->parents[L + par] == touched_list[ti + 1];
+    if (!next_consumes && p->parents[L + par] >= 0 && !p->nuc) {
+      for (int sidx = 1; sidx < n_slots; sidx++)
+        if (!slot_busy[sidx]) {
+          dst = sidx;
+          break;
+        }
+      if (dst > 0) {
+        slot_busy[dst] = 1;
+        slot_of[par] = dst;
+        keep = OP_KEEP;
+      }
+    }
+    entries.back().x |= OP_LAST | keep | (dst << 16);
+    for (const int4 &e : entries) p->ops_host.push_back(e);
+    for (int sidx : release_after) slot_busy[sidx] = 0;
+    recomputed[par] = 1;
     last_final = par;
   }
 }
@@ -172,9 +247,11 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, 
                  const int64_t *q_nodes, int64_t n_q,
                  const double *q, bool q_on_device, int q_is_prob, const double *root_freqs, double *d_logl_out,
                  bool reduce, bool floor_log) {
+  Trace tr("enqueue");
   HIPCHK(hipSetDevice(s.device));
   const int64_t D = p->D, B = p->B;
   const int DP = p->DP;
+  tr.lap("setdevice");
   if (sched_changed && !p->ops_host.empty()) {
     HIPCHK(hipStreamSynchronize(s.stream));
     memcpy(s.h_ops, p->ops_host.data(), p->ops_host.size() * sizeof(int4));
@@ -186,7 +263,9 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, 
     for (int64_t k = 0; k < D; k++) pi[k] = root_freqs[k];
     if (upload_small(s, pi.data(), pi.size(), s.pi)) return -1;
   }
+  tr.lap("ops+pi");
   HIPCHK(hipEventRecord(s.ev[0], s.stream));
+  tr.lap("event0");
   if (n_q > 0) {
     int32_t *h_slots = s.h_slots + (size_t)cat * B, *d_slots = s.slots + (size_t)cat * B;
     if (slots_changed) {
@@ -218,12 +297,15 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, 
       ea.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
       ea.PTg = s.PTg + (size_t)cat * B * DP * DP;
     }
+    tr.lap("slots+q");
     launch_expm(ea, s.stream);
+    tr.lap("launch_expm");
   }
   HIPCHK(hipEventRecord(s.ev[1], s.stream));
   const int n_ops = (int)p->ops_host.size();
   double *site_lik = s.site_lik + (size_t)cat * s.S_pad;
   int32_t *site_cnt = s.site_cnt + (size_t)cat * s.S_pad;
+  int n_wg = 0;
   if (p->nuc) {
     NucArgs na;
     na.ops = s.ops;
@@ -238,6 +320,11 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, 
     na.pi = s.pi;
     na.site_lik = site_lik;
     na.site_cnt = site_cnt;
+    na.freq = s.freq;
+    na.wg_sum = s.wg_sum;
+    na.wg_cnt = s.wg_cnt;
+    na.wg_flag = s.wg_flag;
+    n_wg = prune_nuc_grid(na);
     launch_prune_nuc(na, s.stream);
   } else {
     PruneArgs pa;
@@ -248,6 +335,8 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, 
     pa.S_pad = s.S_pad;
     pa.ntiles = s.ntiles;
     pa.root_inode = (int)p->I - 1;
+    pa.L = (int)p->L;
+    pa.codes_in_lds = ((size_t)p->L * s.T * 32 + (size_t)(p->L + p->I) * 16 <= 24576) ? 1 : 0;
     pa.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
     pa.PTg = s.PTg + (size_t)cat * B * DP * DP;
     pa.codes = s.codes;
@@ -257,14 +346,25 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, 
     pa.pi = s.pi;
     pa.site_lik = site_lik;
     pa.site_cnt = site_cnt;
+    pa.freq = s.freq;
+    pa.wg_sum = s.wg_sum;
+    pa.wg_cnt = s.wg_cnt;
+    pa.wg_flag = s.wg_flag;
+    n_wg = prune_mfma_grid(pa);
     launch_prune_mfma(pa, s.stream);
   }
+  tr.lap("launch_prune");
   HIPCHK(hipEventRecord(s.ev[2], s.stream));
-  if (reduce)
-    launch_site_reduce(site_lik, site_cnt, s.freq, s.S_pad, floor_log ? 1 : 0, d_logl_out ? d_logl_out : s.out,
-                       s.out + 1, s.stream);
+  if (reduce) {
+    if (n_ops > 0 && !floor_log)  // the pruning kernel left per-workgroup partial sums
+      launch_wg_reduce(s.wg_sum, s.wg_cnt, s.wg_flag, n_wg, d_logl_out ? d_logl_out : s.out, s.out + 1, s.stream);
+    else  // nothing was recomputed (or category mode): reduce the stored per-pattern values
+      launch_site_reduce(site_lik, site_cnt, s.freq, s.S_pad, floor_log ? 1 : 0, d_logl_out ? d_logl_out : s.out,
+                         s.out + 1, s.stream);
+  }
   HIPCHK(hipEventRecord(s.ev[3], s.stream));
   HIPCHK(hipGetLastError());
+  tr.lap("reduce+events");
   return 0;
 }
 
@@ -382,6 +482,10 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
   }
   if (S < 1 || L < 2 || I < 1 || C < 1 || !flat_parents || !leaf_codes || !pattern_freq)
     return fail("invalid partition dimensions / null input");
+  if (L > 65535) {
+    g_last_error = "more than 65535 leaves: packed schedule entries unsupported in this version";
+    return 1;
+  }
   if (n_ambig > 32767) {
     g_last_error = "too many distinct ambiguity vectors for the packed leaf table";
     return 1;
@@ -441,12 +545,14 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     const int64_t tiles = (s.S + 15) / 16;
     int T = 1;
     if (!p->nuc) {
-      T = (int)std::min<int64_t>(4, std::max<int64_t>(1, (tiles + cus - 1) / cus));
+      // one 16-pattern tile per workgroup keeps >= 2-3 waves per SIMD in flight (the FP64 matrix pipe
+      // needs that to saturate, tools/ubench_mfma_f64); larger T only once the grid is many waves deep
+      T = tiles <= 8 * cus ? 1 : (tiles <= 24 * cus ? 2 : 4);
       if (tiles_override >= 1 && tiles_override <= 4) T = tiles_override;
     }
     s.T = T;
     if (p->nuc) {
-      s.S_pad = (int)((s.S + 63) / 64 * 64);
+      s.S_pad = (int)((s.S + 255) / 256 * 256);
       s.ntiles = 0;
       s.partial_stride = (size_t)I * 4 * s.S_pad;
     } else {
@@ -455,7 +561,8 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       s.partial_stride = (size_t)I * s.ntiles * 16 * DP;
     }
 #define A_(ptr, n) if (hipMalloc((void **)&(ptr), (n)) != hipSuccess) { hyphy_hip_destroy(p); return fail("hipMalloc failed (" #ptr ")"); }
-    hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking);
+    s.stream = s.own_stream;
     for (auto &e : s.ev) hipEventCreate(&e);
     A_(s.codes, (size_t)L * s.S_pad * sizeof(int16_t));
     A_(s.freq, (size_t)s.S_pad * sizeof(double));
@@ -479,6 +586,10 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     A_(s.out, 2 * sizeof(double));
     A_(s.status, sizeof(int32_t));
     A_(s.weights, (size_t)C * sizeof(double));
+    s.wg_cap = p->nuc ? (s.S_pad + 255) / 256 : s.ntiles;
+    A_(s.wg_sum, (size_t)s.wg_cap * sizeof(double));
+    A_(s.wg_cnt, (size_t)s.wg_cap * sizeof(long long));
+    A_(s.wg_flag, (size_t)s.wg_cap * sizeof(int));
 #undef A_
     s.h_small_cap = (size_t)std::max<int64_t>(std::max<int64_t>(DP, C), 64);
     if (hipHostMalloc((void **)&s.h_ops, ops_capacity(p) * sizeof(int4)) != hipSuccess ||
@@ -568,6 +679,8 @@ int hyphy_hip_evaluate_device(hyphy_hip_partition *p, int64_t cat, const int64_t
                               const double *root_freqs, double *d_logl_out) {
   if (!p) return fail("partition == NULL");
   if (p->shards.size() != 1) return fail("evaluate_device needs a single-device partition");
+  Trace tr("evaluate_device");
+  struct Fin { Trace &t; ~Fin() { t.lap("total"); } } fin{tr};
   return eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, d_q, true, q_is_probability, root_freqs, d_logl_out,
                      true, false);
 }
@@ -692,10 +805,13 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
 int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs) {
   if (!p || !p->K) return fail("build_q: templates not set");
   if (n < 0 || n > p->C * p->B || !coeffs) return fail("build_q: bad arguments");
+  Trace tr("build_q");
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
     HIPCHK(hipMemcpyAsync(s.coeffs, coeffs, (size_t)n * p->K * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    tr.lap("memcpy");
     launch_build_q(s.templates, s.coeffs, (int)n, (int)p->K, (int)p->D, s.qbuf, s.stream);
+    tr.lap("launch");
   }
   return 0;
 }
@@ -708,6 +824,16 @@ int hyphy_hip_synchronize(hyphy_hip_partition *p) {
     HIPCHK(hipSetDevice(s.device));
     HIPCHK(hipStreamSynchronize(s.stream));
   }
+  return 0;
+}
+
+int hyphy_hip_set_stream(hyphy_hip_partition *p, void *stream) {
+  if (!p) return fail("partition == NULL");
+  if (p->shards.size() != 1) return fail("set_stream needs a single-device partition");
+  Shard &s = p->shards[0];
+  HIPCHK(hipSetDevice(s.device));
+  HIPCHK(hipStreamSynchronize(s.stream));
+  s.stream = (stream == HYPHY_HIP_OWN_STREAM) ? s.own_stream : (hipStream_t)stream;
   return 0;
 }
 

@@ -33,13 +33,20 @@ constexpr double kLogScaler = 64.0 * 0.69314718055994530942;    // _logLFScaler
 // ---------------------------------------------------------------------------------------
 __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1) * 64 + lane) << 1) + (kk & 1); }
 
-// Schedule entry: one child edge.  x = child node code, y = parent internal index, z = flags.
+// Schedule entry (int4).  x = flags | (n_leaves << 8), y = parent internal index.
+//   internal child edge: z = child node code, w = child internal index
+//   leaf group (up to 4 leaf children of the same parent): z = leaf0 | leaf1 << 16, w = leaf2 | leaf3 << 16
 enum : int {
   OP_FIRST = 1,   // first child of this parent: initialise the running product to 1
   OP_LAST = 2,    // last child: finalise (exchange, rescale, persist) the parent
   OP_LEAF = 4,    // child is a leaf (column gather / ambiguity vector)
   OP_INREGS = 8,  // child is the node finalised by the previous op: conditionals still in registers
+  OP_KEEP = 16,   // (with OP_LAST) the finished node stays cached in its LDS slot for a later entry
+  OP_GSYNC = 32,  // child is read from the persisted copy written earlier in THIS launch: full fence first
 };
+// x also carries: bits 16-23 destination LDS slot of an OP_LAST entry, bits 24-31 source LDS slot of an
+// internal child (0xff = read the persisted copy from HBM).  Slot 0 is the scratch exchange slot.
+__host__ __device__ constexpr int lds_slots(int T) { return T == 1 ? 5 : (T == 2 ? 4 : 2); }
 
 struct PruneArgs {
   const int4 *ops;
@@ -49,6 +56,8 @@ struct PruneArgs {
   int S_pad;                 // patterns padded to 16*T
   int ntiles;                // S_pad / 16
   int root_inode;            // I - 1
+  int L;                     // leaves
+  int codes_in_lds;          // leaf codes of the workgroup's tiles are staged in LDS (L*T*32 bytes fit)
   const double *Pfrag;       // [B][NW][NKK*64]      A-operand images of the transition matrices
   const double *PTg;         // [B][DP][NW][4][4]    column-gather images (leaf edges)
   const int16_t *codes;      // [L][S_pad]           >= 0 state, < 0 -> -(k+1) ambiguity row
@@ -58,6 +67,10 @@ struct PruneArgs {
   const double *pi;          // [DP] root frequencies (zero padded)
   double *site_lik;          // [S_pad]
   int32_t *site_cnt;         // [S_pad]
+  const double *freq;        // [S_pad] pattern frequencies (0 for padding)
+  double *wg_sum;            // [n workgroups] sum_s f_s log L_s over the workgroup's patterns
+  long long *wg_cnt;         // [n workgroups] sum_s f_s c_s
+  int *wg_flag;              // [n workgroups] 1: zero-likelihood pattern, 2: NaN
 };
 
 struct NucArgs {
@@ -73,6 +86,10 @@ struct NucArgs {
   const double *pi;          // [4]
   double *site_lik;
   int32_t *site_cnt;
+  const double *freq;
+  double *wg_sum;
+  long long *wg_cnt;
+  int *wg_flag;
 };
 
 struct ExpmArgs {
@@ -93,6 +110,10 @@ void launch_prune_mfma(const PruneArgs &a, hipStream_t stream);
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream);
 void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,
                         double *out_logl, double *out_cnt, hipStream_t stream);
+void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *wg_flag, int n, double *out_logl,
+                      double *out_cnt, hipStream_t stream);
+int prune_mfma_grid(const PruneArgs &a);
+int prune_nuc_grid(const NucArgs &a);
 void launch_mix_categories(const double *site_lik /*[C][S_pad]*/, const int32_t *site_cnt, const double *weights_dev,
                            int C, int S_pad, double *mixed_lik, int32_t *mixed_cnt, hipStream_t stream);
 void launch_build_q(const double *templates, const double *coeffs, int n, int K, int D, double *Q, hipStream_t stream);

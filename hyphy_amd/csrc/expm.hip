@@ -376,25 +376,28 @@ __global__ void expm_nuc_kernel(ExpmArgs a) {
 }
 
 // Q_b = sum_k coeff[b][k] T_k off-diagonal, diagonal = -(row sum)   
-__global__ void build_q_kernel(const double *__restrict__ templates, const double *__restrict__ coeffs, int K, int D,
-                               double *__restrict__ Q) {
+__global__ __launch_bounds__(256) void build_q_kernel(const double *__restrict__ templates,
+                                                      const double *__restrict__ coeffs, int K, int D,
+                                                      double *__restrict__ Q) {
   const int b = blockIdx.x;
-  extern __shared__ double rowsum[];
+  extern __shared__ double qs[];  // [D*D]
   double *out = Q + (size_t)b * D * D;
-  for (int r = threadIdx.x; r < D; r += blockDim.x) rowsum[r] = 0.;
+  const int N = D * D;
+  for (int idx = threadIdx.x; idx < N; idx += 256) {
+    double v = 0.;
+    for (int k = 0; k < K; k++) v += coeffs[(size_t)b * K + k] * templates[(size_t)k * N + idx];
+    qs[idx] = v;
+  }
   __syncthreads();
   // one thread per row keeps the column-order subtraction of MultByFreqs (matrix.cpp:1664-1674)
-  for (int r = threadIdx.x; r < D; r += blockDim.x) {
+  for (int r = threadIdx.x; r < D; r += 256) {
     double d = 0.;
-    for (int c = 0; c < D; c++) {
-      if (c == r) continue;
-      double v = 0.;
-      for (int k = 0; k < K; k++) v += coeffs[(size_t)b * K + k] * templates[((size_t)k * D + r) * D + c];
-      out[r * D + c] = v;
-      d -= v;
-    }
-    out[r * D + r] = d;
+    for (int c = 0; c < D; c++)
+      if (c != r) d -= qs[r * D + c];
+    qs[r * D + r] = d;
   }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < N; idx += 256) out[idx] = qs[idx];
 }
 
 }  // namespace
@@ -405,6 +408,7 @@ void launch_expm(const ExpmArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(expm_nuc_kernel, dim3((a.n + 63) / 64), dim3(64), 0, stream, a);
     return;
   }
+  static bool attr_done[5] = {false, false, false, false, false};  // per process; one device kind only
   const int NT = (a.D + 15) / 16;
   const int DP = 16 * NT, LD = DP + 2;
   const size_t lds = (size_t)(3 * DP * LD + 2 * DP + 8) * sizeof(double);
@@ -416,13 +420,19 @@ void launch_expm(const ExpmArgs &a, hipStream_t stream) {
       hipLaunchKernelGGL(expm_mfma_kernel<2>, dim3(a.n), dim3(128), lds, stream, a);
       break;
     case 3:
-      hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<3>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (!attr_done[3]) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<3>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done[3] = true;
+      }
       hipLaunchKernelGGL(expm_mfma_kernel<3>, dim3(a.n), dim3(192), lds, stream, a);
       break;
     default:
-      hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<4>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (!attr_done[4]) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done[4] = true;
+      }
       hipLaunchKernelGGL(expm_mfma_kernel<4>, dim3(a.n), dim3(256), lds, stream, a);
       break;
   }
@@ -430,7 +440,8 @@ void launch_expm(const ExpmArgs &a, hipStream_t stream) {
 
 void launch_build_q(const double *templates, const double *coeffs, int n, int K, int D, double *Q, hipStream_t stream) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(build_q_kernel, dim3(n), dim3(64), D * sizeof(double), stream, templates, coeffs, K, D, Q);
+  hipLaunchKernelGGL(build_q_kernel, dim3(n), dim3(256), (size_t)D * D * sizeof(double), stream, templates, coeffs, K,
+                     D, Q);
 }
 
 }  // namespace hyhip

@@ -21,7 +21,7 @@ EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
     "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
-    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
+    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
 
@@ -71,6 +71,8 @@ def load():
     lib.hyphy_hip_synchronize.argtypes = [vp]
     lib.hyphy_hip_stream.restype = vp
     lib.hyphy_hip_stream.argtypes = [vp]
+    lib.hyphy_hip_set_stream.restype = C.c_int
+    lib.hyphy_hip_set_stream.argtypes = [vp, vp]
     lib.hyphy_hip_last_timings.restype = C.c_int
     lib.hyphy_hip_last_timings.argtypes = [vp, dp]
     lib.hyphy_hip_last_error.restype = C.c_char_p
@@ -171,6 +173,30 @@ class HipPartition:
                                                    C.c_void_p(d_q_ptr), int(q_is_probability), _d(rf),
                                                    C.c_void_p(d_logl_ptr)))
 
+    def prepare_device_step(self, update_nodes, q_nodes, root_freqs, d_logl_ptr: int, coeffs: np.ndarray,
+                            cat: int = -1):
+        """Returns a zero-argument callable that enqueues ``build_q(coeffs)`` + ``evaluate_device`` with
+        all ctypes arguments marshalled ONCE (numpy's ``.ctypes.data_as`` costs tens of microseconds per
+        call — more than the C-ABI calls themselves).  ``coeffs`` is read at call time (update it in
+        place between calls)."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        assert coeffs.flags.c_contiguous and coeffs.dtype == np.float64
+        keep = (un, qn, rf, coeffs)
+        lib, h = self._lib, self._h
+        pun, pqn, prf, pco = _l(un), _l(qn), _d(rf), _d(coeffs)
+        nun, nqn, nco = len(un), len(qn), coeffs.shape[0]
+        dq, dl = C.c_void_p(self.q_buffer()), C.c_void_p(d_logl_ptr)
+
+        def step(_keep=keep):
+            rc = lib.hyphy_hip_build_q(h, nco, pco)
+            if rc == 0:
+                rc = lib.hyphy_hip_evaluate_device(h, cat, pun, nun, pqn, nqn, dq, 0, prf, dl)
+            if rc:
+                _check(rc)
+        return step
+
     def evaluate_categories(self, update_nodes, q_nodes, q_dense, weights, root_freqs, q_is_probability: bool = False,
                             per_site: bool = False):
         un = np.ascontiguousarray(update_nodes, dtype=np.int64)
@@ -209,6 +235,9 @@ class HipPartition:
 
     def stream(self) -> int:
         return int(self._lib.hyphy_hip_stream(self._h) or 0)
+
+    def set_stream(self, stream_ptr: int):
+        _check(self._lib.hyphy_hip_set_stream(self._h, C.c_void_p(stream_ptr)))
 
     def last_timings(self) -> np.ndarray:
         out = np.zeros(3)

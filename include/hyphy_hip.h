@@ -162,6 +162,13 @@ int hyphy_hip_synchronize(hyphy_hip_partition *p);
 /* The HIP stream (hipStream_t) work is enqueued on for shard 0 — for event timing. */
 void *hyphy_hip_stream(hyphy_hip_partition *p);
 
+/* Enqueue all further work of a single-device partition on the caller's stream (e.g. the
+ * current PyTorch stream, so that an RCCL all-reduce of d_logl_out is ordered in-stream).
+ * Any hipStream_t is accepted, including NULL (the legacy default stream);
+ * HYPHY_HIP_OWN_STREAM restores the partition's own stream. */
+#define HYPHY_HIP_OWN_STREAM ((void *)(intptr_t)-1)
+int hyphy_hip_set_stream(hyphy_hip_partition *p, void *stream);
+
 /* Per-call device timers of the last evaluation, milliseconds (SURVEY §5 tracing row):
  * out[0] = expm kernel(s), out[1] = pruning kernel, out[2] = root/site reduction. */
 int hyphy_hip_last_timings(hyphy_hip_partition *p, double out[3]);

@@ -10,6 +10,8 @@ Cases (SURVEY §8c "Fixtures to commit"):
   codon_small   8 taxa x 40 codons, MG94xREV, logL + per-site logL
   codon_ambig   same tree, 5% gaps / N / partial ambiguities
   codon_deep    120-taxon ladder tree, longer branches -> forces 2^64 rescaling
+  codon_wide    random 64-taxon tree (the benchmark's shape) x 60 codons
+  nuc_wide      random 100-taxon tree x 200 sites
   codon_cat3    3 discrete rate classes (weights .7/.25/.05, rates .1/1/5) -> category mixing
   nuc_small     HKY85, 8 taxa x 300 sites (pattern compression, freq > 1)
   nuc_ambig     GTR with ambiguities
@@ -126,6 +128,8 @@ def main():
     codon_case("codon_deep", 120, 12, seed=13, ladder=True, tlo=0.2, thi=0.6, p_change=0.3)
     codon_case("codon_cat3", 10, 50, seed=14,
                category=dict(name="rc", weights=[0.7, 0.25, 0.05], values=[0.1, 1.0, 5.0]))
+    codon_case("codon_wide", 64, 60, seed=15)        # random 64-taxon tree: deep nesting, many pending subtrees
+    nuc_case("nuc_wide", 100, 200, seed=24)
     nuc_case("nuc_small", 8, 300, seed=21)
     nuc_case("nuc_ambig", 12, 200, seed=22, missing=0.05, rev=dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4))
     nuc_case("nuc_deep", 300, 40, seed=23, ladder=True, tlo=0.1, thi=0.5, p_change=0.25)

@@ -9,7 +9,7 @@ from tests import common
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-10
-CASES = ["codon_small", "codon_ambig", "codon_deep", "nuc_small", "nuc_ambig", "nuc_deep"]
+CASES = ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "nuc_small", "nuc_ambig", "nuc_deep", "nuc_wide"]
 
 
 def _hip():
@@ -103,7 +103,55 @@ def test_q_is_probability_path():
     assert abs(ll - float(fx["logl"])) <= RTOL * abs(float(fx["logl"]))
 
 
-@pytest.mark.parametrize("name", ["codon_deep", "nuc_deep", "codon_small"])
+@pytest.mark.parametrize("seed,taxa,trif", [(1, 64, True), (2, 96, True), (3, 33, False)])
+def test_random_trees_match_oracle(seed, taxa, trif, monkeypatch):
+    """Random topologies at the benchmark's shape (many pending subtrees -> exercises the LDS slot
+    cache, slot exhaustion and the register hand-off), every tile-count variant of the kernel."""
+    from hyphy_amd import data, models, tree
+    from oracle import oracle
+    rng = np.random.default_rng(seed)
+    root = tree.random_tree(taxa, rng, trifurcating_root=trif)
+    syn = data.evolve(taxa, 150, 3, seed=seed, tree=root)
+    pd = data.from_states(syn.states, 61)
+    flat = syn.flat
+    pf = np.array([[0.3, 0.2, 0.25, 0.25], [0.2, 0.3, 0.3, 0.2], [0.25, 0.25, 0.2, 0.3]])
+    Q = models.mg94rev_Q_batch(rng.uniform(0.01, 0.3, flat.n_branches), 0.5,
+                               dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4), pf)
+    pi = models.f3x4_codon_freqs(pf)
+    nodes = np.arange(flat.n_branches, dtype=np.int64)
+    op = oracle.OraclePartition(61, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq)
+    op.set_P(nodes, oracle.expm(Q, True))
+    ref = op.compute_block(nodes, pi)
+    hip = _hip()
+    for tiles in ("1", "2", "3", "4"):
+        monkeypatch.setenv("HYPHY_HIP_TILES", tiles)
+        with hip.HipPartition(61, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq) as part:
+            ll = part.evaluate(nodes, nodes, Q, pi)
+        assert abs(ll - ref) <= RTOL * abs(ref), (tiles, ll, ref)
+
+
+def test_multifurcating_tree_matches_oracle():
+    from hyphy_amd import data, models, tree
+    from oracle import oracle
+    newick = "((a,b,c,d,e)X,(f,(g,h,i)Y,j)Z,k,(l,m)W,n)"
+    root = tree.parse_newick(newick)
+    syn = data.evolve(14, 120, 3, seed=9, tree=root)
+    pd = data.from_states(syn.states, 61)
+    flat = syn.flat
+    pf = np.array([[0.3, 0.2, 0.25, 0.25], [0.2, 0.3, 0.3, 0.2], [0.25, 0.25, 0.2, 0.3]])
+    Q = models.mg94rev_Q_batch(np.linspace(0.02, 0.4, flat.n_branches), 0.4,
+                               dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4), pf)
+    pi = models.f3x4_codon_freqs(pf)
+    nodes = np.arange(flat.n_branches, dtype=np.int64)
+    op = oracle.OraclePartition(61, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq)
+    op.set_P(nodes, oracle.expm(Q, True))
+    ref = op.compute_block(nodes, pi)
+    with _hip().HipPartition(61, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq) as part:
+        ll = part.evaluate(nodes, nodes, Q, pi)
+    assert abs(ll - ref) <= RTOL * abs(ref)
+
+
+@pytest.mark.parametrize("name", ["codon_deep", "nuc_deep", "codon_small", "codon_wide"])
 def test_partial_update_equals_full(name):
     """DetermineNodesForUpdate-style dirty lists: change one branch at a time."""
     from hyphy_amd import tree

@@ -6,7 +6,7 @@ import pytest
 from oracle import oracle
 from tests import common
 
-CASES = ["codon_small", "codon_ambig", "codon_deep", "nuc_small", "nuc_ambig", "nuc_deep"]
+CASES = ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "nuc_small", "nuc_ambig", "nuc_deep", "nuc_wide"]
 
 
 def _partition(fx, C=1):
