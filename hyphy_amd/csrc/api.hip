@@ -102,19 +102,21 @@ struct hyphy_hip_partition {
   std::vector<std::vector<int>> children;    // per internal node, ascending node codes
   std::vector<Shard> shards;
   std::vector<char> initialized;             // per class: a full evaluation has populated the caches
+  std::vector<char> leaf_has_ambig;          // per leaf: any ambiguity code in its row of the leaf table
   std::vector<int4> ops_host;
   std::vector<int64_t> cached_update;        // update list the device schedule was built for
   bool cached_full = false;
   int cached_valid = 0;
   std::vector<double> cached_pi;             // root frequencies currently on the device
   std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
+  int root_slot = 0, n_ops_real = 0, n_ops_padded = 0;
   int64_t K = 0;                             // Q templates
   double timings[3] = {0, 0, 0};
 };
 
 namespace {
 
-size_t ops_capacity(const hyphy_hip_partition *p) { return (size_t)(p->L + p->I); }
+size_t ops_capacity(const hyphy_hip_partition *p) { return (size_t)(p->L + p->I) + 4; }
 
 void free_shard(Shard &s) {
   hipSetDevice(s.device);
@@ -156,81 +158,109 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
   }
   p->ops_host.clear();
   const int T = p->shards.empty() ? 1 : p->shards[0].T;
-  const int G = p->nuc ? 1 : (T == 1 ? 4 : (T == 2 ? 2 : 1));  // leaves per leaf-group entry (prune.hip)
-  // which touched node is consumed by which later entry: a finished node whose parent is the next
-  // touched node stays in registers; otherwise it is parked in an LDS slot (1..lds_slots(T)-1) until its
-  // parent comes up, or — when the slots run out — re-read from the persisted copy in HBM.
+  const int G = p->nuc ? 1 : (T <= 2 ? 2 : 1);  // leaves per leaf-group entry (prune.hip)
+  // A finished node whose parent is the next touched node is read by that parent straight from the
+  // exchange slot it was finalised into (slots 0/1 alternate with the finalisation count, so the
+  // writer of the NEXT finalisation never touches it); otherwise it is parked in an LDS slot
+  // (2..lds_slots(T)-1) until its parent comes up or — when the slots run out — re-read from the
+  // persisted copy in HBM.
   std::vector<int> touched_list;
   for (int par = 0; par < I; par++)
     if (touched[par]) touched_list.push_back(par);
-  std::vector<int> slot_of(I, -1);      // LDS slot currently caching internal node i
+  std::vector<int> slot_of(I, -1);      // LDS slot holding internal node i (valid until consumed)
   std::vector<char> recomputed(I, 0);   // finalised earlier in this schedule
   const int n_slots = lds_slots(T);
   std::vector<char> slot_busy(n_slots, 0);
-  int last_final = -1;  // internal index of the node finalised by the previous entry
+  int fin = 0;
   for (size_t ti = 0; ti < touched_list.size(); ti++) {
     const int par = touched_list[ti];
     const std::vector<int> &ch = p->children[par];
-    // order: [node still in registers] -> leaves (grouped) -> remaining internal children (ascending)
     std::vector<int4> entries;
     std::vector<int> release_after;
-    int inreg = -1;
-    for (int c : ch)
-      if (c >= L && c - L == last_final) inreg = c;
-    auto internal_entry = [&](int c, int extra) {
-      int src = 0xff;
-      if (!(extra & OP_INREGS) && slot_of[c - L] > 0) {
-        src = slot_of[c - L];
-        release_after.push_back(src);  // reusable only after this parent's finalisation barriers
-        slot_of[c - L] = -1;
-      } else if (!(extra & OP_INREGS) && recomputed[c - L]) {
-        extra |= OP_GSYNC;  // slots ran out: the persisted copy was written earlier in this launch
-      }
+    auto internal_entry = [&](int c) {
       int4 op;
-      op.x = extra | (src << 24);
       op.y = par;
       op.z = c;
       op.w = c - L;
+      const int sl = p->nuc ? -1 : slot_of[c - L];
+      if (sl >= 0) {
+        op.x = OPK_INTERNAL | (sl << 24);
+        if (sl >= 2) release_after.push_back(sl);  // reusable only after this parent's barrier
+        slot_of[c - L] = -1;
+      } else {
+        op.x = OPK_INTERNAL_GLOBAL | (0xff << 24);
+        if (recomputed[c - L]) op.x |= OPF_GSYNC;
+        if (p->nuc && ti > 0 && touched_list[ti - 1] == c - L) op.x |= OPF_INREGS;
+      }
       entries.push_back(op);
     };
-    if (inreg >= 0) internal_entry(inreg, OP_INREGS);
+    // order: [child finalised by the previous entry] -> leaves (grouped) -> other internal children
+    int first_internal = -1;
+    if (ti > 0)
+      for (int c : ch)
+        if (c >= L && c - L == touched_list[ti - 1]) first_internal = c;
+    if (first_internal >= 0) internal_entry(first_internal);
     std::vector<int> leaves;
     for (int c : ch)
       if (c < L) leaves.push_back(c);
     for (size_t k = 0; k < leaves.size(); k += G) {
       const int nl = (int)std::min<size_t>(G, leaves.size() - k);
-      unsigned pk[4] = {0, 0, 0, 0};
-      for (int i = 0; i < nl; i++) pk[i] = (unsigned)leaves[k + i];
+      const unsigned l0 = (unsigned)leaves[k], l1 = nl > 1 ? (unsigned)leaves[k + 1] : l0;
+      int amb = 0;
+      for (int i = 0; i < nl; i++)
+        if (p->leaf_has_ambig[leaves[k + i]]) amb = OPF_AMBIG;
       int4 op;
-      op.x = OP_LEAF | (nl << 8) | (0xff << 24);
+      op.x = OPK_LEAF | amb | (nl << 8) | (0xff << 24);
       op.y = par;
-      op.z = (int)(pk[0] | (pk[1] << 16));
-      op.w = (int)(pk[2] | (pk[3] << 16));
+      op.z = (int)(l0 | (l1 << 16));
+      op.w = 0;
       entries.push_back(op);
     }
     for (int c : ch)
-      if (c >= L && c != inreg) internal_entry(c, 0);
-    entries.front().x |= OP_FIRST;
+      if (c >= L && c != first_internal) internal_entry(c);
     // destination slot of the finished node
-    int dst = 0, keep = 0;
+    int dst = fin & 1;
     const bool next_consumes = ti + 1 < touched_list.size() && p->parents[L + par] == touched_list[ti + 1];
-    if (!next_consumes && p->parents[L + par] >= 0 && !p->nuc) {
-      for (int sidx = 1; sidx < n_slots; sidx++)
-        if (!slot_busy[sidx]) {
-          dst = sidx;
-          break;
+    if (!p->nuc) {
+      if (!next_consumes && p->parents[L + par] >= 0) {
+        dst = -1;
+        for (int sidx = 2; sidx < n_slots; sidx++)
+          if (!slot_busy[sidx]) {
+            dst = sidx;
+            break;
+          }
+        if (dst >= 0) {
+          slot_busy[dst] = 1;
+          slot_of[par] = dst;
+        } else {
+          dst = fin & 1;  // no parking slot free: the consumer will re-read the persisted copy
         }
-      if (dst > 0) {
-        slot_busy[dst] = 1;
-        slot_of[par] = dst;
-        keep = OP_KEEP;
+      } else {
+        slot_of[par] = dst;  // consumed by the very next parent from the exchange slot
       }
     }
-    entries.back().x |= OP_LAST | keep | (dst << 16);
+    entries.back().x |= OPF_LAST | ((fin & 1) ? OPF_PARITY : 0) | (dst << 16);
     for (const int4 &e : entries) p->ops_host.push_back(e);
     for (int sidx : release_after) slot_busy[sidx] = 0;
     recomputed[par] = 1;
-    last_final = par;
+    p->root_slot = dst;
+    fin++;
+  }
+  // pad: even entry count + two trailing no-ops (empty leaf groups) so the device loop, unrolled by
+  // two and fetching entries two ahead, needs no bounds tests
+  p->n_ops_real = (int)p->ops_host.size();
+  if (!p->ops_host.empty()) {
+    int4 nop;
+    nop.x = OPK_LEAF | (0xff << 24);
+    nop.y = 0;
+    nop.z = 0;
+    nop.w = 0;
+    if (p->ops_host.size() & 1) p->ops_host.push_back(nop);
+    p->n_ops_padded = (int)p->ops_host.size();
+    p->ops_host.push_back(nop);
+    p->ops_host.push_back(nop);
+  } else {
+    p->n_ops_padded = 0;
   }
 }
 
@@ -302,7 +332,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, 
     tr.lap("launch_expm");
   }
   HIPCHK(hipEventRecord(s.ev[1], s.stream));
-  const int n_ops = (int)p->ops_host.size();
+  const int n_ops = p->n_ops_padded;
   double *site_lik = s.site_lik + (size_t)cat * s.S_pad;
   int32_t *site_cnt = s.site_cnt + (size_t)cat * s.S_pad;
   int n_wg = 0;
@@ -335,6 +365,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, 
     pa.S_pad = s.S_pad;
     pa.ntiles = s.ntiles;
     pa.root_inode = (int)p->I - 1;
+    pa.root_slot = p->root_slot;
     pa.L = (int)p->L;
     pa.codes_in_lds = ((size_t)p->L * s.T * 32 + (size_t)(p->L + p->I) * 16 <= 24576) ? 1 : 0;
     pa.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
@@ -350,8 +381,33 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, 
     pa.wg_sum = s.wg_sum;
     pa.wg_cnt = s.wg_cnt;
     pa.wg_flag = s.wg_flag;
+    pa.timeline = nullptr;
+    pa.ablate = 0;
+    if (const char *ab = getenv("HYPHY_HIP_ABLATE")) pa.ablate = atoi(ab);
+    const char *tl_path = getenv("HYPHY_HIP_TIMELINE");
+    const size_t tl_n = (size_t)kTraceWG * p->NW * std::max(1, n_ops) * 4;
+    if (tl_path && n_ops > 0 && s.T == 1) {
+      HIPCHK(hipMalloc((void **)&pa.timeline, tl_n * sizeof(long long)));
+      HIPCHK(hipMemsetAsync(pa.timeline, 0, tl_n * sizeof(long long), s.stream));
+    }
     n_wg = prune_mfma_grid(pa);
     launch_prune_mfma(pa, s.stream);
+    if (pa.timeline) {  // tracing only: synchronous dump of the per-entry s_memtime stamps
+      std::vector<long long> h(tl_n);
+      HIPCHK(hipStreamSynchronize(s.stream));
+      HIPCHK(hipMemcpy(h.data(), pa.timeline, tl_n * sizeof(long long), hipMemcpyDeviceToHost));
+      hipFree(pa.timeline);
+      if (FILE *f = fopen(tl_path, "w")) {
+        fprintf(f, "# wg wave entry flags t_start t_compute_done t_after_barrier t_finalised\n");
+        for (int b = 0; b < kTraceWG; b++)
+          for (int w = 0; w < p->NW; w++)
+            for (int o = 0; o < n_ops; o++) {
+              const long long *r = &h[(((size_t)b * p->NW + w) * n_ops + o) * 4];
+              fprintf(f, "%d %d %d %d %lld %lld %lld %lld\n", b, w, o, p->ops_host[o].x & 0xff, r[0], r[1], r[2], r[3]);
+            }
+        fclose(f);
+      }
+    }
   }
   tr.lap("launch_prune");
   HIPCHK(hipEventRecord(s.ev[2], s.stream));
@@ -518,6 +574,13 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
   for (int64_t k = 0; k < L * S; k++)
     if (leaf_codes[k] >= D || leaf_codes[k] < -n_ambig) { delete p; return fail("leaf code out of range"); }
   p->initialized.assign(C, 0);
+  p->leaf_has_ambig.assign(L, 0);
+  for (int64_t l = 0; l < L; l++)
+    for (int64_t k = 0; k < S; k++)
+      if (leaf_codes[l * S + k] < 0) {
+        p->leaf_has_ambig[l] = 1;
+        break;
+      }
 
   const int DP = p->DP;
   const int64_t B = p->B;

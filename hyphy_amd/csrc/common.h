@@ -33,24 +33,29 @@ constexpr double kLogScaler = 64.0 * 0.69314718055994530942;    // _logLFScaler
 // ---------------------------------------------------------------------------------------
 __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1) * 64 + lane) << 1) + (kk & 1); }
 
-// Schedule entry (int4).  x = flags | (n_leaves << 8), y = parent internal index.
-//   internal child edge: z = child node code, w = child internal index
-//   leaf group (up to 4 leaf children of the same parent): z = leaf0 | leaf1 << 16, w = leaf2 | leaf3 << 16
-enum : int {
-  OP_FIRST = 1,   // first child of this parent: initialise the running product to 1
-  OP_LAST = 2,    // last child: finalise (exchange, rescale, persist) the parent
-  OP_LEAF = 4,    // child is a leaf (column gather / ambiguity vector)
-  OP_INREGS = 8,  // child is the node finalised by the previous op: conditionals still in registers
-  OP_KEEP = 16,   // (with OP_LAST) the finished node stays cached in its LDS slot for a later entry
-  OP_GSYNC = 32,  // child is read from the persisted copy written earlier in THIS launch: full fence first
-};
-// x also carries: bits 16-23 destination LDS slot of an OP_LAST entry, bits 24-31 source LDS slot of an
-// internal child (0xff = read the persisted copy from HBM).  Slot 0 is the scratch exchange slot.
-__host__ __device__ constexpr int lds_slots(int T) { return T == 1 ? 5 : (T == 2 ? 4 : 2); }
+// Host-compiled schedule entry (int4), built by build_schedule() in api.hip:
+//   x  bits 0-1  kind: OPK_LEAF (group of <= 2 leaf children), OPK_INTERNAL (child vector in an LDS
+//                slot), OPK_INTERNAL_GLOBAL (child vector = persisted copy in HBM)
+//      bit  3    OPF_LAST    last child of its parent: finalise the parent
+//      bit  4    parity of this finalisation (which psum buffer / exchange slot pair member)
+//      bit  5    OPF_GSYNC   (internal-global) copy was written earlier in THIS launch: full fence first
+//      bit  6    OPF_AMBIG   (leaf group) some leaf of the group carries ambiguity codes in this shard
+//      bit  7    OPF_INREGS  (nucleotide kernel only) child is the node finalised by the previous entry
+//      bits 8-15 number of leaves in a leaf group
+//      bits 16-23 destination LDS slot of the finalised parent (0/1 exchange slots, >= 2 parking)
+//      bits 24-31 source LDS slot of an OPK_INTERNAL child
+//   y  parent internal index
+//   z  internal: child node code (= transition-matrix slot);  leaf group: leaf0 | leaf1 << 16
+//   w  internal: child internal index
+// A parent's first entry needs no flag: the running product is reset when a parent is finalised.
+enum : int { OPK_LEAF = 0, OPK_INTERNAL = 1, OPK_INTERNAL_GLOBAL = 2 };
+enum : int { OPF_LAST = 8, OPF_PARITY = 16, OPF_GSYNC = 32, OPF_AMBIG = 64, OPF_INREGS = 128 };
+__host__ __device__ constexpr int lds_slots(int T) { return T == 1 ? 5 : (T == 2 ? 4 : (T == 3 ? 3 : 2)); }
 
 struct PruneArgs {
   const int4 *ops;
-  int n_ops;
+  int n_ops;                 // even; two further no-op entries follow in memory
+  int root_slot;             // LDS slot the root was finalised into
   int NW;                    // row blocks (waves per workgroup) = DP/16
   int T;                     // 16-pattern tiles per workgroup
   int S_pad;                 // patterns padded to 16*T
@@ -71,7 +76,11 @@ struct PruneArgs {
   double *wg_sum;            // [n workgroups] sum_s f_s log L_s over the workgroup's patterns
   long long *wg_cnt;         // [n workgroups] sum_s f_s c_s
   int *wg_flag;              // [n workgroups] 1: zero-likelihood pattern, 2: NaN
+  int ablate;                // DIAGNOSTIC ONLY (HYPHY_HIP_ABLATE bitmask, results invalid): 1 no MFMA, 2 no barrier,
+                             // 4 no persist stores, 8 no leaf gathers, 16 no operand prefetch, 32 no LDS exchange
+  long long *timeline;       // optional tracing: [kTraceWG][NW][n_ops][4] s_memtime stamps (HYPHY_HIP_TIMELINE)
 };
+constexpr int kTraceWG = 8;
 
 struct NucArgs {
   const int4 *ops;

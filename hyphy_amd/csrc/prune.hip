@@ -58,36 +58,54 @@ __device__ __forceinline__ int rescale_decision(double tot, double &sc) {
   return m;
 }
 
+// 16-byte access at (wave-uniform base) + (32-bit per-lane byte offset): lets the compiler keep the
+// base in SGPRs and a single VGPR offset instead of a 64-bit per-lane pointer per stream.
+__device__ __forceinline__ f64x2 ld16(const double *ubase, unsigned byte_off) {
+  return *reinterpret_cast<const f64x2 *>(reinterpret_cast<const char *>(ubase) + byte_off);
+}
+__device__ __forceinline__ void st16(double *ubase, unsigned byte_off, f64x2 v) {
+  *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(ubase) + byte_off) = v;
+}
+
 // Operand bundle fetched one schedule entry ahead: 16 doubles per lane, either the A-operand image
 // of the next internal edge's transition matrix or the gathered columns of the next leaf group.
 struct Payload {
   f64x2 v[8];
 };
 
-// CLDS: leaf codes of the workgroup's tiles and the schedule are staged in LDS (the common case);
-// the !CLDS variant (thousands of taxa) reads both from global memory.
-template <int NW, int T, bool CLDS>
-__global__ __launch_bounds__(64 * NW, (T == 1 ? 3 : 1)) void prune_mfma_kernel(PruneArgs a) {
+// The pruning kernel interprets a host-compiled schedule (api.hip: build_schedule).  Everything that
+// can be decided on the host is: entry kind, which LDS slot a finished node goes to (including the
+// ping-pong parity of the two exchange slots), where a child vector is read from.  The device loop is
+// kept as branch-poor as possible — with only ~2.4 waves per SIMD at the benchmark size, every
+// dependent scalar/LDS round trip in the interpreter is exposed latency (measured: an interpreter with
+// ~160 branches cost more than the MFMAs themselves).
+//
+// CLDS: leaf codes of the workgroup's tiles are staged in LDS (the common case); the !CLDS variant
+// (thousands of taxa) reads them from global memory.
+template <int NW, int T, bool CLDS, bool TRACE, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, (T == 1 ? 3 : 1)) void prune_mfma_kernel(const int4 *__restrict__ ops,
+                                                                               PruneArgs a) {
   constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
-  constexpr int G = (T == 1) ? 4 : (T == 2 ? 2 : 1);  // leaves per leaf-group entry (T*G*4 doubles <= 16)
+  constexpr int G = (T <= 2) ? 2 : 1;  // leaves per leaf-group entry (T*G*4 doubles <= 16)
   static_assert(NW == 4 || NKK <= 16, "payload sized for DP <= 64");
-  // LDS: NS slots of T tiles (exchange buffers that double as a cache for finished nodes whose parent
-  // is not the next schedule entry — host-allocated, see build_schedule), per-site sums, slot exponents,
-  // then (dynamic) the leaf codes of this workgroup's tiles.
+  // LDS: NS slots of T tiles.  Slots 0/1 are the ping-pong exchange buffers of successive node
+  // finalisations (one barrier per node); slots >= 2 park finished nodes whose parent is not the next
+  // schedule entry.  Slot data is unscaled; each wave keeps its own copy of the per-site scale and
+  // exponent of every slot (written and read by the same wave: no cross-wave ordering needed).
   constexpr int NS = lds_slots(T);
-  __shared__ __align__(16) double xbuf[NS * T * TILE + T * NW * 16];
-  __shared__ int slot_cnt[NS * T * 16];
-  extern __shared__ __align__(16) int4 dyn_lds[];  // CLDS: [n_ops] schedule, then [L][T*16] int16 leaf codes
-  int4 *ops_lds = dyn_lds;
-  int16_t *codes_lds = reinterpret_cast<int16_t *>(dyn_lds + a.n_ops);
-  double *sums = xbuf + NS * T * TILE;
+  __shared__ __align__(16) double xbuf[NS * T * TILE];
+  __shared__ double psum[2][T][NW * 64];            // per-lane partial site sums of a finalisation
+  __shared__ double slot_scale[NS][NW][T][16];
+  __shared__ int slot_cnt[NS][NW][T][16];
+  extern __shared__ __align__(16) int16_t codes_lds[];  // CLDS: [L][T*16] leaf codes
 
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sl = lane & 15;
+  const int lane = threadIdx.x & 63, g = lane >> 4, sl = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR: scalar bases
   const int tile0 = blockIdx.x * T;
   const int S_pad = a.S_pad;
+  constexpr int ablate = ABL;  // DIAGNOSTIC builds only (HYPHY_HIP_ABLATE); 0 in production
 
   if (CLDS) {
-    for (int i = threadIdx.x; i < a.n_ops; i += 64 * NW) ops_lds[i] = a.ops[i];
     const int n = a.L * T * 16;
     for (int i = threadIdx.x; i < n; i += 64 * NW) {
       const int leaf = i / (T * 16), off = i - leaf * (T * 16);
@@ -99,235 +117,256 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? 3 : 1)) void prune_mfma_kernel(P
     if (CLDS) return (int)codes_lds[leaf * (T * 16) + t * 16 + sl];
     return (int)a.codes[(size_t)leaf * S_pad + (tile0 + t) * 16 + sl];
   };
-  // schedule entry -> SGPRs (wave-uniform control flow, no vector-memory wait in the way)
-  auto load_op = [&](int i) -> int4 {
-    const int4 v = CLDS ? ops_lds[i] : a.ops[i];
-    int4 r;
-    r.x = __builtin_amdgcn_readfirstlane(v.x);
-    r.y = __builtin_amdgcn_readfirstlane(v.y);
-    r.z = __builtin_amdgcn_readfirstlane(v.z);
-    r.w = __builtin_amdgcn_readfirstlane(v.w);
-    return r;
-  };
-  auto leaf_of = [](const int4 &op, int i) -> int {
-    const unsigned packed = (i < 2) ? (unsigned)op.z : (unsigned)op.w;
-    return (int)((packed >> ((i & 1) * 16)) & 0xffffu);
-  };
-  // issue the global loads for a schedule entry (they complete while the previous entry computes)
+  // Issue the global loads for a schedule entry (they complete while the previous entry computes).
+  // STRAIGHT-LINE on purpose: exactly 8 x 16-byte loads per lane for every entry kind, addresses
+  // chosen with wave-uniform selects.  With an if/else per kind the two paths load into different
+  // registers and the compiler joins them with "s_waitcnt vmcnt(0) + 16 x v_mov_b64" — i.e. it waits
+  // for the prefetch right after issuing it (seen in the ISA; it made every earlier attempt at
+  // hiding the operand latency a no-op).
   auto prefetch = [&](const int4 &op, Payload &pay) {
-    const int flags = op.x & 0xff;
-    if (flags & OP_LEAF) {
-      const int nl = (op.x >> 8) & 0xff;
+    if (ablate & 16) return;
+    const bool is_leaf = (op.x & 3) == OPK_LEAF;
+    const int leaf0 = is_leaf ? (op.z & 0xffff) : 0, leaf1 = is_leaf ? ((op.z >> 16) & 0xffff) : 0;
+    int code[2][T];
 #pragma unroll
-      for (int i = 0; i < G; i++) {
-        if (i < nl) {
-          const int leaf = leaf_of(op, i);
+    for (int t = 0; t < T; t++) {
+      const int c0 = leaf_code(leaf0, t), c1 = (G > 1) ? leaf_code(leaf1, t) : 0;
+      code[0][t] = c0 < 0 ? 0 : c0;  // ambiguous sites: gathered value unused (slow path)
+      code[1][t] = c1 < 0 ? 0 : c1;
+    }
+    const double *bl0 = a.PTg + ((size_t)leaf0 * DP * NW + w) * 16;     // uniform
+    const double *bl1 = a.PTg + ((size_t)leaf1 * DP * NW + w) * 16;     // uniform
+    const double *bfr = a.Pfrag + ((size_t)op.z * NW + w) * TILE;       // uniform (internal entries)
+    constexpr int NLOADS = G * T * 2;  // gather loads of a leaf group (<= 8)
 #pragma unroll
-          for (int t = 0; t < T; t++) {
-            int code = leaf_code(leaf, t);
-            code = code < 0 ? 0 : code;  // ambiguous sites: value unused (MFMA path below)
-            const f64x2 *src =
-                reinterpret_cast<const f64x2 *>(a.PTg + (((size_t)leaf * DP + code) * NW + w) * 16 + g * 4);
-            pay.v[(i * T + t) * 2] = src[0];
-            pay.v[(i * T + t) * 2 + 1] = src[1];
-          }
-        }
-      }
-    } else {
-      const double *Af = a.Pfrag + ((size_t)op.z * NW + w) * TILE;
-#pragma unroll
-      for (int k2 = 0; k2 < NKK / 2; k2++) pay.v[k2 % 8] = *reinterpret_cast<const f64x2 *>(Af + (k2 * 64 + lane) * 2);
+    for (int k = 0; k < 8; k++) {
+      const int kl = k % NLOADS, i = kl / (2 * T), t = (kl >> 1) % T, h = kl & 1;
+      const double *base = is_leaf ? (i ? bl1 : bl0) : bfr;
+      const unsigned off_leaf = (unsigned)(code[i][t] * NW * 16 + g * 4) * 8u + (unsigned)h * 16u;
+      const unsigned off_frag = (unsigned)((k % (NKK / 2)) * 64 + lane) * 16u;
+      if (k < NLOADS) {
+        pay.v[k] = ld16(base, is_leaf ? off_leaf : off_frag);  // both kinds: same registers, one path
+      } else if (!is_leaf) {
+        pay.v[k] = ld16(bfr, off_frag);  // only internal entries need the rest of the A image; a leaf
+      }                                  // entry leaves these registers untouched (no join copies)
     }
   };
+  // ARRIVE: a dummy use of a payload.  It makes the compiler put its vector-memory wait HERE instead
+  // of (as vmcnt(0), because the number of loads in flight differs per path) before the first MFMA of
+  // the next entry, where it would also drain the loads just issued for the entry after that.
+  auto arrive = [](const Payload &q) {
+    asm volatile("" ::"v"(q.v[0]), "v"(q.v[1]), "v"(q.v[2]), "v"(q.v[3]), "v"(q.v[4]), "v"(q.v[5]), "v"(q.v[6]),
+                 "v"(q.v[7]));
+  };
 
-  double slot_keep_scale[T];
-  double B[T][NKK];   // child conditionals, B-operand image (also: the node finalised last)
-  f64x4 acc[T];       // this wave's 16 parent states x 16 sites running product
-  int cnt[T], bcnt[T];
+  f64x4 acc[T];  // this wave's 16 parent states x 16 sites running product
+  int cnt[T];    // 2^64-exponent of the running product
 #pragma unroll
   for (int t = 0; t < T; t++) {
     acc[t] = (f64x4){1., 1., 1., 1.};
     cnt[t] = 0;
-    bcnt[t] = 0;
-#pragma unroll
-    for (int kk = 0; kk < NKK; kk++) B[t][kk] = 0.;
   }
 
-  // schedule entries are fetched two ahead so the scalar load never sits in the prefetch address chain
-  const int last_op = a.n_ops - 1;
-  int4 nxt = load_op(0);
-  int4 nxt2 = load_op(last_op < 1 ? last_op : 1);
-  Payload pnext;
-  prefetch(nxt, pnext);
+  // one schedule entry: multiply one child edge (or leaf group) into the parent's running product and,
+  // after the parent's last child, finalise it.  `nxt` = payload of the following entry (in flight).
+  auto body = [&](const int4 &op, const Payload &pay, const Payload &nxt, int oi) {
+    const int kind = op.x & 3;
+    const bool trace = TRACE && a.timeline != nullptr && blockIdx.x < kTraceWG;
+    long long *tl = trace ? a.timeline + (((size_t)blockIdx.x * NW + w) * a.n_ops + oi) * 4 : nullptr;
+    if (trace && lane == 0) tl[0] = clock64();
 
-  for (int oi = 0; oi < a.n_ops; oi++) {
-    const int4 op = nxt;
-    const Payload pay = pnext;
-    nxt = nxt2;
-    nxt2 = load_op(oi + 2 < last_op ? oi + 2 : last_op);
-    if (oi + 1 < a.n_ops) prefetch(nxt, pnext);
-    const int flags = op.x & 0xff, parent = op.y;
-    const int dst_slot = (op.x >> 16) & 0xff, src_slot = (op.x >> 24) & 0xff;
-    if (flags & OP_FIRST) {
-#pragma unroll
-      for (int t = 0; t < T; t++) {
-        acc[t] = (f64x4){1., 1., 1., 1.};
-        cnt[t] = 0;
-      }
-    }
-
-    if (flags & OP_LEAF) {
+    if (kind == OPK_LEAF) {
+      // K4: parent[k] *= P[k][state] — the columns were gathered one entry ahead
       const int nl = (op.x >> 8) & 0xff;
-#pragma unroll
-      for (int i = 0; i < G; i++) {
-        if (i < nl) {
-          const int leaf = leaf_of(op, i);
-          int code[T];
-          bool amb = false;
+      if (!(op.x & OPF_AMBIG)) {
+        {
+          const bool one = nl > 0;  // (nl == 0: padding entry)
 #pragma unroll
           for (int t = 0; t < T; t++) {
-            code[t] = leaf_code(leaf, t);
-            amb |= code[t] < 0;
+            const f64x4 m = (f64x4){pay.v[t * 2][0], pay.v[t * 2][1], pay.v[t * 2 + 1][0], pay.v[t * 2 + 1][1]};
+            acc[t] *= one ? m : (f64x4){1., 1., 1., 1.};
           }
-          if (!__any(amb)) {
-            // K4: parent[k] *= P[k][state] — columns were gathered one entry ahead
+        }
+        if (G > 1) {  // second leaf of the group: uniform select instead of a branch
+          const bool two = nl > 1;
+#pragma unroll
+          for (int t = 0; t < T; t++) {
+            const f64x4 m = (f64x4){pay.v[(T + t) * 2][0], pay.v[(T + t) * 2][1], pay.v[(T + t) * 2 + 1][0],
+                                    pay.v[(T + t) * 2 + 1][1]};
+            acc[t] *= two ? m : (f64x4){1., 1., 1., 1.};
+          }
+        }
+      } else {
+        // slow path: some leaf of the group carries ambiguity codes.  Tiles containing one take the
+        // full product with the resolution vector as B operand (operands streamed, not staged).
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+          if (i < nl) {
+            const int leaf = (op.z >> (16 * i)) & 0xffff;
+            const double *Af = a.Pfrag + ((size_t)leaf * NW + w) * TILE;
 #pragma unroll
             for (int t = 0; t < T; t++) {
-              const f64x2 lo = pay.v[(i * T + t) * 2], hi = pay.v[(i * T + t) * 2 + 1];
-              acc[t] *= (f64x4){lo[0], lo[1], hi[0], hi[1]};
-            }
-          } else {
-            // ambiguity codes in this tile: full product with the resolution vector as B operand
-            // (rare path: operands are streamed, not staged in registers, to keep the hot path lean)
-            const double *Af = a.Pfrag + ((size_t)leaf * NW + w) * TILE;
-#pragma unroll 1
-            for (int t = 0; t < T; t++) {
-              f64x4 d = (f64x4){0., 0., 0., 0.};
-              const int c = code[t];
-              const double *av = a.ambig + (size_t)(c < 0 ? -c - 1 : 0) * DP;
+              const int c = leaf_code(leaf, t);
+              if (!__any(c < 0)) {
+                acc[t] *= (f64x4){pay.v[(i * T + t) * 2][0], pay.v[(i * T + t) * 2][1], pay.v[(i * T + t) * 2 + 1][0],
+                                  pay.v[(i * T + t) * 2 + 1][1]};
+              } else {
+                f64x4 d = (f64x4){0., 0., 0., 0.};
+                const double *av = a.ambig + (size_t)(c < 0 ? -c - 1 : 0) * DP;
 #pragma unroll 2
-              for (int kk = 0; kk < NKK; kk++) {
-                const double bv = (c >= 0) ? ((4 * kk + g == c) ? 1.0 : 0.0) : av[4 * kk + g];
-                d = mfma(Af[frag_index(kk, lane)], bv, d);
+                for (int kk = 0; kk < NKK; kk++) {
+                  const double bv = (c >= 0) ? ((4 * kk + g == c) ? 1.0 : 0.0) : av[4 * kk + g];
+                  d = mfma(Af[frag_index(kk, lane)], bv, d);
+                }
+                acc[t] *= d;
               }
-              acc[t] *= d;
             }
           }
         }
       }
     } else {
-      const int cinode = op.w;  // internal index of the child
-      if (!(flags & OP_INREGS)) {
-        if (flags & OP_GSYNC) __syncthreads();
-        if (src_slot != 0xff) {  // still cached in LDS
-#pragma unroll
-          for (int t = 0; t < T; t++) {
-            const double *src = xbuf + (src_slot * T + t) * TILE;
-#pragma unroll
-            for (int k2 = 0; k2 < NKK / 2; k2++) {
-              const f64x2 v = *reinterpret_cast<const f64x2 *>(src + (k2 * 64 + lane) * 2);
-              B[t][2 * k2] = v[0];
-              B[t][2 * k2 + 1] = v[1];
-            }
-            bcnt[t] = slot_cnt[(src_slot * T + t) * 16 + sl];
-          }
-        } else {  // persisted copy (node not recomputed in this call, or the LDS slots ran out)
-#pragma unroll
-          for (int t = 0; t < T; t++) {
-            const double *src = a.partials + ((size_t)cinode * a.ntiles + tile0 + t) * TILE;
-#pragma unroll
-            for (int k2 = 0; k2 < NKK / 2; k2++) {
-              const f64x2 v = *reinterpret_cast<const f64x2 *>(src + (k2 * 64 + lane) * 2);
-              B[t][2 * k2] = v[0];
-              B[t][2 * k2 + 1] = v[1];
-            }
-            bcnt[t] = a.counts[(size_t)cinode * S_pad + (tile0 + t) * 16 + sl];
-          }
-        }
-      }
-      // two accumulator chains per tile: the f64 MFMA's dependent-issue latency (~200 cycles) exceeds
-      // its independent issue interval (~143), tools/ubench_mfma_f64
+      // internal child: its conditional vector is the B operand, streamed from its LDS slot (exchange
+      // slot of the previous finalisation, or a parking slot) while the MFMAs run; the per-site
+      // power-of-two scale is applied to the product (columns are sites).  Two accumulator chains per
+      // tile: one wave cannot issue f64 MFMAs back to back on one accumulator.
       f64x4 d0[T], d1[T];
+      double csc[T];
+      int ccnt[T];
 #pragma unroll
       for (int t = 0; t < T; t++) d0[t] = d1[t] = (f64x4){0., 0., 0., 0.};
-#pragma unroll
-      for (int kk = 0; kk < NKK; kk += 2)
+      if (kind == OPK_INTERNAL) {
+        const int slot = (op.x >> 24) & 0xff;
 #pragma unroll
         for (int t = 0; t < T; t++) {
-          d0[t] = mfma(pay.v[(kk >> 1) % 8][0], B[t][kk], d0[t]);
-          d1[t] = mfma(pay.v[(kk >> 1) % 8][1], B[t][kk + 1], d1[t]);
+          csc[t] = slot_scale[slot][w][t][sl];
+          ccnt[t] = slot_cnt[slot][w][t][sl];
         }
+        if (!(ablate & 1)) {
+#pragma unroll
+          for (int k2 = 0; k2 < NKK / 2; k2++)
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+              const f64x2 bv =
+                  *reinterpret_cast<const f64x2 *>(xbuf + (slot * T + t) * TILE + (k2 * 64 + lane) * 2);
+              d0[t] = mfma(pay.v[k2 % 8][0], bv[0], d0[t]);
+              d1[t] = mfma(pay.v[k2 % 8][1], bv[1], d1[t]);
+            }
+        }
+      } else {
+        // child not recomputed in this call (or the LDS slots ran out): persisted copy in HBM
+        const int cinode = op.w;
+        if (op.x & OPF_GSYNC) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+          const double *src = a.partials + ((size_t)cinode * a.ntiles + tile0 + t) * TILE;  // uniform
+          csc[t] = 1.;
+          ccnt[t] = a.counts[(size_t)cinode * S_pad + (tile0 + t) * 16 + sl];
+#pragma unroll
+          for (int k2 = 0; k2 < NKK / 2; k2++) {
+            const f64x2 bv = ld16(src, (unsigned)(k2 * 64 + lane) * 16u);
+            d0[t] = mfma(pay.v[k2 % 8][0], bv[0], d0[t]);
+            d1[t] = mfma(pay.v[k2 % 8][1], bv[1], d1[t]);
+          }
+          // consume every load of this (rarer) path INSIDE the branch: a load still in flight at the
+          // join would make the compiler guard the common path with vmcnt(0) as well
+          asm volatile("" ::"v"(ccnt[t]));
+        }
+      }
 #pragma unroll
       for (int t = 0; t < T; t++) {
-        acc[t] *= (d0[t] + d1[t]);
-        cnt[t] += bcnt[t];
+        acc[t] *= (d0[t] + d1[t]) * csc[t];
+        cnt[t] += ccnt[t];
       }
     }
 
-    if (flags & OP_LAST) {
-      // exchange the row blocks + per-site sums through LDS
-#pragma unroll
-      for (int t = 0; t < T; t++) {
-        double s = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (g == 0) sums[(t * NW + w) * 16 + sl] = s;
-        double *dst = xbuf + (dst_slot * T + t) * TILE;
-        // kk = 4w + r  ->  frag_index(kk, lane): two 16-byte stores
-        *reinterpret_cast<f64x2 *>(dst + ((2 * w) * 64 + lane) * 2) = (f64x2){acc[t][0], acc[t][1]};
-        *reinterpret_cast<f64x2 *>(dst + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){acc[t][2], acc[t][3]};
-      }
-      lds_barrier();
-#pragma unroll
-      for (int t = 0; t < T; t++) {
-        const double *src = xbuf + (dst_slot * T + t) * TILE;
-#pragma unroll
-        for (int k2 = 0; k2 < NKK / 2; k2++) {
-          const f64x2 v = *reinterpret_cast<const f64x2 *>(src + (k2 * 64 + lane) * 2);
-          B[t][2 * k2] = v[0];
-          B[t][2 * k2 + 1] = v[1];
-        }
-        double tot = sums[(t * NW) * 16 + sl];
-#pragma unroll
-        for (int ww = 1; ww < NW; ww++) tot += sums[(t * NW + ww) * 16 + sl];
-        double sc;
-        const int m = rescale_decision(tot, sc);
-        if (m != 0) {
-#pragma unroll
-          for (int kk = 0; kk < NKK; kk++) B[t][kk] *= sc;
-        }
-        cnt[t] += m;
-        bcnt[t] = cnt[t];
-        // persist this wave's quarter (k-steps 4w .. 4w+3 == its own accumulator, times the exact
-        // power-of-two scale) and the exponent
-        double *out = a.partials + ((size_t)parent * a.ntiles + tile0 + t) * TILE;
-        const f64x4 q = acc[t] * sc;
-        *reinterpret_cast<f64x2 *>(out + ((2 * w) * 64 + lane) * 2) = (f64x2){q[0], q[1]};
-        *reinterpret_cast<f64x2 *>(out + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){q[2], q[3]};
-        if (w == 0 && g == 0) a.counts[(size_t)parent * S_pad + (tile0 + t) * 16 + sl] = cnt[t];
-        if (flags & OP_KEEP) {  // the slot will be read again later: it must hold the rescaled vector
-          slot_keep_scale[t] = sc;
-          if (w == 0 && g == 0) slot_cnt[(dst_slot * T + t) * 16 + sl] = cnt[t];
-        }
-      }
-      lds_barrier();  // every wave has read the slot and the sums
-      if (flags & OP_KEEP) {
-#pragma unroll
-        for (int t = 0; t < T; t++) {
-          if (__any(slot_keep_scale[t] != 1.0)) {
-            double *dst = xbuf + (dst_slot * T + t) * TILE;
-            const f64x4 q = acc[t] * slot_keep_scale[t];
-            *reinterpret_cast<f64x2 *>(dst + ((2 * w) * 64 + lane) * 2) = (f64x2){q[0], q[1]};
-            *reinterpret_cast<f64x2 *>(dst + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){q[2], q[3]};
-          }
-        }
-      }
+    if (trace) {
+      asm volatile("" ::"v"(acc[0][0]));
+      if (lane == 0) tl[1] = clock64();
     }
+    if (op.x & OPF_LAST) {
+      // Finalise the parent: publish this wave's 16 rows and its partial site sums, ONE barrier,
+      // decide the rescale, persist.  The exchange slot and psum buffer alternate between successive
+      // finalisations (parity chosen by the host), so a wave that runs ahead writes into the other
+      // buffer and cannot get two nodes ahead (it has to pass the next node's barrier first).
+      const int par2 = (op.x >> 4) & 1;
+      const int slot = (op.x >> 16) & 0xff;
+      const int parent = op.y;
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        psum[par2][t][w * 64 + lane] = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+        double *dst = xbuf + (slot * T + t) * TILE;
+        if (!(ablate & 32)) {  // kk = 4w + r  ->  frag_index(kk, lane): two 16-byte stores
+          *reinterpret_cast<f64x2 *>(dst + ((2 * w) * 64 + lane) * 2) = (f64x2){acc[t][0], acc[t][1]};
+          *reinterpret_cast<f64x2 *>(dst + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){acc[t][2], acc[t][3]};
+        }
+      }
+      if (!(ablate & 2)) lds_barrier();
+      if (trace && lane == 0) tl[2] = clock64();
+      double sc[T];
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        // site total over all NW*4 row groups, fixed order (identical in every wave)
+        double tot = 0.;
+#pragma unroll
+        for (int q = 0; q < NW * 4; q++) tot += psum[par2][t][q * 16 + sl];
+        sc[t] = 1.0;
+        int m = 0;
+        if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) m = rescale_decision(tot, sc[t]);  // rare
+        cnt[t] += m;
+        slot_scale[slot][w][t][sl] = sc[t];  // (the 4 row-group lanes of a site store the same value)
+        slot_cnt[slot][w][t][sl] = cnt[t];
+      }
+      // ARRIVE before the persist stores are issued: the vector-memory counter is in-order and counts
+      // stores; this way the stores have the whole following entry to complete.
+      arrive(nxt);
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        // persist this wave's rows (== its own accumulator, times the exact power-of-two scale) and
+        // the exponent: fire and forget
+        double *out = a.partials + ((size_t)parent * a.ntiles + tile0 + t) * TILE + (size_t)w * 256;  // uniform
+        const f64x4 q = acc[t] * sc[t];
+        if (!(ablate & 4)) {
+          st16(out, (unsigned)lane * 16u, (f64x2){q[0], q[1]});
+          st16(out, (unsigned)(64 + lane) * 16u, (f64x2){q[2], q[3]});
+          if (w == 0 && g == 0) a.counts[(size_t)parent * S_pad + (tile0 + t) * 16 + sl] = cnt[t];
+        }
+        acc[t] = (f64x4){1., 1., 1., 1.};  // the next entry starts a new parent
+        cnt[t] = 0;
+      }
+      if (trace && lane == 0) tl[3] = clock64();
+    } else {
+      arrive(nxt);
+    }
+  };
+
+  // Software pipeline over the schedule, unrolled by two with ping-pong operand registers.
+  // Per entry i:   issue loads(i+1)  ->  compute(i)  ->  ARRIVE(i+1).
+  // Schedule entries come through scalar loads (SGPRs, uniform control flow), fetched two ahead.
+  // The host pads the schedule to an even number of entries and appends two more no-op entries
+  // (empty leaf groups), so the loop needs no bounds tests besides its own.
+  const int n_ops = a.n_ops;  // even
+  int4 opA = ops[0];
+  int4 opB = ops[1];
+  Payload pA, pB;
+#pragma unroll
+  for (int k = 0; k < 8; k++) pA.v[k] = pB.v[k] = (f64x2){0., 0.};
+  prefetch(opA, pA);
+  arrive(pA);
+  for (int oi = 0; oi < ((ablate & 64) ? 0 : n_ops); oi += 2) {
+    prefetch(opB, pB);
+    const int4 opC = ops[oi + 2];
+    body(opA, pA, pB, oi);
+    prefetch(opC, pA);
+    const int4 opD = ops[oi + 3];
+    body(opB, pB, pA, oi + 1);
+    opA = opC;
+    opB = opD;
   }
 
   // root: L_s = sum_k root[s][k] pi[k]; this workgroup's share of sum_s f_s log L_s
   // (tree_evaluator.cpp:4046-4128) and of the integer scaler sum (likefunc.cpp:11123)
   if (a.n_ops > 0) {
+    const int rslot = a.root_slot;
     double pk[NKK];
 #pragma unroll
     for (int kk = 0; kk < NKK; kk++) pk[kk] = a.pi[4 * kk + g];
@@ -337,21 +376,24 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? 3 : 1)) void prune_mfma_kernel(P
 #pragma unroll
     for (int t = 0; t < T; t++) {
       double s = 0.;
+      const double *rootv = xbuf + (rslot * T + t) * TILE;
 #pragma unroll
-      for (int kk = 0; kk < NKK; kk++) s = fma(B[t][kk], pk[kk], s);
+      for (int kk = 0; kk < NKK; kk++) s = fma(rootv[frag_index(kk, lane)], pk[kk], s);
+      s *= slot_scale[rslot][w][t][sl];
+      const int rcnt = slot_cnt[rslot][w][t][sl];
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
       if (w == 0 && g == 0) {
         const int site = (tile0 + t) * 16 + sl;
         a.site_lik[site] = s;
-        a.site_cnt[site] = bcnt[t];
+        a.site_cnt[site] = rcnt;
         const double f = a.freq[site];
         if (f != 0.) {
           if (s != s || isinf(s)) wflag |= 2;
           else if (s <= 0.) wflag |= 1;
           else {
             wsum += log(s) * f;
-            wcnt += (long long)bcnt[t] * (long long)f;
+            wcnt += (long long)rcnt * (long long)f;
           }
         }
       }
@@ -385,16 +427,14 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(NucArgs a) {
   int cnt = 0, bcnt = 0;
   for (int oi = 0; oi < a.n_ops; oi++) {
     const int4 op = a.ops[oi];
-    const int flags = op.x & 0xff, parent = op.y;
-    const int child = (flags & OP_LEAF) ? (op.z & 0xffff) : op.z;  // nucleotide schedules use 1 leaf per entry
-    if (flags & OP_FIRST) {
-      acc[0] = acc[1] = acc[2] = acc[3] = 1.;
-      cnt = 0;
-    }
+    const int kind = op.x & 3, parent = op.y;
+    const bool is_leaf = kind == OPK_LEAF;
+    if (is_leaf && ((op.x >> 8) & 0xff) == 0) continue;  // padding entry
+    const int child = is_leaf ? (op.z & 0xffff) : op.z;  // nucleotide schedules use 1 leaf per entry
     const double *__restrict__ P = a.P + (size_t)child * 16;
     double cv[4];
     bool matvec = true;
-    if (flags & OP_LEAF) {
+    if (is_leaf) {
       const int code = a.codes[(size_t)child * S_pad + s];
       if (code >= 0) {
         matvec = false;
@@ -408,7 +448,7 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(NucArgs a) {
         for (int j = 0; j < 4; j++) cv[j] = a.ambig[(size_t)(-code - 1) * 4 + j];
       }
     } else {
-      if (!(flags & OP_INREGS)) {
+      if (!(op.x & OPF_INREGS)) {
         const size_t base = (size_t)op.w * 4 * S_pad + s;
 #pragma unroll
         for (int j = 0; j < 4; j++) b[j] = a.partials[base + j * S_pad];
@@ -428,7 +468,7 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(NucArgs a) {
         acc[i] *= m;
       }
     }
-    if (flags & OP_LAST) {
+    if (op.x & OPF_LAST) {
       const double tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
       double sc;
       const int m = rescale_decision(tot, sc);
@@ -440,6 +480,8 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(NucArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; j++) a.partials[base + j * S_pad] = b[j];
       a.counts[(size_t)parent * S_pad + s] = cnt;
+      acc[0] = acc[1] = acc[2] = acc[3] = 1.;  // the next entry starts a new parent
+      cnt = 0;
     }
   }
   __shared__ double rs[256];
@@ -647,19 +689,34 @@ __global__ void unpack_partials_kernel(const double *__restrict__ partials, int 
 template <int NW, bool CLDS>
 void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
   const dim3 grid(a.ntiles / a.T), block(64 * NW);
-  const size_t lds = CLDS ? (size_t)a.n_ops * sizeof(int4) + (size_t)a.L * a.T * 16 * sizeof(int16_t) : 0;
+  const size_t lds = CLDS ? (size_t)a.L * a.T * 16 * sizeof(int16_t) : 0;
+  if (a.timeline) {  // tracing build of the kernel (HYPHY_HIP_TIMELINE), T = 1 only
+    hipLaunchKernelGGL((prune_mfma_kernel<NW, 1, CLDS, true>), grid, block, lds, stream, a.ops, a);
+    return;
+  }
+  if (NW == 4 && CLDS && a.T == 1 && a.ablate) {  // diagnostic ablation builds (results invalid)
+#define ABL_CASE(v)                                                                                     \
+  case v:                                                                                               \
+    hipLaunchKernelGGL((prune_mfma_kernel<4, 1, true, false, v>), grid, block, lds, stream, a.ops, a); \
+    return;
+    switch (a.ablate) {
+      ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(16) ABL_CASE(62) ABL_CASE(63) ABL_CASE(127)
+      default: break;
+    }
+#undef ABL_CASE
+  }
   switch (a.T) {
     case 1:
-      hipLaunchKernelGGL((prune_mfma_kernel<NW, 1, CLDS>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((prune_mfma_kernel<NW, 1, CLDS, false>), grid, block, lds, stream, a.ops, a);
       break;
     case 2:
-      hipLaunchKernelGGL((prune_mfma_kernel<NW, 2, CLDS>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((prune_mfma_kernel<NW, 2, CLDS, false>), grid, block, lds, stream, a.ops, a);
       break;
     case 3:
-      hipLaunchKernelGGL((prune_mfma_kernel<NW, 3, CLDS>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((prune_mfma_kernel<NW, 3, CLDS, false>), grid, block, lds, stream, a.ops, a);
       break;
     default:
-      hipLaunchKernelGGL((prune_mfma_kernel<NW, 4, CLDS>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((prune_mfma_kernel<NW, 4, CLDS, false>), grid, block, lds, stream, a.ops, a);
       break;
   }
 }
