@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from hyphy_amd import data, hip, models  # noqa: E402
+from hyphy_amd import dist as hdist  # noqa: E402
 
 POS_FREQS = np.array([[0.30, 0.20, 0.25, 0.25], [0.20, 0.30, 0.30, 0.20], [0.25, 0.25, 0.20, 0.30]])
 REV = dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4)
@@ -138,10 +139,7 @@ def main():
     flat = syn.flat
     S_all, L, I, B = pd_all.S, flat.L, flat.I, flat.n_branches
     # contiguous pattern shard of this rank (the reference's OpenMP site blocks, likefunc.cpp:10995-11044)
-    lo = (S_all * rank) // N
-    hi = (S_all * (rank + 1)) // N
-    codes = np.ascontiguousarray(pd_all.leaf_codes[:, lo:hi])
-    freq = np.ascontiguousarray(pd_all.pattern_freq[lo:hi])
+    codes, freq, (lo, hi) = hdist.shard_patterns(pd_all.leaf_codes, pd_all.pattern_freq, rank, N)
 
     T, pi = templates_for(wl["unit"])
     t_branch = 0.05
@@ -164,7 +162,7 @@ def main():
         coeffs[:, 1] = tb * omega
         enqueue()      # device-side Q for every branch, then expm + pruning + reduction (C-ABI calls)
         if N > 1:
-            dist.all_reduce(d_logl[:1])                        # one RCCL all-reduce per evaluation
+            hdist.allreduce_logl(d_logl[:1])                   # one RCCL all-reduce per evaluation
         if sync:
             return float(d_logl[0].item())                     # log-L back on the host (synchronises)
         return None
@@ -240,7 +238,7 @@ def main():
         if pipelined:
             out["value_pipelined_no_host_sync"] = pipelined
         if not args.no_cpu_baseline and N == 1:
-            nthr = args.cpu_threads or min(os.cpu_count() or 1, 32)
+            nthr = args.cpu_threads or min(os.cpu_count() or 1, 16)   # 16 = best of the 1..128 sweep (profiles/)
             cb = None
             try:
                 cb, ref_ll, _ = cpu_baseline(wl, syn, omega0, t_branch, nthr)

@@ -1,0 +1,138 @@
+"""The host-adapter code that INTEGRATION.md describes, as text blocks that integration/build.py
+splices into a COPY of the reference's src/core/likefunc.cpp (never into /root/reference, and the
+patched copy is never committed).  Everything here is our own code; the anchors are short unique
+strings of the reference file used only to locate the insertion points."""
+
+# ---- block 1: helpers, after the last project #include ---------------------------------------------
+HELPERS = r'''
+#ifdef HYPHY_HIP
+// ===== MI355X likelihood core: host adapter (see INTEGRATION.md) =====================================
+#include "hyphy_hip.h"
+#include <map>
+#include <unordered_map>
+#include <cstdlib>
+struct _HyHipPart {
+  hyphy_hip_partition *part = nullptr;
+  std::unordered_map<const void *, long> code_of;  // _CalcNode* -> node code (flatLeaves, then flatTree)
+  std::vector<double> pbuf;
+  std::vector<int64_t> qnodes;
+  std::vector<char> cat_seen;
+};
+static std::map<const void *, std::vector<_HyHipPart>> _hyhip_lfs;
+long _hyhip_calls = 0L;
+
+static bool _hyphy_hip_enabled(void) {
+  static int state = -1;
+  if (state < 0) {
+    const char *v = getenv("HYPHY_HIP");
+    state = (v && atoi(v) > 0 && hyphy_hip_device_count() > 0) ? 1 : 0;
+  }
+  return state == 1;
+}
+
+static void _hyphy_hip_teardown(const void *lf) {
+  auto it = _hyhip_lfs.find(lf);
+  if (it == _hyhip_lfs.end()) return;
+  for (auto &hp : it->second) hyphy_hip_destroy(hp.part);
+  _hyhip_lfs.erase(it);
+  if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %ld ComputeBlock evaluations ran on the device so far\n", _hyhip_calls);
+}
+
+static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_parts, _TheTree *cT,
+                             _DataSetFilter const *theFilter, long const *leaf_codes, _Vector *ambigs) {
+  if (!_hyphy_hip_enabled()) return;
+  auto &v = _hyhip_lfs[lf];
+  if (v.size() < n_parts) v.resize(n_parts);
+  _HyHipPart &hp = v[i];
+  hyphy_hip_destroy(hp.part);
+  hp.part = nullptr;
+  const long D = theFilter->GetDimension(), S = theFilter->GetPatternCount(), L = cT->GetLeafCount(),
+             I = cT->GetINodeCount();
+  if (L < 2 || I < 1) return;
+  const _SimpleList &fp = cT->flatParents;  // (upstream: a public accessor, see INTEGRATION.md)
+  std::vector<int64_t> parents(L + I), freq(S), codes((size_t)L * S);
+  for (long k = 0; k < L + I; k++) parents[k] = fp.list_data[k];
+  for (long s = 0; s < S; s++) freq[s] = theFilter->theFrequencies.get(s);
+  for (size_t k = 0; k < (size_t)L * S; k++) codes[k] = leaf_codes[k];
+  const long n_amb = (long)ambigs->get_used() / D;
+  const char *dv = getenv("HYPHY_HIP_DEVICE");
+  int rc = hyphy_hip_create(&hp.part, D, S, L, I, cT->categoryCount, parents.data(), codes.data(),
+                            n_amb ? ambigs->theData : nullptr, n_amb, freq.data(), dv ? atoi(dv) : 0, 1);
+  if (rc != 0) {  // > 0: unsupported here -> the CPU path keeps working; < 0: report and use the CPU path
+    hp.part = nullptr;
+    ReportWarning(_String("hyphy_hip_create: ") & hyphy_hip_last_error());
+    return;
+  }
+  hp.code_of.clear();
+  for (long code = 0; code < L + I; code++) hp.code_of[cT->GetNodeFromFlatIndex(code)] = code;
+  hp.cat_seen.assign(cT->categoryCount > 0 ? cT->categoryCount : 1, 0);
+}
+
+static bool _hyphy_hip_active(const void *lf, long index) {
+  auto it = _hyhip_lfs.find(lf);
+  return it != _hyhip_lfs.end() && index < (long)it->second.size() && it->second[index].part != nullptr;
+}
+
+// one ComputeBlock evaluation on the device; returns 0 when *result is valid
+static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catID, _SimpleList &branches,
+                              _List &matrices, hyFloat *siteRes, long *scc, hyFloat *result) {
+  _HyHipPart &hp = _hyhip_lfs[lf][index];
+  const long D = t->GetCodeBase();
+  const long B = t->GetLeafCount() + t->GetINodeCount() - 1;
+  const long cat = catID < 0 ? 0 : catID;
+  long n_q = matrices.lLength;
+  const bool first = !hp.cat_seen[cat];
+  if (first) n_q = B;  // first evaluation of a rate class: hand over every transition matrix
+  hp.pbuf.resize((size_t)n_q * D * D);
+  hp.qnodes.resize(n_q);
+  for (long k = 0; k < n_q; k++) {
+    _CalcNode *n = first ? (_CalcNode *)t->GetNodeFromFlatIndex(k) : (_CalcNode *)matrices(k);
+    _Matrix *P = n->GetCompExp(catID);
+    if (!P || !P->theData) return 1;
+    memcpy(hp.pbuf.data() + (size_t)k * D * D, P->theData, sizeof(double) * D * D);
+    hp.qnodes[k] = first ? k : hp.code_of.at(n);
+  }
+  double ll = 0.;
+  int rc = hyphy_hip_evaluate(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength,
+                              hp.qnodes.data(), n_q, hp.pbuf.data(), /* q_is_probability = */ 1, t->GetProbs(),
+                              &ll, siteRes, (int64_t *)scc);
+  if (rc < 0) {
+    HandleApplicationError(_String("hyphy_hip_evaluate: ") & hyphy_hip_last_error());
+    return rc;
+  }
+  if (rc == 0) {
+    hp.cat_seen[cat] = 1;
+    _hyhip_calls++;
+    *result = ll;
+  }
+  return rc;
+}
+#endif
+'''
+
+# ---- block 2: SetupLFCaches, once the leaf table of partition i is complete ------------------------
+SETUP = r'''
+#ifdef HYPHY_HIP
+    _hyphy_hip_setup(this, i, theTrees.lLength, cT, theFilter, conditionalTerminalNodeStateFlag[i], ambigs);
+#endif
+'''
+
+# ---- block 3: DeleteCaches ---------------------------------------------------------------------------
+TEARDOWN = r'''
+#ifdef HYPHY_HIP
+  _hyphy_hip_teardown(this);
+#endif
+'''
+
+# ---- block 4: ComputeBlock, between ExponentiateMatrices and the OpenMP pruning loop -----------------
+COMPUTE = r'''
+#ifdef HYPHY_HIP
+      if (branchIndex < 0 && doCachedComp == 0 && _hyphy_hip_active(this, index)) {
+        hyFloat hip_result = 0.;
+        if (_hyphy_hip_compute(this, index, t, catID, *branches, *matrices, siteRes, scc, &hip_result) == 0) {
+          return hip_result;  // already  sum_s f_s log L_s - 64 ln2 * scalers  (likefunc.cpp:11123)
+        }
+      }
+#endif
+'''
+

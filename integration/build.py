@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Builds integration/_build/hyphy_hip: the reference HyPhy with its ComputeBlock routed through
+libhyphy_hip.so.  Needs /root/reference (build container only); the result is a binary (git-ignored)
+that travels to the GPU box.  Re-uses the reference objects already compiled by oracle/Makefile.ref —
+only likefunc.cpp is recompiled, from a patched COPY that lives in integration/_build/."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("HYPHY_REF", "/root/reference")
+OUT = os.path.join(HERE, "_build")
+sys.path.insert(0, HERE)
+import adapter_blocks as AB  # noqa: E402
+
+
+def splice(text, anchor, block, before=False, count=1):
+    n = text.count(anchor)
+    if n < count:
+        raise SystemExit(f"anchor not found ({n}x): {anchor!r}")
+    idx = text.index(anchor)
+    if before:
+        return text[:idx] + block + text[idx:]
+    idx += len(anchor)
+    return text[:idx] + block + text[idx:]
+
+
+def main():
+    os.makedirs(os.path.join(OUT, "include"), exist_ok=True)
+    # likefunc.cpp copy with the four adapter blocks.  _TheTree::flatParents is protected and
+    # _LikelihoodFunction is not a friend; an upstream patch would add a one-line public accessor to
+    # tree.h.  Headers are found next to their includers first, so a shadow copy of
+    # tree.h cannot be injected from here: this translation unit relaxes `protected` while it reads the
+    # project headers instead (no layout change, one TU only).
+    lf = open(os.path.join(REF, "src/core/likefunc.cpp")).read()
+    lf = splice(lf, '#include "batchlan.h"\n', "#define protected public\n", before=True)
+    lf = splice(lf, '#include "vector.h"\n', "#undef protected\n" + AB.HELPERS)
+    lf = splice(lf, "#ifdef MDSOCL\n    OCLEval[i].init(", AB.SETUP, before=True)
+    lf = splice(lf, "void _LikelihoodFunction::DeleteCaches(bool all) {\n", AB.TEARDOWN)
+    # device path active -> do not engage the host branch-cache state machine: its caches
+    # live in host memory that the device path never fills
+    lf = splice(lf, "if (computedLocalUpdatePolicy.lLength && branchIndex < 0) {",
+                "", before=True)
+    lf = lf.replace("if (computedLocalUpdatePolicy.lLength && branchIndex < 0) {",
+                    "if (computedLocalUpdatePolicy.lLength && branchIndex < 0\n#ifdef HYPHY_HIP\n"
+                    "          && !_hyphy_hip_active(this, index)\n#endif\n      ) {", 1)
+    lf = splice(lf, "      hyFloat sum = 0.;\n\n      if (doCachedComp >= 3) {", AB.COMPUTE, before=True)
+    src = os.path.join(OUT, "likefunc_hip.cpp")
+    open(src, "w").write(lf)
+    # 3. compile that one file with the reference's flags (oracle/Makefile.ref) + -DHYPHY_HIP
+    refobj = os.path.join(ROOT, "oracle", "_ref", "obj")
+    if not os.path.isdir(refobj):
+        subprocess.check_call(["make", "-f", os.path.join(ROOT, "oracle", "Makefile.ref"), "-j8"])
+    flags = ("-std=c++17 -fsigned-char -O3 -fopenmp -w -mavx -mavx2 -mfma -D_SLKP_USE_AVX_INTRINSICS "
+             "-D_SLKP_USE_FMA3_INTRINSICS -D__AFYP_REWRITE_BGM__ -D__UNIX__ -D__MP__ -D__MP2__ -DHYPHY_HIP "
+             f"-D_HYPHY_LIBDIRECTORY_=\"/nonexistent\" -I{OUT}/include -I{ROOT}/include "
+             f"-I{REF}/src/core/include -I{REF}/src/contrib -I{REF}/src/lib/Link -I{REF}/src/new/include").split()
+    obj = os.path.join(OUT, "likefunc_hip.o")
+    subprocess.check_call(["g++"] + flags + ["-c", src, "-o", obj])
+    objs = []
+    for dp, _, files in os.walk(refobj):
+        for f in files:
+            if f.endswith(".o") and not (f == "likefunc.o" and dp.endswith("core")):
+                objs.append(os.path.join(dp, f))
+    libdir = os.path.join(ROOT, "hyphy_amd", "lib")
+    exe = os.path.join(OUT, "hyphy_hip")
+    subprocess.check_call(["g++", "-fopenmp", "-o", exe, obj] + sorted(objs) +
+                          [f"-L{libdir}", "-lhyphy_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,$ORIGIN/../../hyphy_amd/lib",
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-ldl"])
+    print("built", exe)
+
+
+if __name__ == "__main__":
+    main()

@@ -77,7 +77,7 @@ def nuc_model_block(freqs, rate_expr: str = "t") -> str:
 def build_script(*, fasta: str, newick: str, unit: int, model_block: str, model_name: str,
                  globals_: Dict[str, float], branch_t: Dict[str, float],
                  out_path: str, sweep: Optional[Dict] = None, threads: int = 0,
-                 category: Optional[Dict] = None, per_site: bool = True) -> str:
+                 category: Optional[Dict] = None, per_site: bool = True, optimize: bool = False) -> str:
     """One self-contained batch file.  ``sweep`` = {"param": "R", "start": .3, "step": .001,
     "n": N} runs the SURVEY A.8 timing loop and reports wall-clock seconds via Time(1)."""
     L: List[str] = ["VERBOSITY_LEVEL = -1;", "PRINT_DIGITS = 17;"]
@@ -118,6 +118,10 @@ def build_script(*, fasta: str, newick: str, unit: int, model_block: str, model_
         L.append(f'fprintf ("{out_path}", "SWEEP_SECONDS ", Format (t1_-t0_, 20, 6), "\\n", "SWEEP_LAST ", Format (res_, 30, 17), "\\n");')
         L.append(f"{p} = {_fmt(globals_[p])};")
     L.append("LFCompute (lf, LF_DONE_COMPUTE);")
+    if optimize:   # full maximum-likelihood fit (Optimize = the reference's "train()" analogue)
+        L.append("OPTIMIZATION_PRECISION = 0.001; VERBOSITY_LEVEL = -1;")
+        L.append("Optimize (mles2_, lf);")
+        L.append(f'fprintf ("{out_path}", "OPT_LOGL ", Format (mles2_[1][0], 30, 17), "\\n");')
     if per_site:
         L.append("ConstructCategoryMatrix (sl_, lf, SITE_LOG_LIKELIHOODS);")
         L.append(f'fprintf ("{out_path}", "SITES ", Columns (sl_), "\\n");')
@@ -125,7 +129,8 @@ def build_script(*, fasta: str, newick: str, unit: int, model_block: str, model_
     return "\n".join(L) + "\n"
 
 
-def run_script(script_text: str, workdir: str, cpus: int = 1, timeout: float = 3600.0) -> str:
+def run_script(script_text: str, workdir: str, cpus: int = 1, timeout: float = 3600.0, binary: Optional[str] = None,
+               extra_env: Optional[Dict[str, str]] = None) -> str:
     bf = os.path.join(workdir, "driver.bf")
     with open(bf, "w") as fh:
         fh.write(script_text)
@@ -133,7 +138,9 @@ def run_script(script_text: str, workdir: str, cpus: int = 1, timeout: float = 3
     os.makedirs(lib, exist_ok=True)
     env = dict(os.environ)
     env.pop("OMP_PROC_BIND", None)
-    r = subprocess.run([REF_BIN, f"LIBPATH={lib}", f"CPU={cpus}", bf], cwd=workdir, env=env,
+    if extra_env:
+        env.update(extra_env)
+    r = subprocess.run([binary or REF_BIN, f"LIBPATH={lib}", f"CPU={cpus}", bf], cwd=workdir, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
     if r.returncode != 0:
         raise RuntimeError(f"reference hyphy failed ({r.returncode}):\n{r.stdout[-4000:]}")
@@ -149,6 +156,8 @@ def parse_output(path: str) -> Dict:
         ln = lines[i].strip()
         if ln.startswith("LOGL "):
             out["logl"] = float(ln.split()[1])
+        elif ln.startswith("OPT_LOGL "):
+            out["opt_logl"] = float(ln.split()[1])
         elif ln.startswith("SWEEP_SECONDS "):
             out["sweep_seconds"] = float(ln.split()[1])
         elif ln.startswith("SWEEP_LAST "):
@@ -162,7 +171,8 @@ def parse_output(path: str) -> Dict:
 
 
 def evaluate(*, names, seqs, newick, unit, model_block, model_name, globals_, branch_t,
-             sweep=None, threads=0, category=None, per_site=True, workdir=None, timeout=3600.0) -> Dict:
+             sweep=None, threads=0, category=None, per_site=True, workdir=None, timeout=3600.0,
+             binary=None, extra_env=None, optimize=False) -> Dict:
     """Write fasta + script into a scratch dir, run the reference, parse the results."""
     own = workdir is None
     tmp = tempfile.mkdtemp(prefix="hyref_") if own else workdir
@@ -172,8 +182,8 @@ def evaluate(*, names, seqs, newick, unit, model_block, model_name, globals_, br
     txt = build_script(fasta=fasta, newick=newick, unit=unit, model_block=model_block,
                        model_name=model_name, globals_=globals_, branch_t=branch_t,
                        out_path=outp, sweep=sweep, threads=threads, category=category,
-                       per_site=per_site)
-    stdout = run_script(txt, tmp, cpus=max(1, threads), timeout=timeout)
+                       per_site=per_site, optimize=optimize)
+    stdout = run_script(txt, tmp, cpus=max(1, threads), timeout=timeout, binary=binary, extra_env=extra_env)
     res = parse_output(outp)
     res["stdout"] = stdout
     return res

@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: world_size-2 gloo.  Covers the host logic that bench.py --gpus N and a
+multi-rank host adapter rely on: disjoint/exhaustive pattern shards, ONE all-reduce of the
+partial log-likelihood per evaluation, all-gather of per-site vectors, -inf propagation.
+The per-shard arithmetic here is done by the CPU oracle (the checker) — the HIP path itself is
+exercised on the GPU by tests/test_gpu_parity.py::test_sharded_partition_equals_single."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hyphy_amd import dist as hdist
+from tests import common
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, name, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    fx = common.load(name)
+    codes, freq, (lo, hi) = hdist.shard_patterns(fx["leaf_codes"], fx["pattern_freq"], rank, world)
+    part = oracle.OraclePartition(int(fx["D"]), fx["flat_parents"], int(fx["L"]), codes, fx["ambig"], freq)
+    nodes = common.all_nodes(fx)
+    part.set_P(nodes, oracle.expm(common.fixture_Q(fx), str(fx["kind"]) == "codon"))
+    lik, sc = part.site_block(nodes, fx["root_freqs"])
+    site_ll = np.log(lik) - sc * 64 * np.log(2.0)
+    partial = torch.tensor([float((site_ll * freq).sum())], dtype=torch.float64)
+    hdist.allreduce_logl(partial)
+    full = hdist.allgather_sites(torch.from_numpy(site_ll), fx["leaf_codes"].shape[1], rank, world)
+    # a rank whose shard contains a zero-likelihood pattern makes the whole evaluation -inf
+    bad = torch.tensor([-float("inf") if rank == 1 else -1.0], dtype=torch.float64)
+    hdist.allreduce_logl(bad)
+    if rank == 0:
+        out_q.put((float(partial[0]), full.numpy(), float(bad[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["codon_small", "nuc_small"])
+def test_two_rank_site_sharding_matches_reference(name):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    total, sites, bad = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fx = common.load(name)
+    ref = float(fx["logl"])
+    assert abs(total - ref) <= 1e-11 * abs(ref)
+    got = sites[fx["site_to_pattern"]]
+    assert np.max(np.abs(got - fx["site_logl"]) / np.abs(fx["site_logl"])) < 1e-11
+    assert bad == -np.inf
+
+
+def test_shard_ranges_are_a_partition():
+    for n in (1, 2, 7, 16, 1000, 9974):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = hdist.shard_range(n, r, world)
+                assert 0 <= lo <= hi <= n
+                cover.extend(range(lo, hi))
+            assert cover == list(range(n))
+            sizes = [hdist.shard_range(n, r, world)[1] - hdist.shard_range(n, r, world)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,110 @@
+"""End-to-end drop-in check on the GPU: the REAL HyPhy host (reference sources + the adapter of
+INTEGRATION.md, built by integration/build.py into integration/_build/hyphy_hip) runs HBL batch
+files with its ComputeBlock routed through libhyphy_hip.so.  Compared with the golden vectors of the
+unmodified reference and — for a full Optimize() fit — with the unmodified reference binary run
+side by side on the box.  Both binaries are prebuilt in the build container (they travel with the
+snapshot); nothing here reads /root/reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_BIN = os.path.join(ROOT, "integration", "_build", "hyphy_hip")
+ENV = {"HYPHY_HIP": "1", "HYPHY_HIP_VERBOSE": "1"}
+
+
+def _need_binaries():
+    from oracle import hbl
+    if not (os.path.isfile(HIP_BIN) and hbl.have_reference()):
+        pytest.skip("integration/_build/hyphy_hip or oracle/_ref/hyphy not built (build container: "
+                    "python integration/build.py)")
+
+
+def _case(kind, n_taxa, n_sites, seed, category=None, ladder=False, **kw):
+    """Same deterministic inputs as oracle/make_golden.py."""
+    from hyphy_amd import data, models, tree
+    from oracle import hbl, make_golden as mg
+    tr = tree.caterpillar_tree(n_taxa) if ladder else None
+    syn = data.evolve(n_taxa, n_sites, 3 if kind == "codon" else 1, seed=seed, tree=tr, **kw)
+    flat = syn.flat
+    if kind == "codon":
+        bt = mg.branch_lengths(flat, seed + 7, 0.02, 0.12)
+        rate = "t" if category is None else f"{category['name']}*t"
+        block = hbl.codon_model_block(models.mg94rev_template(mg.POS_FREQS), models.f3x4_codon_freqs(mg.POS_FREQS),
+                                      rate_expr=rate)
+        args = dict(unit=3, model_block=block, model_name="MGM", globals_=dict(R=0.3, **mg.REV))
+    else:
+        bt = mg.branch_lengths(flat, seed + 7, 0.02, 0.2)
+        args = dict(unit=1, model_block=hbl.nuc_model_block(mg.NUC_FREQS), model_name="NM",
+                    globals_=dict(models.hky85_rev(0.35)))
+    return dict(names=flat.leaf_names, seqs=syn.seqs, newick=tree.to_newick(syn.tree), branch_t=bt,
+                category=category, **args)
+
+
+def _device_calls(stdout):
+    m = re.findall(r"\[hyphy_hip\] (\d+) ComputeBlock evaluations ran on the device", stdout)
+    return max(int(x) for x in m) if m else 0
+
+
+@pytest.mark.parametrize("name,kind,taxa,sites,seed", [("codon_small", "codon", 8, 40, 11),
+                                                       ("codon_wide", "codon", 64, 60, 15),
+                                                       ("nuc_small", "nuc", 8, 300, 21)])
+def test_hbl_lfcompute_through_device_matches_reference_goldens(name, kind, taxa, sites, seed):
+    _need_binaries()
+    from oracle import hbl
+    fx = common.load(name)
+    res = hbl.evaluate(binary=HIP_BIN, extra_env=ENV, **_case(kind, taxa, sites, seed))
+    assert _device_calls(res["stdout"]) > 0, "the device path was not taken"
+    ref = float(fx["logl"])
+    assert abs(res["logl"] - ref) <= 1e-10 * abs(ref)
+    assert np.max(np.abs(res["site_logl"] - fx["site_logl"]) / np.abs(fx["site_logl"])) < 1e-10
+
+
+def test_hbl_rate_categories_through_device():
+    """3 discrete rate classes: HyPhy's own PopulateConditionalProbabilities / SumUpSiteLikelihoods mix the
+    per-class (l_s, c_s) pairs that the device returns through siteRes / siteCorrections."""
+    _need_binaries()
+    from oracle import hbl
+    fx = common.load("codon_cat3")
+    cat = dict(name="rc", weights=[0.7, 0.25, 0.05], values=[0.1, 1.0, 5.0])
+    res = hbl.evaluate(binary=HIP_BIN, extra_env=ENV, **_case("codon", 10, 50, 14, category=cat))
+    assert _device_calls(res["stdout"]) > 0
+    ref = float(fx["logl"])
+    assert abs(res["logl"] - ref) <= 1e-10 * abs(ref)
+    assert np.max(np.abs(res["site_logl"] - fx["site_logl"]) / np.abs(fx["site_logl"])) < 1e-10
+
+
+def test_hbl_deep_tree_rescaling_through_device():
+    _need_binaries()
+    from oracle import hbl, make_golden as mg
+    from hyphy_amd import data, models, tree
+    fx = common.load("codon_deep")
+    syn = data.evolve(120, 12, 3, seed=13, p_change=0.3, tree=tree.caterpillar_tree(120))
+    bt = mg.branch_lengths(syn.flat, 20, 0.2, 0.6)
+    res = hbl.evaluate(binary=HIP_BIN, extra_env=ENV, names=syn.flat.leaf_names, seqs=syn.seqs,
+                       newick=tree.to_newick(syn.tree), unit=3,
+                       model_block=hbl.codon_model_block(models.mg94rev_template(mg.POS_FREQS),
+                                                         models.f3x4_codon_freqs(mg.POS_FREQS)),
+                       model_name="MGM", globals_=dict(R=0.3, **mg.REV), branch_t=bt)
+    assert _device_calls(res["stdout"]) > 0
+    ref = float(fx["logl"])
+    assert abs(res["logl"] - ref) <= 1e-10 * abs(ref)
+
+
+def test_hbl_optimize_through_device_matches_cpu_fit():
+    """A complete maximum-likelihood fit (HBL Optimize: hundreds of ComputeBlock calls, most of them
+    partial updates driven by DetermineNodesForUpdate) reaches the same optimum as the CPU reference."""
+    _need_binaries()
+    from oracle import hbl
+    case = _case("codon", 8, 40, 11)
+    cpu = hbl.evaluate(optimize=True, **case)
+    gpu = hbl.evaluate(optimize=True, binary=HIP_BIN, extra_env=ENV, **case)
+    assert _device_calls(gpu["stdout"]) > 50
+    assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3       # 2 x OPTIMIZATION_PRECISION, the reference's own test bar
+    assert abs(gpu["logl"] - cpu["logl"]) <= 1e-10 * abs(cpu["logl"])
