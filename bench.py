@@ -39,6 +39,11 @@ WORKLOADS = {
     "mg94_32x5k": dict(taxa=32, sites=5000, unit=3, seed=2),
     "mg94_128x100k": dict(taxa=128, sites=100000, unit=3, seed=4),
     "hky_8x1k": dict(taxa=8, sites=1000, unit=1, seed=1),
+    # configs[2]: BUSTED-style, 3 omega classes (weights .7/.25/.05, omega .1/1/5 scaled by the swept factor),
+    # classes batched into one expm launch + one pruning launch, mixed on the device
+    "busted3_64x10k": dict(taxa=64, sites=10000, unit=3, seed=3, classes=3),
+    "gtr_32x50k": dict(taxa=32, sites=50000, unit=1, seed=5, p_change=0.25),   # one partition of configs[4]
+    "gtr_32x1m": dict(taxa=32, sites=1000000, unit=1, seed=6, p_change=0.25),  # same shape, large enough to leave the L2/MALL
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (== vector) peak, AMD datasheet; see DESIGN.md §roofline
 HBM_PEAK_GBS = 8000.0
@@ -133,9 +138,11 @@ def main():
     torch.cuda.set_device(local if N > 1 else 0)
 
     wl = WORKLOADS[args.workload]
-    syn = data.evolve(wl["taxa"], wl["sites"], wl["unit"], seed=wl["seed"])
+    syn = data.evolve(wl["taxa"], wl["sites"], wl["unit"], seed=wl["seed"], p_change=wl.get("p_change", 0.04))
     D = 61 if wl["unit"] == 3 else 4
-    pd_all = data.from_states(syn.states, D)
+    # nucleotide workloads keep every site as its own pattern (4^32 possible columns: the interesting
+    # regime for the HBM-bound kernel is S = sites; compression would leave a few thousand patterns)
+    pd_all = data.from_states(syn.states, D, compress_patterns=(D > 4))
     flat = syn.flat
     S_all, L, I, B = pd_all.S, flat.L, flat.I, flat.n_branches
     # contiguous pattern shard of this rank (the reference's OpenMP site blocks, likefunc.cpp:10995-11044)
@@ -147,19 +154,33 @@ def main():
     nodes = np.arange(B, dtype=np.int64)
     omega0 = 0.3
 
-    part = hip.HipPartition(D, flat.flat_parents, L, codes, None, freq, device_first=(local if N > 1 else 0))
+    n_classes = wl.get("classes", 1)
+    if n_classes > 1 and N > 1:
+        raise SystemExit("the rate-class workload is single-GPU in this version")
+    part = hip.HipPartition(D, flat.flat_parents, L, codes, None, freq, C_cat=n_classes,
+                            device_first=(local if N > 1 else 0))
     part.set_q_templates(T)
     stream = torch.cuda.Stream()             # everything (kernels, RCCL, the .item() copy) in ONE stream
     torch.cuda.set_stream(stream)
     part.set_stream(stream.cuda_stream)
     d_logl = torch.zeros(2, dtype=torch.float64, device="cuda")
-    coeffs = np.empty((B, 2))
-    coeffs[:, 0] = tb
-    enqueue = part.prepare_device_step(nodes, nodes, pi, d_logl.data_ptr(), coeffs)
+    coeffs = np.empty((B * n_classes, 2))
+    coeffs[:, 0] = np.tile(tb, n_classes)
+    class_omega = np.array([0.1, 1.0, 5.0][:n_classes]) / 0.3 if n_classes > 1 else np.array([1.0])
+    class_w = np.array([0.7, 0.25, 0.05])
+    if n_classes > 1:
+        cat_step = part.prepare_built_categories_step(nodes, nodes, class_w, pi, coeffs)
+    else:
+        enqueue = part.prepare_device_step(nodes, nodes, pi, d_logl.data_ptr(), coeffs)
+        sync_step = part.prepare_built_step(nodes, nodes, pi, coeffs)   # N == 1: synchronous C-ABI entry point
 
     def step(k, sync=True):
         omega = omega0 + 0.001 * k
-        coeffs[:, 1] = tb * omega
+        coeffs[:, 1] = np.repeat(class_omega * omega, B) * coeffs[:, 0]
+        if n_classes > 1:
+            return cat_step()      # build_q (3 x 125 matrices) + expm + batched pruning + mixing + reduction
+        if N == 1 and sync:
+            return sync_step()     # build_q + evaluate_built: log-L returned by the C-ABI call itself
         enqueue()      # device-side Q for every branch, then expm + pruning + reduction (C-ABI calls)
         if N > 1:
             hdist.allreduce_logl(d_logl[:1])                   # one RCCL all-reduce per evaluation
@@ -190,7 +211,7 @@ def main():
         dt = float(tmax.item())
 
     pipelined = None
-    if args.pipelined:
+    if args.pipelined and n_classes == 1:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for k in range(args.steps):
@@ -201,6 +222,8 @@ def main():
     if rank == 0:
         S_rank = hi - lo
         flops, bytes_ = alg_work(D, S_rank, L, I)
+        flops *= n_classes
+        bytes_ *= n_classes
         prune_ms = t_prune / args.steps
         bound = "mfma" if D > 4 else "hbm"
         if bound == "mfma":
@@ -223,12 +246,13 @@ def main():
             except Exception:
                 pass
         out = {
-            "metric": "full-tree log-L evals/sec, 61-state MG94 codon, 64 taxa x 10k codons",
+            "metric": "full-tree log-L evals/sec, 61-state MG94 codon, 64 taxa x 10k codons" if args.workload == "mg94_64x10k"
+                      else f"full-tree log-L evals/sec ({args.workload})",
             "value": args.steps / dt, "unit": "evals/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "states": D, "taxa": L, "codons" if D > 4 else "sites": wl["sites"],
-                       "unique_patterns": int(S_all), "branches": int(B), "rate_classes": 1,
+                       "unique_patterns": int(S_all), "branches": int(B), "rate_classes": n_classes,
                        "parallelism": f"site-shard x{N}" if N > 1 else "single GPU",
                        "step": "device Q build + expm of all branches + full pruning pass + reduction" +
                                (" + RCCL all-reduce" if N > 1 else "") + ", log-L returned to host every step"},
@@ -237,7 +261,7 @@ def main():
         }
         if pipelined:
             out["value_pipelined_no_host_sync"] = pipelined
-        if not args.no_cpu_baseline and N == 1:
+        if not args.no_cpu_baseline and N == 1 and n_classes == 1:
             nthr = args.cpu_threads or min(os.cpu_count() or 1, 16)   # 16 = best of the 1..128 sweep (profiles/)
             cb = None
             try:

@@ -86,7 +86,9 @@ struct Shard {
   double *h_out = nullptr;
   int32_t *h_status = nullptr;
   int32_t *h_slots = nullptr;
-  double *h_small = nullptr;  // pi / weights / coeffs staging
+  double *h_coeffs = nullptr;  // pinned ring (4 x C*B*K) for build_q coefficients
+  unsigned coeff_turn = 0;
+  double *h_small = nullptr;  // pi / weights staging
   size_t h_small_cap = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t partial_stride = 0;  // doubles per class
@@ -108,8 +110,12 @@ struct hyphy_hip_partition {
   bool cached_full = false;
   int cached_valid = 0;
   std::vector<double> cached_pi;             // root frequencies currently on the device
+  std::vector<double> cached_weights;        // category weights currently on the device
   std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
   int root_slot = 0, n_ops_real = 0, n_ops_padded = 0;
+  int slots_batch_mode = -1;                 // whether the slot table on the device was written for a class batch
+  bool coeffs_pending = false;               // build_q staged coefficients; the next evaluate_device(q_buffer) fuses
+                                             // the rate-matrix construction into the expm kernel
   int64_t K = 0;                             // Q templates
   double timings[3] = {0, 0, 0};
 };
@@ -126,7 +132,7 @@ void free_shard(Shard &s) {
                  s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag};
   for (void *d : dev)
     if (d) hipFree(d);
-  void *host[] = {s.h_ops, s.h_out, s.h_status, s.h_slots, s.h_small};
+  void *host[] = {s.h_ops, s.h_out, s.h_status, s.h_slots, s.h_small, s.h_coeffs};
   for (void *h : host)
     if (h) hipHostFree(h);
   for (auto &e : s.ev)
@@ -273,8 +279,8 @@ int upload_small(Shard &s, const double *src, size_t n, double *dst) {
 }
 
 // Enqueue everything for one rate class on one shard.  q may be a host or device pointer.
-int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, bool pi_changed, bool slots_changed,
-                 const int64_t *q_nodes, int64_t n_q,
+int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, bool sched_changed, bool pi_changed,
+                 bool slots_changed, const int64_t *q_nodes, int64_t n_q,
                  const double *q, bool q_on_device, int q_is_prob, const double *root_freqs, double *d_logl_out,
                  bool reduce, bool floor_log) {
   Trace tr("enqueue");
@@ -297,27 +303,40 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, 
   HIPCHK(hipEventRecord(s.ev[0], s.stream));
   tr.lap("event0");
   if (n_q > 0) {
+    // n_cat_batch > 1: the matrices of ALL rate classes in one expm launch, class-major; destination
+    // slot of matrix (c, k) is c*B + q_nodes[k] relative to class 0's image arrays
+    const int64_t n_mat = n_q * n_cat_batch;
     int32_t *h_slots = s.h_slots + (size_t)cat * B, *d_slots = s.slots + (size_t)cat * B;
     if (slots_changed) {
       HIPCHK(hipStreamSynchronize(s.stream));
-      for (int64_t k = 0; k < n_q; k++) {
-        if (q_nodes[k] < 0 || q_nodes[k] >= B) return fail("q_nodes entry out of range");
-        h_slots[k] = (int32_t)q_nodes[k];
-      }
-      HIPCHK(hipMemcpyAsync(d_slots, h_slots, n_q * sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
+      for (int c = 0; c < n_cat_batch; c++)
+        for (int64_t k = 0; k < n_q; k++) {
+          if (q_nodes[k] < 0 || q_nodes[k] >= B) return fail("q_nodes entry out of range");
+          h_slots[c * n_q + k] = (int32_t)(c * B + q_nodes[k]);
+        }
+      HIPCHK(hipMemcpyAsync(d_slots, h_slots, n_mat * sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
     }
     const double *dq = q;
+    const bool q_from_templates = q_on_device && q == s.qbuf && p->coeffs_pending && !q_is_prob;
     if (!q_on_device) {
-      HIPCHK(hipMemcpyAsync(s.qbuf, q, (size_t)n_q * D * D * sizeof(double), hipMemcpyHostToDevice, s.stream));
+      HIPCHK(hipMemcpyAsync(s.qbuf, q, (size_t)n_mat * D * D * sizeof(double), hipMemcpyHostToDevice, s.stream));
       dq = s.qbuf;
     }
     ExpmArgs ea;
     ea.Q = dq;
     ea.slots = d_slots;
-    ea.n = (int)n_q;
+    ea.n = (int)n_mat;
     ea.D = (int)D;
     ea.is_prob = q_is_prob;
     ea.status = s.status;
+    ea.templates = nullptr;
+    ea.coeffs = nullptr;
+    ea.K = 0;
+    if (q_from_templates) {  // fused build: coefficients were staged by hyphy_hip_build_q
+      ea.templates = s.templates;
+      ea.coeffs = s.coeffs;
+      ea.K = (int)p->K;
+    }
     if (p->nuc) {
       ea.Prow = s.Prow + (size_t)cat * B * 16;
       ea.Pfrag = nullptr;
@@ -381,6 +400,12 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, bool sched_changed, 
     pa.wg_sum = s.wg_sum;
     pa.wg_cnt = s.wg_cnt;
     pa.wg_flag = s.wg_flag;
+    pa.n_cat = n_cat_batch;
+    pa.cs_P = (size_t)B * DP * DP;
+    pa.cs_partials = s.partial_stride;
+    pa.cs_counts = (size_t)p->I * s.S_pad;
+    pa.cs_site = (size_t)s.S_pad;
+    pa.cs_wg = (size_t)s.ntiles / s.T;
     pa.timeline = nullptr;
     pa.ablate = 0;
     if (const char *ab = getenv("HYPHY_HIP_ABLATE")) pa.ablate = atoi(ab);
@@ -650,9 +675,9 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     A_(s.status, sizeof(int32_t));
     A_(s.weights, (size_t)C * sizeof(double));
     s.wg_cap = p->nuc ? (s.S_pad + 255) / 256 : s.ntiles;
-    A_(s.wg_sum, (size_t)s.wg_cap * sizeof(double));
-    A_(s.wg_cnt, (size_t)s.wg_cap * sizeof(long long));
-    A_(s.wg_flag, (size_t)s.wg_cap * sizeof(int));
+    A_(s.wg_sum, (size_t)C * s.wg_cap * sizeof(double));  // x C: rate-class batching writes one row per class
+    A_(s.wg_cnt, (size_t)C * s.wg_cap * sizeof(long long));
+    A_(s.wg_flag, (size_t)C * s.wg_cap * sizeof(int));
 #undef A_
     s.h_small_cap = (size_t)std::max<int64_t>(std::max<int64_t>(DP, C), 64);
     if (hipHostMalloc((void **)&s.h_ops, ops_capacity(p) * sizeof(int4)) != hipSuccess ||
@@ -692,10 +717,16 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
 
 static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                        const int64_t *q_nodes, int64_t n_q, const double *q, bool q_on_device, int q_is_probability,
-                       const double *root_freqs, double *d_logl_out, bool reduce, bool floor_log) {
+                       const double *root_freqs, double *d_logl_out, bool reduce, bool floor_log, bool batch = false) {
   if (!p) return fail("partition == NULL");
   if (cat < 0) cat = 0;
   if (cat >= p->C) return fail("rate class out of range");
+  if (batch) {  // all classes in one launch: bookkeeping is shared, keyed on class 0
+    if (p->nuc) return fail("internal: class batching is for the MFMA path");
+    cat = 0;
+    for (int64_t c = 1; c < p->C; c++)
+      if (p->initialized[c] != p->initialized[0]) p->initialized[0] = 0;  // mixed state: force a full pass
+  }
   if (!root_freqs) return fail("root_freqs == NULL");
   if ((n_update > 0 && !update_nodes) || (n_q > 0 && (!q_nodes || !q))) return fail("null node / matrix list");
   if (n_q > p->B) return fail("more matrices than branches");
@@ -707,13 +738,18 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   if (pi_changed) p->cached_pi.assign(root_freqs, root_freqs + p->D);
   if (p->cached_slots.size() != (size_t)p->C) p->cached_slots.assign(p->C, std::vector<int64_t>());
   std::vector<int64_t> &cs = p->cached_slots[cat];
-  bool slots_changed = cs.size() != (size_t)n_q || (n_q > 0 && memcmp(cs.data(), q_nodes, n_q * sizeof(int64_t)));
+  bool slots_changed = cs.size() != (size_t)n_q || (n_q > 0 && memcmp(cs.data(), q_nodes, n_q * sizeof(int64_t))) ||
+                       p->slots_batch_mode != (batch ? 1 : 0);
   if (slots_changed) cs.assign(q_nodes, q_nodes + n_q);
+  p->slots_batch_mode = batch ? 1 : 0;
   for (Shard &s : p->shards)
-    if (enqueue_eval(p, s, (int)cat, changed, pi_changed, slots_changed, q_nodes, n_q, q, q_on_device,
-                     q_is_probability, root_freqs, d_logl_out, reduce, floor_log))
+    if (enqueue_eval(p, s, (int)cat, batch ? (int)p->C : 1, changed, pi_changed, slots_changed, q_nodes, n_q, q,
+                     q_on_device, q_is_probability, root_freqs, d_logl_out, reduce, floor_log))
       return -1;
+  if (batch)
+    for (int64_t c = 0; c < p->C; c++) p->initialized[c] = 1;
   p->initialized[cat] = 1;
+  if (q_on_device) p->coeffs_pending = false;
   return 0;
 }
 
@@ -737,6 +773,25 @@ int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   return 0;
 }
 
+int hyphy_hip_evaluate_built(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                             const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out) {
+  if (!p) return fail("partition == NULL");
+  if (!p->K) return fail("evaluate_built: templates not set");
+  // q = each shard's own Q buffer (filled / staged by build_q)
+  if (p->shards.size() == 1) {
+    if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, p->shards[0].qbuf, true, 0, root_freqs, nullptr, true,
+                    false))
+      return -1;
+  } else {
+    return fail("evaluate_built: multi-device partitions use hyphy_hip_evaluate");
+  }
+  Shard &s = p->shards[0];
+  HIPCHK(hipMemcpyAsync(s.h_out, s.out, 2 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  if (collect_status(p)) return -1;
+  if (logl_out) *logl_out = s.h_out[0];
+  return 0;
+}
+
 int hyphy_hip_evaluate_device(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                               const int64_t *q_nodes, int64_t n_q, const double *d_q, int q_is_probability,
                               const double *root_freqs, double *d_logl_out) {
@@ -755,12 +810,20 @@ int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_
   if (!p) return fail("partition == NULL");
   if (!weights) return fail("weights == NULL");
   const int64_t D = p->D;
-  for (int64_t c = 0; c < p->C; c++) {
-    // every class shares the dirty set; schedule cache is keyed on the update list only
-    if (!p->initialized[c]) p->cached_valid = 0;
-    if (eval_common(p, c, update_nodes, n_update, q_nodes, n_q, q_dense ? q_dense + (size_t)c * n_q * D * D : nullptr,
-                    false, q_is_probability, root_freqs, nullptr, false, true))
+  if (!p->nuc) {
+    // rate-class batching: ONE expm launch over C*n_q matrices and ONE pruning launch with a grid row
+    // per class (3x the workgroups of a single pass: the matrix pipe finally has enough waves)
+    if (eval_common(p, 0, update_nodes, n_update, q_nodes, n_q, q_dense, false, q_is_probability, root_freqs, nullptr,
+                    false, true, /* batch = */ true))
       return -1;
+  } else {
+    for (int64_t c = 0; c < p->C; c++) {
+      if (!p->initialized[c]) p->cached_valid = 0;
+      if (eval_common(p, c, update_nodes, n_update, q_nodes, n_q,
+                      q_dense ? q_dense + (size_t)c * n_q * D * D : nullptr, false, q_is_probability, root_freqs,
+                      nullptr, false, true))
+        return -1;
+    }
   }
   std::vector<double> parts;
   for (Shard &s : p->shards) {
@@ -774,6 +837,31 @@ int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_
   for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
   if (logl_out) *logl_out = combine(parts);
   if (site_lik_out || site_scaler_out) return gather_sites(p, 0, site_lik_out, site_scaler_out, true);
+  return 0;
+}
+
+int hyphy_hip_evaluate_categories_built(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update,
+                                        const int64_t *q_nodes, int64_t n_q, const double *weights,
+                                        const double *root_freqs, double *logl_out) {
+  if (!p) return fail("partition == NULL");
+  if (!p->K) return fail("evaluate_categories_built: templates not set");
+  if (p->nuc || p->shards.size() != 1) return fail("evaluate_categories_built: single-device MFMA partitions only");
+  if (!weights) return fail("weights == NULL");
+  Shard &s = p->shards[0];
+  if (eval_common(p, 0, update_nodes, n_update, q_nodes, n_q, s.qbuf, true, 0, root_freqs, nullptr, false, true, true))
+    return -1;
+  HIPCHK(hipSetDevice(s.device));
+  const bool w_changed = p->cached_weights.size() != (size_t)p->C ||
+                         memcmp(p->cached_weights.data(), weights, p->C * sizeof(double));
+  if (w_changed) {
+    p->cached_weights.assign(weights, weights + p->C);
+    if (upload_small(s, weights, (size_t)p->C, s.weights)) return -1;
+  }
+  launch_mix_categories(s.site_lik, s.site_cnt, s.weights, (int)p->C, s.S_pad, s.mixed_lik, s.mixed_cnt, s.stream);
+  launch_site_reduce(s.mixed_lik, s.mixed_cnt, s.freq, s.S_pad, 1, s.out, s.out + 1, s.stream);
+  HIPCHK(hipMemcpyAsync(s.h_out, s.out, 2 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  if (collect_status(p)) return -1;
+  if (logl_out) *logl_out = s.h_out[0];
   return 0;
 }
 
@@ -837,6 +925,7 @@ int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_
   ExpmArgs ea;
   ea.Q = dq; ea.slots = nullptr; ea.n = (int)n; ea.D = (int)D; ea.is_prob = 0;
   ea.Prow = dp; ea.Pfrag = nullptr; ea.PTg = nullptr; ea.status = st;
+  ea.templates = nullptr; ea.coeffs = nullptr; ea.K = 0;
   launch_expm(ea, nullptr);
   int32_t hst = 0;
   hipError_t e1 = hipMemcpy(p_out, dp, bytes, hipMemcpyDeviceToHost);
@@ -859,6 +948,8 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
     s.templates = s.coeffs = nullptr;
     HIPCHK(hipMalloc((void **)&s.templates, (size_t)K * D * D * sizeof(double)));
     HIPCHK(hipMalloc((void **)&s.coeffs, (size_t)p->C * p->B * K * sizeof(double)));
+    if (s.h_coeffs) hipHostFree(s.h_coeffs);
+    HIPCHK(hipHostMalloc((void **)&s.h_coeffs, (size_t)4 * p->C * p->B * K * sizeof(double)));
     HIPCHK(hipMemcpy(s.templates, templates, (size_t)K * D * D * sizeof(double), hipMemcpyHostToDevice));
   }
   p->K = K;
@@ -869,13 +960,21 @@ int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs) {
   if (!p || !p->K) return fail("build_q: templates not set");
   if (n < 0 || n > p->C * p->B || !coeffs) return fail("build_q: bad arguments");
   Trace tr("build_q");
+  // When the matrices are consumed by the next hyphy_hip_evaluate_device(q_buffer) — the normal use —
+  // the construction is fused into the expm kernel (no Q round trip through HBM, one launch less).
+  // HYPHY_HIP_MATERIALIZE_Q=1 keeps the stand-alone kernel so that q_buffer can be read back.
+  const bool fuse = getenv("HYPHY_HIP_MATERIALIZE_Q") == nullptr;
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
-    HIPCHK(hipMemcpyAsync(s.coeffs, coeffs, (size_t)n * p->K * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    const size_t nbytes = (size_t)n * p->K * sizeof(double);
+    double *stage = s.h_coeffs + (size_t)(s.coeff_turn++ & 3) * (size_t)p->C * p->B * p->K;  // pinned ring of 4
+    memcpy(stage, coeffs, nbytes);
+    HIPCHK(hipMemcpyAsync(s.coeffs, stage, nbytes, hipMemcpyHostToDevice, s.stream));
     tr.lap("memcpy");
-    launch_build_q(s.templates, s.coeffs, (int)n, (int)p->K, (int)p->D, s.qbuf, s.stream);
+    if (!fuse) launch_build_q(s.templates, s.coeffs, (int)n, (int)p->K, (int)p->D, s.qbuf, s.stream);
     tr.lap("launch");
   }
+  p->coeffs_pending = fuse;
   return 0;
 }
 

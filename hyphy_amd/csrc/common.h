@@ -76,6 +76,13 @@ struct PruneArgs {
   double *wg_sum;            // [n workgroups] sum_s f_s log L_s over the workgroup's patterns
   long long *wg_cnt;         // [n workgroups] sum_s f_s c_s
   int *wg_flag;              // [n workgroups] 1: zero-likelihood pattern, 2: NaN
+  // rate-class batching: blockIdx.y = class; element strides between consecutive classes
+  int n_cat;
+  size_t cs_P;               // Pfrag / PTg       (B*DP*DP)
+  size_t cs_partials;        // partials
+  size_t cs_counts;          // counts            (I*S_pad)
+  size_t cs_site;            // site_lik/site_cnt (S_pad)
+  size_t cs_wg;              // wg_sum/cnt/flag   (workgroups per class)
   int ablate;                // DIAGNOSTIC ONLY (HYPHY_HIP_ABLATE bitmask, results invalid): 1 no MFMA, 2 no barrier,
                              // 4 no persist stores, 8 no leaf gathers, 16 no operand prefetch, 32 no LDS exchange
   long long *timeline;       // optional tracing: [kTraceWG][NW][n_ops][4] s_memtime stamps (HYPHY_HIP_TIMELINE)
@@ -111,6 +118,11 @@ struct ExpmArgs {
   double *Pfrag;             // optional [.][NW][NKK*64]
   double *PTg;               // optional [.][DP][NW][16]
   int32_t *status;           // [1] set to nonzero if any matrix failed (NaN / ill-conditioned)
+  // optional fused rate-matrix construction: Q_m = sum_k coeffs[m][k] * templates[k]
+  // off-diagonal, diagonal = -(row sum); when templates != nullptr, Q is ignored
+  const double *templates;   // [K][D*D]
+  const double *coeffs;      // [n][K]
+  int K;
 };
 
 // launchers (defined in the .hip files)

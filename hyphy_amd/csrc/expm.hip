@@ -35,86 +35,127 @@ __constant__ double kInvFact[13] = {1.0,
                                     1.0 / 39916800.0,
                                     1.0 / 479001600.0};
 
-template <int NT>
+// NT = DP/16 row blocks; CS = column splits: the workgroup has NT*CS waves, wave (w, h) owns row block
+// w and the NTW = NT/CS column tiles [h*NTW, (h+1)*NTW).  CS = 2 for DP = 64 puts two waves on every
+// SIMD: one wave alone cannot issue f64 MFMAs fast enough to keep the pipe busy (tools/ubench_mfma_f64).
+template <int NTW>
 struct Frag {
-  f64x4 t[NT];  // C/D image of this wave's 16-row block: t[c][r] = M[16w + 4r + g][16c + sl]
+  f64x4 t[NTW];  // C/D image: t[c][r] = M[16w + 4r + g][16(c0 + c) + sl]
 };
 
-template <int NT>
-__device__ __forceinline__ Frag<NT> mm(const double *__restrict__ Lm, const double *__restrict__ Rm, int w, int g,
-                                       int sl) {
-  constexpr int DP = 16 * NT, LD = DP + 2, NKK = DP / 4;
-  Frag<NT> d;
+template <int NT, int CS>
+__device__ __forceinline__ Frag<NT / CS> mm(const double *__restrict__ Lm, const double *__restrict__ Rm, int w, int c0,
+                                            int g, int sl) {
+  constexpr int DP = 16 * NT, LD = DP + 2, NKK = DP / 4, NTW = NT / CS;
+  Frag<NTW> d;
 #pragma unroll
-  for (int c = 0; c < NT; c++) d.t[c] = (f64x4){0., 0., 0., 0.};
+  for (int c = 0; c < NTW; c++) d.t[c] = (f64x4){0., 0., 0., 0.};
 #pragma unroll 4
   for (int kk = 0; kk < NKK; kk++) {
     const double av = Lm[(16 * w + sl) * LD + 4 * kk + g];
 #pragma unroll
-    for (int c = 0; c < NT; c++) {
-      const double bv = Rm[(4 * kk + g) * LD + 16 * c + sl];
+    for (int c = 0; c < NTW; c++) {
+      const double bv = Rm[(4 * kk + g) * LD + 16 * (c0 + c) + sl];
       d.t[c] = mfma(av, bv, d.t[c]);
     }
   }
   return d;
 }
 
-template <int NT>
-__device__ __forceinline__ void store_frag(double *__restrict__ M, const Frag<NT> &f, int w, int g, int sl) {
-  constexpr int DP = 16 * NT, LD = DP + 2;
+template <int NT, int CS>
+__device__ __forceinline__ void store_frag(double *__restrict__ M, const Frag<NT / CS> &f, int w, int c0, int g,
+                                           int sl) {
+  constexpr int DP = 16 * NT, LD = DP + 2, NTW = NT / CS;
 #pragma unroll
-  for (int c = 0; c < NT; c++)
+  for (int c = 0; c < NTW; c++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) M[(16 * w + 4 * r + g) * LD + 16 * c + sl] = f.t[c][r];
+    for (int r = 0; r < 4; r++) M[(16 * w + 4 * r + g) * LD + 16 * (c0 + c) + sl] = f.t[c][r];
 }
 
 // Row sums -> R_ii += 1 - sum (diag_populator, matrix.cpp:5837-5852); reports a diagonal > 1
-// (transition_verifier, :5820-5835) or a NaN through `bad` (workgroup-wide OR via LDS).
-template <int NT>
-__device__ __forceinline__ bool diag_fix(Frag<NT> &R, int w, int g, int sl, int *flag) {
+// (transition_verifier, :5820-5835) or a NaN (workgroup-wide OR via LDS).  With CS > 1 the row sums
+// are completed across the column-split waves through `rowpart` ([DP][CS] doubles in LDS).
+template <int NT, int CS>
+__device__ __forceinline__ bool diag_fix(Frag<NT / CS> &R, int w, int h, int c0, int g, int sl, int *flag,
+                                         double *rowpart) {
+  constexpr int NTW = NT / CS;
   bool bad = false;
+  double part[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     double s = 0.;
 #pragma unroll
-    for (int c = 0; c < NT; c++) s += R.t[c][r];
+    for (int c = 0; c < NTW; c++) s += R.t[c][r];
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     s += __shfl_xor(s, 4);
     s += __shfl_xor(s, 8);
-    if (s != s) bad = true;
-    if (sl == 4 * r + g) {  // this lane holds the diagonal of row 16w + 4r + g (column tile c == w)
+    part[r] = s;
+    if (CS > 1 && sl == 0) rowpart[(16 * w + 4 * r + g) * CS + h] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *flag = 0;
 #pragma unroll
-      for (int c = 0; c < NT; c++)
-        if (c == w) {
+  for (int r = 0; r < 4; r++) {
+    double s = part[r];
+    if (CS > 1) {
+      s = 0.;
+#pragma unroll
+      for (int hh = 0; hh < CS; hh++) s += rowpart[(16 * w + 4 * r + g) * CS + hh];
+    }
+    if (s != s) bad = true;
+    if (sl == 4 * r + g) {  // this lane holds the diagonal of row 16w + 4r + g if column tile w is ours
+#pragma unroll
+      for (int c = 0; c < NTW; c++)
+        if (c0 + c == w) {
           if (R.t[c][r] > 1.) bad = true;
           R.t[c][r] += 1. - s;
         }
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) *flag = 0;
-  __syncthreads();
   if (bad) atomicOr(flag, 1);
   __syncthreads();
   return *flag == 0;
 }
 
-template <int NT>
-__global__ __launch_bounds__(64 * NT) void expm_mfma_kernel(ExpmArgs a) {
-  constexpr int DP = 16 * NT, LD = DP + 2, NKK = DP / 4, MS = DP * LD, NW = NT;
+template <int NT, int CS>
+__global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
+  constexpr int DP = 16 * NT, LD = DP + 2, NKK = DP / 4, MS = DP * LD, NWV = NT * CS, NTW = NT / CS,
+                NTHR = 64 * NWV;
   extern __shared__ __align__(16) double sm[];
   double *Xs = sm, *Ys = sm + MS, *Zs = sm + 2 * MS, *red = sm + 3 * MS;  // red: 2*DP + 8 doubles
   int *flag = reinterpret_cast<int *>(red + 2 * DP + 4);
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, sl = lane & 15;
+  double *rowpart = red + 2 * DP + 8;  // [DP][CS]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, sl = lane & 15;
+  const int w = wv % NT, h = wv / NT, c0 = h * NTW;
   const int D = a.D;
   const int m = blockIdx.x;
   const int slot = a.slots ? a.slots[m] : m;
   const double *Q = a.Q + (size_t)m * D * D;
 
-  for (int idx = tid; idx < DP * DP; idx += 64 * NT) {
-    const int r = idx / DP, c = idx - r * DP;
-    Xs[r * LD + c] = (r < D && c < D) ? Q[r * D + c] : 0.0;
+  if (a.templates) {
+    // fused device-side rate-matrix construction: Q = sum_k c_k T_k, then the diagonal by column-order
+    // subtraction (the order of _Matrix::MultByFreqs, matrix.cpp:1664-1674)
+    for (int idx = tid; idx < DP * DP; idx += NTHR) {
+      const int r = idx / DP, c = idx - r * DP;
+      double v = 0.;
+      if (r < D && c < D && r != c)
+        for (int k = 0; k < a.K; k++) v += a.coeffs[(size_t)m * a.K + k] * a.templates[((size_t)k * D + r) * D + c];
+      Xs[r * LD + c] = v;
+    }
+    __syncthreads();
+    if (tid < D) {
+      double d = 0.;
+      for (int c = 0; c < D; c++)
+        if (c != tid) d -= Xs[tid * LD + c];
+      Xs[tid * LD + tid] = d;
+    }
+  } else {
+    for (int idx = tid; idx < DP * DP; idx += NTHR) {
+      const int r = idx / DP, c = idx - r * DP;
+      Xs[r * LD + c] = (r < D && c < D) ? Q[r * D + c] : 0.0;
+    }
   }
   __syncthreads();
 
@@ -145,53 +186,54 @@ __global__ __launch_bounds__(64 * NT) void expm_mfma_kernel(ExpmArgs a) {
       if (s > 1.) p = ilogb(s) + 1;
     }
     // original Q in registers (C/D image) so that a restart can rescale it
-    Frag<NT> Qr;
+    Frag<NTW> Qr;
 #pragma unroll
-    for (int c = 0; c < NT; c++)
+    for (int c = 0; c < NTW; c++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) Qr.t[c][r] = Xs[(16 * w + 4 * r + g) * LD + 16 * c + sl];
+      for (int r = 0; r < 4; r++) Qr.t[c][r] = Xs[(16 * w + 4 * r + g) * LD + 16 * (c0 + c) + sl];
     __syncthreads();
 
-    Frag<NT> R;
+    auto add_diag = [&](Frag<NTW> &f, double v) {
+#pragma unroll
+      for (int c = 0; c < NTW; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (c0 + c == w && sl == 4 * r + g) f.t[c][r] += v;
+    };
+
+    Frag<NTW> R;
     bool done = false, failed = nan_in || !(mnorm < 1e300);
     for (int attempt = 0; attempt < 48 && !done && !failed; attempt++) {
       const double scale = ldexp(1.0, -p);
-      Frag<NT> Xr;
+      Frag<NTW> Xr;
 #pragma unroll
-      for (int c = 0; c < NT; c++) Xr.t[c] = Qr.t[c] * scale;
-      store_frag<NT>(Xs, Xr, w, g, sl);
+      for (int c = 0; c < NTW; c++) Xr.t[c] = Qr.t[c] * scale;
+      store_frag<NT, CS>(Xs, Xr, w, c0, g, sl);
       __syncthreads();
-      Frag<NT> X2 = mm<NT>(Xs, Xs, w, g, sl);
-      store_frag<NT>(Ys, X2, w, g, sl);
+      Frag<NTW> X2 = mm<NT, CS>(Xs, Xs, w, c0, g, sl);
+      store_frag<NT, CS>(Ys, X2, w, c0, g, sl);
       __syncthreads();
-      Frag<NT> X3 = mm<NT>(Xs, Ys, w, g, sl);
-      store_frag<NT>(Zs, X3, w, g, sl);
+      Frag<NTW> X3 = mm<NT, CS>(Xs, Ys, w, c0, g, sl);
+      store_frag<NT, CS>(Zs, X3, w, c0, g, sl);
       // Paterson-Stockmeyer, s = 3:  p(X) = B0 + X3 (B1 + X3 (B2 + X3 (B3 + c12 X3)))
-      Frag<NT> acc;
+      Frag<NTW> acc;
 #pragma unroll
-      for (int c = 0; c < NT; c++) {
+      for (int c = 0; c < NTW; c++)
         acc.t[c] = kInvFact[10] * Xr.t[c] + kInvFact[11] * X2.t[c] + kInvFact[12] * X3.t[c];
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (c == w && sl == 4 * r + g) acc.t[c][r] += kInvFact[9];
-      }
+      add_diag(acc, kInvFact[9]);
 #pragma unroll 1
       for (int blk = 2; blk >= 0; blk--) {
         __syncthreads();  // previous readers of Ys are done (and Zs is complete on the first pass)
-        store_frag<NT>(Ys, acc, w, g, sl);
+        store_frag<NT, CS>(Ys, acc, w, c0, g, sl);
         __syncthreads();
-        acc = mm<NT>(Zs, Ys, w, g, sl);
-        const double c0 = kInvFact[3 * blk], c1 = kInvFact[3 * blk + 1], c2 = kInvFact[3 * blk + 2];
+        acc = mm<NT, CS>(Zs, Ys, w, c0, g, sl);
+        const double k0 = kInvFact[3 * blk], k1 = kInvFact[3 * blk + 1], k2 = kInvFact[3 * blk + 2];
 #pragma unroll
-        for (int c = 0; c < NT; c++) {
-          acc.t[c] += c1 * Xr.t[c] + c2 * X2.t[c];
-#pragma unroll
-          for (int r = 0; r < 4; r++)
-            if (c == w && sl == 4 * r + g) acc.t[c][r] += c0;
-        }
+        for (int c = 0; c < NTW; c++) acc.t[c] += k1 * Xr.t[c] + k2 * X2.t[c];
+        add_diag(acc, k0);
       }
       R = acc;
-      if (!diag_fix<NT>(R, w, g, sl, flag)) {  // matrix.cpp:5854-5864: restart, scale_to *= 100
+      if (!diag_fix<NT, CS>(R, w, h, c0, g, sl, flag, rowpart)) {  // matrix.cpp:5854-5864: restart, scale_to *= 100
         p += 7;
         if (p > 900) failed = true;
         continue;
@@ -199,26 +241,26 @@ __global__ __launch_bounds__(64 * NT) void expm_mfma_kernel(ExpmArgs a) {
       double last_diff = 0.;
       for (int s = 0; s < p; s++) {  // matrix.cpp:5873-5920
         __syncthreads();
-        store_frag<NT>(Xs, R, w, g, sl);
+        store_frag<NT, CS>(Xs, R, w, c0, g, sl);
         __syncthreads();
-        Frag<NT> Rn = mm<NT>(Xs, Xs, w, g, sl);
+        Frag<NTW> Rn = mm<NT, CS>(Xs, Xs, w, c0, g, sl);
         double diff = 0.;
 #pragma unroll
-        for (int c = 0; c < NT; c++)
+        for (int c = 0; c < NTW; c++)
 #pragma unroll
           for (int r = 0; r < 4; r++) diff = fmax(diff, fabs(Rn.t[c][r] - R.t[c][r]));
         R = Rn;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) diff = fmax(diff, __shfl_xor(diff, off));
-        if (lane == 0) red[w] = diff;
+        if (lane == 0) red[wv] = diff;
         __syncthreads();
         diff = red[0];
 #pragma unroll
-        for (int k = 1; k < NW; k++) diff = fmax(diff, red[k]);
+        for (int k = 1; k < NWV; k++) diff = fmax(diff, red[k]);
         if (diff < 2.220446049250313e-16 * 1.e3 || (s >= 10 && diff > last_diff * 100.)) break;
         last_diff = diff;
       }
-      if (p > 0 && !diag_fix<NT>(R, w, g, sl, flag)) {
+      if (p > 0 && !diag_fix<NT, CS>(R, w, h, c0, g, sl, flag, rowpart)) {
         p += 7;
         if (p > 900) failed = true;
         continue;
@@ -230,14 +272,14 @@ __global__ __launch_bounds__(64 * NT) void expm_mfma_kernel(ExpmArgs a) {
       return;
     }
     __syncthreads();
-    store_frag<NT>(Xs, R, w, g, sl);
+    store_frag<NT, CS>(Xs, R, w, c0, g, sl);
     __syncthreads();
   }
 
   // ---- outputs: row-major, A-operand image, column-gather image ----
   if (a.Prow) {
     double *out = a.Prow + (size_t)slot * D * D;
-    for (int idx = tid; idx < D * D; idx += 64 * NT) {
+    for (int idx = tid; idx < D * D; idx += NTHR) {
       const int r = idx / D, c = idx - r * D;
       out[idx] = Xs[r * LD + c];
     }
@@ -245,7 +287,7 @@ __global__ __launch_bounds__(64 * NT) void expm_mfma_kernel(ExpmArgs a) {
   if (a.Pfrag) {
     // wave wb, k-step kk, lane l  <-  P[16 wb + (l & 15)][4 kk + (l >> 4)]
     double *out = a.Pfrag + (size_t)slot * DP * DP;
-    for (int idx = tid; idx < DP * DP; idx += 64 * NT) {
+    for (int idx = tid; idx < DP * DP; idx += NTHR) {
       const int wb = idx / (NKK * 64), rem = idx - wb * (NKK * 64);
       const int kk2 = rem >> 7, l = (rem >> 1) & 63, kb = rem & 1, kk = 2 * kk2 + kb;
       const int rr = 16 * wb + (l & 15), cc = 4 * kk + (l >> 4);
@@ -255,8 +297,8 @@ __global__ __launch_bounds__(64 * NT) void expm_mfma_kernel(ExpmArgs a) {
   if (a.PTg) {
     // [code][wb][gg][r]  <-  P[16 wb + 4 r + gg][code]
     double *out = a.PTg + (size_t)slot * DP * DP;
-    for (int idx = tid; idx < DP * DP; idx += 64 * NT) {
-      const int code = idx / (NW * 16), rem = idx - code * (NW * 16);
+    for (int idx = tid; idx < DP * DP; idx += NTHR) {
+      const int code = idx / (NT * 16), rem = idx - code * (NT * 16);
       const int wb = rem >> 4, gg = (rem >> 2) & 3, r = rem & 3;
       const int rr = 16 * wb + 4 * r + gg;
       out[idx] = (rr < D && code < D) ? Xs[rr * LD + code] : 0.0;
@@ -295,8 +337,24 @@ __global__ void expm_nuc_kernel(ExpmArgs a) {
   if (m >= a.n) return;
   const int slot = a.slots ? a.slots[m] : m;
   double Q[16], R[16];
+  if (a.templates) {
 #pragma unroll
-  for (int k = 0; k < 16; k++) Q[k] = a.Q[(size_t)m * 16 + k];
+    for (int i = 0; i < 4; i++) {
+      double d = 0.;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (j == i) continue;
+        double v = 0.;
+        for (int k = 0; k < a.K; k++) v += a.coeffs[(size_t)m * a.K + k] * a.templates[(size_t)k * 16 + 4 * i + j];
+        Q[4 * i + j] = v;
+        d -= v;
+      }
+      Q[5 * i] = d;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) Q[k] = a.Q[(size_t)m * 16 + k];
+  }
   if (a.is_prob) {
 #pragma unroll
     for (int k = 0; k < 16; k++) R[k] = Q[k];
@@ -411,29 +469,29 @@ void launch_expm(const ExpmArgs &a, hipStream_t stream) {
   static bool attr_done[5] = {false, false, false, false, false};  // per process; one device kind only
   const int NT = (a.D + 15) / 16;
   const int DP = 16 * NT, LD = DP + 2;
-  const size_t lds = (size_t)(3 * DP * LD + 2 * DP + 8) * sizeof(double);
+  const size_t lds = (size_t)(3 * DP * LD + 2 * DP + 8 + 2 * DP) * sizeof(double);
   switch (NT) {
     case 1:
-      hipLaunchKernelGGL(expm_mfma_kernel<1>, dim3(a.n), dim3(64), lds, stream, a);
+      hipLaunchKernelGGL((expm_mfma_kernel<1, 1>), dim3(a.n), dim3(64), lds, stream, a);
       break;
     case 2:
-      hipLaunchKernelGGL(expm_mfma_kernel<2>, dim3(a.n), dim3(128), lds, stream, a);
+      hipLaunchKernelGGL((expm_mfma_kernel<2, 2>), dim3(a.n), dim3(256), lds, stream, a);
       break;
     case 3:
       if (!attr_done[3]) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<3>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<3, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[3] = true;
       }
-      hipLaunchKernelGGL(expm_mfma_kernel<3>, dim3(a.n), dim3(192), lds, stream, a);
+      hipLaunchKernelGGL((expm_mfma_kernel<3, 1>), dim3(a.n), dim3(192), lds, stream, a);
       break;
     default:
       if (!attr_done[4]) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<4>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<4, 2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[4] = true;
       }
-      hipLaunchKernelGGL(expm_mfma_kernel<4>, dim3(a.n), dim3(256), lds, stream, a);
+      hipLaunchKernelGGL((expm_mfma_kernel<4, 2>), dim3(a.n), dim3(512), lds, stream, a);
       break;
   }
 }

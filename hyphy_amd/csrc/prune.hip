@@ -85,6 +85,18 @@ struct Payload {
 template <int NW, int T, bool CLDS, bool TRACE, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, (T == 1 ? 3 : 1)) void prune_mfma_kernel(const int4 *__restrict__ ops,
                                                                                PruneArgs a) {
+  {  // rate-class batching: one grid row per class, same schedule, class-strided buffers
+    const size_t cat = blockIdx.y;
+    a.Pfrag += cat * a.cs_P;
+    a.PTg += cat * a.cs_P;
+    a.partials += cat * a.cs_partials;
+    a.counts += cat * a.cs_counts;
+    a.site_lik += cat * a.cs_site;
+    a.site_cnt += cat * a.cs_site;
+    a.wg_sum += cat * a.cs_wg;
+    a.wg_cnt += cat * a.cs_wg;
+    a.wg_flag += cat * a.cs_wg;
+  }
   constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
   constexpr int G = (T <= 2) ? 2 : 1;  // leaves per leaf-group entry (T*G*4 doubles <= 16)
   static_assert(NW == 4 || NKK <= 16, "payload sized for DP <= 64");
@@ -688,7 +700,7 @@ __global__ void unpack_partials_kernel(const double *__restrict__ partials, int 
 
 template <int NW, bool CLDS>
 void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
-  const dim3 grid(a.ntiles / a.T), block(64 * NW);
+  const dim3 grid(a.ntiles / a.T, a.n_cat > 0 ? a.n_cat : 1), block(64 * NW);
   const size_t lds = CLDS ? (size_t)a.L * a.T * 16 * sizeof(int16_t) : 0;
   if (a.timeline) {  // tracing build of the kernel (HYPHY_HIP_TIMELINE), T = 1 only
     hipLaunchKernelGGL((prune_mfma_kernel<NW, 1, CLDS, true>), grid, block, lds, stream, a.ops, a);

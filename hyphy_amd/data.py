@@ -170,6 +170,9 @@ def evolve(n_leaves: int, n_sites: int, unit: int, seed: int, p_change: float = 
     def mutate(seq: np.ndarray) -> np.ndarray:
         out = seq.copy()
         hit = np.nonzero(rng.random(n_sites) < p_change)[0]
+        if unit == 1:
+            out[hit] = (out[hit] + rng.integers(1, 4, size=len(hit))) % 4
+            return out
         for s in hit:
             if unit == 1:
                 out[s] = (out[s] + rng.integers(1, 4)) % 4

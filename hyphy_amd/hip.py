@@ -21,6 +21,7 @@ EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
     "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
+    "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built",
     "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
@@ -65,6 +66,10 @@ def load():
     lib.hyphy_hip_set_q_templates.argtypes = [vp, C.c_int64, dp]
     lib.hyphy_hip_build_q.restype = C.c_int
     lib.hyphy_hip_build_q.argtypes = [vp, C.c_int64, dp]
+    lib.hyphy_hip_evaluate_built.restype = C.c_int
+    lib.hyphy_hip_evaluate_built.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, dp]
+    lib.hyphy_hip_evaluate_categories_built.restype = C.c_int
+    lib.hyphy_hip_evaluate_categories_built.argtypes = [vp, lp, C.c_int64, lp, C.c_int64, dp, dp, dp]
     lib.hyphy_hip_q_buffer.restype = vp
     lib.hyphy_hip_q_buffer.argtypes = [vp]
     lib.hyphy_hip_synchronize.restype = C.c_int
@@ -195,6 +200,52 @@ class HipPartition:
                 rc = lib.hyphy_hip_evaluate_device(h, cat, pun, nun, pqn, nqn, dq, 0, prf, dl)
             if rc:
                 _check(rc)
+        return step
+
+    def prepare_built_step(self, update_nodes, q_nodes, root_freqs, coeffs: np.ndarray, cat: int = -1):
+        """Zero-argument callable: ``build_q(coeffs)`` + synchronous ``evaluate_built`` -> log-L (float).
+        ctypes arguments are marshalled once; ``coeffs`` is read at call time."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        assert coeffs.flags.c_contiguous and coeffs.dtype == np.float64
+        keep = (un, qn, rf, coeffs)
+        lib, h = self._lib, self._h
+        pun, pqn, prf, pco = _l(un), _l(qn), _d(rf), _d(coeffs)
+        nun, nqn, nco = len(un), len(qn), coeffs.shape[0]
+        out = C.c_double(0.0)
+        pout = C.byref(out)
+
+        def step(_keep=keep):
+            rc = lib.hyphy_hip_build_q(h, nco, pco)
+            if rc == 0:
+                rc = lib.hyphy_hip_evaluate_built(h, cat, pun, nun, pqn, nqn, prf, pout)
+            if rc:
+                _check(rc)
+            return out.value
+        return step
+
+    def prepare_built_categories_step(self, update_nodes, q_nodes, weights, root_freqs, coeffs: np.ndarray):
+        """``build_q`` (C*n_q coefficient rows, class-major) + ``evaluate_categories_built`` -> log-L."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        wt = np.ascontiguousarray(weights, dtype=np.float64)
+        assert coeffs.flags.c_contiguous and coeffs.dtype == np.float64 and coeffs.shape[0] == self.C * len(qn)
+        keep = (un, qn, rf, wt, coeffs)
+        lib, h = self._lib, self._h
+        pun, pqn, prf, pwt, pco = _l(un), _l(qn), _d(rf), _d(wt), _d(coeffs)
+        nun, nqn, nco = len(un), len(qn), coeffs.shape[0]
+        out = C.c_double(0.0)
+        pout = C.byref(out)
+
+        def step(_keep=keep):
+            rc = lib.hyphy_hip_build_q(h, nco, pco)
+            if rc == 0:
+                rc = lib.hyphy_hip_evaluate_categories_built(h, pun, nun, pqn, nqn, pwt, prf, pout)
+            if rc:
+                _check(rc)
+            return out.value
         return step
 
     def evaluate_categories(self, update_nodes, q_nodes, q_dense, weights, root_freqs, q_is_probability: bool = False,

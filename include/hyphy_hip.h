@@ -125,6 +125,11 @@ int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_
                                   int q_is_probability, const double *weights, const double *root_freqs,
                                   double *logl_out, double *site_lik_out, int64_t *site_scaler_out);
 
+/* The same from rate matrices staged by hyphy_hip_build_q (n = C*n_q coefficient rows, class-major). */
+int hyphy_hip_evaluate_categories_built(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update,
+                                        const int64_t *q_nodes, int64_t n_q, const double *weights,
+                                        const double *root_freqs, double *logl_out);
+
 /*
  * Copies device partials back in the reference's host layout for code that reads the caches
  * directly (ReconstructAncestors likefunc2.cpp:416-449, FillInConditionals tree.cpp:3335-3371):
@@ -155,6 +160,11 @@ int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_
 int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *templates /* [K*D*D] */);
 int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs /* host [n*K] */);
 double *hyphy_hip_q_buffer(hyphy_hip_partition *p); /* device pointer, capacity (L+I-1)*C*D*D doubles */
+/* Synchronous evaluation from the rate matrices staged by the last hyphy_hip_build_q() (n matrices,
+ * in the order of q_nodes): template models never move a dense Q across PCIe — only the n*K
+ * coefficients go down and one double comes back.  Same semantics as hyphy_hip_evaluate otherwise. */
+int hyphy_hip_evaluate_built(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                             const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out);
 
 /* Blocks until all work enqueued for the partition has finished. */
 int hyphy_hip_synchronize(hyphy_hip_partition *p);

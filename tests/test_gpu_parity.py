@@ -93,6 +93,42 @@ def test_partials_match_oracle(name):
         assert np.allclose(a / na, b / nb, rtol=1e-9, atol=1e-300), (name, n)
 
 
+@pytest.mark.parametrize("materialize", [False, True])
+def test_device_q_templates_match_host_q(materialize, monkeypatch):
+    """hyphy_hip_set_q_templates / build_q / evaluate_device (device-resident Q, fused into the expm
+    kernel or materialised) agree with host-built rate matrices through hyphy_hip_evaluate."""
+    import torch
+    import bench
+    from hyphy_amd import models
+    if materialize:
+        monkeypatch.setenv("HYPHY_HIP_MATERIALIZE_Q", "1")
+    fx = common.load("codon_wide")
+    nodes = common.all_nodes(fx)
+    T, pi = bench.templates_for(3)
+    tb = np.asarray(fx["t"], dtype=np.float64)
+    omega = 0.37
+    Q = models.mg94rev_Q_batch(tb, omega, bench.REV, bench.POS_FREQS)
+    d_out = torch.zeros(2, dtype=torch.float64, device="cuda")
+    with _mk(fx) as part:
+        ref = part.evaluate(nodes, nodes, Q, pi)
+    with _mk(fx) as part:
+        part.set_q_templates(T)
+        co = np.stack([tb, tb * omega], axis=1).copy()
+        step = part.prepare_device_step(nodes, nodes, pi, d_out.data_ptr(), co)
+        step()
+        part.synchronize()
+        got = float(d_out[0].item())
+        # second call with a different omega re-uses the cached schedule / slots
+        co[:, 1] = tb * 0.5
+        step()
+        part.synchronize()
+        got2 = float(d_out[0].item())
+    with _mk(fx) as part:
+        ref2 = part.evaluate(nodes, nodes, models.mg94rev_Q_batch(tb, 0.5, bench.REV, bench.POS_FREQS), pi)
+    assert abs(got - ref) <= RTOL * abs(ref)
+    assert abs(got2 - ref2) <= RTOL * abs(ref2)
+
+
 def test_q_is_probability_path():
     from oracle import oracle
     fx = common.load("codon_small")
@@ -188,6 +224,30 @@ def test_categories_match_reference():
     assert abs(ll - ref) <= RTOL * abs(ref)
     site = (np.log(lik) - sc * 64 * np.log(2.0))[fx["site_to_pattern"]]
     assert np.max(np.abs(site - fx["site_logl"]) / np.abs(fx["site_logl"])) < RTOL
+
+
+def test_categories_built_on_device_match_host_q():
+    """Device-side Q for all classes (class-major coefficients) + batched pruning + device mixing."""
+    import bench
+    from hyphy_amd import models
+    fx = common.load("codon_cat3")
+    C = len(fx["cat_weights"])
+    nodes = common.all_nodes(fx)
+    tb = np.asarray(fx["t"], dtype=np.float64)
+    omega = float(fx["omega"])
+    T = np.zeros((2, 61, 61))
+    rv = dict(zip(common.REV_KEYS, (float(x) for x in fx["rev"])), AG=1.0)
+    for (i, j, name, ns, pf) in models.mg94rev_template(fx["pos_freqs"]):
+        T[1 if ns else 0, i, j] = rv[name] * pf
+    co = np.concatenate([np.stack([tb * v, tb * v * omega], axis=1) for v in fx["cat_values"]]).copy()
+    with _mk(fx, C) as part:
+        part.set_q_templates(T)
+        step = part.prepare_built_categories_step(nodes, nodes, fx["cat_weights"], fx["root_freqs"], co)
+        ll = step()
+        ll_again = step()
+    ref = float(fx["logl"])
+    assert abs(ll - ref) <= RTOL * abs(ref)
+    assert ll_again == ll
 
 
 def test_sharded_partition_equals_single(monkeypatch):
