@@ -166,6 +166,44 @@ def test_random_trees_match_oracle(seed, taxa, trif, monkeypatch):
         assert abs(ll - ref) <= RTOL * abs(ref), (tiles, ll, ref)
 
 
+@pytest.mark.parametrize("D", [2, 5, 16, 20, 33, 48, 64])
+def test_generic_state_counts_match_oracle(D, monkeypatch):
+    """Every row-block count of the MFMA kernel (NW = 1..4) and the expm variants, on random reversible
+    D-state models (D = 20: amino acids), with ambiguity vectors, against the CPU oracle."""
+    from hyphy_amd import models, tree
+    from oracle import oracle
+    rng = np.random.default_rng(100 + D)
+    root = tree.random_tree(14, rng)
+    flat = tree.flatten(root)
+    L, B, S = flat.L, flat.n_branches, 70
+    pi = rng.dirichlet(np.ones(D) * 4)
+    Sx = rng.uniform(0.1, 2.0, size=(D, D))
+    Sx = (Sx + Sx.T) / 2
+    Q = np.empty((B, D, D))
+    for b, t in enumerate(rng.uniform(0.02, 0.6, B)):
+        q = Sx * pi[None, :] * t
+        np.fill_diagonal(q, 0.0)
+        Q[b] = models.finish_rate_matrix(q)
+    codes = rng.integers(0, D, size=(L, S)).astype(np.int64)
+    ambig = (rng.random((3, D)) < 0.5).astype(np.float64)
+    ambig[:, 0] = 1.0
+    ambig[2, :] = 1.0
+    codes[rng.random((L, S)) < 0.08] = -int(rng.integers(1, 4))
+    freq = rng.integers(1, 5, size=S).astype(np.int64)
+    nodes = np.arange(B, dtype=np.int64)
+    op = oracle.OraclePartition(D, flat.flat_parents, L, codes, ambig, freq)
+    op.set_P(nodes, oracle.expm(Q, False))
+    ref = op.compute_block(nodes, pi)
+    hip = _hip()
+    for tiles in ("1", "2", "4"):
+        monkeypatch.setenv("HYPHY_HIP_TILES", tiles)
+        with hip.HipPartition(D, flat.flat_parents, L, codes, ambig, freq) as part:
+            ll, lik, sc = part.evaluate(nodes, nodes, Q, pi, per_site=True)
+            cache, counts = part.download_partials()
+        assert abs(ll - ref) <= RTOL * abs(ref), (D, tiles, ll, ref)
+        assert cache.shape == (flat.I, S, D) and np.isfinite(cache).all()
+
+
 def test_multifurcating_tree_matches_oracle():
     from hyphy_amd import data, models, tree
     from oracle import oracle
