@@ -57,7 +57,7 @@ struct Shard {
   hipStream_t stream = nullptr;      // stream in use
   hipStream_t own_stream = nullptr;  // stream created (and destroyed) by the library
   int64_t s0 = 0, S = 0;  // pattern range [s0, s0+S) of the partition
-  int S_pad = 0, ntiles = 0, T = 1;
+  int S_pad = 0, ntiles = 0, T = 1, cus = 256;
   int16_t *codes = nullptr;
   double *freq = nullptr;
   double *ambig = nullptr;
@@ -71,6 +71,8 @@ struct Shard {
   double *qbuf = nullptr;                                   // [C*B*D*D]
   int32_t *slots = nullptr;                                 // [C*B]
   int4 *ops = nullptr;
+  int2 *prog = nullptr;       // program table (forest scheduling)
+  int2 *h_prog = nullptr;
   double *pi = nullptr;       // [DP]
   double *out = nullptr;      // [2]
   double *wg_sum = nullptr;   // per-workgroup partial sums of the pruning kernel
@@ -112,7 +114,12 @@ struct hyphy_hip_partition {
   std::vector<double> cached_pi;             // root frequencies currently on the device
   std::vector<double> cached_weights;        // category weights currently on the device
   std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
-  int root_slot = 0, n_ops_real = 0, n_ops_padded = 0;
+  int root_slot = 0;
+  struct Prog { int off, n; };
+  struct Level { int first, count; };
+  std::vector<Prog> programs;                // (offset, padded entry count) into ops_host
+  std::vector<Level> levels;                 // launches: programs [first, first+count) run concurrently
+  int64_t batch_classes = 1;                 // rate classes batched into the pruning launch being scheduled
   int slots_batch_mode = -1;                 // whether the slot table on the device was written for a class batch
   bool coeffs_pending = false;               // build_q staged coefficients; the next evaluate_device(q_buffer) fuses
                                              // the rate-matrix construction into the expm kernel
@@ -122,17 +129,17 @@ struct hyphy_hip_partition {
 
 namespace {
 
-size_t ops_capacity(const hyphy_hip_partition *p) { return (size_t)(p->L + p->I) + 4; }
+size_t ops_capacity(const hyphy_hip_partition *p) { return (size_t)(p->L + p->I) + 4 * (size_t)p->I + 8; }
 
 void free_shard(Shard &s) {
   hipSetDevice(s.device);
   if (s.stream) hipStreamSynchronize(s.stream);
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
-                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag};
+                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog};
   for (void *d : dev)
     if (d) hipFree(d);
-  void *host[] = {s.h_ops, s.h_out, s.h_status, s.h_slots, s.h_small, s.h_coeffs};
+  void *host[] = {s.h_ops, s.h_out, s.h_status, s.h_slots, s.h_small, s.h_coeffs, s.h_prog};
   for (void *h : host)
     if (h) hipHostFree(h);
   for (auto &e : s.ev)
@@ -146,40 +153,27 @@ void free_shard(Shard &s) {
 // children of every touched internal node.  We recompute every internal node that is the parent
 // of a listed node (plus ancestors, defensively) from ALL its children; children whose
 // conditionals were not recomputed in this call are read back from the persisted device copy.
-void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, bool full) {
+// Append one *program* (the schedule of a connected set of touched internal nodes, ascending =
+// post-order) to p->ops_host.  Children that are internal nodes outside `nodes` are read from the
+// persisted copy in HBM (they were finalised by an earlier launch or are unchanged).  The program is
+// padded to an even entry count plus two trailing no-ops (the device loop is unrolled by two and
+// fetches entries two ahead).  Returns the LDS slot its last node was finalised into.
+int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *offset_out, int *n_out) {
   const int L = (int)p->L, I = (int)p->I;
-  std::vector<char> touched(I, 0);
-  if (full) {
-    std::fill(touched.begin(), touched.end(), 1);
-  } else {
-    for (int64_t k = 0; k < n_update; k++) {
-      int64_t n = update_nodes[k];
-      if (n < 0 || n >= L + I) continue;
-      int64_t par = p->parents[n];
-      while (par >= 0 && !touched[par]) {
-        touched[par] = 1;
-        par = p->parents[L + par];
-      }
-    }
-  }
-  p->ops_host.clear();
   const int T = p->shards.empty() ? 1 : p->shards[0].T;
   const int G = p->nuc ? 1 : (T <= 2 ? 2 : 1);  // leaves per leaf-group entry (prune.hip)
-  // A finished node whose parent is the next touched node is read by that parent straight from the
-  // exchange slot it was finalised into (slots 0/1 alternate with the finalisation count, so the
+  // A finished node whose parent is the next node of the program is read by that parent straight from
+  // the exchange slot it was finalised into (slots 0/1 alternate with the finalisation count, so the
   // writer of the NEXT finalisation never touches it); otherwise it is parked in an LDS slot
-  // (2..lds_slots(T)-1) until its parent comes up or — when the slots run out — re-read from the
-  // persisted copy in HBM.
-  std::vector<int> touched_list;
-  for (int par = 0; par < I; par++)
-    if (touched[par]) touched_list.push_back(par);
+  // (2..lds_slots(T)-1) until its parent comes up or — when the slots run out — re-read from HBM.
   std::vector<int> slot_of(I, -1);      // LDS slot holding internal node i (valid until consumed)
-  std::vector<char> recomputed(I, 0);   // finalised earlier in this schedule
+  std::vector<char> recomputed(I, 0);   // finalised earlier in THIS program
   const int n_slots = lds_slots(T);
   std::vector<char> slot_busy(n_slots, 0);
-  int fin = 0;
-  for (size_t ti = 0; ti < touched_list.size(); ti++) {
-    const int par = touched_list[ti];
+  const int off = (int)p->ops_host.size();
+  int fin = 0, root_slot = 0;
+  for (size_t ti = 0; ti < nodes.size(); ti++) {
+    const int par = nodes[ti];
     const std::vector<int> &ch = p->children[par];
     std::vector<int4> entries;
     std::vector<int> release_after;
@@ -196,7 +190,7 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
       } else {
         op.x = OPK_INTERNAL_GLOBAL | (0xff << 24);
         if (recomputed[c - L]) op.x |= OPF_GSYNC;
-        if (p->nuc && ti > 0 && touched_list[ti - 1] == c - L) op.x |= OPF_INREGS;
+        if (p->nuc && ti > 0 && nodes[ti - 1] == c - L) op.x |= OPF_INREGS;
       }
       entries.push_back(op);
     };
@@ -204,7 +198,7 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
     int first_internal = -1;
     if (ti > 0)
       for (int c : ch)
-        if (c >= L && c - L == touched_list[ti - 1]) first_internal = c;
+        if (c >= L && c - L == nodes[ti - 1]) first_internal = c;
     if (first_internal >= 0) internal_entry(first_internal);
     std::vector<int> leaves;
     for (int c : ch)
@@ -226,9 +220,9 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
       if (c >= L && c != first_internal) internal_entry(c);
     // destination slot of the finished node
     int dst = fin & 1;
-    const bool next_consumes = ti + 1 < touched_list.size() && p->parents[L + par] == touched_list[ti + 1];
+    const bool next_consumes = ti + 1 < nodes.size() && p->parents[L + par] == nodes[ti + 1];
     if (!p->nuc) {
-      if (!next_consumes && p->parents[L + par] >= 0) {
+      if (!next_consumes && ti + 1 < nodes.size()) {
         dst = -1;
         for (int sidx = 2; sidx < n_slots; sidx++)
           if (!slot_busy[sidx]) {
@@ -242,31 +236,132 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
           dst = fin & 1;  // no parking slot free: the consumer will re-read the persisted copy
         }
       } else {
-        slot_of[par] = dst;  // consumed by the very next parent from the exchange slot
+        slot_of[par] = dst;  // consumed by the very next parent from the exchange slot (or: last node)
       }
     }
     entries.back().x |= OPF_LAST | ((fin & 1) ? OPF_PARITY : 0) | (dst << 16);
     for (const int4 &e : entries) p->ops_host.push_back(e);
     for (int sidx : release_after) slot_busy[sidx] = 0;
     recomputed[par] = 1;
-    p->root_slot = dst;
+    root_slot = dst;
     fin++;
   }
-  // pad: even entry count + two trailing no-ops (empty leaf groups) so the device loop, unrolled by
-  // two and fetching entries two ahead, needs no bounds tests
-  p->n_ops_real = (int)p->ops_host.size();
-  if (!p->ops_host.empty()) {
-    int4 nop;
-    nop.x = OPK_LEAF | (0xff << 24);
-    nop.y = 0;
-    nop.z = 0;
-    nop.w = 0;
-    if (p->ops_host.size() & 1) p->ops_host.push_back(nop);
-    p->n_ops_padded = (int)p->ops_host.size();
-    p->ops_host.push_back(nop);
-    p->ops_host.push_back(nop);
+  int4 nop;
+  nop.x = OPK_LEAF | (0xff << 24);
+  nop.y = 0;
+  nop.z = 0;
+  nop.w = 0;
+  if ((p->ops_host.size() - off) & 1) p->ops_host.push_back(nop);
+  *offset_out = off;
+  *n_out = (int)p->ops_host.size() - off;
+  p->ops_host.push_back(nop);
+  p->ops_host.push_back(nop);
+  return root_slot;
+}
+
+// Build the device schedule for the nodes the host marked dirty.  update_nodes comes from
+// DetermineNodesForUpdate (tree.cpp:3117-3331): dirty nodes, their ancestors and the direct
+// children of every touched internal node.  We recompute every internal node that is the parent
+// of a listed node (plus ancestors, defensively) from ALL its children; children whose
+// conditionals were not recomputed in this call are read back from the persisted device copy.
+//
+// Full evaluations are cut into LEVELS of independent subtree fragments ("forest scheduling"): the
+// fragments of one level run concurrently as separate workgroups (grid.z), levels are separate
+// launches, fragment roots are handed up through the persisted copy in HBM.  With one workgroup per
+// 16-pattern tile walking the whole tree, 10k codons give only 624 workgroups for 768 resident
+// slots (and 78 per GPU when sharded 8 ways): cutting the tree multiplies the workgroup count.
+void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, bool full) {
+  const int L = (int)p->L, I = (int)p->I;
+  std::vector<char> touched(I, 0);
+  if (full) {
+    std::fill(touched.begin(), touched.end(), 1);
   } else {
-    p->n_ops_padded = 0;
+    for (int64_t k = 0; k < n_update; k++) {
+      int64_t n = update_nodes[k];
+      if (n < 0 || n >= L + I) continue;
+      int64_t par = p->parents[n];
+      while (par >= 0 && !touched[par]) {
+        touched[par] = 1;
+        par = p->parents[L + par];
+      }
+    }
+  }
+  p->ops_host.clear();
+  p->programs.clear();
+  p->levels.clear();
+  std::vector<int> touched_list;
+  for (int par = 0; par < I; par++)
+    if (touched[par]) touched_list.push_back(par);
+  if (touched_list.empty()) return;
+
+  // fragment size: aim at >= ~6 workgroups per CU over the whole launch sequence
+  int max_frag = I;
+  if (full && !p->nuc && !p->shards.empty()) {
+    const Shard &s0 = p->shards[0];
+    const long wgs = std::max(1, s0.ntiles / std::max(1, s0.T)) * (long)std::max<int64_t>(1, p->batch_classes);
+    const long target = 6L * s0.cus;
+    if (const char *e = getenv("HYPHY_HIP_FRAGMENT")) max_frag = std::max(1, atoi(e));
+    else if (wgs < target) max_frag = (int)std::max<long>(4, (long)I * wgs / target);
+  }
+  if (max_frag >= I || !full) {  // one program (also: every partial update)
+    int off, n;
+    p->root_slot = emit_program(p, touched_list, &off, &n);
+    p->programs.push_back({off, n});
+    p->levels.push_back({0, 1});
+    return;
+  }
+  // peel levels: a level's fragments are the maximal subtrees (in what is left of the tree) with at
+  // most max_frag internal nodes; their roots become HBM-resident inputs of the next level
+  std::vector<char> done(I, 0);
+  std::vector<int> size(I, 0);
+  for (;;) {
+    for (int n = 0; n < I; n++) {  // post-order: children before parents
+      if (done[n]) { size[n] = 0; continue; }
+      int sz = 1;
+      for (int c : p->children[n])
+        if (c >= L) sz += size[c - L];
+      size[n] = sz;
+    }
+    const int root = I - 1;
+    const int first_prog = (int)p->programs.size();
+    std::vector<std::vector<int>> frags;
+    if (size[root] <= max_frag) {
+      std::vector<int> rest;
+      for (int n = 0; n < I; n++)
+        if (!done[n]) rest.push_back(n);
+      frags.push_back(rest);
+    } else {
+      // fragment roots: size <= max_frag while the parent's is larger
+      std::vector<int> frag_root(I, -1);
+      for (int n = I - 1; n >= 0; n--) {  // parents before children
+        if (done[n]) continue;
+        const int par = (int)p->parents[L + n];
+        if (par >= 0 && !done[par] && frag_root[par] >= 0) frag_root[n] = frag_root[par];
+        else if (size[n] <= max_frag) frag_root[n] = n;
+      }
+      std::vector<int> index(I, -1);
+      for (int n = 0; n < I; n++) {
+        if (done[n] || frag_root[n] < 0) continue;
+        if (index[frag_root[n]] < 0) {
+          index[frag_root[n]] = (int)frags.size();
+          frags.push_back(std::vector<int>());
+        }
+        frags[index[frag_root[n]]].push_back(n);
+      }
+    }
+    bool finished = false;
+    for (const std::vector<int> &f : frags) {
+      int off, n;
+      const int rs = emit_program(p, f, &off, &n);
+      p->programs.push_back({off, n});
+      for (int nd : f) done[nd] = 1;
+      if (f.back() == root) {
+        p->root_slot = rs;
+        finished = true;
+      }
+    }
+    p->levels.push_back({first_prog, (int)frags.size()});
+    if (finished) break;
   }
 }
 
@@ -292,6 +387,8 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     HIPCHK(hipStreamSynchronize(s.stream));
     memcpy(s.h_ops, p->ops_host.data(), p->ops_host.size() * sizeof(int4));
     HIPCHK(hipMemcpyAsync(s.ops, s.h_ops, p->ops_host.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+    for (size_t k = 0; k < p->programs.size(); k++) s.h_prog[k] = make_int2(p->programs[k].off, p->programs[k].n);
+    HIPCHK(hipMemcpyAsync(s.prog, s.h_prog, p->programs.size() * sizeof(int2), hipMemcpyHostToDevice, s.stream));
   }
   // root frequencies, zero padded (uploaded only when they change)
   if (pi_changed) {
@@ -351,13 +448,14 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     tr.lap("launch_expm");
   }
   HIPCHK(hipEventRecord(s.ev[1], s.stream));
-  const int n_ops = p->n_ops_padded;
+  int n_ops = 0;  // longest program
+  for (const auto &pr : p->programs) n_ops = std::max(n_ops, pr.n);
   double *site_lik = s.site_lik + (size_t)cat * s.S_pad;
   int32_t *site_cnt = s.site_cnt + (size_t)cat * s.S_pad;
   int n_wg = 0;
   if (p->nuc) {
     NucArgs na;
-    na.ops = s.ops;
+    na.ops = s.ops + (p->programs.empty() ? 0 : p->programs[0].off);
     na.n_ops = n_ops;
     na.S_pad = s.S_pad;
     na.root_inode = (int)p->I - 1;
@@ -379,6 +477,9 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     PruneArgs pa;
     pa.ops = s.ops;
     pa.n_ops = n_ops;
+    pa.prog = s.prog;
+    pa.n_prog = 1;
+    pa.do_root = 1;
     pa.NW = p->NW;
     pa.T = s.T;
     pa.S_pad = s.S_pad;
@@ -416,7 +517,12 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       HIPCHK(hipMemsetAsync(pa.timeline, 0, tl_n * sizeof(long long), s.stream));
     }
     n_wg = prune_mfma_grid(pa);
-    launch_prune_mfma(pa, s.stream);
+    for (size_t lv = 0; lv < p->levels.size(); lv++) {  // one launch per level of subtree fragments
+      pa.prog = s.prog + p->levels[lv].first;
+      pa.n_prog = p->levels[lv].count;
+      pa.do_root = (lv + 1 == p->levels.size()) ? 1 : 0;
+      launch_prune_mfma(pa, s.stream);
+    }
     if (pa.timeline) {  // tracing only: synchronous dump of the per-entry s_memtime stamps
       std::vector<long long> h(tl_n);
       HIPCHK(hipStreamSynchronize(s.stream));
@@ -428,7 +534,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
           for (int w = 0; w < p->NW; w++)
             for (int o = 0; o < n_ops; o++) {
               const long long *r = &h[(((size_t)b * p->NW + w) * n_ops + o) * 4];
-              fprintf(f, "%d %d %d %d %lld %lld %lld %lld\n", b, w, o, p->ops_host[o].x & 0xff, r[0], r[1], r[2], r[3]);
+              fprintf(f, "%d %d %d %d %lld %lld %lld %lld\n", b, w, o, o < (int)p->ops_host.size() ? (p->ops_host[o].x & 0xff) : 0, r[0], r[1], r[2], r[3]);
             }
         fclose(f);
       }
@@ -639,6 +745,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       if (tiles_override >= 1 && tiles_override <= 4) T = tiles_override;
     }
     s.T = T;
+    s.cus = cus;
     if (p->nuc) {
       s.S_pad = (int)((s.S + 255) / 256 * 256);
       s.ntiles = 0;
@@ -670,6 +777,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     A_(s.qbuf, (size_t)C * B * D * D * sizeof(double));
     A_(s.slots, (size_t)C * B * sizeof(int32_t));
     A_(s.ops, ops_capacity(p) * sizeof(int4));
+    A_(s.prog, (size_t)(I + 2) * sizeof(int2));
     A_(s.pi, (size_t)DP * sizeof(double));
     A_(s.out, 2 * sizeof(double));
     A_(s.status, sizeof(int32_t));
@@ -681,6 +789,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
 #undef A_
     s.h_small_cap = (size_t)std::max<int64_t>(std::max<int64_t>(DP, C), 64);
     if (hipHostMalloc((void **)&s.h_ops, ops_capacity(p) * sizeof(int4)) != hipSuccess ||
+        hipHostMalloc((void **)&s.h_prog, (size_t)(I + 2) * sizeof(int2)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_out, 2 * sizeof(double)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_status, sizeof(int32_t)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_slots, (size_t)C * B * sizeof(int32_t)) != hipSuccess ||
@@ -733,6 +842,11 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   if (!p->initialized[cat] && n_q < p->B)
     return fail("first evaluation of a rate class must supply all L+I-1 transition matrices");
   bool changed = false;
+  const int64_t bc = batch ? p->C : 1;
+  if (bc != p->batch_classes) {
+    p->batch_classes = bc;
+    p->cached_valid = 0;  // fragment sizing depends on how many classes share the launch
+  }
   if (prepare_schedule(p, (int)cat, update_nodes, n_update, &changed)) return -1;
   bool pi_changed = p->cached_pi.size() != (size_t)p->D || memcmp(p->cached_pi.data(), root_freqs, p->D * sizeof(double));
   if (pi_changed) p->cached_pi.assign(root_freqs, root_freqs + p->D);

@@ -54,7 +54,11 @@ __host__ __device__ constexpr int lds_slots(int T) { return T == 1 ? 5 : (T == 2
 
 struct PruneArgs {
   const int4 *ops;
-  int n_ops;                 // even; two further no-op entries follow in memory
+  const int2 *prog;          // [grid.z] program table of this launch: (offset into ops, padded entry count)
+  int n_prog;                // programs (subtree fragments) in this launch = grid.z
+  int do_root;               // this launch finalises the root: run the root / log-sum epilogue
+  int n_ops;                 // longest program of the launch (trace buffer stride); every program is padded to
+                             // an even count and followed by two no-op entries
   int root_slot;             // LDS slot the root was finalised into
   int NW;                    // row blocks (waves per workgroup) = DP/16
   int T;                     // 16-pattern tiles per workgroup

@@ -85,6 +85,9 @@ struct Payload {
 template <int NW, int T, bool CLDS, bool TRACE, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, (T == 1 ? 3 : 1)) void prune_mfma_kernel(const int4 *__restrict__ ops,
                                                                                PruneArgs a) {
+  // forest scheduling: grid.z = subtree fragment of this level, each with its own program
+  const int2 prg = a.prog[blockIdx.z];
+  ops += prg.x;
   {  // rate-class batching: one grid row per class, same schedule, class-strided buffers
     const size_t cat = blockIdx.y;
     a.Pfrag += cat * a.cs_P;
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? 3 : 1)) void prune_mfma_kernel(c
   // Schedule entries come through scalar loads (SGPRs, uniform control flow), fetched two ahead.
   // The host pads the schedule to an even number of entries and appends two more no-op entries
   // (empty leaf groups), so the loop needs no bounds tests besides its own.
-  const int n_ops = a.n_ops;  // even
+  const int n_ops = prg.y;  // even
   int4 opA = ops[0];
   int4 opB = ops[1];
   Payload pA, pB;
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? 3 : 1)) void prune_mfma_kernel(c
 
   // root: L_s = sum_k root[s][k] pi[k]; this workgroup's share of sum_s f_s log L_s
   // (tree_evaluator.cpp:4046-4128) and of the integer scaler sum (likefunc.cpp:11123)
-  if (a.n_ops > 0) {
+  if (a.do_root) {
     const int rslot = a.root_slot;
     double pk[NKK];
 #pragma unroll
@@ -700,7 +703,7 @@ __global__ void unpack_partials_kernel(const double *__restrict__ partials, int 
 
 template <int NW, bool CLDS>
 void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
-  const dim3 grid(a.ntiles / a.T, a.n_cat > 0 ? a.n_cat : 1), block(64 * NW);
+  const dim3 grid(a.ntiles / a.T, a.n_cat > 0 ? a.n_cat : 1, a.n_prog > 0 ? a.n_prog : 1), block(64 * NW);
   const size_t lds = CLDS ? (size_t)a.L * a.T * 16 * sizeof(int16_t) : 0;
   if (a.timeline) {  // tracing build of the kernel (HYPHY_HIP_TIMELINE), T = 1 only
     hipLaunchKernelGGL((prune_mfma_kernel<NW, 1, CLDS, true>), grid, block, lds, stream, a.ops, a);
