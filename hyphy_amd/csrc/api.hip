@@ -52,6 +52,8 @@ struct Trace {
     }                                                                                             \
   } while (0)
 
+constexpr int kTimingRing = 1024;
+
 struct Shard {
   int device = 0;
   hipStream_t stream = nullptr;      // stream in use
@@ -85,14 +87,16 @@ struct Shard {
   double *coeffs = nullptr;
   // pinned host staging
   int4 *h_ops = nullptr;
-  double *h_out = nullptr;
-  int32_t *h_status = nullptr;
+  double *h_out = nullptr;    // pinned, host-mapped: the reduction kernel writes [log-L, scaler sum, status] here
+  double *d_hout = nullptr;   // device-side address of h_out
   int32_t *h_slots = nullptr;
   double *h_coeffs = nullptr;  // pinned ring (4 x C*B*K) for build_q coefficients
   unsigned coeff_turn = 0;
   double *h_small = nullptr;  // pi / weights staging
   size_t h_small_cap = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ring;  // kTimingRing pairs (start, end) around the pruning launches
+  uint64_t ring_count = 0;       // evaluations stamped so far
   size_t partial_stride = 0;  // doubles per class
 };
 
@@ -121,6 +125,7 @@ struct hyphy_hip_partition {
   std::vector<Level> levels;                 // launches: programs [first, first+count) run concurrently
   int64_t batch_classes = 1;                 // rate classes batched into the pruning launch being scheduled
   int slots_batch_mode = -1;                 // whether the slot table on the device was written for a class batch
+  bool all_timings = getenv("HYPHY_HIP_ALL_TIMINGS") != nullptr;  // also stamp expm / reduction (2 more event records)
   bool coeffs_pending = false;               // build_q staged coefficients; the next evaluate_device(q_buffer) fuses
                                              // the rate-matrix construction into the expm kernel
   int64_t K = 0;                             // Q templates
@@ -139,10 +144,12 @@ void free_shard(Shard &s) {
                  s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog};
   for (void *d : dev)
     if (d) hipFree(d);
-  void *host[] = {s.h_ops, s.h_out, s.h_status, s.h_slots, s.h_small, s.h_coeffs, s.h_prog};
+  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog};
   for (void *h : host)
     if (h) hipHostFree(h);
   for (auto &e : s.ev)
+    if (e) hipEventDestroy(e);
+  for (auto &e : s.ring)
     if (e) hipEventDestroy(e);
   if (s.own_stream) hipStreamDestroy(s.own_stream);
   s = Shard();
@@ -397,7 +404,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     if (upload_small(s, pi.data(), pi.size(), s.pi)) return -1;
   }
   tr.lap("ops+pi");
-  HIPCHK(hipEventRecord(s.ev[0], s.stream));
+  if (p->all_timings) HIPCHK(hipEventRecord(s.ev[0], s.stream));
   tr.lap("event0");
   if (n_q > 0) {
     // n_cat_batch > 1: the matrices of ALL rate classes in one expm launch, class-major; destination
@@ -447,7 +454,9 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     launch_expm(ea, s.stream);
     tr.lap("launch_expm");
   }
-  HIPCHK(hipEventRecord(s.ev[1], s.stream));
+  const size_t ring_slot = (size_t)(s.ring_count % kTimingRing) * 2;
+  HIPCHK(hipEventRecord(s.ring[ring_slot], s.stream));
+  if (p->all_timings) HIPCHK(hipEventRecord(s.ev[1], s.stream));
   int n_ops = 0;  // longest program
   for (const auto &pr : p->programs) n_ops = std::max(n_ops, pr.n);
   double *site_lik = s.site_lik + (size_t)cat * s.S_pad;
@@ -541,15 +550,21 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     }
   }
   tr.lap("launch_prune");
-  HIPCHK(hipEventRecord(s.ev[2], s.stream));
+  HIPCHK(hipEventRecord(s.ring[ring_slot + 1], s.stream));
+  s.ring_count++;
+  if (p->all_timings) HIPCHK(hipEventRecord(s.ev[2], s.stream));
   if (reduce) {
+    // synchronous entry points: the result record goes straight to host-mapped pinned memory (a
+    // posted PCIe write from the kernel) — an SDMA device-to-host copy after the kernels costs far more
+    double *rec = s.d_hout ? s.d_hout : s.out;
+    double *o0 = d_logl_out ? d_logl_out : rec, *o1 = d_logl_out ? s.out + 1 : rec + 1;
+    const int *st = d_logl_out ? nullptr : s.status;
     if (n_ops > 0 && !floor_log)  // the pruning kernel left per-workgroup partial sums
-      launch_wg_reduce(s.wg_sum, s.wg_cnt, s.wg_flag, n_wg, d_logl_out ? d_logl_out : s.out, s.out + 1, s.stream);
+      launch_wg_reduce(s.wg_sum, s.wg_cnt, s.wg_flag, n_wg, o0, o1, st, s.stream);
     else  // nothing was recomputed (or category mode): reduce the stored per-pattern values
-      launch_site_reduce(site_lik, site_cnt, s.freq, s.S_pad, floor_log ? 1 : 0, d_logl_out ? d_logl_out : s.out,
-                         s.out + 1, s.stream);
+      launch_site_reduce(site_lik, site_cnt, s.freq, s.S_pad, floor_log ? 1 : 0, o0, o1, st, s.stream);
   }
-  HIPCHK(hipEventRecord(s.ev[3], s.stream));
+  if (p->all_timings) HIPCHK(hipEventRecord(s.ev[3], s.stream));
   HIPCHK(hipGetLastError());
   tr.lap("reduce+events");
   return 0;
@@ -579,15 +594,13 @@ int prepare_schedule(hyphy_hip_partition *p, int cat, const int64_t *update_node
   return 0;
 }
 
+// Wait for every shard and read its host-mapped result record [log-L, scaler sum, status].
 int collect_status(hyphy_hip_partition *p) {
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
-    HIPCHK(hipMemcpyAsync(s.h_status, s.status, sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
-  }
-  for (Shard &s : p->shards) {
-    HIPCHK(hipSetDevice(s.device));
+    if (!s.d_hout) HIPCHK(hipMemcpyAsync(s.h_out, s.out, 3 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
     HIPCHK(hipStreamSynchronize(s.stream));
-    if (*s.h_status) {
+    if (s.h_out[2] != 0.) {
       hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream);
       return fail("Failed to compute a valid transition matrix; this is usually caused by ill-conditioned rate "
                   "matrices (e.g. very large rate values)");
@@ -601,6 +614,12 @@ void record_timings(hyphy_hip_partition *p) {
   float t;
   for (int k = 0; k < 3; k++) {
     t = 0.f;
+    if (k == 1 && s.ring_count > 0) {
+      const size_t slot = (size_t)((s.ring_count - 1) % kTimingRing) * 2;
+      if (hipEventElapsedTime(&t, s.ring[slot], s.ring[slot + 1]) == hipSuccess) p->timings[1] = t;
+      continue;
+    }
+    if (!p->all_timings) continue;
     if (hipEventElapsedTime(&t, s.ev[k], s.ev[k + 1]) == hipSuccess) p->timings[k] = t;
   }
 }
@@ -644,6 +663,22 @@ int gather_sites(hyphy_hip_partition *p, int cat, double *site_lik_out, int64_t 
 extern "C" {
 
 const char *hyphy_hip_last_error(void) { return g_last_error.c_str(); }
+
+int64_t hyphy_hip_prune_timings(hyphy_hip_partition *p, double *out_ms, int64_t n) {
+  if (!p || !out_ms || n <= 0 || p->shards.empty()) return 0;
+  Shard &s = p->shards[0];
+  if (hipSetDevice(s.device) != hipSuccess || hipStreamSynchronize(s.stream) != hipSuccess) return 0;
+  const int64_t have = (int64_t)std::min<uint64_t>(s.ring_count, (uint64_t)kTimingRing);
+  const int64_t m = std::min(n, have);
+  for (int64_t k = 0; k < m; k++) {
+    const uint64_t idx = s.ring_count - (uint64_t)m + (uint64_t)k;
+    const size_t slot = (size_t)(idx % kTimingRing) * 2;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, s.ring[slot], s.ring[slot + 1]) != hipSuccess) t = 0.f;
+    out_ms[k] = t;
+  }
+  return m;
+}
 const char *hyphy_hip_version(void) { return "hyphy_hip 0.1 (gfx950, FP64 MFMA)"; }
 
 int hyphy_hip_device_count(void) {
@@ -759,6 +794,8 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking);
     s.stream = s.own_stream;
     for (auto &e : s.ev) hipEventCreate(&e);
+    s.ring.assign(2 * kTimingRing, nullptr);
+    for (auto &e : s.ring) hipEventCreate(&e);
     A_(s.codes, (size_t)L * s.S_pad * sizeof(int16_t));
     A_(s.freq, (size_t)s.S_pad * sizeof(double));
     A_(s.ambig, (size_t)std::max<int64_t>(1, n_ambig) * DP * sizeof(double));
@@ -779,8 +816,8 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     A_(s.ops, ops_capacity(p) * sizeof(int4));
     A_(s.prog, (size_t)(I + 2) * sizeof(int2));
     A_(s.pi, (size_t)DP * sizeof(double));
-    A_(s.out, 2 * sizeof(double));
-    A_(s.status, sizeof(int32_t));
+    A_(s.out, 4 * sizeof(double));  // device-side result record [log-L, scaler sum, status copy, pad]
+    A_(s.status, sizeof(int32_t));  // set by the expm kernel when a matrix fails
     A_(s.weights, (size_t)C * sizeof(double));
     s.wg_cap = p->nuc ? (s.S_pad + 255) / 256 : s.ntiles;
     A_(s.wg_sum, (size_t)C * s.wg_cap * sizeof(double));  // x C: rate-class batching writes one row per class
@@ -790,14 +827,14 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     s.h_small_cap = (size_t)std::max<int64_t>(std::max<int64_t>(DP, C), 64);
     if (hipHostMalloc((void **)&s.h_ops, ops_capacity(p) * sizeof(int4)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_prog, (size_t)(I + 2) * sizeof(int2)) != hipSuccess ||
-        hipHostMalloc((void **)&s.h_out, 2 * sizeof(double)) != hipSuccess ||
-        hipHostMalloc((void **)&s.h_status, sizeof(int32_t)) != hipSuccess ||
+        hipHostMalloc((void **)&s.h_out, 4 * sizeof(double)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_slots, (size_t)C * B * sizeof(int32_t)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_small, s.h_small_cap * sizeof(double)) != hipSuccess) {
       hyphy_hip_destroy(p);
       return fail("hipHostMalloc failed");
     }
     hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream);
+    if (hipHostGetDevicePointer((void **)&s.d_hout, s.h_out, 0) != hipSuccess) s.d_hout = nullptr;
     hipMemsetAsync(s.partials, 0, (size_t)C * s.partial_stride * sizeof(double), s.stream);
     hipMemsetAsync(s.counts, 0, (size_t)C * I * s.S_pad * sizeof(int32_t), s.stream);
     hipMemsetAsync(s.site_lik, 0, (size_t)C * s.S_pad * sizeof(double), s.stream);
@@ -874,10 +911,6 @@ int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
                   true, false))
     return -1;
   std::vector<double> parts;
-  for (Shard &s : p->shards) {
-    HIPCHK(hipSetDevice(s.device));
-    HIPCHK(hipMemcpyAsync(s.h_out, s.out, 2 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
-  }
   if (collect_status(p)) return -1;
   for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
   record_timings(p);
@@ -900,7 +933,6 @@ int hyphy_hip_evaluate_built(hyphy_hip_partition *p, int64_t cat, const int64_t 
     return fail("evaluate_built: multi-device partitions use hyphy_hip_evaluate");
   }
   Shard &s = p->shards[0];
-  HIPCHK(hipMemcpyAsync(s.h_out, s.out, 2 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
   if (collect_status(p)) return -1;
   if (logl_out) *logl_out = s.h_out[0];
   return 0;
@@ -944,8 +976,8 @@ int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_
     HIPCHK(hipSetDevice(s.device));
     if (upload_small(s, weights, (size_t)p->C, s.weights)) return -1;
     launch_mix_categories(s.site_lik, s.site_cnt, s.weights, (int)p->C, s.S_pad, s.mixed_lik, s.mixed_cnt, s.stream);
-    launch_site_reduce(s.mixed_lik, s.mixed_cnt, s.freq, s.S_pad, 1, s.out, s.out + 1, s.stream);
-    HIPCHK(hipMemcpyAsync(s.h_out, s.out, 2 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    double *rec = s.d_hout ? s.d_hout : s.out;
+    launch_site_reduce(s.mixed_lik, s.mixed_cnt, s.freq, s.S_pad, 1, rec, rec + 1, s.status, s.stream);
   }
   if (collect_status(p)) return -1;
   for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
@@ -972,8 +1004,10 @@ int hyphy_hip_evaluate_categories_built(hyphy_hip_partition *p, const int64_t *u
     if (upload_small(s, weights, (size_t)p->C, s.weights)) return -1;
   }
   launch_mix_categories(s.site_lik, s.site_cnt, s.weights, (int)p->C, s.S_pad, s.mixed_lik, s.mixed_cnt, s.stream);
-  launch_site_reduce(s.mixed_lik, s.mixed_cnt, s.freq, s.S_pad, 1, s.out, s.out + 1, s.stream);
-  HIPCHK(hipMemcpyAsync(s.h_out, s.out, 2 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  {
+    double *rec = s.d_hout ? s.d_hout : s.out;
+    launch_site_reduce(s.mixed_lik, s.mixed_cnt, s.freq, s.S_pad, 1, rec, rec + 1, s.status, s.stream);
+  }
   if (collect_status(p)) return -1;
   if (logl_out) *logl_out = s.h_out[0];
   return 0;

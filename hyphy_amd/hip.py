@@ -21,7 +21,7 @@ EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
     "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
-    "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built",
+    "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings",
     "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
@@ -80,6 +80,8 @@ def load():
     lib.hyphy_hip_set_stream.argtypes = [vp, vp]
     lib.hyphy_hip_last_timings.restype = C.c_int
     lib.hyphy_hip_last_timings.argtypes = [vp, dp]
+    lib.hyphy_hip_prune_timings.restype = C.c_int64
+    lib.hyphy_hip_prune_timings.argtypes = [vp, dp, C.c_int64]
     lib.hyphy_hip_last_error.restype = C.c_char_p
     lib.hyphy_hip_version.restype = C.c_char_p
     _lib = lib
@@ -289,6 +291,13 @@ class HipPartition:
 
     def set_stream(self, stream_ptr: int):
         _check(self._lib.hyphy_hip_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def prune_timings(self, n: int) -> np.ndarray:
+        """Durations (ms) of the pruning launches of the last ``n`` evaluations (HIP event ring; queried
+        only now, never while evaluations run)."""
+        out = np.zeros(int(n))
+        m = int(self._lib.hyphy_hip_prune_timings(self._h, _d(out), int(n)))
+        return out[:m]
 
     def last_timings(self) -> np.ndarray:
         out = np.zeros(3)

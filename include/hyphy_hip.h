@@ -183,6 +183,11 @@ int hyphy_hip_set_stream(hyphy_hip_partition *p, void *stream);
  * out[0] = expm kernel(s), out[1] = pruning kernel, out[2] = root/site reduction. */
 int hyphy_hip_last_timings(hyphy_hip_partition *p, double out[3]);
 
+/* Durations (ms) of the pruning launches of the last `n` evaluations, oldest first, from a ring of HIP
+ * event pairs recorded on the partition's stream (shard 0).  Nothing is queried while evaluations run —
+ * call this after the timed region.  Returns the number of entries written (<= n, <= 1024). */
+int64_t hyphy_hip_prune_timings(hyphy_hip_partition *p, double *out_ms, int64_t n);
+
 const char *hyphy_hip_last_error(void);
 const char *hyphy_hip_version(void);
 

@@ -5,10 +5,11 @@ R=${1:-r01}
 OUT=/root/repo/gpurun_out/$R
 mkdir -p $OUT
 cd /root/repo
+HYPHY_HIP_ALL_TIMINGS=1 python bench.py --steps 200 --warmup 20 --pipelined > $OUT/bench_alltimings.json 2>/dev/null
 python bench.py --steps 200 --warmup 20 --pipelined > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python /root/repo/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats.log 2>&1
+HYPHY_HIP_ALL_TIMINGS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python /root/repo/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats.log 2>&1
 # counters: own runs, kernel-trace only (guide: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2 -> separate passes)
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
