@@ -241,11 +241,18 @@ def main():
             ach = bytes_ / (prune_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
         roof["kernel"] = "prune_mfma_kernel" if D > 4 else "prune_nuc_kernel"
+        # forest scheduling: the pruning pass of ONE evaluation is `launches_per_step` launches of the same
+        # kernel (levels of subtree fragments).  achieved = (algorithmic work of the pass / launches) / (mean
+        # launch duration) = work of the pass / time of the pass; rocprofv3's per-launch average x launches
+        # per step must agree with kernel_ms_per_step.
+        nl = part.prune_launches()
+        roof["launches_per_step"] = nl
+        roof["kernel_ms_per_launch"] = prune_ms / nl
         roof["kernel_ms"] = prune_ms
         roof["expm_ms"] = t_exp / args.steps
         roof["reduce_ms"] = t_red / args.steps
-        roof["alg_flops_per_launch"] = flops
-        roof["alg_bytes_per_launch"] = bytes_
+        roof["alg_flops_per_step"] = flops
+        roof["alg_bytes_per_step"] = bytes_
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:

@@ -664,6 +664,8 @@ extern "C" {
 
 const char *hyphy_hip_last_error(void) { return g_last_error.c_str(); }
 
+int hyphy_hip_prune_launches(hyphy_hip_partition *p) { return p ? (int)std::max<size_t>(1, p->levels.size()) : 0; }
+
 int64_t hyphy_hip_prune_timings(hyphy_hip_partition *p, double *out_ms, int64_t n) {
   if (!p || !out_ms || n <= 0 || p->shards.empty()) return 0;
   Shard &s = p->shards[0];

@@ -21,7 +21,7 @@ EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
     "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
-    "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings",
+    "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
@@ -82,6 +82,8 @@ def load():
     lib.hyphy_hip_last_timings.argtypes = [vp, dp]
     lib.hyphy_hip_prune_timings.restype = C.c_int64
     lib.hyphy_hip_prune_timings.argtypes = [vp, dp, C.c_int64]
+    lib.hyphy_hip_prune_launches.restype = C.c_int
+    lib.hyphy_hip_prune_launches.argtypes = [vp]
     lib.hyphy_hip_last_error.restype = C.c_char_p
     lib.hyphy_hip_version.restype = C.c_char_p
     _lib = lib
@@ -298,6 +300,9 @@ class HipPartition:
         out = np.zeros(int(n))
         m = int(self._lib.hyphy_hip_prune_timings(self._h, _d(out), int(n)))
         return out[:m]
+
+    def prune_launches(self) -> int:
+        return int(self._lib.hyphy_hip_prune_launches(self._h))
 
     def last_timings(self) -> np.ndarray:
         out = np.zeros(3)

@@ -187,6 +187,9 @@ int hyphy_hip_last_timings(hyphy_hip_partition *p, double out[3]);
  * event pairs recorded on the partition's stream (shard 0).  Nothing is queried while evaluations run —
  * call this after the timed region.  Returns the number of entries written (<= n, <= 1024). */
 int64_t hyphy_hip_prune_timings(hyphy_hip_partition *p, double *out_ms, int64_t n);
+/* Pruning-kernel launches per evaluation under the current schedule (forest scheduling cuts a full
+ * evaluation into levels of subtree fragments, one launch per level; partial updates use one). */
+int hyphy_hip_prune_launches(hyphy_hip_partition *p);
 
 const char *hyphy_hip_last_error(void);
 const char *hyphy_hip_version(void);
