@@ -73,8 +73,10 @@ struct Shard {
   double *qbuf = nullptr;                                   // [C*B*D*D]
   int32_t *slots = nullptr;                                 // [C*B]
   int4 *ops = nullptr;
-  int2 *prog = nullptr;       // program table (forest scheduling)
-  int2 *h_prog = nullptr;
+  int4 *prog = nullptr;       // program table (forest scheduling): (offset, entries, parent program, child programs)
+  int4 *h_prog = nullptr;
+  int *frag_ctr = nullptr;    // [classes][programs][tiles] arrivals of child fragments (wave-per-tile kernel)
+  int32_t *hand_cnt = nullptr;  // [classes][I][tiles][32] 2^64-exponents of fragment roots (own 128-byte line each)
   double *pi = nullptr;       // [DP]
   double *out = nullptr;      // [2]
   double *wg_sum = nullptr;   // per-workgroup partial sums of the pruning kernel
@@ -119,7 +121,9 @@ struct hyphy_hip_partition {
   std::vector<double> cached_weights;        // category weights currently on the device
   std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
   int root_slot = 0;
-  struct Prog { int off, n; };
+  int variant = 0;                           // pruning kernel variant (common.h PruneArgs::variant)
+  int n_slots = 0;                           // LDS slots the schedules are compiled for (0: lds_slots(T))
+  struct Prog { int off, n, parent = -1, need = 0; };
   struct Level { int first, count; };
   std::vector<Prog> programs;                // (offset, padded entry count) into ops_host
   std::vector<Level> levels;                 // launches: programs [first, first+count) run concurrently
@@ -141,7 +145,7 @@ void free_shard(Shard &s) {
   if (s.stream) hipStreamSynchronize(s.stream);
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
-                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog};
+                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt};
   for (void *d : dev)
     if (d) hipFree(d);
   void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog};
@@ -165,7 +169,8 @@ void free_shard(Shard &s) {
 // persisted copy in HBM (they were finalised by an earlier launch or are unchanged).  The program is
 // padded to an even entry count plus two trailing no-ops (the device loop is unrolled by two and
 // fetches entries two ahead).  Returns the LDS slot its last node was finalised into.
-int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *offset_out, int *n_out) {
+int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *offset_out, int *n_out,
+                 bool handoff = false, bool is_root_program = true) {
   const int L = (int)p->L, I = (int)p->I;
   const int T = p->shards.empty() ? 1 : p->shards[0].T;
   const int G = p->nuc ? 1 : (T <= 2 ? 2 : 1);  // leaves per leaf-group entry (prune.hip)
@@ -175,7 +180,7 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
   // (2..lds_slots(T)-1) until its parent comes up or — when the slots run out — re-read from HBM.
   std::vector<int> slot_of(I, -1);      // LDS slot holding internal node i (valid until consumed)
   std::vector<char> recomputed(I, 0);   // finalised earlier in THIS program
-  const int n_slots = lds_slots(T);
+  const int n_slots = p->n_slots > 0 ? p->n_slots : lds_slots(T);
   std::vector<char> slot_busy(n_slots, 0);
   const int off = (int)p->ops_host.size();
   int fin = 0, root_slot = 0;
@@ -197,6 +202,7 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
       } else {
         op.x = OPK_INTERNAL_GLOBAL | (0xff << 24);
         if (recomputed[c - L]) op.x |= OPF_GSYNC;
+        else if (handoff) op.x |= OPF_HANDOFF;  // root of a child fragment finished by another workgroup of this launch
         if (p->nuc && ti > 0 && nodes[ti - 1] == c - L) op.x |= OPF_INREGS;
       }
       entries.push_back(op);
@@ -210,18 +216,20 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
     std::vector<int> leaves;
     for (int c : ch)
       if (c < L) leaves.push_back(c);
-    for (size_t k = 0; k < leaves.size(); k += G) {
-      const int nl = (int)std::min<size_t>(G, leaves.size() - k);
+    // leaves in groups of G; a leaf that carries ambiguity codes (in this shard) forms a group of its own
+    // (its tiles may need a full matrix product instead of the column gather)
+    for (size_t k = 0; k < leaves.size();) {
+      int nl = 1;
+      const bool amb0 = p->leaf_has_ambig[leaves[k]];
+      if (!amb0 && G > 1 && k + 1 < leaves.size() && !p->leaf_has_ambig[leaves[k + 1]]) nl = 2;
       const unsigned l0 = (unsigned)leaves[k], l1 = nl > 1 ? (unsigned)leaves[k + 1] : l0;
-      int amb = 0;
-      for (int i = 0; i < nl; i++)
-        if (p->leaf_has_ambig[leaves[k + i]]) amb = OPF_AMBIG;
       int4 op;
-      op.x = OPK_LEAF | amb | (nl << 8) | (0xff << 24);
+      op.x = OPK_LEAF | (amb0 ? OPF_AMBIG : 0) | (nl << 8) | (0xff << 24);
       op.y = par;
       op.z = (int)(l0 | (l1 << 16));
       op.w = 0;
       entries.push_back(op);
+      k += nl;
     }
     for (int c : ch)
       if (c >= L && c != first_internal) internal_entry(c);
@@ -247,6 +255,7 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
       }
     }
     entries.back().x |= OPF_LAST | ((fin & 1) ? OPF_PARITY : 0) | (dst << 16);
+    if (handoff && !is_root_program && ti + 1 == nodes.size()) entries.back().x |= OPF_HANDOFF;  // fragment root
     for (const int4 &e : entries) p->ops_host.push_back(e);
     for (int sidx : release_after) slot_busy[sidx] = 0;
     recomputed[par] = 1;
@@ -318,7 +327,12 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
     return;
   }
   // peel levels: a level's fragments are the maximal subtrees (in what is left of the tree) with at
-  // most max_frag internal nodes; their roots become HBM-resident inputs of the next level
+  // most max_frag internal nodes; their roots become HBM-resident inputs of the next level.
+  // Wave-per-tile kernel: ONE launch; the fragments are chained on the device — the workgroup that
+  // completes the last child fragment of a program (per tile) goes on to run that program itself
+  // (arrival counters, prune.hip), so the levels below only define the cut, not launches.
+  const bool chained = p->variant >= 1;
+  std::vector<int> prog_of(I, -1);
   std::vector<char> done(I, 0);
   std::vector<int> size(I, 0);
   for (;;) {
@@ -359,8 +373,9 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
     bool finished = false;
     for (const std::vector<int> &f : frags) {
       int off, n;
-      const int rs = emit_program(p, f, &off, &n);
+      const int rs = emit_program(p, f, &off, &n, chained, f.back() == root);
       p->programs.push_back({off, n});
+      for (int nd : f) prog_of[nd] = (int)p->programs.size() - 1;
       for (int nd : f) done[nd] = 1;
       if (f.back() == root) {
         p->root_slot = rs;
@@ -368,7 +383,30 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
       }
     }
     p->levels.push_back({first_prog, (int)frags.size()});
+    if (getenv("HYPHY_HIP_VERBOSE")) {
+      fprintf(stderr, "[hyphy_hip] level %zu: %zu fragment(s), internal nodes:", p->levels.size() - 1, frags.size());
+      for (const std::vector<int> &f : frags) fprintf(stderr, " %zu", f.size());
+      fprintf(stderr, "\n");
+    }
     if (finished) break;
+  }
+  if (chained) {
+    for (size_t k = 0; k < p->programs.size(); k++) {
+      // the fragment root is the parent (y) of the last OPF_LAST entry of the program
+      int froot = -1;
+      for (int e = 0; e < p->programs[k].n; e++) {
+        const int4 &op = p->ops_host[p->programs[k].off + e];
+        if (op.x & OPF_LAST) froot = op.y;
+      }
+      const int par_node = froot >= 0 ? (int)p->parents[L + froot] : -1;
+      if (par_node >= 0) {
+        p->programs[k].parent = prog_of[par_node];
+        p->programs[p->programs[k].parent].need++;
+      }
+    }
+    const auto l0 = p->levels[0];
+    p->levels.clear();
+    p->levels.push_back(l0);  // one launch: grid.z = the leaf fragments; the rest is reached by chaining
   }
 }
 
@@ -394,8 +432,9 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     HIPCHK(hipStreamSynchronize(s.stream));
     memcpy(s.h_ops, p->ops_host.data(), p->ops_host.size() * sizeof(int4));
     HIPCHK(hipMemcpyAsync(s.ops, s.h_ops, p->ops_host.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
-    for (size_t k = 0; k < p->programs.size(); k++) s.h_prog[k] = make_int2(p->programs[k].off, p->programs[k].n);
-    HIPCHK(hipMemcpyAsync(s.prog, s.h_prog, p->programs.size() * sizeof(int2), hipMemcpyHostToDevice, s.stream));
+    for (size_t k = 0; k < p->programs.size(); k++)
+      s.h_prog[k] = make_int4(p->programs[k].off, p->programs[k].n, p->programs[k].parent, p->programs[k].need);
+    HIPCHK(hipMemcpyAsync(s.prog, s.h_prog, p->programs.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
   }
   // root frequencies, zero padded (uploaded only when they change)
   if (pi_changed) {
@@ -449,6 +488,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       ea.Prow = nullptr;
       ea.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
       ea.PTg = s.PTg + (size_t)cat * B * DP * DP;
+      ea.ptg_layout = p->variant == 2 ? 1 : 0;
     }
     tr.lap("slots+q");
     launch_expm(ea, s.stream);
@@ -496,6 +536,8 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     pa.root_inode = (int)p->I - 1;
     pa.root_slot = p->root_slot;
     pa.L = (int)p->L;
+    pa.variant = p->variant;
+    pa.n_slots = p->n_slots;
     pa.codes_in_lds = ((size_t)p->L * s.T * 32 + (size_t)(p->L + p->I) * 16 <= 24576) ? 1 : 0;
     pa.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
     pa.PTg = s.PTg + (size_t)cat * B * DP * DP;
@@ -526,6 +568,9 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       HIPCHK(hipMemsetAsync(pa.timeline, 0, tl_n * sizeof(long long), s.stream));
     }
     n_wg = prune_mfma_grid(pa);
+    pa.frag_ctr = s.frag_ctr;
+    pa.hand_cnt = s.hand_cnt;
+    pa.n_prog_total = (int)p->programs.size();
     for (size_t lv = 0; lv < p->levels.size(); lv++) {  // one launch per level of subtree fragments
       pa.prog = s.prog + p->levels[lv].first;
       pa.n_prog = p->levels[lv].count;
@@ -537,7 +582,17 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       HIPCHK(hipStreamSynchronize(s.stream));
       HIPCHK(hipMemcpy(h.data(), pa.timeline, tl_n * sizeof(long long), hipMemcpyDeviceToHost));
       hipFree(pa.timeline);
-      if (FILE *f = fopen(tl_path, "w")) {
+      if (p->variant == 2) {  // phase profile of the 4x4x4 wave kernel: [wg][16] = cycles[4], counts[4] (x2)
+        if (FILE *f = fopen(tl_path, "w")) {
+          fprintf(f, "# wg  cycles(leaf, internal, finalise, -)  counts(leaf, internal, finalise, -)\n");
+          for (int b = 0; b < kTraceWG; b++) {
+            fprintf(f, "%d", b);
+            for (int i = 0; i < 8; i++) fprintf(f, " %lld", h[(size_t)b * 16 + i]);
+            fprintf(f, "\n");
+          }
+          fclose(f);
+        }
+      } else if (FILE *f = fopen(tl_path, "w")) {
         fprintf(f, "# wg wave entry flags t_start t_compute_done t_after_barrier t_finalised\n");
         for (int b = 0; b < kTraceWG; b++)
           for (int w = 0; w < p->NW; w++)
@@ -783,6 +838,17 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     }
     s.T = T;
     s.cus = cus;
+    if (!p->nuc) {
+      // T = 1: wave-per-tile kernel (no cross-wave exchange); T > 1: workgroup-per-tile kernel
+      p->variant = 1;
+      if (const char *e = getenv("HYPHY_HIP_KERNEL")) p->variant = std::min(2, std::max(0, atoi(e)));
+      if (T != 1) p->variant = 0;
+      p->n_slots = lds_slots(T);
+      if (p->variant >= 1) {
+        p->n_slots = 3;  // two "exchange" ids (register hand-over) + one wave-private LDS parking slot
+        if (const char *e = getenv("HYPHY_HIP_SLOTS")) p->n_slots = atoi(e) == 2 ? 2 : 3;
+      }
+    }
     if (p->nuc) {
       s.S_pad = (int)((s.S + 255) / 256 * 256);
       s.ntiles = 0;
@@ -816,7 +882,12 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     A_(s.qbuf, (size_t)C * B * D * D * sizeof(double));
     A_(s.slots, (size_t)C * B * sizeof(int32_t));
     A_(s.ops, ops_capacity(p) * sizeof(int4));
-    A_(s.prog, (size_t)(I + 2) * sizeof(int2));
+    A_(s.prog, (size_t)(I + 2) * sizeof(int4));
+    if (!p->nuc) {
+      A_(s.frag_ctr, (size_t)C * (I + 2) * s.ntiles * sizeof(int));
+      hipMemset(s.frag_ctr, 0, (size_t)C * (I + 2) * s.ntiles * sizeof(int));
+      A_(s.hand_cnt, (size_t)C * I * s.ntiles * 32 * sizeof(int32_t));
+    }
     A_(s.pi, (size_t)DP * sizeof(double));
     A_(s.out, 4 * sizeof(double));  // device-side result record [log-L, scaler sum, status copy, pad]
     A_(s.status, sizeof(int32_t));  // set by the expm kernel when a matrix fails
@@ -828,7 +899,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
 #undef A_
     s.h_small_cap = (size_t)std::max<int64_t>(std::max<int64_t>(DP, C), 64);
     if (hipHostMalloc((void **)&s.h_ops, ops_capacity(p) * sizeof(int4)) != hipSuccess ||
-        hipHostMalloc((void **)&s.h_prog, (size_t)(I + 2) * sizeof(int2)) != hipSuccess ||
+        hipHostMalloc((void **)&s.h_prog, (size_t)(I + 2) * sizeof(int4)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_out, 4 * sizeof(double)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_slots, (size_t)C * B * sizeof(int32_t)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_small, s.h_small_cap * sizeof(double)) != hipSuccess) {
@@ -1036,7 +1107,7 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
         double *dtmp = nullptr;
         HIPCHK(hipMalloc((void **)&dtmp, (size_t)I * s.S * D * sizeof(double)));
         launch_unpack_partials_mfma(s.partials + (size_t)cat * s.partial_stride, (int)I, s.ntiles, p->NW, (int)D,
-                                    (int)s.S, s.s0, S, dtmp, s.stream);
+                                    (int)s.S, p->variant == 2 ? 1 : 0, dtmp, s.stream);
         hipError_t e = hipMemcpy2DAsync(inode_cache + s.s0 * D, (size_t)S * D * sizeof(double), dtmp,
                                         (size_t)s.S * D * sizeof(double), (size_t)s.S * D * sizeof(double), (size_t)I,
                                         hipMemcpyDeviceToHost, s.stream);
@@ -1050,7 +1121,11 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
       HIPCHK(hipMemcpy(tmp.data(), s.counts + (size_t)cat * I * s.S_pad, tmp.size() * sizeof(int32_t),
                        hipMemcpyDeviceToHost));
       for (int64_t n = 0; n < I; n++)
-        for (int64_t k = 0; k < s.S; k++) scaler_counts[n * S + s.s0 + k] = tmp[(size_t)n * s.S_pad + k];
+        for (int64_t k = 0; k < s.S; k++) {
+          // the 4x4x4 kernel keeps a tile's exponents as [site & 3][site >> 2] (one int4 per lane)
+          const int64_t within = p->variant == 2 ? (k & ~15) + (k & 3) * 4 + ((k >> 2) & 3) : k;
+          scaler_counts[n * S + s.s0 + k] = tmp[(size_t)n * s.S_pad + within];
+        }
     }
   }
   return 0;
@@ -1074,7 +1149,7 @@ int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_
   HIPCHK(hipMemcpy(dq, q_dense, bytes, hipMemcpyHostToDevice));
   ExpmArgs ea;
   ea.Q = dq; ea.slots = nullptr; ea.n = (int)n; ea.D = (int)D; ea.is_prob = 0;
-  ea.Prow = dp; ea.Pfrag = nullptr; ea.PTg = nullptr; ea.status = st;
+  ea.Prow = dp; ea.Pfrag = nullptr; ea.PTg = nullptr; ea.ptg_layout = 0; ea.status = st;
   ea.templates = nullptr; ea.coeffs = nullptr; ea.K = 0;
   launch_expm(ea, nullptr);
   int32_t hst = 0;

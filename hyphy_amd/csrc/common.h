@@ -36,6 +36,9 @@ __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1)
 // Host-compiled schedule entry (int4), built by build_schedule() in api.hip:
 //   x  bits 0-1  kind: OPK_LEAF (group of <= 2 leaf children), OPK_INTERNAL (child vector in an LDS
 //                slot), OPK_INTERNAL_GLOBAL (child vector = persisted copy in HBM)
+//      bit  2    OPF_HANDOFF (wave-per-tile kernel, chained fragments) internal-global entry: the child is the root of
+//                a fragment finished by ANOTHER workgroup of this launch — read it with agent-scope (sc1) loads;
+//                OPF_LAST entry: the finalised parent is such a fragment root — publish it with sc1 stores
 //      bit  3    OPF_LAST    last child of its parent: finalise the parent
 //      bit  4    parity of this finalisation (which psum buffer / exchange slot pair member)
 //      bit  5    OPF_GSYNC   (internal-global) copy was written earlier in THIS launch: full fence first
@@ -49,12 +52,16 @@ __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1)
 //   w  internal: child internal index
 // A parent's first entry needs no flag: the running product is reset when a parent is finalised.
 enum : int { OPK_LEAF = 0, OPK_INTERNAL = 1, OPK_INTERNAL_GLOBAL = 2 };
-enum : int { OPF_LAST = 8, OPF_PARITY = 16, OPF_GSYNC = 32, OPF_AMBIG = 64, OPF_INREGS = 128 };
-__host__ __device__ constexpr int lds_slots(int T) { return T == 1 ? 5 : (T == 2 ? 4 : (T == 3 ? 3 : 2)); }
+enum : int { OPF_HANDOFF = 4, OPF_LAST = 8, OPF_PARITY = 16, OPF_GSYNC = 32, OPF_AMBIG = 64, OPF_INREGS = 128 };
+#ifndef HYPHY_SLOTS1
+#define HYPHY_SLOTS1 5
+#endif
+__host__ __device__ constexpr int lds_slots(int T) { return T == 1 ? HYPHY_SLOTS1 : (T == 2 ? 4 : (T == 3 ? 3 : 2)); }
 
 struct PruneArgs {
   const int4 *ops;
-  const int2 *prog;          // [grid.z] program table of this launch: (offset into ops, padded entry count)
+  const int4 *prog;          // program table: (offset into ops, padded entry count, parent program or -1, number of
+                             // child programs); grid.z indexes the programs of this launch
   int n_prog;                // programs (subtree fragments) in this launch = grid.z
   int do_root;               // this launch finalises the root: run the root / log-sum epilogue
   int n_ops;                 // longest program of the launch (trace buffer stride); every program is padded to
@@ -67,6 +74,12 @@ struct PruneArgs {
   int root_inode;            // I - 1
   int L;                     // leaves
   int codes_in_lds;          // leaf codes of the workgroup's tiles are staged in LDS (L*T*32 bytes fit)
+  int n_prog_total;          // programs in the whole table (chained fragments: stride of frag_ctr)
+  int *frag_ctr;             // [class][program][tile] arrivals of finished child fragments (zero between launches)
+  int32_t *hand_cnt;         // [class][I][tile][32] exponents of fragment roots handed between workgroups
+  int variant;               // 0: workgroup-per-tile kernel (prune_mfma_kernel), 1: wave-per-tile kernel (T = 1),
+                             // 2: wave-per-tile kernel on the 4x4x4 MFMA (tile-layout partials, PTg layout 1)
+  int n_slots;               // LDS slots the schedule was compiled for (2 exchange + parking)
   const double *Pfrag;       // [B][NW][NKK*64]      A-operand images of the transition matrices
   const double *PTg;         // [B][DP][NW][4][4]    column-gather images (leaf edges)
   const int16_t *codes;      // [L][S_pad]           >= 0 state, < 0 -> -(k+1) ambiguity row
@@ -120,7 +133,8 @@ struct ExpmArgs {
   int is_prob;
   double *Prow;              // optional [.][D*D] row-major output (slot-indexed)
   double *Pfrag;             // optional [.][NW][NKK*64]
-  double *PTg;               // optional [.][DP][NW][16]
+  double *PTg;               // optional [.][DP][NW][16]  column-gather image (leaf edges), layout below
+  int ptg_layout;            // 0: [code][wb][g][r] = P[16wb + 4r + g][code];  1: [code][q][R] = P[16R + q][code]
   int32_t *status;           // [1] set to nonzero if any matrix failed (NaN / ill-conditioned)
   // optional fused rate-matrix construction: Q_m = sum_k coeffs[m][k] * templates[k]
   // off-diagonal, diagonal = -(row sum); when templates != nullptr, Q is ignored
@@ -142,7 +156,7 @@ int prune_nuc_grid(const NucArgs &a);
 void launch_mix_categories(const double *site_lik /*[C][S_pad]*/, const int32_t *site_cnt, const double *weights_dev,
                            int C, int S_pad, double *mixed_lik, int32_t *mixed_cnt, hipStream_t stream);
 void launch_build_q(const double *templates, const double *coeffs, int n, int K, int D, double *Q, hipStream_t stream);
-void launch_unpack_partials_mfma(const double *partials, int I, int ntiles, int NW, int D, int S, int64_t s0,
-                                 int64_t S_total, double *out /* device [I*S*D] shard-local */, hipStream_t stream);
+void launch_unpack_partials_mfma(const double *partials, int I, int ntiles, int NW, int D, int S, int tile_layout,
+                                 double *out, hipStream_t stream);
 
 }  // namespace hyhip

@@ -17,6 +17,10 @@
 //    the tree; observable contract of SURVEY A.5 (l_s, c_s with L_s = l_s 2^(-64 c_s)).
 #include "common.h"
 
+#ifndef HYPHY_OCC
+#define HYPHY_OCC 3  // waves per SIMD the T = 1 pruning kernel is compiled for
+#endif
+
 namespace hyhip {
 
 namespace {
@@ -73,6 +77,61 @@ struct Payload {
   f64x2 v[8];
 };
 
+// Root epilogue shared by the pruning kernels: L_s = sum_k root[s][k] pi[k]; this workgroup's share of
+// sum_s f_s log L_s (tree_evaluator.cpp:4046-4128) and of the integer scaler sum (likefunc.cpp:11123).
+// `rootv` = the root's unscaled conditional tiles in LDS (fragment layout), `rscale`/`rcnt` = this wave's
+// copy of the root's per-site scale and 2^64-exponent ([T][16]).
+template <int NW, int T>
+__device__ __forceinline__ void root_epilogue(const PruneArgs &a, const double *rootv0, const double *rscale,
+                                              const int *rcntv, int tile0, int w, int lane) {
+  constexpr int NKK = 4 * NW, TILE = NKK * 64;
+  const int g = lane >> 4, sl = lane & 15;
+  double pk[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; kk++) pk[kk] = a.pi[4 * kk + g];
+  double wsum = 0.;
+  long long wcnt = 0;
+  int wflag = 0;
+#pragma unroll
+  for (int t = 0; t < T; t++) {
+    double s = 0.;
+    const double *rootv = rootv0 + t * TILE;
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++) s = fma(rootv[frag_index(kk, lane)], pk[kk], s);
+    s *= rscale[t * 16 + sl];
+    const int rcnt = rcntv[t * 16 + sl];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (w == 0 && g == 0) {
+      const int site = (tile0 + t) * 16 + sl;
+      a.site_lik[site] = s;
+      a.site_cnt[site] = rcnt;
+      const double f = a.freq[site];
+      if (f != 0.) {
+        if (s != s || isinf(s)) wflag |= 2;
+        else if (s <= 0.) wflag |= 1;
+        else {
+          wsum += log(s) * f;
+          wcnt += (long long)rcnt * (long long)f;
+        }
+      }
+    }
+  }
+  if (w == 0) {  // fixed-order butterfly over the 16 site lanes (lanes >= 16 hold zeros)
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      wsum += __shfl_xor(wsum, off);
+      wcnt += __shfl_xor(wcnt, off);
+      wflag |= __shfl_xor(wflag, off);
+    }
+    if (lane == 0) {
+      a.wg_sum[blockIdx.x] = wsum;
+      a.wg_cnt[blockIdx.x] = wcnt;
+      a.wg_flag[blockIdx.x] = wflag;
+    }
+  }
+}
+
 // The pruning kernel interprets a host-compiled schedule (api.hip: build_schedule).  Everything that
 // can be decided on the host is: entry kind, which LDS slot a finished node goes to (including the
 // ping-pong parity of the two exchange slots), where a child vector is read from.  The device loop is
@@ -83,10 +142,10 @@ struct Payload {
 // CLDS: leaf codes of the workgroup's tiles are staged in LDS (the common case); the !CLDS variant
 // (thousands of taxa) reads them from global memory.
 template <int NW, int T, bool CLDS, bool TRACE, int ABL = 0>
-__global__ __launch_bounds__(64 * NW, (T == 1 ? 3 : 1)) void prune_mfma_kernel(const int4 *__restrict__ ops,
+__global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_kernel(const int4 *__restrict__ ops,
                                                                                PruneArgs a) {
   // forest scheduling: grid.z = subtree fragment of this level, each with its own program
-  const int2 prg = a.prog[blockIdx.z];
+  const int4 prg = a.prog[blockIdx.z];
   ops += prg.x;
   {  // rate-class batching: one grid row per class, same schedule, class-strided buffers
     const size_t cat = blockIdx.y;
@@ -378,53 +437,721 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? 3 : 1)) void prune_mfma_kernel(c
     opB = opD;
   }
 
-  // root: L_s = sum_k root[s][k] pi[k]; this workgroup's share of sum_s f_s log L_s
-  // (tree_evaluator.cpp:4046-4128) and of the integer scaler sum (likefunc.cpp:11123)
-  if (a.do_root) {
-    const int rslot = a.root_slot;
-    double pk[NKK];
+  if (a.do_root)
+    root_epilogue<NW, T>(a, xbuf + (size_t)a.root_slot * T * TILE, &slot_scale[a.root_slot][w][0][0],
+                         &slot_cnt[a.root_slot][w][0][0], tile0, w, lane);
+}
+
+// sum over the four 16-lane rows of a wave (every lane ends up with the same value, same order)
+__device__ __forceinline__ double row_sum4(double x) {
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-per-tile variant (T = 1): ONE wave owns a 16-pattern tile and all DP parent rows, so there is
+// no cross-wave exchange at all — no barrier, no LDS round trip for the common child -> parent hand
+// over.  The MFMA C/D image equals the B-operand image (kk = 4w + r), so the node finalised last is
+// the next product's B operand straight from registers; per child edge the wave issues NW*NKK MFMAs
+// on NW independent accumulator chains while streaming P's A-operand image from L2.  Nodes whose
+// parent is not the next schedule entry are parked in a wave-private LDS slot (NP of them) or re-read
+// from their persisted copy.  Workgroup = one wave; the grid is (tiles, classes, fragments).
+// ---------------------------------------------------------------------------------------------
+#ifndef HYPHY_OCC3
+#define HYPHY_OCC3 2
+#endif
+
+template <int NW, int NP, bool CLDS>
+__global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *__restrict__ ops, const int4 *__restrict__ prog,
+                                                                             PruneArgs a) {
+  int cur = blockIdx.z;  // program (subtree fragment) this wave starts with
+  {
+    const size_t cat = blockIdx.y;
+    a.frag_ctr += cat * (size_t)a.n_prog_total * a.ntiles;
+    a.hand_cnt += cat * (size_t)(a.root_inode + 1) * a.ntiles * 32;
+    a.Pfrag += cat * a.cs_P;
+    a.PTg += cat * a.cs_P;
+    a.partials += cat * a.cs_partials;
+    a.counts += cat * a.cs_counts;
+    a.site_lik += cat * a.cs_site;
+    a.site_cnt += cat * a.cs_site;
+    a.wg_sum += cat * a.cs_wg;
+    a.wg_cnt += cat * a.cs_wg;
+    a.wg_flag += cat * a.cs_wg;
+  }
+  constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
+  __shared__ __align__(16) double park[(NP > 0 ? NP : 1) * TILE];  // parked nodes (scaled), fragment layout
+  __shared__ int park_cnt[(NP > 0 ? NP : 1)][16];
+  extern __shared__ __align__(16) int16_t codes_lds[];  // CLDS: [L][16]
+
+  const int lane = threadIdx.x, g = lane >> 4, sl = lane & 15;
+  const int tile0 = blockIdx.x;
+  const int S_pad = a.S_pad;
+
+  if (CLDS) {
+    const int n = a.L * 16;
+    for (int i = lane; i < n; i += 64) codes_lds[i] = a.codes[(size_t)(i >> 4) * S_pad + tile0 * 16 + (i & 15)];
+    __syncthreads();
+  }
+  auto leaf_code = [&](int leaf) -> int {
+    if (CLDS) return (int)codes_lds[leaf * 16 + sl];
+    return (int)a.codes[(size_t)leaf * S_pad + tile0 * 16 + sl];
+  };
+
+  const f64x4 ones = (f64x4){1., 1., 1., 1.}, zeros = (f64x4){0., 0., 0., 0.};
+  f64x4 acc[NW], bch[NW];  // running product of the current parent / the node finalised last (scaled)
+  int cnt = 0, bcnt = 0;
 #pragma unroll
-    for (int kk = 0; kk < NKK; kk++) pk[kk] = a.pi[4 * kk + g];
+  for (int w = 0; w < NW; w++) acc[w] = ones, bch[w] = zeros;
+
+  // acc[w'] *= sum_kk A[w'][kk] * B[kk]: `bsrc(k2)` yields the B operands of k-steps 2*k2, 2*k2 + 1.
+  // Explicit two-stage software pipeline: the operands of step k2 + 1 are requested before the MFMAs of
+  // step k2 are issued (sched_barrier: left alone, the scheduler sinks the loads below the MFMAs to save
+  // registers and then waits for them with vmcnt(0) — eight exposed L2 round trips per edge).
+  auto edge_product = [&](int branch, auto bsrc) {
+    const double *pf = a.Pfrag + (size_t)branch * NW * TILE;  // uniform
+    f64x4 D[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) D[w] = zeros;
+    f64x2 Ac[NW], An[NW], bc, bn;
+#pragma unroll
+    for (int w = 0; w < NW; w++) Ac[w] = ld16(pf, (unsigned)((w * TILE + lane * 2) * 8));
+    bc = bsrc(0);
+#pragma unroll
+    for (int k2 = 0; k2 < NKK / 2; k2++) {
+      if (k2 + 1 < NKK / 2) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) An[w] = ld16(pf, (unsigned)((w * TILE + ((k2 + 1) * 64 + lane) * 2) * 8));
+        bn = bsrc(k2 + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int w = 0; w < NW; w++) D[w] = mfma(Ac[w][0], bc[0], D[w]);
+#pragma unroll
+      for (int w = 0; w < NW; w++) D[w] = mfma(Ac[w][1], bc[1], D[w]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int w = 0; w < NW; w++) Ac[w] = An[w];
+      bc = bn;
+    }
+#pragma unroll
+    for (int w = 0; w < NW; w++) acc[w] *= D[w];
+  };
+  auto leaf_gather = [&](int lf, int c) {
+    const double *bl = a.PTg + (size_t)lf * DP * DP;  // uniform; [code][w][g][r]
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const unsigned off = (unsigned)((c * NW + w) * 16 + g * 4) * 8u;
+      const f64x2 v0 = ld16(bl, off), v1 = ld16(bl, off + 16u);
+      acc[w] *= (f64x4){v0[0], v0[1], v1[0], v1[1]};
+    }
+  };
+
+  // agent-scope 8-byte accesses for data handed between workgroups (fragment roots): write-through
+  // stores / L1-bypassing loads, valid under any workgroup -> XCD placement
+  auto ld_agent = [](const double *p) -> double {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto st_agent = [](double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+
+ for (;;) {  // chained fragments: run program `cur`, then possibly its parent program
+  const int4 prg = prog[cur];  // (scalar load: uniform control flow, schedule entries in SGPRs)
+  const int4 *__restrict__ pops = ops + prg.x;
+  const int n_ops = prg.y;
+  int4 op = pops[0];
+  for (int oi = 0; oi < n_ops; oi++) {
+    const int4 nxt = pops[oi + 1];
+    const int kind = op.x & 3;
+    if (kind == OPK_LEAF) {
+      const int nl = (op.x >> 8) & 0xff;
+      for (int i = 0; i < nl; i++) {
+        const int lf = (op.z >> (16 * i)) & 0xffff;
+        const int c = leaf_code(lf);
+        if (!(op.x & OPF_AMBIG) || !__any(c < 0)) {
+          leaf_gather(lf, c < 0 ? 0 : c);
+        } else {  // ambiguity codes in this tile: full product with the resolution vector
+          const double *av = a.ambig + (size_t)(c < 0 ? -c - 1 : 0) * DP;
+          edge_product(lf, [&](int k2) -> f64x2 {
+            f64x2 b;
+            b[0] = (c >= 0) ? ((8 * k2 + g == c) ? 1.0 : 0.0) : av[8 * k2 + g];
+            b[1] = (c >= 0) ? ((8 * k2 + 4 + g == c) ? 1.0 : 0.0) : av[8 * k2 + 4 + g];
+            return b;
+          });
+        }
+      }
+    } else if (kind == OPK_INTERNAL) {
+      const int slot = (op.x >> 24) & 0xff;
+      if (slot < 2) {  // the node finalised by the previous entry: operand straight from registers
+        edge_product(op.z, [&](int k2) -> f64x2 {
+          return (f64x2){bch[k2 >> 1][(k2 & 1) * 2], bch[k2 >> 1][(k2 & 1) * 2 + 1]};
+        });
+        cnt += bcnt;
+      } else {
+        const double *src = park + (slot - 2) * TILE;
+        const int ccnt = park_cnt[slot - 2][sl];
+        edge_product(op.z, [&](int k2) -> f64x2 {
+          return *reinterpret_cast<const f64x2 *>(src + (k2 * 64 + lane) * 2);
+        });
+        cnt += ccnt;
+      }
+    } else if (op.x & OPF_HANDOFF) {
+      // root of a child fragment, finished by another workgroup of this launch (its arrival was counted
+      // before this program started): agent-scope loads
+      const double *src = a.partials + ((size_t)op.w * a.ntiles + tile0) * TILE;  // uniform
+      const int ccnt = __hip_atomic_load(a.hand_cnt + ((size_t)op.w * a.ntiles + tile0) * 32 + sl, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+      edge_product(op.z, [&](int k2) -> f64x2 {
+        const double *q = src + (k2 * 64 + lane) * 2;
+        return (f64x2){ld_agent(q), ld_agent(q + 1)};
+      });
+      cnt += ccnt;
+    } else {
+      // child not recomputed by this program, or no parking slot was free: persisted copy
+      if (op.x & OPF_GSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own stores visible in L2
+      const double *src = a.partials + ((size_t)op.w * a.ntiles + tile0) * TILE;  // uniform
+      const int ccnt = a.counts[(size_t)op.w * S_pad + tile0 * 16 + sl];
+      edge_product(op.z, [&](int k2) -> f64x2 { return ld16(src, (unsigned)(k2 * 64 + lane) * 16u); });
+      cnt += ccnt;
+    }
+
+    if (op.x & OPF_LAST) {
+      const int slot = (op.x >> 16) & 0xff;
+      double s = 0.;
+#pragma unroll
+      for (int w = 0; w < NW; w++) s += (acc[w][0] + acc[w][1]) + (acc[w][2] + acc[w][3]);
+      const double tot = row_sum4(s);
+      double sc = 1.0;
+      int m = 0;
+      if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) m = rescale_decision(tot, sc);  // rare
+      cnt += m;
+      double *out = a.partials + ((size_t)op.y * a.ntiles + tile0) * TILE;  // uniform
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        bch[w] = acc[w] * sc;
+        acc[w] = ones;
+      }
+      if (op.x & OPF_HANDOFF) {  // fragment root: another workgroup may consume it in this launch
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          double *q = out + ((2 * w) * 64 + lane) * 2;
+          st_agent(q, bch[w][0]);
+          st_agent(q + 1, bch[w][1]);
+          st_agent(q + 128, bch[w][2]);
+          st_agent(q + 129, bch[w][3]);
+        }
+        if (g == 0)
+          __hip_atomic_store(a.hand_cnt + ((size_t)op.y * a.ntiles + tile0) * 32 + sl, cnt, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          st16(out, (unsigned)((2 * w) * 64 + lane) * 16u, (f64x2){bch[w][0], bch[w][1]});
+          st16(out, (unsigned)((2 * w + 1) * 64 + lane) * 16u, (f64x2){bch[w][2], bch[w][3]});
+        }
+      }
+      if (g == 0) a.counts[(size_t)op.y * S_pad + tile0 * 16 + sl] = cnt;
+      if (NP > 0 && slot >= 2) {  // park for a later parent
+        double *dst = park + (slot - 2) * TILE;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          *reinterpret_cast<f64x2 *>(dst + ((2 * w) * 64 + lane) * 2) = (f64x2){bch[w][0], bch[w][1]};
+          *reinterpret_cast<f64x2 *>(dst + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){bch[w][2], bch[w][3]};
+        }
+        park_cnt[slot - 2][sl] = cnt;
+      }
+      bcnt = cnt;
+      cnt = 0;
+    }
+    op = nxt;
+  }
+  if (prg.z < 0) break;  // the root program (or a stand-alone one)
+  // arrival at the parent program: the wave that completes the parent's last child fragment (for this
+  // tile) continues with the parent; every other wave retires.  Payload stores were write-through.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int *ctr = a.frag_ctr + (size_t)prg.z * a.ntiles + tile0;
+  int old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old + 1 < prog[prg.z].w) return;
+  if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  cur = prg.z;
+ }
+
+  if (a.do_root) {
+    // root: L_s = sum_k root[s][k] pi[k]; bch holds the (scaled) root conditionals, bcnt its exponent
+    double s = 0.;
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++) s = fma(bch[kk >> 2][kk & 3], a.pi[4 * kk + g], s);
+    s = row_sum4(s);
     double wsum = 0.;
     long long wcnt = 0;
     int wflag = 0;
-#pragma unroll
-    for (int t = 0; t < T; t++) {
-      double s = 0.;
-      const double *rootv = xbuf + (rslot * T + t) * TILE;
-#pragma unroll
-      for (int kk = 0; kk < NKK; kk++) s = fma(rootv[frag_index(kk, lane)], pk[kk], s);
-      s *= slot_scale[rslot][w][t][sl];
-      const int rcnt = slot_cnt[rslot][w][t][sl];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (w == 0 && g == 0) {
-        const int site = (tile0 + t) * 16 + sl;
-        a.site_lik[site] = s;
-        a.site_cnt[site] = rcnt;
-        const double f = a.freq[site];
-        if (f != 0.) {
-          if (s != s || isinf(s)) wflag |= 2;
-          else if (s <= 0.) wflag |= 1;
-          else {
-            wsum += log(s) * f;
-            wcnt += (long long)rcnt * (long long)f;
-          }
+    if (g == 0) {
+      const int site = tile0 * 16 + sl;
+      a.site_lik[site] = s;
+      a.site_cnt[site] = bcnt;
+      const double f = a.freq[site];
+      if (f != 0.) {
+        if (s != s || isinf(s)) wflag |= 2;
+        else if (s <= 0.) wflag |= 1;
+        else {
+          wsum += log(s) * f;
+          wcnt += (long long)bcnt * (long long)f;
         }
       }
     }
-    if (w == 0) {  // fixed-order butterfly over the 16 site lanes (lanes >= 16 hold zeros)
 #pragma unroll
-      for (int off = 8; off > 0; off >>= 1) {
-        wsum += __shfl_xor(wsum, off);
-        wcnt += __shfl_xor(wcnt, off);
-        wflag |= __shfl_xor(wflag, off);
+    for (int off = 8; off > 0; off >>= 1) {  // fixed-order butterfly over the 16 site lanes
+      wsum += __shfl_xor(wsum, off);
+      wcnt += __shfl_xor(wcnt, off);
+      wflag |= __shfl_xor(wflag, off);
+    }
+    if (lane == 0) {
+      a.wg_sum[blockIdx.x] = wsum;
+      a.wg_cnt[blockIdx.x] = wcnt;
+      a.wg_flag[blockIdx.x] = wflag;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-per-tile kernel on v_mfma_f64_4x4x4_4b_f64 (T = 1, "tile layout" partials).
+//
+// Measured on MI355X (tools/ubench_mfma_f64, tools/probe_mfma_4x4x4): the 16x16x4 f64 MFMA sustains
+// one instruction per ~100 cycles per SIMD (49 TFLOP/s chip-wide, a single wave only one per ~143),
+// while the four-block 4x4x4 f64 MFMA issues every ~18 cycles (62-73 TFLOP/s, 85 % of that from ONE
+// wave per SIMD).  Operand lanes of the 4x4x4 form (probe): A[b][i][k] <- lane i + 4b + 16k,
+// B[b][k][j] <- lane j + 4b + 16k, D[b][i][j] -> lane j + 4b + 16i (block b, no broadcast modes).
+//
+// Mapping: block b = 4-row group inside a 16-row block R of the parent (row = 16R + 4b + i), so the
+// A operand of (R, k-step) is exactly the Pfrag image the 16x16x4 kernels use; the B operand of
+// (k-step, site quad J) is a 4 x 4 piece of the child's conditionals replicated over the blocks — a
+// broadcast read of the child's tile from wave-private LDS (lanes differing only in b read the same
+// address).  D(R, J): lane (j, b, i) holds parent[16R + 4b + i][site 4J + j]; 4 NW accumulators of 16
+// independent chains.  A finished node is written once to the wave's LDS tile (feeds the next
+// product) and once to HBM (persist), both in the "quad layout": element (state 16R + 4b + i, site 4J + j)
+// at ((2R + (J >> 1))*64 + j + 4i + 16b)*2 + (J & 1) — every wave store is one contiguous 1 KiB line, and
+// the 16 distinct 16-byte chunks of a B-operand read tile the 64 LDS banks exactly (no conflicts).
+// ---------------------------------------------------------------------------------------------
+#ifndef HYPHY_OCC4
+#define HYPHY_OCC4 2
+#endif
+#ifndef HYPHY_PF
+#define HYPHY_PF 1  // A-operand prefetch distance in steps of 32 MFMAs
+#endif
+
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+// butterfly sum over lane bits 2..5 (the 16 (b, i) lanes of a site column): bit-identical in all lanes
+__device__ __forceinline__ double col_sum16(double x) {
+  x += __shfl_xor(x, 4);
+  x += __shfl_xor(x, 8);
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+
+template <int NW, int NP, bool CLDS, bool PROF>
+__global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__restrict__ ops, const int4 *__restrict__ prog,
+                                                                           PruneArgs a) {
+  int cur = blockIdx.z;  // program (subtree fragment) this wave starts with
+  {
+    const size_t cat = blockIdx.y;
+    a.frag_ctr += cat * (size_t)a.n_prog_total * a.ntiles;
+    a.hand_cnt += cat * (size_t)(a.root_inode + 1) * a.ntiles * 32;
+    a.Pfrag += cat * a.cs_P;
+    a.PTg += cat * a.cs_P;
+    a.partials += cat * a.cs_partials;
+    a.counts += cat * a.cs_counts;
+    a.site_lik += cat * a.cs_site;
+    a.site_cnt += cat * a.cs_site;
+    a.wg_sum += cat * a.cs_wg;
+    a.wg_cnt += cat * a.cs_wg;
+    a.wg_flag += cat * a.cs_wg;
+  }
+  constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = DP * 16;
+  __shared__ __align__(16) double xl[(1 + NP) * TILE];  // [0]: node finalised last; [1..NP]: parked nodes (scaled)
+  __shared__ __align__(16) int xcnt[1 + NP][16];        // their 2^64-exponents, [j][J]
+  extern __shared__ __align__(16) int16_t codes_lds[];  // CLDS: [L][16]
+
+  const int lane = threadIdx.x;
+  const int j = lane & 3, bq = (lane >> 2) & 3, iq = lane >> 4;  // D-operand roles of this lane
+  const int q16 = 4 * bq + iq;                                  // its row inside a 16-row block
+  const int kB = lane >> 4;                                     // B-operand role: k inside a k-step
+  const int posw = j + 4 * iq + 16 * bq;                        // chunk this lane owns in a tile (quad layout)
+  // Per-lane byte offsets, kept in ONE register each; everything else in an address is wave-uniform and
+  // goes into the scalar base / the immediate (a per-lane 64-bit address per unrolled access makes the
+  // compiler hoist dozens of them out of the schedule loop and spill them).
+  const unsigned lane16 = (unsigned)lane * 16u, posw16 = (unsigned)posw * 16u, blane16 = (unsigned)(4 * kB + j) * 16u;
+  const int tile0 = blockIdx.x;
+  const int S_pad = a.S_pad;
+
+  if (CLDS) {
+    const int n = a.L * 16;
+    for (int i = lane; i < n; i += 64) codes_lds[i] = a.codes[(size_t)(i >> 4) * S_pad + tile0 * 16 + (i & 15)];
+    __syncthreads();
+  }
+  auto leaf_code = [&](int leaf, int site) -> int {
+    if (CLDS) return (int)codes_lds[leaf * 16 + site];
+    return (int)a.codes[(size_t)leaf * S_pad + tile0 * 16 + site];
+  };
+  auto ld_agent = [](const double *p) -> double {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto st_agent = [](double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+
+  double acc[NW][4];  // running product of the current parent: rows 16R + q16, sites 4J + j
+  int cnt[4];         // 2^64-exponent of the running product, sites 4J + j
+#pragma unroll
+  for (int J = 0; J < 4; J++) {
+    cnt[J] = 0;
+#pragma unroll
+    for (int R = 0; R < NW; R++) acc[R][J] = 1.0;
+  }
+  // B operand of k-step kk (state rows 4kk..4kk+3 = block R' = kk >> 2, quad c = kk & 3): the two chunks
+  // (site quads J = 0,1 and 2,3) owned by writer lane j + 4 kB + 16 c; element offset inside a tile:
+  auto b_elem = [](int kk) -> int { return (((kk >> 2) * 2) * 64 + 16 * (kk & 3)) * 2; };  // + blane16 bytes
+
+  // A (P's operand image, L2/MALL-resident) is requested PF steps of 32 MFMAs ahead, and the first PF
+  // steps of an edge already while the PREVIOUS schedule entry finishes (prefetch_A): one step is
+  // ~600 cycles of MFMAs, an L2 round trip under load ~1300.
+  constexpr int NS2 = NKK / 2, PF = NS2 < HYPHY_PF ? NS2 : HYPHY_PF;
+  f64x2 Ar[PF + 1][NW];
+#pragma unroll
+  for (int st = 0; st <= PF; st++)
+#pragma unroll
+    for (int R = 0; R < NW; R++) Ar[st][R] = (f64x2){0., 0.};
+  auto prefetch_A = [&](int branch) {
+    const double *pf = a.Pfrag + (size_t)branch * DP * DP;  // uniform
+#pragma unroll
+    for (int st = 0; st < PF; st++)
+#pragma unroll
+      for (int R = 0; R < NW; R++) Ar[st][R] = ld16(pf + R * NKK * 64 + st * 128, lane16);
+  };
+  // acc(R, J) *= sum_k A(R, k) B(k, J) with B = tile `xi` of the wave's LDS (every child goes through LDS:
+  // the node finalised last, a parked node, or a staged copy — ONE instance of the MFMA block).
+  // Precondition: prefetch_A(branch) was issued.
+  auto edge_product = [&](int branch, int xi) {
+    const double *pf = a.Pfrag + (size_t)branch * DP * DP;  // uniform
+    const char *src = reinterpret_cast<const char *>(xl + xi * TILE) + blane16;
+    auto bsrc = [&](int kk) -> f64x4 {
+      const f64x2 u0 = *reinterpret_cast<const f64x2 *>(src + b_elem(kk) * 8),
+                  u1 = *reinterpret_cast<const f64x2 *>(src + b_elem(kk) * 8 + 1024);
+      return (f64x4){u0[0], u0[1], u1[0], u1[1]};
+    };
+    double D[NW][4];
+#pragma unroll
+    for (int R = 0; R < NW; R++)
+#pragma unroll
+      for (int J = 0; J < 4; J++) D[R][J] = 0.;
+    f64x4 Bc[2], Bn[2];
+    Bc[0] = bsrc(0);
+    Bc[1] = bsrc(1);
+#pragma unroll
+    for (int k2 = 0; k2 < NS2; k2++) {
+      if (k2 + PF < NS2) {
+#pragma unroll
+        for (int R = 0; R < NW; R++) Ar[(k2 + PF) % (PF + 1)][R] = ld16(pf + R * NKK * 64 + (k2 + PF) * 128, lane16);
       }
-      if (lane == 0) {
-        a.wg_sum[blockIdx.x] = wsum;
-        a.wg_cnt[blockIdx.x] = wcnt;
-        a.wg_flag[blockIdx.x] = wflag;
+      if (k2 + 1 < NS2) {
+        Bn[0] = bsrc(2 * k2 + 2);
+        Bn[1] = bsrc(2 * k2 + 3);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int R = 0; R < NW; R++)
+#pragma unroll
+          for (int J = 0; J < 4; J++) D[R][J] = mfma4(Ar[k2 % (PF + 1)][R][e], Bc[e][J], D[R][J]);
+      __builtin_amdgcn_sched_barrier(0);
+      Bc[0] = Bn[0];
+      Bc[1] = Bn[1];
+    }
+#pragma unroll
+    for (int R = 0; R < NW; R++)
+#pragma unroll
+      for (int J = 0; J < 4; J++) acc[R][J] *= D[R][J];
+  };
+  // K4: column gather from the transposed image of P, [code][q16][R] = P[16R + q16][code]
+  auto gather_issue = [&](int lf, const int (&c)[4], double (&v)[NW][4]) {
+    const double *bl = a.PTg + (size_t)lf * DP * DP;  // uniform
+#pragma unroll
+    for (int J = 0; J < 4; J++) {
+      const unsigned off = (unsigned)(((c[J] < 0 ? 0 : c[J]) * 16 + q16) * NW) * 8u;
+      if (NW == 4) {
+        const f64x2 v0 = ld16(bl, off), v1 = ld16(bl, off + 16u);
+        v[0][J] = v0[0], v[1][J] = v0[1], v[2][J] = v1[0], v[3][J] = v1[1];
+      } else {
+#pragma unroll
+        for (int R = 0; R < NW; R++) v[R][J] = bl[off / 8 + R];
+      }
+    }
+  };
+
+  double vp0[NW][4], vp1[NW][4];  // gathered columns of the next leaf group (in flight across a finalisation)
+#pragma unroll
+  for (int R = 0; R < NW; R++)
+#pragma unroll
+    for (int J = 0; J < 4; J++) vp0[R][J] = vp1[R][J] = 1.0;
+  auto prefetch_next = [&](const int4 &nx) {
+    if ((nx.x & 3) != OPK_LEAF) {
+      prefetch_A(nx.z);
+    } else if (!(nx.x & OPF_AMBIG)) {
+      const int l0 = nx.z & 0xffff, l1 = (nx.z >> 16) & 0xffff;
+      int c0[4], c1[4];
+#pragma unroll
+      for (int J = 0; J < 4; J++) {
+        c0[J] = leaf_code(l0, 4 * J + j);
+        c1[J] = leaf_code(l1, 4 * J + j);
+      }
+      gather_issue(l0, c0, vp0);
+      gather_issue(l1, c1, vp1);
+    }
+  };
+
+  // optional phase profile (HYPHY_HIP_TIMELINE): cycles spent in leaf entries / internal products /
+  // rescale decisions / publishing by the first kTraceWG workgroups
+  const bool prof = PROF && a.timeline != nullptr && blockIdx.x < kTraceWG && blockIdx.y == 0;
+  long long tph[4] = {0, 0, 0, 0}, tmark = prof ? clock64() : 0;
+  int nph[4] = {0, 0, 0, 0};
+  auto phase_end = [&](int ph) {
+    if (!prof) return;
+    const long long t = clock64();
+    tph[ph] += t - tmark;
+    nph[ph]++;
+    tmark = t;
+  };
+  for (;;) {  // chained fragments: run program `cur`, then possibly its parent program
+    const int4 prg = prog[cur];  // (scalar load: uniform control flow, schedule entries in SGPRs)
+    const int4 *__restrict__ pops = ops + prg.x;
+    const int n_ops = prg.y;
+    int4 op = pops[0];
+    prefetch_next(op);
+    for (int oi = 0; oi < n_ops; oi++) {
+      const int4 nxt = pops[oi + 1];
+      const int kind = op.x & 3;
+      int ep_tile = -1, ep_branch = op.z;  // tile / branch of this entry's matrix product (if any)
+      if (kind == OPK_LEAF) {
+        const int nl = (op.x >> 8) & 0xff;
+        const int lf0 = op.z & 0xffff, lf1 = (op.z >> 16) & 0xffff;
+        int c0[4];
+        bool amb = false;
+        if (op.x & OPF_AMBIG) {  // (the host emits a leaf with ambiguity codes as a group of its own)
+#pragma unroll
+          for (int J = 0; J < 4; J++) {
+            c0[J] = leaf_code(lf0, 4 * J + j);
+            amb |= c0[J] < 0;
+          }
+          amb = __any(amb);
+          if (!amb) gather_issue(lf0, c0, vp0);
+        }
+        if (!amb) {  // columns were requested while the previous entry finished (prefetch_next)
+#pragma unroll
+          for (int R = 0; R < NW; R++)
+#pragma unroll
+            for (int J = 0; J < 4; J++) acc[R][J] *= (nl > 0 ? vp0[R][J] : 1.0) * (nl > 1 ? vp1[R][J] : 1.0);
+        } else {
+          // ambiguity codes in this tile: full product with the resolution vectors as the child tile,
+          // staged in the (free) exchange tile: element (state, site) = resolution[site][state]
+          prefetch_A(lf0);
+#pragma unroll
+          for (int R = 0; R < NW; R++)
+#pragma unroll
+            for (int Jp = 0; Jp < 2; Jp++) {
+              f64x2 qv;
+#pragma unroll
+              for (int h = 0; h < 2; h++) {
+                const int c = c0[2 * Jp + h], st = 16 * R + q16;
+                qv[h] = (c >= 0) ? ((st == c) ? 1.0 : 0.0) : a.ambig[(size_t)(-c - 1) * DP + st];
+              }
+              *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(xl + (R * 2 + Jp) * 128) + posw16) = qv;
+            }
+          ep_tile = 0;
+          ep_branch = lf0;
+        }
+      } else if (kind == OPK_INTERNAL) {
+        const int slot = (op.x >> 24) & 0xff;
+        ep_tile = slot < 2 ? 0 : slot - 1;  // exchange tile, or parking tile
+        const int4 cc = *reinterpret_cast<const int4 *>(&xcnt[ep_tile][4 * j]);
+        cnt[0] += cc.x, cnt[1] += cc.y, cnt[2] += cc.z, cnt[3] += cc.w;
+      } else {
+        // The child's tile is in global memory: stage it in the exchange tile (free: only a parent's
+        // FIRST entry reads the node finalised before it).  Either the root of a child fragment finished by
+        // another workgroup of this launch (agent-scope loads), or a node not recomputed by this program /
+        // one that found no parking tile (persisted copy).
+        const double *src = a.partials + ((size_t)op.w * a.ntiles + tile0) * TILE;  // uniform
+        if (op.x & OPF_HANDOFF) {
+          const int32_t *hc = a.hand_cnt + ((size_t)op.w * a.ntiles + tile0) * 32;
+#pragma unroll
+          for (int J = 0; J < 4; J++)
+            cnt[J] += __hip_atomic_load(hc + 4 * j + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int c = 0; c < TILE / 128; c++) {
+            const double *q = src + c * 128 + lane * 2;
+            *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(xl + c * 128) + lane16) = (f64x2){ld_agent(q), ld_agent(q + 1)};
+          }
+        } else {
+          if (op.x & OPF_GSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own stores visible in L2
+          const int4 cc = *reinterpret_cast<const int4 *>(a.counts + (size_t)op.w * S_pad + tile0 * 16 + 4 * j);
+          cnt[0] += cc.x, cnt[1] += cc.y, cnt[2] += cc.z, cnt[3] += cc.w;
+#pragma unroll
+          for (int c = 0; c < TILE / 128; c++)
+            *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(xl + c * 128) + lane16) = ld16(src + c * 128, lane16);
+        }
+        ep_tile = 0;
+      }
+      if (ep_tile >= 0) edge_product(ep_branch, ep_tile);
+      // operands of the NEXT entry: requested before this node's stores (the vector-memory counter is
+      // in-order) and early enough to land while this entry is finalised
+      prefetch_next(nxt);
+
+      if (prof) asm volatile("" ::"v"(acc[0][0]), "v"(acc[NW - 1][3]));
+      phase_end(kind == OPK_LEAF ? 0 : 1);
+      if (op.x & OPF_LAST) {
+        // finalise the parent
+        const int slot = (op.x >> 16) & 0xff;
+        const int xi = slot < 2 ? 0 : slot - 1;
+        // Rescaling is decided from the site totals (sum over all DP rows, 16 lanes per site).  The exact
+        // butterfly costs ~2k cycles per node and almost never changes anything — so first a cheap
+        // sufficient test on wave ballots: a site needs no rescale if SOME lane of its column already
+        // holds >= 2^-64 and NO lane exceeds 2^64 / 16 (partial sums are non-negative).  Only when that
+        // fails for some site of the tile are the exact totals formed (same decisions as always forming them).
+        double part[4];
+        unsigned long long lo_ok = ~0ull, hi_bad = 0ull;
+#pragma unroll
+        for (int J = 0; J < 4; J++) {
+          double s = acc[0][J];
+#pragma unroll
+          for (int R = 1; R < NW; R++) s += acc[R][J];
+          part[J] = s;
+          unsigned long long m = __ballot(s >= kScalerThreshold);  // column of site 4J + j: lanes = j mod 4
+          m |= m >> 32;
+          m |= m >> 16;
+          m |= m >> 8;
+          m |= m >> 4;  // low nibble: bit j = some lane of column j passed
+          lo_ok &= m;
+          hi_bad |= __ballot(!(s <= kScalerUp * 0.0625));
+        }
+        if (!((lo_ok & 0xf) == 0xf && hi_bad == 0) || (PROF && (a.ablate & 8))) {  // rare
+          double sc[4];
+          bool odd = false;
+#pragma unroll
+          for (int J = 0; J < 4; J++) {
+            sc[J] = col_sum16(part[J]);  // (holds the total for now)
+            odd |= !(sc[J] >= kScalerThreshold && sc[J] <= kScalerUp);
+          }
+          if (__any(odd)) {
+#pragma unroll
+            for (int J = 0; J < 4; J++) {
+              double f;
+              cnt[J] += rescale_decision(sc[J], f);
+#pragma unroll
+              for (int R = 0; R < NW; R++) acc[R][J] *= f;
+            }
+          }
+        }
+        if (prof) asm volatile("" ::"v"(acc[0][0]), "v"(acc[NW - 1][3]));
+        phase_end(2);
+        double *out = a.partials + ((size_t)op.y * a.ntiles + tile0) * TILE;  // uniform
+        const bool hand = op.x & OPF_HANDOFF;
+#pragma unroll
+        for (int R = 0; R < NW; R++)
+#pragma unroll
+          for (int Jp = 0; Jp < 2; Jp++) {
+            const f64x2 qv = (f64x2){acc[R][2 * Jp], acc[R][2 * Jp + 1]};
+            const int eu = (R * 2 + Jp) * 128;  // quad layout: one contiguous 1 KiB line per wave store
+            if (xi <= NP && !(PROF && (a.ablate & 4)))
+              *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(xl + xi * TILE + eu) + posw16) = qv;
+            if (hand) {  // fragment root: another workgroup may consume it in this launch
+              st_agent(out + eu + posw * 2, qv[0]);
+              st_agent(out + eu + posw * 2 + 1, qv[1]);
+            } else if (!(PROF && (a.ablate & 2))) {
+              st16(out + eu, posw16, qv);
+            }
+          }
+#pragma unroll
+        for (int R = 0; R < NW; R++)
+#pragma unroll
+          for (int J = 0; J < 4; J++) acc[R][J] = 1.0;
+        if (q16 == 0) {
+          const int4 cc = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);
+          if (xi <= NP) *reinterpret_cast<int4 *>(&xcnt[xi][4 * j]) = cc;
+          *reinterpret_cast<int4 *>(a.counts + (size_t)op.y * S_pad + tile0 * 16 + 4 * j) = cc;
+          if (hand) {
+#pragma unroll
+            for (int J = 0; J < 4; J++)
+              __hip_atomic_store(a.hand_cnt + ((size_t)op.y * a.ntiles + tile0) * 32 + 4 * j + J, cnt[J], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+#pragma unroll
+        for (int J = 0; J < 4; J++) cnt[J] = 0;
+        phase_end(3);
+      }
+      op = nxt;
+    }
+    if (prof && lane == 0) {
+      long long *tl = a.timeline + ((size_t)blockIdx.x * 16 + (blockIdx.z & 1) * 8);
+      for (int i = 0; i < 4; i++) {
+        tl[i] = tph[i];
+        tl[4 + i] = nph[i];
+      }
+    }
+    if (prg.z < 0) break;  // the root program (or a stand-alone one)
+    // arrival at the parent program: the wave that completes the parent's last child fragment (for this
+    // tile) continues with the parent; every other wave retires.  Payload stores were write-through.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int *ctr = a.frag_ctr + (size_t)prg.z * a.ntiles + tile0;
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old + 1 < prog[prg.z].w) return;
+    if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    cur = prg.z;
+  }
+
+  if (a.do_root) {
+    // root: L_s = sum_k root[k][s] pi[k] from the wave's LDS tile (the root was finalised last)
+    const int sl = lane & 15, g = lane >> 4;
+    const int xi = a.root_slot < 2 ? 0 : a.root_slot - 1;
+    const double *rootv = xl + xi * TILE + ((((sl >> 3) * 64) + (sl & 3) + 4 * g) * 2 + ((sl >> 2) & 1));
+    double s = 0.;
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++)  // state 4kk + g: block kk >> 2, quad kk & 3, row-in-quad g
+      s = fma(rootv[((kk >> 2) * 2 * 64 + 16 * (kk & 3)) * 2], a.pi[4 * kk + g], s);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const int rcnt = xcnt[xi][(sl & 3) * 4 + (sl >> 2)];
+    double wsum = 0.;
+    long long wcnt = 0;
+    int wflag = 0;
+    if (g == 0) {
+      const int site = tile0 * 16 + sl;
+      a.site_lik[site] = s;
+      a.site_cnt[site] = rcnt;
+      const double f = a.freq[site];
+      if (f != 0.) {
+        if (s != s || isinf(s)) wflag |= 2;
+        else if (s <= 0.) wflag |= 1;
+        else {
+          wsum += log(s) * f;
+          wcnt += (long long)rcnt * (long long)f;
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {  // fixed-order butterfly over the 16 site lanes
+      wsum += __shfl_xor(wsum, off);
+      wcnt += __shfl_xor(wcnt, off);
+      wflag |= __shfl_xor(wflag, off);
+    }
+    if (lane == 0) {
+      a.wg_sum[blockIdx.x] = wsum;
+      a.wg_cnt[blockIdx.x] = wcnt;
+      a.wg_flag[blockIdx.x] = wflag;
     }
   }
 }
@@ -691,7 +1418,7 @@ __global__ void mix_categories_kernel(const double *__restrict__ site_lik, const
 
 // fragment layout -> reference iNodeCache layout [(node*S + pattern)*D + state]
 __global__ void unpack_partials_kernel(const double *__restrict__ partials, int I, int ntiles, int NW, int D, int S,
-                                       double *__restrict__ out) {
+                                       int tile_layout, double *__restrict__ out) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)I * S * D;
   if (idx >= total) return;
@@ -702,13 +1429,35 @@ __global__ void unpack_partials_kernel(const double *__restrict__ partials, int 
   const int tile = pat >> 4, sl = pat & 15;
   const int kk = state >> 2, lane = (state & 3) * 16 + sl;
   const int TILE = NW * 4 * 64;
-  out[idx] = partials[((size_t)node * ntiles + tile) * TILE + frag_index(kk, lane)];
+  // tile_layout 1 = the 4x4x4 kernel's quad layout (see prune_w4_kernel)
+  const int within = tile_layout ? (((state >> 4) * 2 + (sl >> 3)) * 64 + (sl & 3) + 4 * (state & 3) + 16 * ((state >> 2) & 3)) * 2 +
+                                       ((sl >> 2) & 1)
+                                 : frag_index(kk, lane);
+  out[idx] = partials[((size_t)node * ntiles + tile) * TILE + within];
 }
 
 template <int NW, bool CLDS>
 void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
   const dim3 grid(a.ntiles / a.T, a.n_cat > 0 ? a.n_cat : 1, a.n_prog > 0 ? a.n_prog : 1), block(64 * NW);
   const size_t lds = CLDS ? (size_t)a.L * a.T * 16 * sizeof(int16_t) : 0;
+  if (a.variant == 2 && a.T == 1) {  // wave-per-tile kernel on the 4x4x4 MFMA (tile-layout partials)
+    const dim3 block1(64);
+    const size_t lds1 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
+    if (a.timeline || a.ablate) {  // diagnostic build: phase profile / ablation (HYPHY_HIP_TIMELINE, HYPHY_HIP_ABLATE)
+      hipLaunchKernelGGL((prune_w4_kernel<NW, 1, CLDS, true>), grid, block1, lds1, stream, a.ops, a.prog, a);
+      return;
+    }
+    if (a.n_slots <= 2) hipLaunchKernelGGL((prune_w4_kernel<NW, 0, CLDS, false>), grid, block1, lds1, stream, a.ops, a.prog, a);
+    else hipLaunchKernelGGL((prune_w4_kernel<NW, 1, CLDS, false>), grid, block1, lds1, stream, a.ops, a.prog, a);
+    return;
+  }
+  if (a.variant == 1 && a.T == 1) {  // wave-per-tile kernel: one wave per workgroup
+    const dim3 block1(64);
+    const size_t lds1 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
+    if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<NW, 0, CLDS>), grid, block1, lds1, stream, a.ops, a.prog, a);
+    else hipLaunchKernelGGL((prune_wave_kernel<NW, 1, CLDS>), grid, block1, lds1, stream, a.ops, a.prog, a);
+    return;
+  }
   if (a.timeline) {  // tracing build of the kernel (HYPHY_HIP_TIMELINE), T = 1 only
     hipLaunchKernelGGL((prune_mfma_kernel<NW, 1, CLDS, true>), grid, block, lds, stream, a.ops, a);
     return;
@@ -792,11 +1541,11 @@ void launch_mix_categories(const double *site_lik, const int32_t *site_cnt, cons
                      weights_dev, C, S_pad, mixed_lik, mixed_cnt);
 }
 
-void launch_unpack_partials_mfma(const double *partials, int I, int ntiles, int NW, int D, int S, int64_t, int64_t,
+void launch_unpack_partials_mfma(const double *partials, int I, int ntiles, int NW, int D, int S, int tile_layout,
                                  double *out, hipStream_t stream) {
   const size_t total = (size_t)I * S * D;
   hipLaunchKernelGGL(unpack_partials_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partials, I,
-                     ntiles, NW, D, S, out);
+                     ntiles, NW, D, S, tile_layout, out);
 }
 
 }  // namespace hyhip

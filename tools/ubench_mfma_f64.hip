@@ -25,6 +25,38 @@ __global__ __launch_bounds__(256) void k(double *out, long long *cyc, int iters,
   if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks per instruction (512 flops)
+template <int NACC>
+__global__ __launch_bounds__(256) void k4(double *out, int iters, double a0, double b0) {
+  double acc[NACC];
+  for (int i = 0; i < NACC; i++) acc[i] = 0;
+  double a = a0 + threadIdx.x * 1e-9, b = b0;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0;
+  for (int i = 0; i < NACC; i++) s += acc[i];
+  if (s == 12345.678) out[0] = s;
+}
+template <int NACC>
+void run4(int wg_per_cu) {
+  double *d; hipMalloc(&d, 8);
+  int iters = 20000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  dim3 grid(256 * wg_per_cu), block(256);
+  hipLaunchKernelGGL((k4<NACC>), grid, block, 0, 0, d, 100, 1.0, 1e-3);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k4<NACC>), grid, block, 0, 0, d, iters, 1.0, 1e-3);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double n = (double)grid.x * 4 * iters * NACC;
+  printf("mfma_f64_4x4x4_4b %dacc waves/SIMD=%d: %.3f ms  %.1f TF  (%.1f cycles per instruction per SIMD at 2.39 GHz)\n", NACC,
+         wg_per_cu, ms, n * 512.0 / ms / 1e9, ms * 1e-3 * 2.39e9 / (n / 1024.0));
+  hipFree(d);
+}
+
 template <int NACC, int VALU>
 void run(const char *name, int wg_per_cu, int waves) {
   double *d; long long *c; hipMalloc(&d, 8); hipMalloc(&c, 8);
@@ -47,6 +79,7 @@ void run(const char *name, int wg_per_cu, int waves) {
   hipFree(d); hipFree(c);
 }
 int main() {
+  run4<4>(1); run4<8>(1); run4<8>(2); run4<8>(4); run4<8>(8);
   run<4, 0>("mfma only 4acc", 1, 4);
   run<4, 0>("mfma only 4acc", 2, 4);
   run<4, 0>("mfma only 4acc", 3, 4);
@@ -54,6 +87,11 @@ int main() {
   run<4, 0>("mfma only 4acc", 6, 4);
   run<4, 0>("mfma only 4acc", 8, 4);
   run<1, 0>("mfma 1acc dependent", 1, 4);
+  run<2, 0>("mfma only 2acc", 1, 4);
+  run<8, 0>("mfma only 8acc", 1, 4);
+  run<8, 0>("mfma only 8acc", 2, 4);
+  run<1, 0>("mfma 1acc dependent", 4, 4);
+  run<1, 0>("mfma 1acc dependent", 8, 4);
   run<0, 8>("valu fma only", 1, 4);
   run<0, 8>("valu fma only", 4, 4);
   run<4, 8>("mfma+32 vfma", 1, 4);
