@@ -39,6 +39,7 @@ WORKLOADS = {
     "mg94_32x5k": dict(taxa=32, sites=5000, unit=3, seed=2),
     "mg94_64x1250": dict(taxa=64, sites=1250, unit=3, seed=3),    # one rank's share of the headline workload at 8 GPUs
     "mg94_64x2500": dict(taxa=64, sites=2500, unit=3, seed=3),    # ... at 4 GPUs
+    "mg94_64x5000": dict(taxa=64, sites=5000, unit=3, seed=3),    # ... at 2 GPUs
     "mg94_128x100k": dict(taxa=128, sites=100000, unit=3, seed=4),
     "hky_8x1k": dict(taxa=8, sites=1000, unit=1, seed=1),
     # configs[2]: BUSTED-style, 3 omega classes (weights .7/.25/.05, omega .1/1/5 scaled by the swept factor),

@@ -73,6 +73,7 @@ struct Shard {
   double *qbuf = nullptr;                                   // [C*B*D*D]
   int32_t *slots = nullptr;                                 // [C*B]
   int4 *ops = nullptr;
+  int16_t *codes_tile = nullptr;  // [tile][L][16] copy of the leaf table (wave-per-tile kernels)
   int4 *prog = nullptr;       // program table (forest scheduling): (offset, entries, parent program, child programs)
   int4 *h_prog = nullptr;
   int *frag_ctr = nullptr;    // [classes][programs][tiles] arrivals of child fragments (wave-per-tile kernel)
@@ -145,7 +146,7 @@ void free_shard(Shard &s) {
   if (s.stream) hipStreamSynchronize(s.stream);
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
-                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt};
+                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.codes_tile};
   for (void *d : dev)
     if (d) hipFree(d);
   void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog};
@@ -370,6 +371,11 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
         frags[index[frag_root[n]]].push_back(n);
       }
     }
+    // longest fragments first: the grid is dispatched in program order within a tile, and a tile's chained
+    // parent program can only start after its slowest child
+    if (chained)
+      std::stable_sort(frags.begin(), frags.end(),
+                       [](const std::vector<int> &x, const std::vector<int> &y) { return x.size() > y.size(); });
     bool finished = false;
     for (const std::vector<int> &f : frags) {
       int off, n;
@@ -542,6 +548,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     pa.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
     pa.PTg = s.PTg + (size_t)cat * B * DP * DP;
     pa.codes = s.codes;
+    pa.codes_tile = s.codes_tile;
     pa.ambig = s.ambig;
     pa.partials = s.partials + (size_t)cat * s.partial_stride;
     pa.counts = s.counts + (size_t)cat * p->I * s.S_pad;
@@ -839,8 +846,12 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     s.T = T;
     s.cus = cus;
     if (!p->nuc) {
-      // T = 1: wave-per-tile kernel (no cross-wave exchange); T > 1: workgroup-per-tile kernel
-      p->variant = 1;
+      // Kernel choice (measured, tools/sweep_small_shards.sh): the wave-per-tile kernel (no cross-wave
+      // exchange, child -> parent through registers) wins once every SIMD holds ~2 waves of it — 160 vs 183 us
+      // at 624 tiles; below that its 64-MFMA-per-edge chains are pure latency (167 us at 312 tiles as at
+      // 624) and the workgroup-per-tile kernel, which splits a tile's rows over four waves, is faster
+      // (123 us at 312 tiles, 63 us at 78).
+      p->variant = tiles >= (7 * (int64_t)cus) / 4 ? 1 : 0;
       if (const char *e = getenv("HYPHY_HIP_KERNEL")) p->variant = std::min(2, std::max(0, atoi(e)));
       if (T != 1) p->variant = 0;
       p->n_slots = lds_slots(T);
@@ -865,6 +876,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     s.ring.assign(2 * kTimingRing, nullptr);
     for (auto &e : s.ring) hipEventCreate(&e);
     A_(s.codes, (size_t)L * s.S_pad * sizeof(int16_t));
+    if (!p->nuc) A_(s.codes_tile, (size_t)L * s.S_pad * sizeof(int16_t));
     A_(s.freq, (size_t)s.S_pad * sizeof(double));
     A_(s.ambig, (size_t)std::max<int64_t>(1, n_ambig) * DP * sizeof(double));
     A_(s.partials, (size_t)C * s.partial_stride * sizeof(double));
@@ -923,6 +935,12 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     for (int64_t a = 0; a < n_ambig; a++)
       for (int64_t k = 0; k < D; k++) amb[a * astride + k] = ambig[a * D + k];
     hipMemcpy(s.codes, codes.data(), codes.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+    if (!p->nuc) {  // tile-major copy [tile][L][16] for the wave-per-tile kernels: a tile's codes are one 32 L-byte run
+      std::vector<int16_t> ct((size_t)L * s.S_pad, 0);
+      for (int64_t l = 0; l < L; l++)
+        for (int64_t k = 0; k < s.S_pad; k++) ct[((size_t)(k >> 4) * L + l) * 16 + (k & 15)] = codes[(size_t)l * s.S_pad + k];
+      hipMemcpy(s.codes_tile, ct.data(), ct.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+    }
     hipMemcpy(s.freq, fr.data(), fr.size() * sizeof(double), hipMemcpyHostToDevice);
     hipMemcpy(s.ambig, amb.data(), amb.size() * sizeof(double), hipMemcpyHostToDevice);
     if (hipStreamSynchronize(s.stream) != hipSuccess || hipGetLastError() != hipSuccess) {

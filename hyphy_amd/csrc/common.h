@@ -83,6 +83,7 @@ struct PruneArgs {
   const double *Pfrag;       // [B][NW][NKK*64]      A-operand images of the transition matrices
   const double *PTg;         // [B][DP][NW][4][4]    column-gather images (leaf edges)
   const int16_t *codes;      // [L][S_pad]           >= 0 state, < 0 -> -(k+1) ambiguity row
+  const int16_t *codes_tile; // [ntiles][L][16]      the same table, tile-major (wave-per-tile kernels)
   const double *ambig;       // [n_ambig][DP]
   double *partials;          // [I][ntiles][NKK*64]  conditionals, fragment layout
   int32_t *counts;           // [I][S_pad]           cumulative 2^64-exponent of the subtree

@@ -71,6 +71,26 @@ __device__ __forceinline__ void st16(double *ubase, unsigned byte_off, f64x2 v) 
   *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(ubase) + byte_off) = v;
 }
 
+// The same at AGENT scope (sc1: write-through store / L1-bypassing load) for data handed between
+// workgroups inside a launch — valid under any workgroup -> XCD placement (microarch guide, inter-
+// workgroup visibility).  Raw buffer instructions carry the cache-policy bits and are tracked by the
+// compiler's s_waitcnt insertion (inline asm would not be).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t agent_rsrc(const double *ubase) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(ubase), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f64x2 ld16_agent(const double *ubase, unsigned byte_off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(agent_rsrc(ubase), byte_off, 0, 16);
+  f64x2 r;
+  __builtin_memcpy(&r, &v, 16);
+  return r;
+}
+__device__ __forceinline__ void st16_agent(double *ubase, unsigned byte_off, f64x2 x) {
+  u32x4_t v;
+  __builtin_memcpy(&v, &x, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(v, agent_rsrc(ubase), byte_off, 0, 16);
+}
+
 // Operand bundle fetched one schedule entry ahead: 16 doubles per lane, either the A-operand image
 // of the next internal edge's transition matrix or the gathered columns of the next leaf group.
 struct Payload {
@@ -465,7 +485,9 @@ __device__ __forceinline__ double row_sum4(double x) {
 template <int NW, int NP, bool CLDS>
 __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *__restrict__ ops, const int4 *__restrict__ prog,
                                                                              PruneArgs a) {
-  int cur = blockIdx.z;  // program (subtree fragment) this wave starts with
+  // grid = (leaf programs, classes, tiles): tile-major dispatch order, so that a tile's chained parent
+  // programs start while other tiles still run their leaf fragments (no low-occupancy tail)
+  int cur = blockIdx.x;  // program (subtree fragment) this wave starts with
   {
     const size_t cat = blockIdx.y;
     a.frag_ctr += cat * (size_t)a.n_prog_total * a.ntiles;
@@ -483,20 +505,22 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
   constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
   __shared__ __align__(16) double park[(NP > 0 ? NP : 1) * TILE];  // parked nodes (scaled), fragment layout
   __shared__ int park_cnt[(NP > 0 ? NP : 1)][16];
+  __shared__ __align__(16) double stage[TILE];  // a child tile fetched from global memory (bulk copy, then LDS operand)
   extern __shared__ __align__(16) int16_t codes_lds[];  // CLDS: [L][16]
 
   const int lane = threadIdx.x, g = lane >> 4, sl = lane & 15;
-  const int tile0 = blockIdx.x;
+  const int tile0 = blockIdx.z;
   const int S_pad = a.S_pad;
 
-  if (CLDS) {
-    const int n = a.L * 16;
-    for (int i = lane; i < n; i += 64) codes_lds[i] = a.codes[(size_t)(i >> 4) * S_pad + tile0 * 16 + (i & 15)];
+  if (CLDS) {  // the tile's leaf codes: one contiguous run of 32 L bytes in the tile-major table
+    const int4 *src = reinterpret_cast<const int4 *>(a.codes_tile + (size_t)tile0 * a.L * 16);
+    int4 *dst = reinterpret_cast<int4 *>(codes_lds);
+    for (int i = lane; i < a.L * 2; i += 64) dst[i] = src[i];
     __syncthreads();
   }
   auto leaf_code = [&](int leaf) -> int {
     if (CLDS) return (int)codes_lds[leaf * 16 + sl];
-    return (int)a.codes[(size_t)leaf * S_pad + tile0 * 16 + sl];
+    return (int)a.codes_tile[((size_t)tile0 * a.L + leaf) * 16 + sl];
   };
 
   const f64x4 ones = (f64x4){1., 1., 1., 1.}, zeros = (f64x4){0., 0., 0., 0.};
@@ -548,12 +572,6 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
     }
   };
 
-  // agent-scope 8-byte accesses for data handed between workgroups (fragment roots): write-through
-  // stores / L1-bypassing loads, valid under any workgroup -> XCD placement
-  auto ld_agent = [](const double *p) -> double {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  auto st_agent = [](double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
  for (;;) {  // chained fragments: run program `cur`, then possibly its parent program
   const int4 prg = prog[cur];  // (scalar load: uniform control flow, schedule entries in SGPRs)
@@ -595,23 +613,27 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
         });
         cnt += ccnt;
       }
-    } else if (op.x & OPF_HANDOFF) {
-      // root of a child fragment, finished by another workgroup of this launch (its arrival was counted
-      // before this program started): agent-scope loads
-      const double *src = a.partials + ((size_t)op.w * a.ntiles + tile0) * TILE;  // uniform
-      const int ccnt = __hip_atomic_load(a.hand_cnt + ((size_t)op.w * a.ntiles + tile0) * 32 + sl, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-      edge_product(op.z, [&](int k2) -> f64x2 {
-        const double *q = src + (k2 * 64 + lane) * 2;
-        return (f64x2){ld_agent(q), ld_agent(q + 1)};
-      });
-      cnt += ccnt;
     } else {
-      // child not recomputed by this program, or no parking slot was free: persisted copy
-      if (op.x & OPF_GSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own stores visible in L2
+      // The child's tile is in global memory — the root of a child fragment finished by another workgroup
+      // of this launch (agent-scope loads; its arrival was counted before this program started), or a node
+      // not recomputed by this program / one that found no parking slot (persisted copy).  Bulk copy into
+      // LDS first (all loads in flight together: ONE memory round trip instead of one per k-step).
       const double *src = a.partials + ((size_t)op.w * a.ntiles + tile0) * TILE;  // uniform
-      const int ccnt = a.counts[(size_t)op.w * S_pad + tile0 * 16 + sl];
-      edge_product(op.z, [&](int k2) -> f64x2 { return ld16(src, (unsigned)(k2 * 64 + lane) * 16u); });
+      int ccnt;
+      if (op.x & OPF_HANDOFF) {
+        ccnt = __hip_atomic_load(a.hand_cnt + ((size_t)op.w * a.ntiles + tile0) * 32 + sl, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k2 = 0; k2 < NKK / 2; k2++)
+          *reinterpret_cast<f64x2 *>(stage + (k2 * 64 + lane) * 2) = ld16_agent(src, (unsigned)(k2 * 64 + lane) * 16u);
+      } else {
+        if (op.x & OPF_GSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own stores visible in L2
+        ccnt = a.counts[(size_t)op.w * S_pad + tile0 * 16 + sl];
+#pragma unroll
+        for (int k2 = 0; k2 < NKK / 2; k2++)
+          *reinterpret_cast<f64x2 *>(stage + (k2 * 64 + lane) * 2) = ld16(src, (unsigned)(k2 * 64 + lane) * 16u);
+      }
+      edge_product(op.z, [&](int k2) -> f64x2 { return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2); });
       cnt += ccnt;
     }
 
@@ -634,16 +656,13 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
       if (op.x & OPF_HANDOFF) {  // fragment root: another workgroup may consume it in this launch
 #pragma unroll
         for (int w = 0; w < NW; w++) {
-          double *q = out + ((2 * w) * 64 + lane) * 2;
-          st_agent(q, bch[w][0]);
-          st_agent(q + 1, bch[w][1]);
-          st_agent(q + 128, bch[w][2]);
-          st_agent(q + 129, bch[w][3]);
+          st16_agent(out, (unsigned)((2 * w) * 64 + lane) * 16u, (f64x2){bch[w][0], bch[w][1]});
+          st16_agent(out, (unsigned)((2 * w + 1) * 64 + lane) * 16u, (f64x2){bch[w][2], bch[w][3]});
         }
         if (g == 0)
           __hip_atomic_store(a.hand_cnt + ((size_t)op.y * a.ntiles + tile0) * 32 + sl, cnt, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
-      } else {
+      } else if (!(a.ablate & 2)) {
 #pragma unroll
         for (int w = 0; w < NW; w++) {
           st16(out, (unsigned)((2 * w) * 64 + lane) * 16u, (f64x2){bch[w][0], bch[w][1]});
@@ -708,9 +727,9 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
       wflag |= __shfl_xor(wflag, off);
     }
     if (lane == 0) {
-      a.wg_sum[blockIdx.x] = wsum;
-      a.wg_cnt[blockIdx.x] = wcnt;
-      a.wg_flag[blockIdx.x] = wflag;
+      a.wg_sum[tile0] = wsum;
+      a.wg_cnt[tile0] = wcnt;
+      a.wg_flag[tile0] = wflag;
     }
   }
 }
@@ -756,7 +775,9 @@ __device__ __forceinline__ double col_sum16(double x) {
 template <int NW, int NP, bool CLDS, bool PROF>
 __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__restrict__ ops, const int4 *__restrict__ prog,
                                                                            PruneArgs a) {
-  int cur = blockIdx.z;  // program (subtree fragment) this wave starts with
+  // grid = (leaf programs, classes, tiles): tile-major dispatch order, so that a tile's chained parent
+  // programs start while other tiles still run their leaf fragments (no low-occupancy tail)
+  int cur = blockIdx.x;  // program (subtree fragment) this wave starts with
   {
     const size_t cat = blockIdx.y;
     a.frag_ctr += cat * (size_t)a.n_prog_total * a.ntiles;
@@ -785,22 +806,19 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
   // goes into the scalar base / the immediate (a per-lane 64-bit address per unrolled access makes the
   // compiler hoist dozens of them out of the schedule loop and spill them).
   const unsigned lane16 = (unsigned)lane * 16u, posw16 = (unsigned)posw * 16u, blane16 = (unsigned)(4 * kB + j) * 16u;
-  const int tile0 = blockIdx.x;
+  const int tile0 = blockIdx.z;
   const int S_pad = a.S_pad;
 
-  if (CLDS) {
-    const int n = a.L * 16;
-    for (int i = lane; i < n; i += 64) codes_lds[i] = a.codes[(size_t)(i >> 4) * S_pad + tile0 * 16 + (i & 15)];
+  if (CLDS) {  // the tile's leaf codes: one contiguous run of 32 L bytes in the tile-major table
+    const int4 *src = reinterpret_cast<const int4 *>(a.codes_tile + (size_t)tile0 * a.L * 16);
+    int4 *dst = reinterpret_cast<int4 *>(codes_lds);
+    for (int i = lane; i < a.L * 2; i += 64) dst[i] = src[i];
     __syncthreads();
   }
   auto leaf_code = [&](int leaf, int site) -> int {
     if (CLDS) return (int)codes_lds[leaf * 16 + site];
-    return (int)a.codes[(size_t)leaf * S_pad + tile0 * 16 + site];
+    return (int)a.codes_tile[((size_t)tile0 * a.L + leaf) * 16 + site];
   };
-  auto ld_agent = [](const double *p) -> double {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  auto st_agent = [](double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
   double acc[NW][4];  // running product of the current parent: rows 16R + q16, sites 4J + j
   int cnt[4];         // 2^64-exponent of the running product, sites 4J + j
@@ -896,10 +914,11 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
   for (int R = 0; R < NW; R++)
 #pragma unroll
     for (int J = 0; J < 4; J++) vp0[R][J] = vp1[R][J] = 1.0;
-  auto prefetch_next = [&](const int4 &nx) {
-    if ((nx.x & 3) != OPK_LEAF) {
-      prefetch_A(nx.z);
-    } else if (!(nx.x & OPF_AMBIG)) {
+  // Operands of the NEXT schedule entry.  Leaf columns are requested before the current entry's matrix
+  // product is issued (a whole MFMA block to land in); the first A stages after it (the stage registers
+  // are busy until then), but before this node's stores — the vector-memory counter is in-order.
+  auto prefetch_leaf = [&](const int4 &nx) {
+    if ((nx.x & 3) == OPK_LEAF && !(nx.x & OPF_AMBIG)) {
       const int l0 = nx.z & 0xffff, l1 = (nx.z >> 16) & 0xffff;
       int c0[4], c1[4];
 #pragma unroll
@@ -911,10 +930,13 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
       gather_issue(l1, c1, vp1);
     }
   };
+  auto prefetch_next = [&](const int4 &nx) {
+    if ((nx.x & 3) != OPK_LEAF) prefetch_A(nx.z);
+  };
 
   // optional phase profile (HYPHY_HIP_TIMELINE): cycles spent in leaf entries / internal products /
   // rescale decisions / publishing by the first kTraceWG workgroups
-  const bool prof = PROF && a.timeline != nullptr && blockIdx.x < kTraceWG && blockIdx.y == 0;
+  const bool prof = PROF && a.timeline != nullptr && blockIdx.z < kTraceWG && blockIdx.y == 0;
   long long tph[4] = {0, 0, 0, 0}, tmark = prof ? clock64() : 0;
   int nph[4] = {0, 0, 0, 0};
   auto phase_end = [&](int ph) {
@@ -929,6 +951,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
     const int4 *__restrict__ pops = ops + prg.x;
     const int n_ops = prg.y;
     int4 op = pops[0];
+    prefetch_leaf(op);
     prefetch_next(op);
     for (int oi = 0; oi < n_ops; oi++) {
       const int4 nxt = pops[oi + 1];
@@ -936,7 +959,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
       int ep_tile = -1, ep_branch = op.z;  // tile / branch of this entry's matrix product (if any)
       if (kind == OPK_LEAF) {
         const int nl = (op.x >> 8) & 0xff;
-        const int lf0 = op.z & 0xffff, lf1 = (op.z >> 16) & 0xffff;
+        const int lf0 = op.z & 0xffff;
         int c0[4];
         bool amb = false;
         if (op.x & OPF_AMBIG) {  // (the host emits a leaf with ambiguity codes as a group of its own)
@@ -989,10 +1012,8 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
           for (int J = 0; J < 4; J++)
             cnt[J] += __hip_atomic_load(hc + 4 * j + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-          for (int c = 0; c < TILE / 128; c++) {
-            const double *q = src + c * 128 + lane * 2;
-            *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(xl + c * 128) + lane16) = (f64x2){ld_agent(q), ld_agent(q + 1)};
-          }
+          for (int c = 0; c < TILE / 128; c++)
+            *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(xl + c * 128) + lane16) = ld16_agent(src + c * 128, lane16);
         } else {
           if (op.x & OPF_GSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own stores visible in L2
           const int4 cc = *reinterpret_cast<const int4 *>(a.counts + (size_t)op.w * S_pad + tile0 * 16 + 4 * j);
@@ -1003,9 +1024,9 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
         }
         ep_tile = 0;
       }
+      if (kind != OPK_LEAF) prefetch_leaf(nxt);  // (a leaf entry: only after its own columns were consumed)
       if (ep_tile >= 0) edge_product(ep_branch, ep_tile);
-      // operands of the NEXT entry: requested before this node's stores (the vector-memory counter is
-      // in-order) and early enough to land while this entry is finalised
+      if (kind == OPK_LEAF) prefetch_leaf(nxt);
       prefetch_next(nxt);
 
       if (prof) asm volatile("" ::"v"(acc[0][0]), "v"(acc[NW - 1][3]));
@@ -1066,8 +1087,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
             if (xi <= NP && !(PROF && (a.ablate & 4)))
               *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(xl + xi * TILE + eu) + posw16) = qv;
             if (hand) {  // fragment root: another workgroup may consume it in this launch
-              st_agent(out + eu + posw * 2, qv[0]);
-              st_agent(out + eu + posw * 2 + 1, qv[1]);
+              st16_agent(out + eu, posw16, qv);
             } else if (!(PROF && (a.ablate & 2))) {
               st16(out + eu, posw16, qv);
             }
@@ -1094,7 +1114,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
       op = nxt;
     }
     if (prof && lane == 0) {
-      long long *tl = a.timeline + ((size_t)blockIdx.x * 16 + (blockIdx.z & 1) * 8);
+      long long *tl = a.timeline + ((size_t)blockIdx.z * 16 + (blockIdx.x & 1) * 8);
       for (int i = 0; i < 4; i++) {
         tl[i] = tph[i];
         tl[4 + i] = nph[i];
@@ -1149,9 +1169,9 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
       wflag |= __shfl_xor(wflag, off);
     }
     if (lane == 0) {
-      a.wg_sum[blockIdx.x] = wsum;
-      a.wg_cnt[blockIdx.x] = wcnt;
-      a.wg_flag[blockIdx.x] = wflag;
+      a.wg_sum[tile0] = wsum;
+      a.wg_cnt[tile0] = wcnt;
+      a.wg_flag[tile0] = wflag;
     }
   }
 }
@@ -1440,22 +1460,23 @@ template <int NW, bool CLDS>
 void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
   const dim3 grid(a.ntiles / a.T, a.n_cat > 0 ? a.n_cat : 1, a.n_prog > 0 ? a.n_prog : 1), block(64 * NW);
   const size_t lds = CLDS ? (size_t)a.L * a.T * 16 * sizeof(int16_t) : 0;
+  const dim3 gridw(a.n_prog > 0 ? a.n_prog : 1, a.n_cat > 0 ? a.n_cat : 1, a.ntiles);  // wave kernels: tile-major
   if (a.variant == 2 && a.T == 1) {  // wave-per-tile kernel on the 4x4x4 MFMA (tile-layout partials)
     const dim3 block1(64);
     const size_t lds1 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
     if (a.timeline || a.ablate) {  // diagnostic build: phase profile / ablation (HYPHY_HIP_TIMELINE, HYPHY_HIP_ABLATE)
-      hipLaunchKernelGGL((prune_w4_kernel<NW, 1, CLDS, true>), grid, block1, lds1, stream, a.ops, a.prog, a);
+      hipLaunchKernelGGL((prune_w4_kernel<NW, 1, CLDS, true>), gridw, block1, lds1, stream, a.ops, a.prog, a);
       return;
     }
-    if (a.n_slots <= 2) hipLaunchKernelGGL((prune_w4_kernel<NW, 0, CLDS, false>), grid, block1, lds1, stream, a.ops, a.prog, a);
-    else hipLaunchKernelGGL((prune_w4_kernel<NW, 1, CLDS, false>), grid, block1, lds1, stream, a.ops, a.prog, a);
+    if (a.n_slots <= 2) hipLaunchKernelGGL((prune_w4_kernel<NW, 0, CLDS, false>), gridw, block1, lds1, stream, a.ops, a.prog, a);
+    else hipLaunchKernelGGL((prune_w4_kernel<NW, 1, CLDS, false>), gridw, block1, lds1, stream, a.ops, a.prog, a);
     return;
   }
   if (a.variant == 1 && a.T == 1) {  // wave-per-tile kernel: one wave per workgroup
     const dim3 block1(64);
     const size_t lds1 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
-    if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<NW, 0, CLDS>), grid, block1, lds1, stream, a.ops, a.prog, a);
-    else hipLaunchKernelGGL((prune_wave_kernel<NW, 1, CLDS>), grid, block1, lds1, stream, a.ops, a.prog, a);
+    if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<NW, 0, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a);
+    else hipLaunchKernelGGL((prune_wave_kernel<NW, 1, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a);
     return;
   }
   if (a.timeline) {  // tracing build of the kernel (HYPHY_HIP_TIMELINE), T = 1 only
