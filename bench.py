@@ -241,7 +241,13 @@ def main():
         else:
             ach = bytes_ / (prune_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
-        roof["kernel"] = "prune_mfma_kernel" if D > 4 else "prune_nuc_kernel"
+        roof["kernel"] = part.prune_kernel_name()
+        if bound == "mfma":
+            # measured ceiling of the instruction the kernel issues (tools/ubench_mfma_f64 under PMC,
+            # profiles/r01_ubench_mfma_f64.txt): v_mfma_f64_16x16x4_f64 sustains ~49 TFLOP/s chip-wide at 2.39 GHz
+            # (one per ~100 cycles per SIMD); `peak` stays the datasheet figure
+            roof["instruction"] = "v_mfma_f64_16x16x4_f64" if roof["kernel"] != "prune_w4_kernel" else "v_mfma_f64_4x4x4_4b_f64"
+            roof["instruction_peak_measured"] = 49.2 if roof["kernel"] != "prune_w4_kernel" else 72.8
         # forest scheduling: the pruning pass of ONE evaluation is `launches_per_step` launches of the same
         # kernel (levels of subtree fragments).  achieved = (algorithmic work of the pass / launches) / (mean
         # launch duration) = work of the pass / time of the pass; rocprofv3's per-launch average x launches
@@ -257,7 +263,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                roof["traffic"] = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc)).get(args.workload, {})
+                if rec.get("kernel") == roof["kernel"]:
+                    roof["traffic"] = rec.get("hbm_bytes_per_launch")
             except Exception:
                 pass
         out = {

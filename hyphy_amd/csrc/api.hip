@@ -728,6 +728,12 @@ const char *hyphy_hip_last_error(void) { return g_last_error.c_str(); }
 
 int hyphy_hip_prune_launches(hyphy_hip_partition *p) { return p ? (int)std::max<size_t>(1, p->levels.size()) : 0; }
 
+const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p) {
+  if (!p) return "";
+  if (p->nuc) return "prune_nuc_kernel";
+  return p->variant == 2 ? "prune_w4_kernel" : (p->variant == 1 ? "prune_wave_kernel" : "prune_mfma_kernel");
+}
+
 int64_t hyphy_hip_prune_timings(hyphy_hip_partition *p, double *out_ms, int64_t n) {
   if (!p || !out_ms || n <= 0 || p->shards.empty()) return 0;
   Shard &s = p->shards[0];

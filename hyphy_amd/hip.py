@@ -22,6 +22,7 @@ EXPORTS = [
     "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
+    "hyphy_hip_prune_kernel_name",
     "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
@@ -84,6 +85,8 @@ def load():
     lib.hyphy_hip_prune_timings.argtypes = [vp, dp, C.c_int64]
     lib.hyphy_hip_prune_launches.restype = C.c_int
     lib.hyphy_hip_prune_launches.argtypes = [vp]
+    lib.hyphy_hip_prune_kernel_name.restype = C.c_char_p
+    lib.hyphy_hip_prune_kernel_name.argtypes = [vp]
     lib.hyphy_hip_last_error.restype = C.c_char_p
     lib.hyphy_hip_version.restype = C.c_char_p
     _lib = lib
@@ -303,6 +306,9 @@ class HipPartition:
 
     def prune_launches(self) -> int:
         return int(self._lib.hyphy_hip_prune_launches(self._h))
+
+    def prune_kernel_name(self) -> str:
+        return self._lib.hyphy_hip_prune_kernel_name(self._h).decode()
 
     def last_timings(self) -> np.ndarray:
         out = np.zeros(3)

@@ -190,6 +190,9 @@ int64_t hyphy_hip_prune_timings(hyphy_hip_partition *p, double *out_ms, int64_t 
 /* Pruning-kernel launches per evaluation under the current schedule (forest scheduling cuts a full
  * evaluation into levels of subtree fragments, one launch per level; partial updates use one). */
 int hyphy_hip_prune_launches(hyphy_hip_partition *p);
+/* Name of the pruning kernel this partition's evaluations launch (chosen by shard size and state count;
+ * as it appears in a rocprofv3 kernel trace).  Static string. */
+const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p);
 
 const char *hyphy_hip_last_error(void);
 const char *hyphy_hip_version(void);
