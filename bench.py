@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--pipelined", action="store_true", help="also report throughput with no per-step host sync")
+    ap.add_argument("--branch-cache", action="store_true",
+                    help="also time one-branch line-search evaluations through the device branch cache (SURVEY 8f-1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,6 +220,36 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    branch_cache = None
+    if args.branch_cache and n_classes == 1 and N == 1 and D > 4:
+        # one-branch line search (the optimiser's inner loop): all parameters fixed, ONE branch
+        # length varies; each evaluation = 1 expm + 1 [D x D] x [D x S] contraction + reduction
+        node = L + I // 2                                  # an internal branch in the middle of the tree
+        omega = omega0
+        Qb = np.zeros((B, D, D))
+        for b in range(B):
+            Qb[b] = tb[b] * (T[0] + omega * T[1])
+            np.fill_diagonal(Qb[b], 0.0)
+            np.fill_diagonal(Qb[b], -Qb[b].sum(1))
+        full = part.evaluate(nodes, nodes, Qb, pi)
+        tb0 = time.perf_counter()
+        part.branch_cache_build(node)
+        part.synchronize()
+        build_ms = 1e3 * (time.perf_counter() - tb0)
+        qn = np.ascontiguousarray(Qb[node])
+        bstep = part.prepare_branch_cache_step(node, qn)
+        same = bstep()
+        for k in range(args.warmup):
+            bstep()
+        tb1 = time.perf_counter()
+        for k in range(args.steps):
+            qn[:] = Qb[node] * (1.0 + 0.002 * (k + 1))
+            lastb = bstep()
+        dtb = time.perf_counter() - tb1
+        branch_cache = {"node": int(node), "evals_per_s": args.steps / dtb, "ms_per_eval": 1e3 * dtb / args.steps,
+                        "build_ms": build_ms, "logl_full": full, "logl_cached_same_length": same,
+                        "rel_err_vs_full": abs(same - full) / abs(full), "logl_last": lastb}
+
     pipelined = None
     if args.pipelined and n_classes == 1:
         torch.cuda.synchronize()
@@ -281,6 +313,7 @@ def main():
                                (" + RCCL all-reduce" if N > 1 else "") + ", log-L returned to host every step"},
             "logl_first": ll0, "logl_last": last,
             "roofline": roof,
+            **({"branch_cache": branch_cache} if branch_cache else {}),
         }
         if pipelined:
             out["value_pipelined_no_host_sync"] = pipelined

@@ -74,6 +74,10 @@ struct Shard {
   int32_t *slots = nullptr;                                 // [C*B]
   int4 *ops = nullptr;
   int16_t *codes_tile = nullptr;  // [tile][L][16] copy of the leaf table (wave-per-tile kernels)
+  int4 *bc_ops = nullptr;         // branch cache: schedule of the re-rooted chain, its one-entry program table,
+  int4 *bc_prog = nullptr;        //   the slot word and the rate matrix of the cached branch
+  int32_t *bc_slot = nullptr;
+  double *bc_q = nullptr;
   int4 *prog = nullptr;       // program table (forest scheduling): (offset, entries, parent program, child programs)
   int4 *h_prog = nullptr;
   int *frag_ctr = nullptr;    // [classes][programs][tiles] arrivals of child fragments (wave-per-tile kernel)
@@ -122,6 +126,8 @@ struct hyphy_hip_partition {
   std::vector<double> cached_weights;        // category weights currently on the device
   std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
   int root_slot = 0;
+  std::vector<int64_t> bc_node;              // per rate class: branch whose outside vector is resident (-1: none)
+  std::vector<int> bc_use_pi;                // ... hangs off the root (frequencies applied at evaluation)
   int variant = 0;                           // pruning kernel variant (common.h PruneArgs::variant)
   int n_slots = 0;                           // LDS slots the schedules are compiled for (0: lds_slots(T))
   struct Prog { int off, n, parent = -1, need = 0; };
@@ -146,7 +152,8 @@ void free_shard(Shard &s) {
   if (s.stream) hipStreamSynchronize(s.stream);
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
-                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.codes_tile};
+                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.codes_tile,
+                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q};
   for (void *d : dev)
     if (d) hipFree(d);
   void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog};
@@ -424,6 +431,54 @@ int upload_small(Shard &s, const double *src, size_t n, double *dst) {
   return 0;
 }
 
+// Everything in a PruneArgs that does not depend on the schedule being launched.
+PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch) {
+  const int64_t B = p->B;
+  const int DP = p->DP;
+  PruneArgs pa;
+  pa.ops = nullptr;
+  pa.n_ops = 0;
+  pa.prog = nullptr;
+  pa.n_prog = 1;
+  pa.do_root = 1;
+  pa.NW = p->NW;
+  pa.T = s.T;
+  pa.S_pad = s.S_pad;
+  pa.ntiles = s.ntiles;
+  pa.root_inode = (int)p->I - 1;
+  pa.root_slot = p->root_slot;
+  pa.L = (int)p->L;
+  pa.variant = p->variant;
+  pa.n_slots = p->n_slots;
+  pa.codes_in_lds = ((size_t)p->L * s.T * 32 + (size_t)(p->L + p->I) * 16 <= 24576) ? 1 : 0;
+  pa.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
+  pa.PTg = s.PTg + (size_t)cat * B * DP * DP;
+  pa.codes = s.codes;
+  pa.codes_tile = s.codes_tile;
+  pa.ambig = s.ambig;
+  pa.partials = s.partials + (size_t)cat * s.partial_stride;
+  pa.counts = s.counts + (size_t)cat * p->I * s.S_pad;
+  pa.pi = s.pi;
+  pa.site_lik = s.site_lik + (size_t)cat * s.S_pad;
+  pa.site_cnt = s.site_cnt + (size_t)cat * s.S_pad;
+  pa.freq = s.freq;
+  pa.wg_sum = s.wg_sum;
+  pa.wg_cnt = s.wg_cnt;
+  pa.wg_flag = s.wg_flag;
+  pa.n_cat = n_cat_batch;
+  pa.cs_P = (size_t)B * DP * DP;
+  pa.cs_partials = s.partial_stride;
+  pa.cs_counts = (size_t)p->I * s.S_pad;
+  pa.cs_site = (size_t)s.S_pad;
+  pa.cs_wg = (size_t)s.ntiles / s.T;
+  pa.timeline = nullptr;
+  pa.ablate = 0;
+  pa.frag_ctr = s.frag_ctr;
+  pa.hand_cnt = s.hand_cnt;
+  pa.n_prog_total = 1;
+  return pa;
+}
+
 // Enqueue everything for one rate class on one shard.  q may be a host or device pointer.
 int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, bool sched_changed, bool pi_changed,
                  bool slots_changed, const int64_t *q_nodes, int64_t n_q,
@@ -529,42 +584,12 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     n_wg = prune_nuc_grid(na);
     launch_prune_nuc(na, s.stream);
   } else {
-    PruneArgs pa;
+    PruneArgs pa = base_prune_args(p, s, cat, n_cat_batch);
     pa.ops = s.ops;
     pa.n_ops = n_ops;
     pa.prog = s.prog;
-    pa.n_prog = 1;
-    pa.do_root = 1;
-    pa.NW = p->NW;
-    pa.T = s.T;
-    pa.S_pad = s.S_pad;
-    pa.ntiles = s.ntiles;
-    pa.root_inode = (int)p->I - 1;
-    pa.root_slot = p->root_slot;
-    pa.L = (int)p->L;
-    pa.variant = p->variant;
-    pa.n_slots = p->n_slots;
-    pa.codes_in_lds = ((size_t)p->L * s.T * 32 + (size_t)(p->L + p->I) * 16 <= 24576) ? 1 : 0;
-    pa.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
-    pa.PTg = s.PTg + (size_t)cat * B * DP * DP;
-    pa.codes = s.codes;
-    pa.codes_tile = s.codes_tile;
-    pa.ambig = s.ambig;
-    pa.partials = s.partials + (size_t)cat * s.partial_stride;
-    pa.counts = s.counts + (size_t)cat * p->I * s.S_pad;
-    pa.pi = s.pi;
     pa.site_lik = site_lik;
     pa.site_cnt = site_cnt;
-    pa.freq = s.freq;
-    pa.wg_sum = s.wg_sum;
-    pa.wg_cnt = s.wg_cnt;
-    pa.wg_flag = s.wg_flag;
-    pa.n_cat = n_cat_batch;
-    pa.cs_P = (size_t)B * DP * DP;
-    pa.cs_partials = s.partial_stride;
-    pa.cs_counts = (size_t)p->I * s.S_pad;
-    pa.cs_site = (size_t)s.S_pad;
-    pa.cs_wg = (size_t)s.ntiles / s.T;
     pa.timeline = nullptr;
     pa.ablate = 0;
     if (const char *ab = getenv("HYPHY_HIP_ABLATE")) pa.ablate = atoi(ab);
@@ -810,6 +835,8 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
   for (int64_t k = 0; k < L * S; k++)
     if (leaf_codes[k] >= D || leaf_codes[k] < -n_ambig) { delete p; return fail("leaf code out of range"); }
   p->initialized.assign(C, 0);
+  p->bc_node.assign(C, -1);
+  p->bc_use_pi.assign(C, 0);
   p->leaf_has_ambig.assign(L, 0);
   for (int64_t l = 0; l < L; l++)
     for (int64_t k = 0; k < S; k++)
@@ -882,11 +909,20 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     s.ring.assign(2 * kTimingRing, nullptr);
     for (auto &e : s.ring) hipEventCreate(&e);
     A_(s.codes, (size_t)L * s.S_pad * sizeof(int16_t));
-    if (!p->nuc) A_(s.codes_tile, (size_t)L * s.S_pad * sizeof(int16_t));
+    if (!p->nuc) {
+      A_(s.codes_tile, (size_t)L * s.S_pad * sizeof(int16_t));
+      A_(s.bc_ops, ops_capacity(p) * sizeof(int4));
+      A_(s.bc_prog, sizeof(int4));
+      A_(s.bc_slot, (size_t)C * sizeof(int32_t));
+      A_(s.bc_q, (size_t)D * D * sizeof(double));
+    }
     A_(s.freq, (size_t)s.S_pad * sizeof(double));
     A_(s.ambig, (size_t)std::max<int64_t>(1, n_ambig) * DP * sizeof(double));
-    A_(s.partials, (size_t)C * s.partial_stride * sizeof(double));
-    A_(s.counts, (size_t)C * I * s.S_pad * sizeof(int32_t));
+    // (+2 node slots per class behind the last class: outside vector of the cached branch and a scratch slot, see
+    //  hyphy_hip_branch_cache_build)
+    const size_t node_stride = p->nuc ? (size_t)4 * s.S_pad : (size_t)s.ntiles * 16 * DP;
+    A_(s.partials, ((size_t)C * s.partial_stride + 2 * C * node_stride) * sizeof(double));
+    A_(s.counts, ((size_t)C * I + 2 * C) * s.S_pad * sizeof(int32_t));
     A_(s.site_lik, (size_t)C * s.S_pad * sizeof(double));
     A_(s.site_cnt, (size_t)C * s.S_pad * sizeof(int32_t));
     A_(s.mixed_lik, (size_t)s.S_pad * sizeof(double));
@@ -894,7 +930,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     if (p->nuc) {
       A_(s.Prow, (size_t)C * B * 16 * sizeof(double));
     } else {
-      A_(s.Pfrag, (size_t)C * B * DP * DP * sizeof(double));
+      A_(s.Pfrag, ((size_t)C * B + (size_t)C * (I + 2)) * DP * DP * sizeof(double));  // (+ transposed path matrices of the branch cache)
       A_(s.PTg, (size_t)C * B * DP * DP * sizeof(double));
     }
     A_(s.qbuf, (size_t)C * B * D * D * sizeof(double));
@@ -970,6 +1006,9 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
     for (int64_t c = 1; c < p->C; c++)
       if (p->initialized[c] != p->initialized[0]) p->initialized[0] = 0;  // mixed state: force a full pass
   }
+  // any ordinary evaluation invalidates the branch cache of its class (as the reference resets cachedBranches)
+  if (batch) std::fill(p->bc_node.begin(), p->bc_node.end(), -1);
+  else if (cat >= 0 && cat < (int64_t)p->bc_node.size()) p->bc_node[cat] = -1;
   if (!root_freqs) return fail("root_freqs == NULL");
   if ((n_update > 0 && !update_nodes) || (n_q > 0 && (!q_nodes || !q))) return fail("null node / matrix list");
   if (n_q > p->B) return fail("more matrices than branches");
@@ -1152,6 +1191,187 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
         }
     }
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Branch cache: _TheTree::ComputeBranchCache (tree_evaluator.cpp:4286-4845) builds, for one
+// branch, everything the likelihood needs except that branch's transition matrix; ComputeLLWithBranchCache
+// (tree.cpp:3383-3936) then evaluates L(t) with one [D x D] x [D x S] contraction per call while the
+// optimiser's line search varies the branch length (policy code likefunc.cpp:10886-10948, 11125-11258).
+// ---------------------------------------------------------------------------------------------------
+int hyphy_hip_branch_cache_build(hyphy_hip_partition *p, int64_t cat, int64_t node) {
+  if (!p) return fail("partition == NULL");
+  if (p->nuc || p->variant == 2) {
+    g_last_error = "branch cache: not available for this partition (4-state path / quad-layout kernel)";
+    return 1;
+  }
+  if (cat < 0) cat = 0;
+  if (cat >= p->C) return fail("rate class out of range");
+  if (node < 0 || node >= p->B) return fail("branch cache: node out of range (the root has no branch)");
+  if (!p->initialized[cat]) return fail("branch cache: evaluate the partition first (conditionals must be resident)");
+  const int L = (int)p->L, I = (int)p->I, C = (int)p->C;
+  const int64_t B = p->B;
+  const int DP = p->DP;
+  // ancestors of the branch's parent up to the root; a[0] = root ... a[m] = parent of `node`
+  std::vector<int> a;
+  for (int64_t x = p->parents[node]; x >= 0; x = p->parents[L + x]) a.push_back((int)x);
+  std::reverse(a.begin(), a.end());
+  const int m = (int)a.size() - 1;
+  if (m < 0) return fail("branch cache: node has no parent");
+  const int vbase = (C - (int)cat) * I + 2 * (int)cat;        // node slots behind the last class, relative to this class
+  const int tbase = (int)((C - cat) * B + cat * (I + 2));     // matrix slots behind the last class, relative to this class
+  std::vector<int4> ops;
+  for (int k = 0; k <= m; k++) {
+    const int vid = k == m ? vbase : vbase + 1;
+    const int exclude = k < m ? L + a[k + 1] : (int)node;
+    std::vector<int4> entries;
+    if (k >= 1) {  // the rest of the tree above: previous chain node through the transposed matrix of a[k]'s branch
+      int4 op;
+      op.x = OPK_INTERNAL | (((k - 1) & 1) << 24);
+      op.y = vid;
+      op.z = tbase + k;
+      op.w = 0;
+      entries.push_back(op);
+    }
+    const std::vector<int> &ch = p->children[a[k]];
+    const int G = p->shards[0].T <= 2 ? 2 : 1;
+    std::vector<int> leaves;
+    for (int c : ch)
+      if (c < L && c != exclude) leaves.push_back(c);
+    for (size_t i = 0; i < leaves.size();) {
+      int nl = 1;
+      const bool amb0 = p->leaf_has_ambig[leaves[i]];
+      if (!amb0 && G > 1 && i + 1 < leaves.size() && !p->leaf_has_ambig[leaves[i + 1]]) nl = 2;
+      const unsigned l0 = (unsigned)leaves[i], l1 = nl > 1 ? (unsigned)leaves[i + 1] : l0;
+      int4 op;
+      op.x = OPK_LEAF | (amb0 ? OPF_AMBIG : 0) | (nl << 8) | (0xff << 24);
+      op.y = vid;
+      op.z = (int)(l0 | (l1 << 16));
+      op.w = 0;
+      entries.push_back(op);
+      i += nl;
+    }
+    for (int c : ch)
+      if (c >= L && c != exclude) {
+        int4 op;
+        op.x = OPK_INTERNAL_GLOBAL | (0xff << 24);
+        op.y = vid;
+        op.z = c;
+        op.w = c - L;
+        entries.push_back(op);
+      }
+    if (entries.empty()) {  // (a root whose only other child is the excluded one: the outside vector is all ones)
+      int4 op;
+      op.x = OPK_LEAF | (0xff << 24);
+      op.y = vid;
+      op.z = 0;
+      op.w = 0;
+      entries.push_back(op);
+    }
+    entries.back().x |= OPF_LAST | ((k & 1) ? OPF_PARITY : 0) | ((k & 1) << 16);
+    for (const int4 &e : entries) ops.push_back(e);
+  }
+  int4 nop;
+  nop.x = OPK_LEAF | (0xff << 24);
+  nop.y = vbase + 1;
+  nop.z = 0;
+  nop.w = 0;
+  if (ops.size() & 1) ops.push_back(nop);
+  const int n = (int)ops.size();
+  ops.push_back(nop);
+  ops.push_back(nop);
+  if (ops.size() > ops_capacity(p)) return fail("internal: branch-cache schedule overflow");
+  const int4 prog = make_int4(0, n, -1, 0);
+  const int32_t slot = (int32_t)node;
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipMemcpyAsync(s.bc_ops, ops.data(), ops.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+    HIPCHK(hipMemcpyAsync(s.bc_prog, &prog, sizeof(int4), hipMemcpyHostToDevice, s.stream));
+    HIPCHK(hipMemcpyAsync(s.bc_slot + cat, &slot, sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));  // (the host vectors go out of scope)
+    double *Pf = s.Pfrag + (size_t)cat * B * DP * DP;
+    for (int k = 1; k <= m; k++)  // M_k[j][i] = P_{a[k]}[i][j], times pi_i on the edge that leaves the old root
+      launch_transpose_frag(Pf + (size_t)(L + a[k]) * DP * DP, Pf + (size_t)(tbase + k) * DP * DP, k == 1 ? s.pi : nullptr,
+                            p->NW, s.stream);
+    PruneArgs pa = base_prune_args(p, s, (int)cat, 1);
+    pa.ops = s.bc_ops;
+    pa.prog = s.bc_prog;
+    pa.n_ops = n;
+    pa.n_prog = 1;
+    pa.do_root = 0;
+    pa.n_prog_total = 1;
+    launch_prune_mfma(pa, s.stream);
+    HIPCHK(hipGetLastError());
+  }
+  p->bc_node[cat] = node;
+  p->bc_use_pi[cat] = m == 0 ? 1 : 0;
+  return 0;
+}
+
+int hyphy_hip_branch_cache_evaluate(hyphy_hip_partition *p, int64_t cat, int64_t node, const double *q_dense,
+                                    int q_is_probability, double *logl_out, double *site_lik_out,
+                                    int64_t *site_scaler_out) {
+  if (!p) return fail("partition == NULL");
+  if (cat < 0) cat = 0;
+  if (cat >= p->C) return fail("rate class out of range");
+  if (p->bc_node[cat] < 0 || p->bc_node[cat] != node)
+    return fail("branch cache: no cache resident for this branch (call hyphy_hip_branch_cache_build after an evaluation)");
+  if (!q_dense) return fail("null matrix pointer");
+  const int L = (int)p->L, I = (int)p->I, C = (int)p->C;
+  const int64_t B = p->B, D = p->D;
+  const int DP = p->DP;
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipMemcpyAsync(s.bc_q, q_dense, (size_t)D * D * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    ExpmArgs ea;
+    ea.Q = s.bc_q;
+    ea.slots = s.bc_slot + cat;
+    ea.n = 1;
+    ea.D = (int)D;
+    ea.is_prob = q_is_probability;
+    ea.status = s.status;
+    ea.templates = nullptr;
+    ea.coeffs = nullptr;
+    ea.K = 0;
+    ea.Prow = nullptr;
+    ea.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
+    ea.PTg = s.PTg + (size_t)cat * B * DP * DP;
+    ea.ptg_layout = 0;
+    launch_expm(ea, s.stream);
+    BcArgs ba;
+    ba.NW = p->NW;
+    ba.S_pad = s.S_pad;
+    ba.ntiles = s.ntiles;
+    ba.L = L;
+    ba.node_A = (C - (int)cat) * I + 2 * (int)cat;
+    ba.child_internal = node >= L ? (int)(node - L) : -1;
+    ba.child_leaf = node < L ? (int)node : 0;
+    ba.use_pi = p->bc_use_pi[cat];
+    ba.Pfrag = ea.Pfrag + (size_t)node * DP * DP;
+    ba.PTg = ea.PTg + (size_t)node * DP * DP;
+    ba.codes_tile = s.codes_tile;
+    ba.ambig = s.ambig;
+    ba.partials = s.partials + (size_t)cat * s.partial_stride;
+    ba.counts = s.counts + (size_t)cat * I * s.S_pad;
+    ba.pi = s.pi;
+    ba.freq = s.freq;
+    ba.site_lik = s.site_lik + (size_t)cat * s.S_pad;
+    ba.site_cnt = s.site_cnt + (size_t)cat * s.S_pad;
+    ba.wg_sum = s.wg_sum;
+    ba.wg_cnt = s.wg_cnt;
+    ba.wg_flag = s.wg_flag;
+    launch_bc_eval(ba, s.stream);
+    double *rec = s.d_hout ? s.d_hout : s.out;
+    launch_wg_reduce(s.wg_sum, s.wg_cnt, s.wg_flag, s.ntiles, rec, rec + 1, s.status, s.stream);
+    HIPCHK(hipGetLastError());
+  }
+  if (collect_status(p)) return -1;
+  std::vector<double> parts;
+  for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
+  if (logl_out) *logl_out = combine(parts);
+  if (site_lik_out || site_scaler_out) return gather_sites(p, (int)cat, site_lik_out, site_scaler_out, false);
   return 0;
 }
 

@@ -144,7 +144,31 @@ struct ExpmArgs {
   int K;
 };
 
+// Branch-cache evaluation (hyphy_hip_branch_cache_evaluate): L_s = sum_i A_s[i] (P_c B_s)[i]
+struct BcArgs {
+  int NW, S_pad, ntiles, L;
+  int node_A;                // (virtual) node slot holding the outside vector A, relative to `partials`
+  int child_internal;        // internal index of the cached branch's child node, or -1: it is leaf `child_leaf`
+  int child_leaf;
+  int use_pi;                // the branch hangs off the root: A does not contain the root frequencies yet
+  const double *Pfrag;       // A-operand image of the branch's transition matrix
+  const double *PTg;         // its column-gather image (leaf child)
+  const int16_t *codes_tile;
+  const double *ambig;
+  const double *partials;
+  const int32_t *counts;
+  const double *pi;
+  const double *freq;
+  double *site_lik;
+  int32_t *site_cnt;
+  double *wg_sum;
+  long long *wg_cnt;
+  int *wg_flag;
+};
+
 // launchers (defined in the .hip files)
+void launch_transpose_frag(const double *src_image, double *dst_image, const double *row_scale, int NW, hipStream_t stream);
+void launch_bc_eval(const BcArgs &a, hipStream_t stream);
 void launch_expm(const ExpmArgs &a, hipStream_t stream);
 void launch_prune_mfma(const PruneArgs &a, hipStream_t stream);
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream);

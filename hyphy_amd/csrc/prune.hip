@@ -1177,6 +1177,116 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Branch cache (device counterpart of _TheTree::ComputeBranchCache tree_evaluator.cpp:4286-4845 and
+// _TheTree::ComputeLLWithBranchCache tree.cpp:3383-3936).  While the optimiser varies ONE branch length,
+// L_s(t) = sum_i A_s[i] sum_j P_c(t)[i][j] B_s[j]: B = conditionals of the branch's child node, A = the
+// rest of the tree seen from the branch's parent (root frequencies and all other subtrees folded in).
+// A is produced by the ordinary pruning kernel run over the tree RE-ROOTED at the parent: the edges
+// between the old root and the parent are traversed upside down, i.e. with the transposed transition
+// matrix (no reversibility assumption, unlike the reference).  transpose_frag_kernel makes the A-operand
+// image of M[j][i] = scale[i] P[i][j] from the image of P; bc_eval_kernel is the one-edge evaluation.
+// ---------------------------------------------------------------------------------------------
+__global__ void transpose_frag_kernel(const double *__restrict__ src, double *__restrict__ dst,
+                                      const double *__restrict__ row_scale, int NW) {
+  const int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
+  for (int idx = threadIdx.x; idx < DP * DP; idx += blockDim.x) {
+    const int w = idx / TILE, rem = idx - w * TILE;
+    const int k2 = rem >> 7, l = (rem >> 1) & 63, kk = 2 * k2 + (rem & 1);
+    const int r = 16 * w + (l & 15), c = 4 * kk + (l >> 4);  // dst element M[r][c] = scale[c] * P[c][r]
+    const double v = src[(c >> 4) * TILE + frag_index(r >> 2, (r & 3) * 16 + (c & 15))];
+    dst[idx] = row_scale ? v * row_scale[c] : v;
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64) void bc_eval_kernel(BcArgs a) {
+  constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
+  const int lane = threadIdx.x, g = lane >> 4, sl = lane & 15;
+  const int tile0 = blockIdx.x;
+  f64x4 prod[NW];
+  int ccnt = 0;
+  if (a.child_internal >= 0) {
+    const double *src = a.partials + ((size_t)a.child_internal * a.ntiles + tile0) * TILE;
+    ccnt = a.counts[(size_t)a.child_internal * a.S_pad + tile0 * 16 + sl];
+#pragma unroll
+    for (int w = 0; w < NW; w++) prod[w] = (f64x4){0., 0., 0., 0.};
+#pragma unroll 2
+    for (int k2 = 0; k2 < NKK / 2; k2++) {
+      const f64x2 b = ld16(src, (unsigned)(k2 * 64 + lane) * 16u);
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        const f64x2 av = ld16(a.Pfrag + w * TILE, (unsigned)(k2 * 64 + lane) * 16u);
+        prod[w] = mfma(av[0], b[0], prod[w]);
+        prod[w] = mfma(av[1], b[1], prod[w]);
+      }
+    }
+  } else {
+    const int c = (int)a.codes_tile[((size_t)tile0 * a.L + a.child_leaf) * 16 + sl];
+    if (!__any(c < 0)) {  // column gather, [code][w][g][r] = P[16w + 4r + g][code]
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        const unsigned off = (unsigned)((c * NW + w) * 16 + g * 4) * 8u;
+        const f64x2 v0 = ld16(a.PTg, off), v1 = ld16(a.PTg, off + 16u);
+        prod[w] = (f64x4){v0[0], v0[1], v1[0], v1[1]};
+      }
+    } else {  // ambiguity codes in this tile: product with the resolution vectors
+      const double *av = a.ambig + (size_t)(c < 0 ? -c - 1 : 0) * DP;
+#pragma unroll
+      for (int w = 0; w < NW; w++) prod[w] = (f64x4){0., 0., 0., 0.};
+      for (int kk = 0; kk < NKK; kk++) {
+        const double bv = (c >= 0) ? ((4 * kk + g == c) ? 1.0 : 0.0) : av[4 * kk + g];
+#pragma unroll
+        for (int w = 0; w < NW; w++) prod[w] = mfma(a.Pfrag[w * TILE + frag_index(kk, lane)], bv, prod[w]);
+      }
+    }
+  }
+  // L_s = sum_i A_s[i] prod_s[i]  (rows 16w + 4r + g of the C/D image; A is stored as a persisted node)
+  const double *Asrc = a.partials + ((size_t)a.node_A * a.ntiles + tile0) * TILE;
+  double s = 0.;
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    const f64x2 a0 = ld16(Asrc, (unsigned)((2 * w) * 64 + lane) * 16u), a1 = ld16(Asrc, (unsigned)((2 * w + 1) * 64 + lane) * 16u);
+    const double av[4] = {a0[0], a0[1], a1[0], a1[1]};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      double t = av[r] * prod[w][r];
+      if (a.use_pi) t *= a.pi[16 * w + 4 * r + g];
+      s += t;
+    }
+  }
+  s = row_sum4(s);
+  const int rcnt = ccnt + a.counts[(size_t)a.node_A * a.S_pad + tile0 * 16 + sl];
+  double wsum = 0.;
+  long long wcnt = 0;
+  int wflag = 0;
+  if (g == 0) {
+    const int site = tile0 * 16 + sl;
+    a.site_lik[site] = s;
+    a.site_cnt[site] = rcnt;
+    const double f = a.freq[site];
+    if (f != 0.) {
+      if (s != s || isinf(s)) wflag |= 2;
+      else if (s <= 0.) wflag |= 1;
+      else {
+        wsum += log(s) * f;
+        wcnt += (long long)rcnt * (long long)f;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    wsum += __shfl_xor(wsum, off);
+    wcnt += __shfl_xor(wcnt, off);
+    wflag |= __shfl_xor(wflag, off);
+  }
+  if (lane == 0) {
+    a.wg_sum[tile0] = wsum;
+    a.wg_cnt[tile0] = wcnt;
+    a.wg_flag[tile0] = wflag;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 4-state (nucleotide) kernel: one thread per site pattern walks the whole schedule; P matrices
 // are wave-uniform (scalar loads), conditionals live in registers and are persisted as
 // state-major planes so every global access is a coalesced 512-byte line per wave.
@@ -1554,6 +1664,19 @@ void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *
 }
 
 int prune_mfma_grid(const PruneArgs &a) { return a.ntiles / a.T; }
+
+void launch_transpose_frag(const double *src_image, double *dst_image, const double *row_scale, int NW, hipStream_t stream) {
+  hipLaunchKernelGGL(transpose_frag_kernel, dim3(1), dim3(256), 0, stream, src_image, dst_image, row_scale, NW);
+}
+void launch_bc_eval(const BcArgs &a, hipStream_t stream) {
+  const dim3 grid(a.ntiles), block(64);
+  switch (a.NW) {
+    case 1: hipLaunchKernelGGL(bc_eval_kernel<1>, grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(bc_eval_kernel<2>, grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(bc_eval_kernel<3>, grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL(bc_eval_kernel<4>, grid, block, 0, stream, a); break;
+  }
+}
 int prune_nuc_grid(const NucArgs &a) { return (a.S_pad + 255) / 256; }
 
 void launch_mix_categories(const double *site_lik, const int32_t *site_cnt, const double *weights_dev, int C,

@@ -22,7 +22,7 @@ EXPORTS = [
     "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
-    "hyphy_hip_prune_kernel_name",
+    "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
     "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
@@ -85,6 +85,10 @@ def load():
     lib.hyphy_hip_prune_timings.argtypes = [vp, dp, C.c_int64]
     lib.hyphy_hip_prune_launches.restype = C.c_int
     lib.hyphy_hip_prune_launches.argtypes = [vp]
+    lib.hyphy_hip_branch_cache_build.restype = C.c_int
+    lib.hyphy_hip_branch_cache_build.argtypes = [vp, C.c_int64, C.c_int64]
+    lib.hyphy_hip_branch_cache_evaluate.restype = C.c_int
+    lib.hyphy_hip_branch_cache_evaluate.argtypes = [vp, C.c_int64, C.c_int64, dp, C.c_int, dp, dp, lp]
     lib.hyphy_hip_prune_kernel_name.restype = C.c_char_p
     lib.hyphy_hip_prune_kernel_name.argtypes = [vp]
     lib.hyphy_hip_last_error.restype = C.c_char_p
@@ -275,6 +279,34 @@ class HipPartition:
         counts = np.zeros((self.I, self.S), dtype=np.int64)
         _check(self._lib.hyphy_hip_download_partials(self._h, cat, _d(cache), _l(counts)))
         return cache, counts
+
+    # -- branch cache (one-branch line searches) --------------------------------------------------
+    def branch_cache_build(self, node: int, cat: int = 0):
+        """Prepare the device branch cache for branch ``node`` (call after an ``evaluate``)."""
+        _check(self._lib.hyphy_hip_branch_cache_build(self._h, cat, int(node)))
+
+    def branch_cache_evaluate(self, node: int, q_dense: np.ndarray, cat: int = 0, q_is_probability: bool = False,
+                              per_site: bool = False):
+        """log-L with branch ``node``'s matrix replaced by exp(q_dense); everything else as at build time."""
+        q = np.ascontiguousarray(q_dense, dtype=np.float64)
+        out = C.c_double(0.0)
+        sl = np.zeros(self.S) if per_site else None
+        sc = np.zeros(self.S, dtype=np.int64) if per_site else None
+        _check(self._lib.hyphy_hip_branch_cache_evaluate(self._h, cat, int(node), _d(q), int(q_is_probability),
+                                                         C.byref(out), _d(sl), _l(sc)))
+        return (out.value, sl, sc) if per_site else out.value
+
+    def prepare_branch_cache_step(self, node: int, q_dense: np.ndarray, cat: int = 0):
+        """Zero-argument callable evaluating the cached branch with the CURRENT contents of ``q_dense``
+        (update it in place between calls); arguments marshalled once."""
+        assert q_dense.flags.c_contiguous and q_dense.dtype == np.float64
+        lib, h, pq, out = self._lib, self._h, _d(q_dense), C.c_double(0.0)
+        ref = C.byref(out)
+
+        def step(_keep=q_dense):
+            _check(lib.hyphy_hip_branch_cache_evaluate(h, cat, int(node), pq, 0, ref, None, None))
+            return out.value
+        return step
 
     # -- device-side Q construction -------------------------------------------------------------
     def set_q_templates(self, templates: np.ndarray):

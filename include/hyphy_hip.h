@@ -183,6 +183,25 @@ int hyphy_hip_set_stream(hyphy_hip_partition *p, void *stream);
  * out[0] = expm kernel(s), out[1] = pruning kernel, out[2] = root/site reduction. */
 int hyphy_hip_last_timings(hyphy_hip_partition *p, double out[3]);
 
+/* ---- branch cache ---------------------------------------------------------------------
+ * Replaces _TheTree::ComputeBranchCache (src/core/tree_evaluator.cpp:4286-4845) and
+ * _TheTree::ComputeLLWithBranchCache (src/core/tree.cpp:3383-3936), driven by the policy code of
+ * _LikelihoodFunction::ComputeBlock (src/core/likefunc.cpp:10886-10948, 11125-11258): while the optimiser
+ * varies ONE branch length, every evaluation is a single [D x D] x [D x S] contraction.
+ *
+ * build: after an ordinary hyphy_hip_evaluate* call (conditionals and transition matrices resident, all
+ * parameters at the values the line search keeps fixed), prepare the cache for branch `node` (node code:
+ * leaf l -> l, internal i -> L + i; not the root).  Works for any model (the tree is re-rooted with
+ * transposed transition matrices, no reversibility needed).  Returns 1 for the 4-state path.
+ * evaluate: log-likelihood with this branch's matrix replaced by exp(q) (or q itself when
+ * q_is_probability); all other parameters as at build time.  The device keeps the new matrix, as the host
+ * tree does; the next ordinary evaluation of the class invalidates its cache.  One cache per rate class.
+ * site_lik_out / site_scaler_out: per-pattern (l_s, c_s) as hyphy_hip_evaluate returns them. */
+int hyphy_hip_branch_cache_build(hyphy_hip_partition *p, int64_t cat, int64_t node);
+int hyphy_hip_branch_cache_evaluate(hyphy_hip_partition *p, int64_t cat, int64_t node, const double *q_dense,
+                                    int q_is_probability, double *logl_out, double *site_lik_out /* [S] or NULL */,
+                                    int64_t *site_scaler_out /* [S] or NULL */);
+
 /* Durations (ms) of the pruning launches of the last `n` evaluations, oldest first, from a ring of HIP
  * event pairs recorded on the partition's stream (shard 0).  Nothing is queried while evaluations run —
  * call this after the timed region.  Returns the number of entries written (<= n, <= 1024). */

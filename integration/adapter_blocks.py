@@ -19,7 +19,7 @@ struct _HyHipPart {
   std::vector<char> cat_seen;
 };
 static std::map<const void *, std::vector<_HyHipPart>> _hyhip_lfs;
-long _hyhip_calls = 0L;
+long _hyhip_calls = 0L, _hyhip_cached_calls = 0L;
 
 static bool _hyphy_hip_enabled(void) {
   static int state = -1;
@@ -35,7 +35,7 @@ static void _hyphy_hip_teardown(const void *lf) {
   if (it == _hyhip_lfs.end()) return;
   for (auto &hp : it->second) hyphy_hip_destroy(hp.part);
   _hyhip_lfs.erase(it);
-  if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %ld ComputeBlock evaluations ran on the device so far\n", _hyhip_calls);
+  if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %ld ComputeBlock evaluations ran on the device so far (+ %ld through the branch cache)\n", _hyhip_calls, _hyhip_cached_calls);
 }
 
 static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_parts, _TheTree *cT,
@@ -107,6 +107,34 @@ static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catI
   }
   return rc;
 }
+
+// branch cache (SURVEY 8f-1): device counterparts of ComputeBranchCache / ComputeLLWithBranchCache, driven by the
+// reference's own policy state machine (computedLocalUpdatePolicy, likefunc.cpp:10886-10948)
+static int _hyphy_hip_cache_build(const void *lf, long index, long catID, long node) {
+  _HyHipPart &hp = _hyhip_lfs[lf][index];
+  int rc = hyphy_hip_branch_cache_build(hp.part, catID, node);
+  if (rc < 0) ReportWarning(_String("hyphy_hip_branch_cache_build: ") & hyphy_hip_last_error());
+  return rc;
+}
+static int _hyphy_hip_cached(const void *lf, long index, _TheTree *t, long catID, long node, hyFloat *siteRes,
+                             long *scc, hyFloat *result) {
+  _HyHipPart &hp = _hyhip_lfs[lf][index];
+  _CalcNode *n = (_CalcNode *)t->GetNodeFromFlatIndex(node);
+  _Matrix *P = n->GetCompExp(catID);
+  if (!P || !P->theData) return 1;
+  double ll = 0.;
+  int rc = hyphy_hip_branch_cache_evaluate(hp.part, catID, node, P->theData, /* q_is_probability = */ 1, &ll, siteRes,
+                                           (int64_t *)scc);
+  if (rc < 0) {
+    HandleApplicationError(_String("hyphy_hip_branch_cache_evaluate: ") & hyphy_hip_last_error());
+    return rc;
+  }
+  if (rc == 0) {
+    _hyhip_cached_calls++;
+    *result = ll;
+  }
+  return rc;
+}
 #endif
 '''
 
@@ -127,12 +155,25 @@ TEARDOWN = r'''
 # ---- block 4: ComputeBlock, between ExponentiateMatrices and the OpenMP pruning loop -----------------
 COMPUTE = r'''
 #ifdef HYPHY_HIP
-      if (branchIndex < 0 && doCachedComp == 0 && _hyphy_hip_active(this, index)) {
+      if (branchIndex < 0 && _hyphy_hip_active(this, index)) {
         hyFloat hip_result = 0.;
+        if (doCachedComp >= 3) {  // one-branch line search: a single contraction against the device branch cache
+          if (_hyphy_hip_cached(this, index, t, catID, doCachedComp - 3, siteRes, scc, &hip_result) == 0) {
+            return hip_result;
+          }
+          return -INFINITY;  // (the error was reported; the host caches were never filled)
+        }
         if (_hyphy_hip_compute(this, index, t, catID, *branches, *matrices, siteRes, scc, &hip_result) == 0) {
+          if (doCachedComp < 0) {  // the policy asked for a cache of this branch after the normal pass
+            const long nd = -doCachedComp - 1;
+            if (_hyphy_hip_cache_build(this, index, catID, nd) == 0) {
+              *cbid = nd;
+            } else {  // not available (e.g. 4-state path): keep evaluating normally
+              ((_SimpleList *)computedLocalUpdatePolicy(index))->list_data[ciid] = 1;
+            }
+          }
           return hip_result;  // already  sum_s f_s log L_s - 64 ln2 * scalers  (likefunc.cpp:11123)
         }
       }
 #endif
 '''
-

@@ -38,13 +38,10 @@ def main():
     lf = splice(lf, '#include "vector.h"\n', "#undef protected\n" + AB.HELPERS)
     lf = splice(lf, "#ifdef MDSOCL\n    OCLEval[i].init(", AB.SETUP, before=True)
     lf = splice(lf, "void _LikelihoodFunction::DeleteCaches(bool all) {\n", AB.TEARDOWN)
-    # device path active -> do not engage the host branch-cache state machine: its caches
-    # live in host memory that the device path never fills
-    lf = splice(lf, "if (computedLocalUpdatePolicy.lLength && branchIndex < 0) {",
-                "", before=True)
-    lf = lf.replace("if (computedLocalUpdatePolicy.lLength && branchIndex < 0) {",
-                    "if (computedLocalUpdatePolicy.lLength && branchIndex < 0\n#ifdef HYPHY_HIP\n"
-                    "          && !_hyphy_hip_active(this, index)\n#endif\n      ) {", 1)
+    # The branch-cache state machine (computedLocalUpdatePolicy) keeps running on the host; its two hooks —
+    # "build the cache of branch n after this pass" and "evaluate through the cache" — go to the device
+    # (AB.COMPUTE).  The host-side scaling-factor backup/restore around it is harmless: the device path keeps
+    # no sticky scalers.
     lf = splice(lf, "      hyFloat sum = 0.;\n\n      if (doCachedComp >= 3) {", AB.COMPUTE, before=True)
     src = os.path.join(OUT, "likefunc_hip.cpp")
     open(src, "w").write(lf)

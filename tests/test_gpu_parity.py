@@ -251,6 +251,88 @@ def test_partial_update_equals_full(name):
             assert abs(ll - ref) <= RTOL * abs(ref), (name, node, ll, ref)
 
 
+@pytest.mark.parametrize("name,kernel,shards", [("codon_wide", "0", None), ("codon_wide", "1", None), ("codon_deep", "0", None),
+                                                ("codon_deep", "1", None), ("codon_ambig", "1", None),
+                                                ("codon_small", "0", "3"), ("codon_ambig", "0", None)])
+def test_branch_cache_equals_full_evaluation(name, kernel, shards, monkeypatch):
+    """hyphy_hip_branch_cache_build / _evaluate (device ComputeBranchCache + ComputeLLWithBranchCache,
+    tree_evaluator.cpp:4286, tree.cpp:3383): for a sample of branches (leaf branches, internal branches,
+    branches at the root, the deepest ones) the cached one-contraction log-L equals the full evaluation —
+    at the build-time branch length (the reference's own checksum, likefunc.cpp:11177-11250) and at changed
+    lengths — and the oracle's full evaluation with that matrix substituted."""
+    from oracle import oracle
+    monkeypatch.setenv("HYPHY_HIP_KERNEL", kernel)  # workgroup-per-tile / wave-per-tile pruning kernel
+    if shards:
+        monkeypatch.setenv("HYPHY_HIP_FORCE_SHARDS", shards)
+    fx = common.load(name)
+    nodes = common.all_nodes(fx)
+    Q = common.fixture_Q(fx)
+    pi = fx["root_freqs"]
+    L, I = int(fx["L"]), len(fx["flat_parents"]) - int(fx["L"])
+    B = L + I - 1
+    parents = np.asarray(fx["flat_parents"])
+    depth = np.zeros(L + I, dtype=int)  # the root (last internal node) has depth 0; parents have larger indices
+    for n in list(range(L + I - 2, L - 1, -1)) + list(range(L)):
+        depth[n] = depth[L + parents[n]] + 1
+    rng = np.random.default_rng(7)
+    picks = {0, L - 1, L, B - 1, int(np.argmax(depth[:L])), int(np.argmax(depth[L:B]) + L)}
+    picks |= set(int(x) for x in rng.integers(0, B, size=4))
+    D = int(fx["D"])
+    op = oracle.OraclePartition(D, fx["flat_parents"], L, fx["leaf_codes"], fx["ambig"], fx["pattern_freq"])
+    with _mk(fx) as part:
+        full = part.evaluate(nodes, nodes, Q, pi)
+        for node in sorted(picks):
+            part.evaluate(nodes, nodes, Q, pi)  # (an ordinary evaluation drops the cache and restores every matrix)
+            part.branch_cache_build(node)
+            same = part.branch_cache_evaluate(node, Q[node])
+            assert abs(same - full) <= 1e-10 * abs(full), (name, node, same, full)
+            for f in (0.25, 3.0):
+                Q2 = Q.copy()
+                Q2[node] = Q[node] * f
+                cached = part.branch_cache_evaluate(node, Q2[node])
+                op.set_P(nodes, oracle.expm(Q2, True))
+                ref = op.compute_block(nodes, pi)
+                assert abs(cached - ref) <= RTOL * abs(ref), (name, node, f, cached, ref)
+
+
+def test_branch_cache_per_class_and_per_site():
+    """One cache per rate class; per-pattern outputs of the cached evaluation equal those of a full one."""
+    fx = common.load("codon_cat3")
+    nodes = common.all_nodes(fx)
+    pi = fx["root_freqs"]
+    vals = [float(v) for v in fx["cat_values"]]
+    Qs = [common.fixture_Q(fx, v) for v in vals]
+    node = int(fx["L"]) + 2
+    with _mk(fx, C=len(vals)) as part:
+        for c, Q in enumerate(Qs):
+            part.evaluate(nodes, nodes, Q, pi, cat=c)
+        for c in range(len(vals)):
+            part.branch_cache_build(node, cat=c)
+        for c, Q in enumerate(Qs):
+            ll, sl, sc = part.branch_cache_evaluate(node, Q[node] * 1.7, cat=c, per_site=True)
+            Q2 = Q.copy()
+            Q2[node] = Q[node] * 1.7
+            with _mk(fx) as p2:
+                ref, rl, rc = p2.evaluate(nodes, nodes, Q2, pi, per_site=True)
+            assert abs(ll - ref) <= RTOL * abs(ref)
+            assert np.allclose(np.log(sl) - sc * 64 * np.log(2.0), np.log(rl) - rc * 64 * np.log(2.0), rtol=1e-10, atol=1e-9)
+
+
+def test_branch_cache_requires_build_and_is_dropped_by_evaluate():
+    fx = common.load("codon_small")
+    nodes = common.all_nodes(fx)
+    Q = common.fixture_Q(fx)
+    with _mk(fx) as part:
+        part.evaluate(nodes, nodes, Q, fx["root_freqs"])
+        with pytest.raises(RuntimeError):
+            part.branch_cache_evaluate(3, Q[3])
+        part.branch_cache_build(3)
+        part.branch_cache_evaluate(3, Q[3])
+        part.evaluate(nodes, nodes, Q, fx["root_freqs"])
+        with pytest.raises(RuntimeError):
+            part.branch_cache_evaluate(3, Q[3])
+
+
 def test_categories_match_reference():
     fx = common.load("codon_cat3")
     C = len(fx["cat_weights"])

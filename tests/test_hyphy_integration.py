@@ -47,6 +47,11 @@ def _case(kind, n_taxa, n_sites, seed, category=None, ladder=False, **kw):
                 category=category, **args)
 
 
+def _cached_calls(stdout):
+    m = re.findall(r"\(\+ (\d+) through the branch cache\)", stdout)
+    return max(int(x) for x in m) if m else 0
+
+
 def _device_calls(stdout):
     m = re.findall(r"\[hyphy_hip\] (\d+) ComputeBlock evaluations ran on the device", stdout)
     return max(int(x) for x in m) if m else 0
@@ -106,5 +111,8 @@ def test_hbl_optimize_through_device_matches_cpu_fit():
     cpu = hbl.evaluate(optimize=True, **case)
     gpu = hbl.evaluate(optimize=True, binary=HIP_BIN, extra_env=ENV, **case)
     assert _device_calls(gpu["stdout"]) > 50
+    # the optimiser's one-branch line searches went through the device branch cache, driven by
+    # the reference's own computedLocalUpdatePolicy state machine
+    assert _cached_calls(gpu["stdout"]) > 20, gpu["stdout"][-600:]
     assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3       # 2 x OPTIMIZATION_PRECISION, the reference's own test bar
     assert abs(gpu["logl"] - cpu["logl"]) <= 1e-10 * abs(cpu["logl"])
