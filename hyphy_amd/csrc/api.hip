@@ -536,6 +536,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     ea.templates = nullptr;
     ea.coeffs = nullptr;
     ea.K = 0;
+    ea.prof = getenv("HYPHY_HIP_EXPM_PROF") ? 1 : 0;
     if (q_from_templates) {  // fused build: coefficients were staged by hyphy_hip_build_q
       ea.templates = s.templates;
       ea.coeffs = s.coeffs;
@@ -683,10 +684,17 @@ int prepare_schedule(hyphy_hip_partition *p, int cat, const int64_t *update_node
 
 // Wait for every shard and read its host-mapped result record [log-L, scaler sum, status].
 int collect_status(hyphy_hip_partition *p) {
+  static const bool expm_prof = getenv("HYPHY_HIP_EXPM_PROF") != nullptr;
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
     if (!s.d_hout) HIPCHK(hipMemcpyAsync(s.h_out, s.out, 3 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
     HIPCHK(hipStreamSynchronize(s.stream));
+    if (expm_prof) {
+      long long t[8];
+      expm_read_profile(t);
+      fprintf(stderr, "[hyphy_hip] expm phases (cycles): Q build %lld, norms %lld, Taylor %lld, squarings %lld, store %lld, images %lld\n",
+              t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5]);
+    }
     if (s.h_out[2] != 0.) {
       hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream);
       return fail("Failed to compute a valid transition matrix; this is usually caused by ill-conditioned rate "
@@ -1335,6 +1343,7 @@ int hyphy_hip_branch_cache_evaluate(hyphy_hip_partition *p, int64_t cat, int64_t
     ea.templates = nullptr;
     ea.coeffs = nullptr;
     ea.K = 0;
+    ea.prof = 0;
     ea.Prow = nullptr;
     ea.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
     ea.PTg = s.PTg + (size_t)cat * B * DP * DP;
@@ -1393,7 +1402,7 @@ int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_
   HIPCHK(hipMemcpy(dq, q_dense, bytes, hipMemcpyHostToDevice));
   ExpmArgs ea;
   ea.Q = dq; ea.slots = nullptr; ea.n = (int)n; ea.D = (int)D; ea.is_prob = 0;
-  ea.Prow = dp; ea.Pfrag = nullptr; ea.PTg = nullptr; ea.ptg_layout = 0; ea.status = st;
+  ea.Prow = dp; ea.Pfrag = nullptr; ea.PTg = nullptr; ea.ptg_layout = 0; ea.prof = 0; ea.status = st;
   ea.templates = nullptr; ea.coeffs = nullptr; ea.K = 0;
   launch_expm(ea, nullptr);
   int32_t hst = 0;

@@ -142,7 +142,9 @@ struct ExpmArgs {
   const double *templates;   // [K][D*D]
   const double *coeffs;      // [n][K]
   int K;
+  int prof;                  // diagnostic: workgroup 0 stamps its phases (HYPHY_HIP_EXPM_PROF)
 };
+void expm_read_profile(long long out[8]);
 
 // Branch-cache evaluation (hyphy_hip_branch_cache_evaluate): L_s = sum_i A_s[i] (P_c B_s)[i]
 struct BcArgs {

@@ -16,6 +16,10 @@ namespace hyhip {
 
 namespace {
 
+// phase stamps of workgroup 0 (diagnostic, HYPHY_HIP_EXPM_PROF): start, Q built, norms, Taylor polynomial,
+// squarings done, result in LDS, images written
+__device__ long long g_expm_prof[8];
+
 __device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
@@ -131,24 +135,46 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
   const int w = wv % NT, h = wv / NT, c0 = h * NTW;
   const int D = a.D;
   const int m = blockIdx.x;
+  const bool prof = a.prof && blockIdx.x == 0 && tid == 0;
+  if (prof) g_expm_prof[0] = clock64();
   const int slot = a.slots ? a.slots[m] : m;
   const double *Q = a.Q + (size_t)m * D * D;
 
   if (a.templates) {
     // fused device-side rate-matrix construction: Q = sum_k c_k T_k, then the diagonal by column-order
-    // subtraction (the order of _Matrix::MultByFreqs, matrix.cpp:1664-1674)
-    for (int idx = tid; idx < DP * DP; idx += NTHR) {
-      const int r = idx / DP, c = idx - r * DP;
-      double v = 0.;
-      if (r < D && c < D && r != c)
-        for (int k = 0; k < a.K; k++) v += a.coeffs[(size_t)m * a.K + k] * a.templates[((size_t)k * D + r) * D + c];
-      Xs[r * LD + c] = v;
+    // subtraction (the order of _Matrix::MultByFreqs, matrix.cpp:1664-1674).  Every load of a thread is
+    // independent of the others (clamped index + mask instead of a branch), so the whole build costs one
+    // memory round trip instead of one per element.
+    constexpr int EPT = DP * DP / NTHR;  // elements per thread (DP*DP is a multiple of the block size)
+    const int K = a.K;
+    const double *ck = a.coeffs + (size_t)m * K;
+    double v[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) v[e] = 0.;
+    for (int k = 0; k < K; k++) {
+      const double cf = ck[k];
+      const double *Tk = a.templates + (size_t)k * D * D;
+#pragma unroll
+      for (int e = 0; e < EPT; e++) {
+        const int idx = tid + e * NTHR, r = idx / DP, c = idx - r * DP;
+        const bool in = r < D && c < D && r != c;
+        const double t = Tk[in ? r * D + c : 0];
+        v[e] += in ? cf * t : 0.;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      const int idx = tid + e * NTHR, r = idx / DP, c = idx - r * DP;
+      Xs[r * LD + c] = v[e];
     }
     __syncthreads();
     if (tid < D) {
       double d = 0.;
-      for (int c = 0; c < D; c++)
-        if (c != tid) d -= Xs[tid * LD + c];
+#pragma unroll
+      for (int c = 0; c < DP; c++) {  // (unrolled: the LDS reads pipeline; the diagonal itself and padding hold 0)
+        const double x = Xs[tid * LD + c];
+        d -= (c != tid) ? x : 0.;
+      }
       Xs[tid * LD + tid] = d;
     }
   } else {
@@ -158,26 +184,40 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
     }
   }
   __syncthreads();
+  if (prof) g_expm_prof[1] = clock64();
 
   if (!a.is_prob) {
-    // max row / column absolute sums (RowAndColumnMax, matrix.cpp:4901)
-    if (tid < DP) {
+    // max row / column absolute sums (RowAndColumnMax, matrix.cpp:4901): the block's threads split every
+    // row / column into NTHR/DP contiguous parts, combined in fixed order
+    constexpr int PARTS = NTHR / DP >= 1 ? NTHR / DP : 1, SEG = DP / PARTS;
+    {
+      const int line = tid / PARTS, part = tid - line * PARTS;
       double rs = 0., cs = 0.;
-      for (int k = 0; k < DP; k++) {
-        rs += fabs(Xs[tid * LD + k]);
-        cs += fabs(Xs[k * LD + tid]);
+      if (line < DP) {
+#pragma unroll
+        for (int k = 0; k < SEG; k++) {
+          rs += fabs(Xs[line * LD + part * SEG + k]);
+          cs += fabs(Xs[(part * SEG + k) * LD + line]);
+        }
       }
-      red[tid] = rs;
-      red[DP + tid] = cs;
+#pragma unroll
+      for (int off = 1; off < PARTS; off <<= 1) {  // PARTS is a power of two <= 8: partners sit in the same wave
+        rs += __shfl_xor(rs, off);
+        cs += __shfl_xor(cs, off);
+      }
+      if (line < DP && part == 0) {
+        red[line] = rs;
+        red[DP + line] = cs;
+      }
     }
     __syncthreads();
-    double rmax = 0., cmax = 0.;
-    bool nan_in = false;
-    for (int k = 0; k < DP; k++) {
-      const double rv = red[k], cv = red[DP + k];
-      if (rv != rv) nan_in = true;
-      rmax = fmax(rmax, rv);
-      cmax = fmax(cmax, cv);
+    // every wave forms the two maxima for itself (DP <= 64: one value per lane, then a butterfly)
+    double rmax = lane < DP ? red[lane] : 0., cmax = lane < DP ? red[DP + lane] : 0.;
+    const bool nan_in = __any(rmax != rmax || cmax != cmax);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      rmax = fmax(rmax, __shfl_xor(rmax, off));
+      cmax = fmax(cmax, __shfl_xor(cmax, off));
     }
     const double mnorm = rmax * cmax;
     int p = 0;
@@ -186,6 +226,7 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
       if (s > 1.) p = ilogb(s) + 1;
     }
     // original Q in registers (C/D image) so that a restart can rescale it
+    if (prof) g_expm_prof[2] = clock64();
     Frag<NTW> Qr;
 #pragma unroll
     for (int c = 0; c < NTW; c++)
@@ -233,6 +274,7 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
         add_diag(acc, k0);
       }
       R = acc;
+      if (prof) g_expm_prof[3] = clock64();
       if (!diag_fix<NT, CS>(R, w, h, c0, g, sl, flag, rowpart)) {  // matrix.cpp:5854-5864: restart, scale_to *= 100
         p += 7;
         if (p > 900) failed = true;
@@ -271,10 +313,12 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
       if (tid == 0) atomicOr(a.status, 1);
       return;
     }
+    if (prof) g_expm_prof[4] = clock64();
     __syncthreads();
     store_frag<NT, CS>(Xs, R, w, c0, g, sl);
     __syncthreads();
   }
+  if (prof) g_expm_prof[5] = clock64();
 
   // ---- outputs: row-major, A-operand image, column-gather image ----
   if (a.Prow) {
@@ -310,6 +354,7 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
       out[idx] = (rr < D && code < D) ? Xs[rr * LD + code] : 0.0;
     }
   }
+  if (prof) g_expm_prof[6] = clock64();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -465,6 +510,8 @@ __global__ __launch_bounds__(256) void build_q_kernel(const double *__restrict__
 }
 
 }  // namespace
+
+void expm_read_profile(long long out[8]) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_expm_prof), 8 * sizeof(long long)); }
 
 void launch_expm(const ExpmArgs &a, hipStream_t stream) {
   if (a.n <= 0) return;

@@ -69,6 +69,34 @@ def test_logl_and_sites_match_reference(name):
         assert sc.max() > 0  # the rescaling branch was really exercised
 
 
+@pytest.mark.parametrize("kernel", ["1", "2"])
+@pytest.mark.parametrize("name", ["codon_small", "codon_ambig", "codon_deep", "codon_wide"])
+def test_wave_kernels_match_reference(name, kernel, monkeypatch):
+    """The goldens are small shards (the library would pick the workgroup-per-tile kernel): force the
+    wave-per-tile kernels — 16x16x4 MFMA with register hand-over (1) and the 4x4x4-MFMA / quad-layout variant
+    (2) — through the same checks, including the downloaded conditionals of every internal node."""
+    from oracle import oracle
+    monkeypatch.setenv("HYPHY_HIP_KERNEL", kernel)
+    fx = common.load(name)
+    nodes = common.all_nodes(fx)
+    Q = common.fixture_Q(fx)
+    with _mk(fx) as part:
+        assert part.prune_kernel_name() == {"1": "prune_wave_kernel", "2": "prune_w4_kernel"}[kernel]
+        ll, sl, sc = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+        cache, counts = part.download_partials()
+    ref = float(fx["logl"])
+    assert abs(ll - ref) <= RTOL * abs(ref)
+    site = np.log(sl) - sc * 64 * np.log(2.0)
+    op = oracle.OraclePartition(int(fx["D"]), fx["flat_parents"], int(fx["L"]), fx["leaf_codes"], fx["ambig"], fx["pattern_freq"])
+    op.set_P(nodes, oracle.expm(Q, True))
+    osl = op.site_log_likelihoods(nodes, fx["root_freqs"])
+    assert np.allclose(site, osl, rtol=1e-10, atol=1e-9)
+    oc = op.cache[0]   # conditionals node by node (normalised: the exponent bookkeeping differs by design)
+    for n in range(op.I):
+        a, b = cache[n], oc[n]
+        assert np.allclose(a / a.sum(1, keepdims=True), b / b.sum(1, keepdims=True), rtol=1e-9, atol=1e-300), (name, n)
+
+
 @pytest.mark.parametrize("name", ["codon_small", "codon_deep", "nuc_ambig"])
 def test_partials_match_oracle(name):
     """download_partials returns the reference layout; conditionals agree with the CPU
