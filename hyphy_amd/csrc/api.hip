@@ -122,6 +122,14 @@ struct hyphy_hip_partition {
   std::vector<int64_t> cached_update;        // update list the device schedule was built for
   bool cached_full = false;
   int cached_valid = 0;
+  // Lazy persistence of the conditionals (cache_policy 1, default; HYPHY_HIP_CACHE=always turns it off): a full
+  // pass that follows a full pass (a sweep over a global parameter) keeps its nodes in registers / LDS only —
+  // nothing reads the persisted copies before the next full pass overwrites them — except the nodes some later
+  // schedule entry of the same pass re-reads.  `resident[c]`: the persisted copies of class c are current;
+  // a partial update, a branch-cache build or a download that finds them stale first re-runs a persisting pass.
+  int cache_policy = 1;
+  std::vector<char> resident, last_full;
+  bool cached_persist = true, sched_persist = true, sched_full = true;
   std::vector<double> cached_pi;             // root frequencies currently on the device
   std::vector<double> cached_weights;        // category weights currently on the device
   std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
@@ -190,6 +198,8 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
   std::vector<char> recomputed(I, 0);   // finalised earlier in THIS program
   const int n_slots = p->n_slots > 0 ? p->n_slots : lds_slots(T);
   std::vector<char> slot_busy(n_slots, 0);
+  std::vector<int> last_entry(I, -1);   // index (in ops_host) of the OPF_LAST entry of a node finalised by this program
+  const bool lazy = !p->sched_persist && !p->nuc;
   const int off = (int)p->ops_host.size();
   int fin = 0, root_slot = 0;
   for (size_t ti = 0; ti < nodes.size(); ti++) {
@@ -209,7 +219,10 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
         slot_of[c - L] = -1;
       } else {
         op.x = OPK_INTERNAL_GLOBAL | (0xff << 24);
-        if (recomputed[c - L]) op.x |= OPF_GSYNC;
+        if (recomputed[c - L]) {
+          op.x |= OPF_GSYNC;
+          if (last_entry[c - L] >= 0) p->ops_host[last_entry[c - L]].x &= ~OPF_NOPERSIST;  // re-read below: must be stored
+        }
         else if (handoff) op.x |= OPF_HANDOFF;  // root of a child fragment finished by another workgroup of this launch
         if (p->nuc && ti > 0 && nodes[ti - 1] == c - L) op.x |= OPF_INREGS;
       }
@@ -264,6 +277,10 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
     }
     entries.back().x |= OPF_LAST | ((fin & 1) ? OPF_PARITY : 0) | (dst << 16);
     if (handoff && !is_root_program && ti + 1 == nodes.size()) entries.back().x |= OPF_HANDOFF;  // fragment root
+    // lazy persistence: skip the store of this node unless it is the root of a fragment (read by another
+    // program) — a later consumer through the persisted copy clears the flag again
+    if (lazy && (is_root_program || ti + 1 < nodes.size())) entries.back().x |= OPF_NOPERSIST;
+    last_entry[par] = (int)p->ops_host.size() + (int)entries.size() - 1;
     for (const int4 &e : entries) p->ops_host.push_back(e);
     for (int sidx : release_after) slot_busy[sidx] = 0;
     recomputed[par] = 1;
@@ -666,10 +683,19 @@ bool same_update(const hyphy_hip_partition *p, const int64_t *u, int64_t n, bool
   return n == 0 || memcmp(p->cached_update.data(), u, n * sizeof(int64_t)) == 0;
 }
 
-int prepare_schedule(hyphy_hip_partition *p, int cat, const int64_t *update_nodes, int64_t n_update, bool *changed) {
+int prepare_schedule(hyphy_hip_partition *p, int cat, const int64_t *update_nodes, int64_t n_update, bool *changed,
+                     bool force_persist = false) {
   bool full = !p->initialized[cat];
   if (!full && n_update >= p->B) full = true;
-  if (same_update(p, update_nodes, n_update, full)) {
+  const bool requested_full = full;
+  bool persist_all = true;
+  if (!full && !p->resident[cat]) full = true;  // a partial update needs current persisted copies: promote to a persisting full pass
+  else if (full && p->initialized[cat] && p->cache_policy == 1 && p->last_full[cat] && !force_persist && !p->nuc)
+    persist_all = false;
+  p->sched_full = full;
+  p->sched_persist = persist_all;
+  p->last_full[cat] = requested_full ? 1 : 0;
+  if (same_update(p, update_nodes, n_update, full) && p->cached_persist == persist_all) {
     *changed = false;
     return 0;
   }
@@ -677,6 +703,7 @@ int prepare_schedule(hyphy_hip_partition *p, int cat, const int64_t *update_node
   if (p->ops_host.size() > ops_capacity(p)) return fail("internal: schedule overflow");
   p->cached_update.assign(update_nodes, update_nodes + (full ? 0 : n_update));
   p->cached_full = full;
+  p->cached_persist = persist_all;
   p->cached_valid = 1;
   *changed = true;
   return 0;
@@ -845,6 +872,9 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
   p->initialized.assign(C, 0);
   p->bc_node.assign(C, -1);
   p->bc_use_pi.assign(C, 0);
+  p->resident.assign(C, 0);
+  p->last_full.assign(C, 0);
+  if (const char *e = getenv("HYPHY_HIP_CACHE")) p->cache_policy = strcmp(e, "always") == 0 ? 0 : 1;
   p->leaf_has_ambig.assign(L, 0);
   for (int64_t l = 0; l < L; l++)
     for (int64_t k = 0; k < S; k++)
@@ -1004,7 +1034,8 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
 
 static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                        const int64_t *q_nodes, int64_t n_q, const double *q, bool q_on_device, int q_is_probability,
-                       const double *root_freqs, double *d_logl_out, bool reduce, bool floor_log, bool batch = false) {
+                       const double *root_freqs, double *d_logl_out, bool reduce, bool floor_log, bool batch = false,
+                       bool force_persist = false) {
   if (!p) return fail("partition == NULL");
   if (cat < 0) cat = 0;
   if (cat >= p->C) return fail("rate class out of range");
@@ -1028,7 +1059,7 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
     p->batch_classes = bc;
     p->cached_valid = 0;  // fragment sizing depends on how many classes share the launch
   }
-  if (prepare_schedule(p, (int)cat, update_nodes, n_update, &changed)) return -1;
+  if (prepare_schedule(p, (int)cat, update_nodes, n_update, &changed, force_persist)) return -1;
   bool pi_changed = p->cached_pi.size() != (size_t)p->D || memcmp(p->cached_pi.data(), root_freqs, p->D * sizeof(double));
   if (pi_changed) p->cached_pi.assign(root_freqs, root_freqs + p->D);
   if (p->cached_slots.size() != (size_t)p->C) p->cached_slots.assign(p->C, std::vector<int64_t>());
@@ -1042,8 +1073,13 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
                      q_on_device, q_is_probability, root_freqs, d_logl_out, reduce, floor_log))
       return -1;
   if (batch)
-    for (int64_t c = 0; c < p->C; c++) p->initialized[c] = 1;
+    for (int64_t c = 0; c < p->C; c++) {
+      p->initialized[c] = 1;
+      if (p->sched_full) p->resident[c] = p->sched_persist ? 1 : 0;
+      p->last_full[c] = p->last_full[0];
+    }
   p->initialized[cat] = 1;
+  if (p->sched_full) p->resident[cat] = p->sched_persist ? 1 : 0;
   if (q_on_device) p->coeffs_pending = false;
   return 0;
 }
@@ -1157,10 +1193,13 @@ int hyphy_hip_evaluate_categories_built(hyphy_hip_partition *p, const int64_t *u
   return 0;
 }
 
+static int ensure_resident(hyphy_hip_partition *p, int64_t cat);
+
 int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *inode_cache, int64_t *scaler_counts) {
   if (!p) return fail("partition == NULL");
   if (cat < 0) cat = 0;
   if (cat >= p->C) return fail("rate class out of range");
+  if (ensure_resident(p, cat)) return -1;
   const int64_t D = p->D, I = p->I, S = p->S;
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
@@ -1208,6 +1247,21 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
 // (tree.cpp:3383-3936) then evaluates L(t) with one [D x D] x [D x S] contraction per call while the
 // optimiser's line search varies the branch length (policy code likefunc.cpp:10886-10948, 11125-11258).
 // ---------------------------------------------------------------------------------------------------
+// The persisted conditionals of class `cat` are stale (the last full pass ran with lazy persistence): re-run
+// the pruning pass over the resident transition matrices with every node stored.
+static int ensure_resident(hyphy_hip_partition *p, int64_t cat) {
+  if (p->resident[cat]) return 0;
+  if (!p->initialized[cat] || p->cached_pi.size() != (size_t)p->D) return fail("conditionals not resident: evaluate first");
+  std::vector<int64_t> all(p->B);
+  for (int64_t k = 0; k < p->B; k++) all[k] = k;
+  const std::vector<double> pi = p->cached_pi;
+  const std::vector<char> lf = p->last_full;
+  if (eval_common(p, cat, all.data(), p->B, nullptr, 0, nullptr, false, 0, pi.data(), nullptr, true, false, false, true))
+    return -1;
+  p->last_full = lf;  // (an internal pass: the caller's own sequence of evaluations is what the policy looks at)
+  return collect_status(p);
+}
+
 int hyphy_hip_branch_cache_build(hyphy_hip_partition *p, int64_t cat, int64_t node) {
   if (!p) return fail("partition == NULL");
   if (p->nuc || p->variant == 2) {
@@ -1218,6 +1272,7 @@ int hyphy_hip_branch_cache_build(hyphy_hip_partition *p, int64_t cat, int64_t no
   if (cat >= p->C) return fail("rate class out of range");
   if (node < 0 || node >= p->B) return fail("branch cache: node out of range (the root has no branch)");
   if (!p->initialized[cat]) return fail("branch cache: evaluate the partition first (conditionals must be resident)");
+  if (ensure_resident(p, cat)) return -1;
   const int L = (int)p->L, I = (int)p->I, C = (int)p->C;
   const int64_t B = p->B;
   const int DP = p->DP;

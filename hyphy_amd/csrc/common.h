@@ -44,6 +44,7 @@ __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1)
 //      bit  5    OPF_GSYNC   (internal-global) copy was written earlier in THIS launch: full fence first
 //      bit  6    OPF_AMBIG   (leaf group) some leaf of the group carries ambiguity codes in this shard
 //      bit  7    OPF_INREGS  (nucleotide kernel only) child is the node finalised by the previous entry
+//                OPF_NOPERSIST (MFMA kernels, OPF_LAST entries) lazy persistence: do not store the finalised parent
 //      bits 8-15 number of leaves in a leaf group
 //      bits 16-23 destination LDS slot of the finalised parent (0/1 exchange slots, >= 2 parking)
 //      bits 24-31 source LDS slot of an OPK_INTERNAL child
@@ -52,7 +53,8 @@ __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1)
 //   w  internal: child internal index
 // A parent's first entry needs no flag: the running product is reset when a parent is finalised.
 enum : int { OPK_LEAF = 0, OPK_INTERNAL = 1, OPK_INTERNAL_GLOBAL = 2 };
-enum : int { OPF_HANDOFF = 4, OPF_LAST = 8, OPF_PARITY = 16, OPF_GSYNC = 32, OPF_AMBIG = 64, OPF_INREGS = 128 };
+enum : int { OPF_HANDOFF = 4, OPF_LAST = 8, OPF_PARITY = 16, OPF_GSYNC = 32, OPF_AMBIG = 64, OPF_INREGS = 128,
+             OPF_NOPERSIST = 128 };
 #ifndef HYPHY_SLOTS1
 #define HYPHY_SLOTS1 5
 #endif

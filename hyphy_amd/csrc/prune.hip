@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
         // the exponent: fire and forget
         double *out = a.partials + ((size_t)parent * a.ntiles + tile0 + t) * TILE + (size_t)w * 256;  // uniform
         const f64x4 q = acc[t] * sc[t];
-        if (!(ablate & 4)) {
+        if (!(ablate & 4) && !(op.x & OPF_NOPERSIST)) {  // (lazy persistence: the host knows nobody re-reads this node)
           st16(out, (unsigned)lane * 16u, (f64x2){q[0], q[1]});
           st16(out, (unsigned)(64 + lane) * 16u, (f64x2){q[2], q[3]});
           if (w == 0 && g == 0) a.counts[(size_t)parent * S_pad + (tile0 + t) * 16 + sl] = cnt[t];
@@ -662,14 +662,14 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
         if (g == 0)
           __hip_atomic_store(a.hand_cnt + ((size_t)op.y * a.ntiles + tile0) * 32 + sl, cnt, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
-      } else if (!(a.ablate & 2)) {
+      } else if (!(op.x & OPF_NOPERSIST)) {  // (lazy persistence: the host knows nobody re-reads this node)
 #pragma unroll
         for (int w = 0; w < NW; w++) {
           st16(out, (unsigned)((2 * w) * 64 + lane) * 16u, (f64x2){bch[w][0], bch[w][1]});
           st16(out, (unsigned)((2 * w + 1) * 64 + lane) * 16u, (f64x2){bch[w][2], bch[w][3]});
         }
       }
-      if (g == 0) a.counts[(size_t)op.y * S_pad + tile0 * 16 + sl] = cnt;
+      if (g == 0 && !(op.x & OPF_NOPERSIST)) a.counts[(size_t)op.y * S_pad + tile0 * 16 + sl] = cnt;
       if (NP > 0 && slot >= 2) {  // park for a later parent
         double *dst = park + (slot - 2) * TILE;
 #pragma unroll
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
               *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(xl + xi * TILE + eu) + posw16) = qv;
             if (hand) {  // fragment root: another workgroup may consume it in this launch
               st16_agent(out + eu, posw16, qv);
-            } else if (!(PROF && (a.ablate & 2))) {
+            } else if (!(PROF && (a.ablate & 2)) && !(op.x & OPF_NOPERSIST)) {
               st16(out + eu, posw16, qv);
             }
           }
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC4) void prune_w4_kernel(const int4 *__
         if (q16 == 0) {
           const int4 cc = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);
           if (xi <= NP) *reinterpret_cast<int4 *>(&xcnt[xi][4 * j]) = cc;
-          *reinterpret_cast<int4 *>(a.counts + (size_t)op.y * S_pad + tile0 * 16 + 4 * j) = cc;
+          if (!(op.x & OPF_NOPERSIST)) *reinterpret_cast<int4 *>(a.counts + (size_t)op.y * S_pad + tile0 * 16 + 4 * j) = cc;
           if (hand) {
 #pragma unroll
             for (int J = 0; J < 4; J++)

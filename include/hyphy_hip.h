@@ -136,6 +136,10 @@ int hyphy_hip_evaluate_categories_built(hyphy_hip_partition *p, const int64_t *u
  *   inode_cache [I*S*D]  iNodeCache[(node*S + pattern)*D + state] (tree_evaluator.cpp:3608-3617)
  *   scaler_counts [I*S]  cumulative 2^64-exponent of the subtree below (node, pattern): the
  *                        stored vector times 2^(-64*count) is the unscaled conditional.
+ * Cache policy: by default ("lazy"; environment HYPHY_HIP_CACHE=always disables it) a full pass that follows a
+ * full pass — a sweep over a global parameter — does not store its conditionals in HBM; nothing can read them
+ * before the next full pass overwrites them.  This call, a partial update and hyphy_hip_branch_cache_build
+ * first re-run a storing pass when the resident copies are stale, so callers never observe the difference.
  */
 int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *inode_cache, int64_t *scaler_counts);
 

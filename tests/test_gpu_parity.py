@@ -361,6 +361,52 @@ def test_branch_cache_requires_build_and_is_dropped_by_evaluate():
             part.branch_cache_evaluate(3, Q[3])
 
 
+@pytest.mark.parametrize("kernel", ["0", "1"])
+def test_lazy_persistence_is_transparent(kernel, monkeypatch):
+    """Default cache policy: a full pass that follows a full pass does not store its conditionals.  A partial
+    update, a download or a branch-cache build after such a pass must still see current data (the library
+    re-runs a persisting pass first), and HYPHY_HIP_CACHE=always gives the same numbers."""
+    from oracle import oracle
+    monkeypatch.setenv("HYPHY_HIP_KERNEL", kernel)
+    fx = common.load("codon_wide")
+    nodes = common.all_nodes(fx)
+    pi = fx["root_freqs"]
+    L = int(fx["L"])
+    Q1, Q2 = common.fixture_Q(fx), common.fixture_Q(fx, 1.3)
+    op = oracle.OraclePartition(int(fx["D"]), fx["flat_parents"], L, fx["leaf_codes"], fx["ambig"], fx["pattern_freq"])
+
+    def ref(Q):
+        op.set_P(nodes, oracle.expm(Q, True))
+        return op.compute_block(nodes, pi)
+    from hyphy_amd import tree
+    flat = tree.flat_from_parents(fx["flat_parents"], L)
+    changed = np.array([3, L + 5], dtype=np.int64)
+    upd = np.unique(np.concatenate([flat.path_update_nodes(int(n)) for n in changed])).astype(np.int64)
+    Q3 = Q2.copy()
+    Q3[changed] = Q1[changed] * 0.5
+    r2, r3 = ref(Q2), ref(Q3)
+    results = {}
+    for policy in ("lazy", "always"):
+        monkeypatch.setenv("HYPHY_HIP_CACHE", policy)
+        with _mk(fx) as part:
+            part.evaluate(nodes, nodes, Q1, pi)            # first pass: stored
+            a = part.evaluate(nodes, nodes, Q2, pi)        # full after full: lazy -> not stored
+            cache, _ = part.download_partials()            # must reflect Q2
+            b = part.evaluate(nodes, nodes, Q2, pi)        # lazy again
+            c = part.evaluate(upd, changed, Q3[changed], pi)   # partial update on stale copies -> promoted
+            part.branch_cache_build(L + 5)
+            d = part.branch_cache_evaluate(L + 5, Q3[L + 5])
+        results[policy] = (a, b, c, d, cache)
+        assert abs(a - r2) <= RTOL * abs(r2) and abs(b - r2) <= RTOL * abs(r2)
+        assert abs(c - r3) <= RTOL * abs(r3) and abs(d - r3) <= RTOL * abs(r3)
+        op.set_P(nodes, oracle.expm(Q2, True))
+        op.compute_block(nodes, pi)
+        for n in range(op.I):
+            x, y = cache[n], op.cache[0][n]
+            assert np.allclose(x / x.sum(1, keepdims=True), y / y.sum(1, keepdims=True), rtol=1e-9, atol=1e-300), (policy, n)
+    assert results["lazy"][:4] == results["always"][:4]
+
+
 def test_categories_match_reference():
     fx = common.load("codon_cat3")
     C = len(fx["cat_weights"])
