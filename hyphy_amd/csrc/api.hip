@@ -98,12 +98,15 @@ struct Shard {
   double *d_hout = nullptr;   // device-side address of h_out
   int32_t *h_slots = nullptr;
   double *h_coeffs = nullptr;  // pinned ring (4 x C*B*K) for build_q coefficients
+  double *d_hcoeffs = nullptr; // ... as the device sees it (host-mapped): the fused expm kernel reads it directly
+  const double *coeffs_cur = nullptr;  // coefficients of the pending fused build (device-visible pointer)
   unsigned coeff_turn = 0;
   double *h_small = nullptr;  // pi / weights staging
   size_t h_small_cap = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ring;  // kTimingRing pairs (start, end) around the pruning launches
   uint64_t ring_count = 0;       // evaluations stamped so far
+  uint64_t eval_count = 0;
   size_t partial_stride = 0;  // doubles per class
 };
 
@@ -556,7 +559,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     ea.prof = getenv("HYPHY_HIP_EXPM_PROF") ? 1 : 0;
     if (q_from_templates) {  // fused build: coefficients were staged by hyphy_hip_build_q
       ea.templates = s.templates;
-      ea.coeffs = s.coeffs;
+      ea.coeffs = s.coeffs_cur ? s.coeffs_cur : s.coeffs;
       ea.K = (int)p->K;
     }
     if (p->nuc) {
@@ -573,8 +576,11 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     launch_expm(ea, s.stream);
     tr.lap("launch_expm");
   }
+  // kernel-duration stamps: every evaluation by default; HYPHY_HIP_TIMING_EVERY=n keeps one in n
+  static const int timing_every = getenv("HYPHY_HIP_TIMING_EVERY") ? std::max(1, atoi(getenv("HYPHY_HIP_TIMING_EVERY"))) : 1;
+  const bool stamp = timing_every == 1 || (s.eval_count++ % (uint64_t)timing_every) == 0;
   const size_t ring_slot = (size_t)(s.ring_count % kTimingRing) * 2;
-  HIPCHK(hipEventRecord(s.ring[ring_slot], s.stream));
+  if (stamp) HIPCHK(hipEventRecord(s.ring[ring_slot], s.stream));
   if (p->all_timings) HIPCHK(hipEventRecord(s.ev[1], s.stream));
   int n_ops = 0;  // longest program
   for (const auto &pr : p->programs) n_ops = std::max(n_ops, pr.n);
@@ -655,8 +661,10 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     }
   }
   tr.lap("launch_prune");
-  HIPCHK(hipEventRecord(s.ring[ring_slot + 1], s.stream));
-  s.ring_count++;
+  if (stamp) {
+    HIPCHK(hipEventRecord(s.ring[ring_slot + 1], s.stream));
+    s.ring_count++;
+  }
   if (p->all_timings) HIPCHK(hipEventRecord(s.ev[2], s.stream));
   if (reduce) {
     // synchronous entry points: the result record goes straight to host-mapped pinned memory (a
@@ -1483,6 +1491,8 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
     HIPCHK(hipMalloc((void **)&s.coeffs, (size_t)p->C * p->B * K * sizeof(double)));
     if (s.h_coeffs) hipHostFree(s.h_coeffs);
     HIPCHK(hipHostMalloc((void **)&s.h_coeffs, (size_t)4 * p->C * p->B * K * sizeof(double)));
+    if (hipHostGetDevicePointer((void **)&s.d_hcoeffs, s.h_coeffs, 0) != hipSuccess) s.d_hcoeffs = nullptr;
+    s.coeffs_cur = nullptr;
     HIPCHK(hipMemcpy(s.templates, templates, (size_t)K * D * D * sizeof(double), hipMemcpyHostToDevice));
   }
   p->K = K;
@@ -1502,7 +1512,14 @@ int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs) {
     const size_t nbytes = (size_t)n * p->K * sizeof(double);
     double *stage = s.h_coeffs + (size_t)(s.coeff_turn++ & 3) * (size_t)p->C * p->B * p->K;  // pinned ring of 4
     memcpy(stage, coeffs, nbytes);
-    HIPCHK(hipMemcpyAsync(s.coeffs, stage, nbytes, hipMemcpyHostToDevice, s.stream));
+    if (fuse && s.d_hcoeffs) {
+      // the fused expm kernel reads the (few hundred) coefficients straight from the pinned ring slot over
+      // PCIe: no copy kernel, no extra dependency in the stream
+      s.coeffs_cur = s.d_hcoeffs + (stage - s.h_coeffs);
+    } else {
+      s.coeffs_cur = nullptr;
+      HIPCHK(hipMemcpyAsync(s.coeffs, stage, nbytes, hipMemcpyHostToDevice, s.stream));
+    }
     tr.lap("memcpy");
     if (!fuse) launch_build_q(s.templates, s.coeffs, (int)n, (int)p->K, (int)p->D, s.qbuf, s.stream);
     tr.lap("launch");
