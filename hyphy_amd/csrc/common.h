@@ -80,7 +80,7 @@ struct PruneArgs {
   int *frag_ctr;             // [class][program][tile] arrivals of finished child fragments (zero between launches)
   int32_t *hand_cnt;         // [class][I][tile][32] exponents of fragment roots handed between workgroups
   int variant;               // 0: workgroup-per-tile kernel (prune_mfma_kernel), 1: wave-per-tile kernel (T = 1),
-                             // 2: wave-per-tile kernel on the 4x4x4 MFMA (tile-layout partials, PTg layout 1)
+                             // 2: split-tile kernel on the 4x4x4 MFMA (quad-layout conditionals, PTg layout 1)
   int n_slots;               // LDS slots the schedule was compiled for (2 exchange + parking)
   const double *Pfrag;       // [B][NW][NKK*64]      A-operand images of the transition matrices
   const double *PTg;         // [B][DP][NW][4][4]    column-gather images (leaf edges)

@@ -57,6 +57,83 @@ void run4(int wg_per_cu) {
   hipFree(d);
 }
 
+// the 16x16x4 form with DISTINCT A/B operand registers per instruction (a real kernel's pattern)
+template <int NACC>
+__global__ __launch_bounds__(256) void kd(double *out, int iters, double a0, double b0) {
+  f64x4 acc[NACC];
+  double av[NACC], bv[NACC];
+  for (int i = 0; i < NACC; i++) {
+    acc[i] = (f64x4){0, 0, 0, 0};
+    av[i] = a0 + threadIdx.x * 1e-9 + i;
+    bv[i] = b0 + i * 1e-3;
+  }
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[i], acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NACC; i++) { av[i] += 1e-12; bv[i] -= 1e-12; }  // (cheap VALU so the operands really change)
+  }
+  double s = 0;
+  for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s;
+}
+template <int NACC>
+void rund(int wg_per_cu) {
+  double *d; hipMalloc(&d, 8);
+  int iters = 20000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  dim3 grid(256 * wg_per_cu), block(256);
+  hipLaunchKernelGGL((kd<NACC>), grid, block, 0, 0, d, 100, 1.0, 1e-3);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((kd<NACC>), grid, block, 0, 0, d, iters, 1.0, 1e-3);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double n = (double)grid.x * 4 * iters * NACC;
+  printf("mfma_f64_16x16x4 distinct A/B regs %dacc waves/SIMD=%d: %.3f ms  %.1f TF  (%.1f cycles per instruction per SIMD at 2.39 GHz)\n",
+         NACC, wg_per_cu, ms, n * 2048.0 / ms / 1e9, ms * 1e-3 * 2.39e9 / (n / 1024.0));
+  hipFree(d);
+}
+
+// the 4x4x4 form with DISTINCT A/B operand registers per instruction: NA x NB operand grid, NA*NB accumulators
+template <int NA, int NB>
+__global__ __launch_bounds__(256) void kd4(double *out, int iters, double a0, double b0) {
+  double acc[NA][NB], av[NA], bv[NB];
+  for (int i = 0; i < NA; i++) av[i] = a0 + threadIdx.x * 1e-9 + i;
+  for (int j = 0; j < NB; j++) bv[j] = b0 + j * 1e-3;
+  for (int i = 0; i < NA; i++) for (int j = 0; j < NB; j++) acc[i][j] = 0;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < NA; i++)
+#pragma unroll
+      for (int j = 0; j < NB; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NA; i++) av[i] += 1e-12;
+#pragma unroll
+    for (int j = 0; j < NB; j++) bv[j] -= 1e-12;
+  }
+  double s = 0;
+  for (int i = 0; i < NA; i++) for (int j = 0; j < NB; j++) s += acc[i][j];
+  if (s == 12345.678) out[0] = s;
+}
+template <int NA, int NB>
+void rund4(int wg_per_cu) {
+  double *d; hipMalloc(&d, 8);
+  int iters = 20000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  dim3 grid(256 * wg_per_cu), block(256);
+  hipLaunchKernelGGL((kd4<NA, NB>), grid, block, 0, 0, d, 100, 1.0, 1e-3);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((kd4<NA, NB>), grid, block, 0, 0, d, iters, 1.0, 1e-3);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double n = (double)grid.x * 4 * iters * NA * NB;
+  printf("mfma_f64_4x4x4_4b %d x %d operand grid waves/SIMD=%d: %.3f ms  %.1f TF  (%.1f cycles per instruction per SIMD at 2.39 GHz)\n",
+         NA, NB, wg_per_cu, ms, n * 512.0 / ms / 1e9, ms * 1e-3 * 2.39e9 / (n / 1024.0));
+  hipFree(d);
+}
+
 template <int NACC, int VALU>
 void run(const char *name, int wg_per_cu, int waves) {
   double *d; long long *c; hipMalloc(&d, 8); hipMalloc(&c, 8);
@@ -79,6 +156,8 @@ void run(const char *name, int wg_per_cu, int waves) {
   hipFree(d); hipFree(c);
 }
 int main() {
+  rund4<2, 4>(1); rund4<2, 4>(2); rund4<2, 4>(4); rund4<4, 4>(1); rund4<4, 4>(2); rund4<1, 8>(1); rund4<8, 1>(1);
+  rund<4>(1); rund<4>(2); rund<4>(4); rund<8>(2);
   run4<4>(1); run4<8>(1); run4<8>(2); run4<8>(4); run4<8>(8);
   run<4, 0>("mfma only 4acc", 1, 4);
   run<4, 0>("mfma only 4acc", 2, 4);
