@@ -202,7 +202,8 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
   const int n_slots = p->n_slots > 0 ? p->n_slots : lds_slots(T);
   std::vector<char> slot_busy(n_slots, 0);
   std::vector<int> last_entry(I, -1);   // index (in ops_host) of the OPF_LAST entry of a node finalised by this program
-  const bool lazy = !p->sched_persist && !p->nuc;
+  const bool lazy = !p->sched_persist;
+  const int np_flag = p->nuc ? OPF_NOPERSIST_NUC : OPF_NOPERSIST;
   const int off = (int)p->ops_host.size();
   int fin = 0, root_slot = 0;
   for (size_t ti = 0; ti < nodes.size(); ti++) {
@@ -222,12 +223,13 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
         slot_of[c - L] = -1;
       } else {
         op.x = OPK_INTERNAL_GLOBAL | (0xff << 24);
+        const bool inregs = p->nuc && ti > 0 && nodes[ti - 1] == c - L;  // (4-state kernel: child still in registers)
         if (recomputed[c - L]) {
           op.x |= OPF_GSYNC;
-          if (last_entry[c - L] >= 0) p->ops_host[last_entry[c - L]].x &= ~OPF_NOPERSIST;  // re-read below: must be stored
+          if (!inregs && last_entry[c - L] >= 0) p->ops_host[last_entry[c - L]].x &= ~np_flag;  // re-read below: must be stored
         }
         else if (handoff) op.x |= OPF_HANDOFF;  // root of a child fragment finished by another workgroup of this launch
-        if (p->nuc && ti > 0 && nodes[ti - 1] == c - L) op.x |= OPF_INREGS;
+        if (inregs) op.x |= OPF_INREGS;
       }
       entries.push_back(op);
     };
@@ -286,7 +288,7 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
     if (handoff && !is_root_program && ti + 1 == nodes.size()) entries.back().x |= OPF_HANDOFF;  // fragment root
     // lazy persistence: skip the store of this node unless it is the root of a fragment (read by another
     // program) — a later consumer through the persisted copy clears the flag again
-    if (lazy && (is_root_program || ti + 1 < nodes.size())) entries.back().x |= OPF_NOPERSIST;
+    if (lazy && (is_root_program || ti + 1 < nodes.size())) entries.back().x |= np_flag;
     last_entry[par] = (int)p->ops_host.size() + (int)entries.size() - 1;
     for (const int4 &e : entries) p->ops_host.push_back(e);
     for (int sidx : release_after) slot_busy[sidx] = 0;
@@ -702,7 +704,7 @@ int prepare_schedule(hyphy_hip_partition *p, int cat, const int64_t *update_node
   const bool requested_full = full;
   bool persist_all = true;
   if (!full && !p->resident[cat]) full = true;  // a partial update needs current persisted copies: promote to a persisting full pass
-  else if (full && p->initialized[cat] && p->cache_policy == 1 && p->last_full[cat] && !force_persist && !p->nuc)
+  else if (full && p->initialized[cat] && p->cache_policy == 1 && p->last_full[cat] && !force_persist)
     persist_all = false;
   p->sched_full = full;
   p->sched_persist = persist_all;

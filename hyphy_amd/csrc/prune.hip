@@ -1347,10 +1347,12 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(NucArgs a) {
       for (int j = 0; j < 4; j++) b[j] = (m != 0) ? acc[j] * sc : acc[j];
       cnt += m;
       bcnt = cnt;
-      const size_t base = (size_t)parent * 4 * S_pad + s;
+      if (!(op.x & OPF_NOPERSIST_NUC)) {  // (lazy persistence: the host knows nobody re-reads this node)
+        const size_t base = (size_t)parent * 4 * S_pad + s;
 #pragma unroll
-      for (int j = 0; j < 4; j++) a.partials[base + j * S_pad] = b[j];
-      a.counts[(size_t)parent * S_pad + s] = cnt;
+        for (int j = 0; j < 4; j++) a.partials[base + j * S_pad] = b[j];
+        a.counts[(size_t)parent * S_pad + s] = cnt;
+      }
       acc[0] = acc[1] = acc[2] = acc[3] = 1.;  // the next entry starts a new parent
       cnt = 0;
     }

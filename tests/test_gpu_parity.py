@@ -407,6 +407,39 @@ def test_lazy_persistence_is_transparent(kernel, monkeypatch):
     assert results["lazy"][:4] == results["always"][:4]
 
 
+def test_lazy_persistence_nucleotide_path():
+    """Same policy in the 4-state kernel: children still in registers are not stored in a sweep; a partial
+    update and a download afterwards see current data."""
+    from hyphy_amd import tree
+    from oracle import oracle
+    fx = common.load("nuc_wide")
+    nodes = common.all_nodes(fx)
+    pi = fx["root_freqs"]
+    L = int(fx["L"])
+    flat = tree.flat_from_parents(fx["flat_parents"], L)
+    Q1, Q2 = common.fixture_Q(fx), common.fixture_Q(fx, 1.4)
+    op = oracle.OraclePartition(4, fx["flat_parents"], L, fx["leaf_codes"], fx["ambig"], fx["pattern_freq"])
+    op.set_P(nodes, oracle.expm(Q2, False))
+    r2 = op.compute_block(nodes, pi)
+    changed = np.array([5, L + 7], dtype=np.int64)
+    upd = np.unique(np.concatenate([flat.path_update_nodes(int(n)) for n in changed])).astype(np.int64)
+    Q3 = Q2.copy()
+    Q3[changed] = Q1[changed] * 0.6
+    with _mk(fx) as part:
+        part.evaluate(nodes, nodes, Q1, pi)
+        a = part.evaluate(nodes, nodes, Q2, pi)          # full after full: lazy
+        cache, _ = part.download_partials()
+        b = part.evaluate(nodes, nodes, Q2, pi)
+        c = part.evaluate(upd, changed, Q3[changed], pi)  # promoted
+    assert abs(a - r2) <= RTOL * abs(r2) and abs(b - r2) <= RTOL * abs(r2)
+    for n in range(op.I):
+        x, y = cache[n], op.cache[0][n]
+        assert np.allclose(x / x.sum(1, keepdims=True), y / y.sum(1, keepdims=True), rtol=1e-9, atol=1e-300), n
+    op.set_P(nodes, oracle.expm(Q3, False))
+    r3 = op.compute_block(nodes, pi)
+    assert abs(c - r3) <= RTOL * abs(r3)
+
+
 def test_categories_match_reference():
     fx = common.load("codon_cat3")
     C = len(fx["cat_weights"])
