@@ -216,7 +216,8 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
       op.y = par;
       op.z = c;
       op.w = c - L;
-      const int sl = p->nuc ? -1 : slot_of[c - L];
+      // (4-state kernel: only parking slots are LDS; the node finalised last is still in registers)
+      const int sl = p->nuc ? (slot_of[c - L] >= 2 ? slot_of[c - L] : -1) : slot_of[c - L];
       if (sl >= 0) {
         op.x = OPK_INTERNAL | (sl << 24);
         if (sl >= 2) release_after.push_back(sl);  // reusable only after this parent's barrier
@@ -262,7 +263,7 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
     // destination slot of the finished node
     int dst = fin & 1;
     const bool next_consumes = ti + 1 < nodes.size() && p->parents[L + par] == nodes[ti + 1];
-    if (!p->nuc) {
+    {
       if (!next_consumes && ti + 1 < nodes.size()) {
         dst = -1;
         for (int sidx = 2; sidx < n_slots; sidx++)
@@ -930,6 +931,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     }
     s.T = T;
     s.cus = cus;
+    if (p->nuc) p->n_slots = 2 + kNucParkSlots;  // (prune_nuc_kernel parks pending nodes in LDS)
     if (!p->nuc) {
       // Kernel choice (measured, tools/sweep_small_shards.sh): the wave-per-tile kernel (no cross-wave
       // exchange, child -> parent through registers) wins once every SIMD holds ~2 waves of it — 160 vs 183 us

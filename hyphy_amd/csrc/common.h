@@ -108,6 +108,7 @@ struct PruneArgs {
   long long *timeline;       // optional tracing: [kTraceWG][NW][n_ops][4] s_memtime stamps (HYPHY_HIP_TIMELINE)
 };
 constexpr int kTraceWG = 8;
+constexpr int kNucParkSlots = 4;  // LDS parking slots of the 4-state kernel (nodes whose parent is not the next entry)
 
 struct NucArgs {
   const int4 *ops;

@@ -1291,18 +1291,24 @@ __global__ __launch_bounds__(64) void bc_eval_kernel(BcArgs a) {
 // state-major planes so every global access is a coalesced 512-byte line per wave.
 // HBM-bound: per node 32 B/site written (+ re-read of children that are not in registers).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prune_nuc_kernel(NucArgs a) {
+// (ops and P are separate __restrict__ kernel arguments: schedule entries and transition matrices then come
+//  through scalar loads; as members of the by-value argument struct they were 30 vector loads per entry)
+__global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__ ops, const double *__restrict__ Pm,
+                                                        NucArgs a) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;  // S_pad is a multiple of the block size
   const size_t S_pad = a.S_pad;
+  // pending nodes (finished, parent not next) stay on chip: every thread parks its own column in LDS
+  __shared__ double park[kNucParkSlots][4][256];
+  __shared__ int park_cnt[kNucParkSlots][256];
   double acc[4] = {1., 1., 1., 1.}, b[4] = {0., 0., 0., 0.};
   int cnt = 0, bcnt = 0;
   for (int oi = 0; oi < a.n_ops; oi++) {
-    const int4 op = a.ops[oi];
+    const int4 op = ops[oi];
     const int kind = op.x & 3, parent = op.y;
     const bool is_leaf = kind == OPK_LEAF;
     if (is_leaf && ((op.x >> 8) & 0xff) == 0) continue;  // padding entry
     const int child = is_leaf ? (op.z & 0xffff) : op.z;  // nucleotide schedules use 1 leaf per entry
-    const double *__restrict__ P = a.P + (size_t)child * 16;
+    const double *__restrict__ P = Pm + (size_t)child * 16;
     double cv[4];
     bool matvec = true;
     if (is_leaf) {
@@ -1319,7 +1325,12 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(NucArgs a) {
         for (int j = 0; j < 4; j++) cv[j] = a.ambig[(size_t)(-code - 1) * 4 + j];
       }
     } else {
-      if (!(op.x & OPF_INREGS)) {
+      if (kind == OPK_INTERNAL) {  // parked by this thread in LDS (its parent was not the next entry)
+        const int ps = ((op.x >> 24) & 0xff) - 2;
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[j] = park[ps][j][threadIdx.x];
+        bcnt = park_cnt[ps][threadIdx.x];
+      } else if (!(op.x & OPF_INREGS)) {
         const size_t base = (size_t)op.w * 4 * S_pad + s;
 #pragma unroll
         for (int j = 0; j < 4; j++) b[j] = a.partials[base + j * S_pad];
@@ -1347,6 +1358,12 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(NucArgs a) {
       for (int j = 0; j < 4; j++) b[j] = (m != 0) ? acc[j] * sc : acc[j];
       cnt += m;
       bcnt = cnt;
+      const int dslot = (op.x >> 16) & 0xff;
+      if (dslot >= 2) {  // pending node: its parent comes later in the schedule
+#pragma unroll
+        for (int j = 0; j < 4; j++) park[dslot - 2][j][threadIdx.x] = b[j];
+        park_cnt[dslot - 2][threadIdx.x] = cnt;
+      }
       if (!(op.x & OPF_NOPERSIST_NUC)) {  // (lazy persistence: the host knows nobody re-reads this node)
         const size_t base = (size_t)parent * 4 * S_pad + s;
 #pragma unroll
@@ -1647,7 +1664,7 @@ void launch_prune_mfma(const PruneArgs &a, hipStream_t stream) {
 
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream) {
   if (a.n_ops <= 0) return;
-  hipLaunchKernelGGL(prune_nuc_kernel, dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(prune_nuc_kernel, dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a.ops, a.P, a);
 }
 
 void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,
