@@ -1302,17 +1302,27 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
   __shared__ int park_cnt[kNucParkSlots][256];
   double acc[4] = {1., 1., 1., 1.}, b[4] = {0., 0., 0., 0.};
   int cnt = 0, bcnt = 0;
+  // One entry ahead: the schedule word, the 16 entries of its transition matrix (scalar loads) and, for a leaf,
+  // this thread's code — at small shard sizes (< 1 wave per SIMD) the entry-to-entry chain of dependent loads
+  // is the whole run time.  Programs are followed by two no-op entries, so oi + 1 is always readable.
+  auto child_of = [](const int4 &o) { return (o.x & 3) == OPK_LEAF ? (o.z & 0xffff) : o.z; };
+  int4 op = ops[0];
+  double P[16];
+#pragma unroll
+  for (int e = 0; e < 16; e++) P[e] = Pm[(size_t)child_of(op) * 16 + e];
+  int code = (op.x & 3) == OPK_LEAF ? (int)a.codes[(size_t)child_of(op) * S_pad + s] : 0;
   for (int oi = 0; oi < a.n_ops; oi++) {
-    const int4 op = ops[oi];
+    const int4 nxt = ops[oi + 1];
+    double Pn[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) Pn[e] = Pm[(size_t)child_of(nxt) * 16 + e];
+    const int code_n = (nxt.x & 3) == OPK_LEAF ? (int)a.codes[(size_t)child_of(nxt) * S_pad + s] : 0;
     const int kind = op.x & 3, parent = op.y;
     const bool is_leaf = kind == OPK_LEAF;
-    if (is_leaf && ((op.x >> 8) & 0xff) == 0) continue;  // padding entry
-    const int child = is_leaf ? (op.z & 0xffff) : op.z;  // nucleotide schedules use 1 leaf per entry
-    const double *__restrict__ P = Pm + (size_t)child * 16;
+    if (!(is_leaf && ((op.x >> 8) & 0xff) == 0)) {  // (else: padding entry)
     double cv[4];
     bool matvec = true;
     if (is_leaf) {
-      const int code = a.codes[(size_t)child * S_pad + s];
       if (code >= 0) {
         matvec = false;
 #pragma unroll
@@ -1373,6 +1383,11 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
       acc[0] = acc[1] = acc[2] = acc[3] = 1.;  // the next entry starts a new parent
       cnt = 0;
     }
+    }
+    op = nxt;
+    code = code_n;
+#pragma unroll
+    for (int e = 0; e < 16; e++) P[e] = Pn[e];
   }
   __shared__ double rs[256];
   __shared__ long long rc[256];
