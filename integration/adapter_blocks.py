@@ -175,5 +175,11 @@ COMPUTE = r'''
           return hip_result;  // already  sum_s f_s log L_s - 64 ln2 * scalers  (likefunc.cpp:11123)
         }
       }
+      if (_hyphy_hip_active(this, index)) {
+        // This call stays on the CPU (pinned node states for marginal ancestral reconstruction, branchIndex >= 0,
+        // or an "unsupported" return): the host caches were never filled by the device evaluations before it, so
+        // the pass must recompute every node, like the first evaluation after a setup (:10964-10966).
+        branches->Populate(t->GetINodeCount() + t->GetLeafCount() - 1, 0, 1);
+      }
 #endif
 '''

@@ -116,3 +116,32 @@ def test_hbl_optimize_through_device_matches_cpu_fit():
     assert _cached_calls(gpu["stdout"]) > 20, gpu["stdout"][-600:]
     assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3       # 2 x OPTIMIZATION_PRECISION, the reference's own test bar
     assert abs(gpu["logl"] - cpu["logl"]) <= 1e-10 * abs(cpu["logl"])
+
+
+@pytest.mark.parametrize("mode", ["joint", "marginal"])
+def test_hbl_ancestral_reconstruction_through_adapter_matches_cpu(mode):
+    """ReconstructAncestors after device evaluations.  Joint reconstruction recomputes its own tables on the host;
+    MARGINAL pins node states (ComputeBlock with branchIndex >= 0, likefunc2.cpp:932-1040), which stays on the
+    CPU path — the adapter must then recompute every node there, because the host caches were never filled."""
+    _need_binaries()
+    import tempfile
+    from oracle import hbl
+    case = _case("codon", 8, 40, 11)
+
+    def run(binary, env):
+        tmp = tempfile.mkdtemp(prefix="anc_")
+        fasta, outp, ancp = (os.path.join(tmp, n) for n in ("aln.fasta", "out.txt", "anc.txt"))
+        hbl.write_fasta(fasta, case["names"], case["seqs"])
+        txt = hbl.build_script(fasta=fasta, newick=case["newick"], unit=case["unit"], model_block=case["model_block"],
+                               model_name=case["model_name"], globals_=case["globals_"], branch_t=case["branch_t"],
+                               out_path=outp, per_site=False)
+        txt += ("DataSet anc = ReconstructAncestors (lf" + (", MARGINAL" if mode == "marginal" else "") + ");\n"
+                "DataSetFilter af = CreateFilter (anc, 1);\nDATA_FILE_PRINT_FORMAT = 9;\n"
+                f'fprintf ("{ancp}", CLEAR_FILE, af);\n')
+        out = hbl.run_script(txt, tmp, binary=binary, extra_env=env)
+        return open(ancp).read(), out
+
+    cpu, _ = run(None, None)
+    gpu, stdout = run(HIP_BIN, ENV)
+    assert _device_calls(stdout) > 0
+    assert len(cpu) > 100 and cpu == gpu
