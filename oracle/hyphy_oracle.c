@@ -181,6 +181,16 @@ int hy_oracle_expm_batch(long D, long n, const double *Q, int sparse_hint, doubl
 /*   *overallScaler             cumulative scaler count (only touched when !storageVec)  */
 /* P: transition matrices indexed by node code, P[n*D*D + i*D + j] = Pr(i -> j | branch n)*/
 /* ------------------------------------------------------------------------------------ */
+/* Pinned node states ("setBranch", ComputeBlock's branchIndex / branchValues, likefunc.cpp:10950-10957):   */
+/* set_branch = internal index i (< I) pins internal node i, = I + leaf pins a leaf; set_branch_to[s] is    */
+/* the state at pattern s.  Kept as module state so that the entry points keep their signatures.           */
+static long g_set_branch = -1;
+static const long *g_set_branch_to = 0;
+void hy_oracle_set_branch(long set_branch, const long *set_branch_to) {
+  g_set_branch = set_branch_to ? set_branch : -1;
+  g_set_branch_to = set_branch_to;
+}
+
 double hy_oracle_tree_block(long D, long S, long L, long I, const long *flat_parents,
                             const long *update_nodes, long n_update, const double *P,
                             const long *leaf_codes, const double *ambig,
@@ -203,9 +213,15 @@ double hy_oracle_tree_block(long D, long S, long L, long I, const long *flat_par
 
     if (!tagged[parentCode]) { /* first touch: fill with sticky factors, :3618-3664 + :584-605 */
       tagged[parentCode] = 1;
+      const int matchSet = parentCode == g_set_branch; /* tree_evaluator.cpp:3624 */
       for (long s = siteFrom; s < siteTo; s++) {
         double f = scalingAdjustments[parentCode * S + s];
-        for (long k = 0; k < D; k++) parentBase[s * D + k] = f;
+        if (matchSet) { /* __ll_loop_handle_leaf_case, matchSet branch :589-594 */
+          for (long k = 0; k < D; k++) parentBase[s * D + k] = 0.0;
+          parentBase[s * D + g_set_branch_to[s]] = f;
+        } else {
+          for (long k = 0; k < D; k++) parentBase[s * D + k] = f;
+        }
       }
     }
     for (long s = siteFrom; s < siteTo; s++) {
@@ -214,7 +230,8 @@ double hy_oracle_tree_block(long D, long S, long L, long I, const long *flat_par
       double sum = 0.0;
       long didScale = 0;
       if (isLeaf) { /* __ll_handle_conditional_array_initialization :161-260 */
-        long siteState = leaf_codes[nodeCode * S + s];
+        long siteState = (g_set_branch == nodeCode + I) ? g_set_branch_to[s] /* :173-181 */
+                                                        : leaf_codes[nodeCode * S + s];
         if (siteState >= 0) {
           for (long k = 0; k < D; k++) pc[k] *= tMatrix[siteState + D * k];
           continue; /* no rescale check after a resolved-leaf column gather */

@@ -119,6 +119,39 @@ def expm_cases():
     np.savez_compressed(os.path.join(OUT, "expm.npz"), **out)
 
 
+def marginal_support_case(name="codon_small_marginal", n_taxa=8, n_codons=40, seed=11):
+    """Pinned-state evaluations (ComputeBlock with branchIndex >= 0): the support matrix that
+    ReconstructAncestors (lf, MARGINAL) leaves in <dataset>.marginal_support_matrix
+    (likefunc2.cpp:932-1040): rows = internal nodes (in-order index), columns = pattern * D + state,
+    value = L_s(node pinned to state) / L_s; the last state of every pattern is left at 0 by the reference."""
+    import tempfile
+    syn = data.evolve(n_taxa, n_codons, 3, seed=seed)
+    flat = syn.flat
+    bt = branch_lengths(flat, seed + 7, 0.02, 0.12)
+    tmpl = models.mg94rev_template(POS_FREQS)
+    pi = models.f3x4_codon_freqs(POS_FREQS)
+    tmp = tempfile.mkdtemp(prefix="hygold_")
+    fasta, outp, supp = (os.path.join(tmp, n) for n in ("aln.fasta", "out.txt", "support.txt"))
+    hbl.write_fasta(fasta, flat.leaf_names, syn.seqs)
+    txt = hbl.build_script(fasta=fasta, newick=tree.to_newick(syn.tree), unit=3, model_block=hbl.codon_model_block(tmpl, pi),
+                           model_name="MGM", globals_=dict(R=0.3, **REV), branch_t=bt, out_path=outp, per_site=False)
+    txt += ("DataSet anc = ReconstructAncestors (lf, MARGINAL);\n"
+            "m_ = anc.marginal_support_matrix;\n"
+            f'fprintf ("{supp}", CLEAR_FILE, Rows (m_), " ", Columns (m_), "\\n");\n'
+            f'for (i_ = 0; i_ < Rows (m_); i_ += 1) {{ for (j_ = 0; j_ < Columns (m_); j_ += 1) {{ fprintf ("{supp}", Format (m_[i_][j_], 24, 17), "\\n"); }} }}\n')
+    hbl.run_script(txt, tmp)
+    with open(supp) as fh:
+        r, c = (int(x) for x in fh.readline().split())
+        vals = np.array([float(x) for x in fh.read().split()]).reshape(r, c)
+    pd = data.compress(syn.seqs, 3)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), support=vals, D=61, L=flat.L, flat_parents=flat.flat_parents,
+                        leaf_codes=pd.leaf_codes, ambig=pd.ambig, pattern_freq=pd.pattern_freq,
+                        t=np.array([bt[n] for n in flat.branch_names()]), omega=0.3,
+                        rev=np.array([REV[k] for k in ("AC", "AT", "CG", "CT", "GT")]), pos_freqs=POS_FREQS, root_freqs=pi,
+                        kind="codon")
+    print(f"{name}: support matrix {vals.shape}, row sums (first pattern) {vals[:, :61].sum(1)[:3]}")
+
+
 def main():
     if not hbl.have_reference():
         raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
@@ -134,6 +167,7 @@ def main():
     nuc_case("nuc_ambig", 12, 200, seed=22, missing=0.05, rev=dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4))
     nuc_case("nuc_deep", 300, 40, seed=23, ladder=True, tlo=0.1, thi=0.5, p_change=0.25)
     expm_cases()
+    marginal_support_case()
 
 
 if __name__ == "__main__":

@@ -46,6 +46,8 @@ def lib():
         L.hy_oracle_compute_block.argtypes = [C.c_long] * 4 + [lp, lp, C.c_long, dp, lp, dp, lp, dp, dp, dp, lp, C.c_long]
         L.hy_oracle_mix_categories.restype = C.c_double
         L.hy_oracle_mix_categories.argtypes = [C.c_long, C.c_long, dp, dp, lp, lp, dp, lp]
+        L.hy_oracle_set_branch.restype = None
+        L.hy_oracle_set_branch.argtypes = [C.c_long, lp]
     return _lib
 
 
@@ -103,6 +105,18 @@ class OraclePartition:
 
     def set_P(self, node_codes, P, cat: int = 0):
         self.P[cat, np.asarray(node_codes)] = P
+
+    def set_branch(self, node_code=None, states=None):
+        """Pin node ``node_code`` (leaf l -> l, internal i -> L + i) to ``states[pattern]`` for the following
+        evaluations (``ComputeBlock``'s branchIndex / branchValues); ``None`` removes the pin."""
+        if node_code is None:
+            self._pin = None
+            lib().hy_oracle_set_branch(-1, None)
+            return
+        self._pin = np.ascontiguousarray(states, dtype=np.int64)
+        code = int(node_code)
+        ref_code = code - self.L if code >= self.L else self.I + code   # the reference's own encoding
+        lib().hy_oracle_set_branch(ref_code, _l(self._pin))
 
     def compute_block(self, update_nodes, root_freqs, cat: int = 0, np_blocks: int = 1) -> float:
         un = np.ascontiguousarray(update_nodes, dtype=np.int64)

@@ -105,3 +105,33 @@ def test_partial_update_equals_full():
     fresh.set_P(common.all_nodes(fx), Pall)
     ll_full = fresh.compute_block(common.all_nodes(fx), fx["root_freqs"])
     assert abs(ll_partial - ll_full) <= 1e-12 * abs(ll_full)
+
+
+def test_oracle_pinned_states_match_reference_marginal_support():
+    """ComputeBlock with branchIndex >= 0 (pinned node states, tree_evaluator.cpp:163-181, 583-594, 3624): the
+    oracle's set_branch reproduces the support matrix the REAL reference leaves behind after
+    ReconstructAncestors (lf, MARGINAL) — L_s(node pinned to state) / L_s for every internal node, pattern and
+    state (the reference numbers its rows in in-order; rows are matched as a set)."""
+    from oracle import oracle
+    fx = common.load("codon_small_marginal")
+    L = int(fx["L"])
+    nodes = common.all_nodes(fx)
+    Q = common.fixture_Q(fx)
+    op = oracle.OraclePartition(61, fx["flat_parents"], L, fx["leaf_codes"], fx["ambig"], fx["pattern_freq"])
+    op.set_P(nodes, oracle.expm(Q, True))
+    base, bsc = op.site_block(nodes, fx["root_freqs"])
+    S, I = op.S, op.I
+    ours = np.zeros((I, S, 61))
+    for i in range(I):
+        for k in range(60):   # the reference derives the last state as 1 - sum
+            op.set_branch(L + i, np.full(S, k))
+            lk, sc = op.site_block(nodes, fx["root_freqs"])
+            ours[i, :, k] = lk / base * np.exp(-(sc - bsc) * 64 * np.log(2.0))
+    op.set_branch(None)
+    ours[:, :, 60] = 1.0 - ours[:, :, :60].sum(2)
+    ref = fx["support"].reshape(I, S, 61)
+    used = set()
+    for i in range(I):
+        match = [r for r in range(I) if r not in used and np.allclose(ours[i], ref[r], rtol=1e-9, atol=1e-12)]
+        assert match, i
+        used.add(match[0])
