@@ -74,6 +74,7 @@ struct Shard {
   int32_t *slots = nullptr;                                 // [C*B]
   int4 *ops = nullptr;
   int16_t *codes_tile = nullptr;  // [tile][L][16] copy of the leaf table (wave-per-tile kernels)
+  int16_t *pin = nullptr;         // [S_pad] pinned states (hyphy_hip_set_pinned_states)
   int4 *bc_ops = nullptr;         // branch cache: schedule of the re-rooted chain, its one-entry program table,
   int4 *bc_prog = nullptr;        //   the slot word and the rate matrix of the cached branch
   int32_t *bc_slot = nullptr;
@@ -137,6 +138,7 @@ struct hyphy_hip_partition {
   std::vector<double> cached_weights;        // category weights currently on the device
   std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
   int root_slot = 0;
+  int64_t pin_node = -1;                     // node code whose states are pinned for the evaluations that follow (-1: none)
   std::vector<int64_t> bc_node;              // per rate class: branch whose outside vector is resident (-1: none)
   std::vector<int> bc_use_pi;                // ... hangs off the root (frequencies applied at evaluation)
   int variant = 0;                           // pruning kernel variant (common.h PruneArgs::variant)
@@ -164,7 +166,7 @@ void free_shard(Shard &s) {
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
                  s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.codes_tile,
-                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q};
+                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin};
   for (void *d : dev)
     if (d) hipFree(d);
   void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog};
@@ -482,6 +484,9 @@ PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
   pa.PTg = s.PTg + (size_t)cat * B * DP * DP;
   pa.codes = s.codes;
   pa.codes_tile = s.codes_tile;
+  pa.pin = s.pin;
+  pa.pin_leaf = (p->pin_node >= 0 && p->pin_node < p->L) ? (int)p->pin_node : -1;
+  pa.pin_inode = p->pin_node >= p->L ? (int)(p->pin_node - p->L) : -1;
   pa.ambig = s.ambig;
   pa.partials = s.partials + (size_t)cat * s.partial_stride;
   pa.counts = s.counts + (size_t)cat * p->I * s.S_pad;
@@ -602,6 +607,9 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     na.root_inode = (int)p->I - 1;
     na.P = s.Prow + (size_t)cat * B * 16;
     na.codes = s.codes;
+    na.pin = s.pin;
+    na.pin_leaf = (p->pin_node >= 0 && p->pin_node < p->L) ? (int)p->pin_node : -1;
+    na.pin_inode = p->pin_node >= p->L ? (int)(p->pin_node - p->L) : -1;
     na.ambig = s.ambig;
     na.partials = s.partials + (size_t)cat * s.partial_stride;
     na.counts = s.counts + (size_t)cat * p->I * s.S_pad;
@@ -972,6 +980,8 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       A_(s.bc_q, (size_t)D * D * sizeof(double));
     }
     A_(s.freq, (size_t)s.S_pad * sizeof(double));
+    A_(s.pin, (size_t)s.S_pad * sizeof(int16_t));
+    hipMemset(s.pin, 0, (size_t)s.S_pad * sizeof(int16_t));
     A_(s.ambig, (size_t)std::max<int64_t>(1, n_ambig) * DP * sizeof(double));
     // (+2 node slots per class behind the last class: outside vector of the cached branch and a scratch slot, see
     //  hyphy_hip_branch_cache_build)
@@ -1257,6 +1267,35 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
         }
     }
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pinned node states: ComputeBlock's branchIndex / branchValues ("setBranch", likefunc.cpp:10950-10957;
+// tree_evaluator.cpp:163-181 for a leaf, :583-594 + :3624 for an internal node) — the evaluations that follow
+// see node `node` fixed to states[pattern].  Used by marginal ancestral reconstruction
+// (RecoverAncestralSequencesMarginal, likefunc2.cpp:932-1040: one pinned evaluation per node and state).
+// ---------------------------------------------------------------------------------------------------
+int hyphy_hip_set_pinned_states(hyphy_hip_partition *p, int64_t node, const int64_t *states) {
+  if (!p) return fail("partition == NULL");
+  if (node < 0 || !states) {
+    p->pin_node = -1;
+    return 0;
+  }
+  if (node >= p->L + p->I) return fail("set_pinned_states: node out of range");
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    std::vector<int16_t> h(s.S_pad, 0);
+    for (int64_t k = 0; k < s.S; k++) {
+      const int64_t st = states[s.s0 + k];
+      if (st < 0 || st >= p->D) return fail("set_pinned_states: state out of range");
+      h[k] = (int16_t)st;
+    }
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipMemcpy(s.pin, h.data(), h.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  }
+  p->pin_node = node;
+  std::fill(p->bc_node.begin(), p->bc_node.end(), -1);
   return 0;
 }
 

@@ -86,6 +86,9 @@ struct PruneArgs {
   const double *PTg;         // [B][DP][NW][4][4]    column-gather images (leaf edges)
   const int16_t *codes;      // [L][S_pad]           >= 0 state, < 0 -> -(k+1) ambiguity row
   const int16_t *codes_tile; // [ntiles][L][16]      the same table, tile-major (wave-per-tile kernels)
+  // pinned node states (hyphy_hip_set_pinned_states; ComputeBlock's branchIndex / branchValues): at most one node
+  int pin_inode, pin_leaf;   // internal index / leaf index of the pinned node, -1 = none
+  const int16_t *pin;        // [S_pad] state the node is fixed to at each pattern
   const double *ambig;       // [n_ambig][DP]
   double *partials;          // [I][ntiles][NKK*64]  conditionals, fragment layout
   int32_t *counts;           // [I][S_pad]           cumulative 2^64-exponent of the subtree
@@ -117,6 +120,8 @@ struct NucArgs {
   int root_inode;
   const double *P;           // [B][16] row-major 4x4
   const int16_t *codes;      // [L][S_pad]
+  int pin_inode, pin_leaf;   // pinned node (see PruneArgs)
+  const int16_t *pin;
   const double *ambig;       // [n_ambig][4]
   double *partials;          // [I][4][S_pad]  state-major planes (coalesced per state)
   int32_t *counts;           // [I][S_pad]

@@ -203,12 +203,14 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
     const int n = a.L * T * 16;
     for (int i = threadIdx.x; i < n; i += 64 * NW) {
       const int leaf = i / (T * 16), off = i - leaf * (T * 16);
-      codes_lds[i] = a.codes[(size_t)leaf * S_pad + tile0 * 16 + off];
+      codes_lds[i] = (leaf == a.pin_leaf) ? a.pin[tile0 * 16 + off]  // pinned leaf: its states replace the data
+                                          : a.codes[(size_t)leaf * S_pad + tile0 * 16 + off];
     }
     __syncthreads();
   }
   auto leaf_code = [&](int leaf, int t) -> int {
     if (CLDS) return (int)codes_lds[leaf * (T * 16) + t * 16 + sl];
+    if (leaf == a.pin_leaf) return (int)a.pin[(tile0 + t) * 16 + sl];
     return (int)a.codes[(size_t)leaf * S_pad + (tile0 + t) * 16 + sl];
   };
   // Issue the global loads for a schedule entry (they complete while the previous entry computes).
@@ -385,6 +387,14 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
       const int par2 = (op.x >> 4) & 1;
       const int slot = (op.x >> 16) & 0xff;
       const int parent = op.y;
+      if (parent == a.pin_inode) {  // pinned internal node: only the pinned state survives (tree_evaluator.cpp:589-594)
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+          const int ps = (int)a.pin[(tile0 + t) * 16 + sl];
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[t][r] = (16 * w + 4 * r + g == ps) ? acc[t][r] : 0.;
+        }
+      }
 #pragma unroll
       for (int t = 0; t < T; t++) {
         psum[par2][t][w * 64 + lane] = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
@@ -517,9 +527,12 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
     int4 *dst = reinterpret_cast<int4 *>(codes_lds);
     for (int i = lane; i < a.L * 2; i += 64) dst[i] = src[i];
     __syncthreads();
+    if (a.pin_leaf >= 0 && lane < 16) codes_lds[a.pin_leaf * 16 + lane] = a.pin[tile0 * 16 + lane];  // pinned leaf
+    __syncthreads();
   }
   auto leaf_code = [&](int leaf) -> int {
     if (CLDS) return (int)codes_lds[leaf * 16 + sl];
+    if (leaf == a.pin_leaf) return (int)a.pin[tile0 * 16 + sl];
     return (int)a.codes_tile[((size_t)tile0 * a.L + leaf) * 16 + sl];
   };
 
@@ -639,6 +652,13 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
 
     if (op.x & OPF_LAST) {
       const int slot = (op.x >> 16) & 0xff;
+      if (op.y == a.pin_inode) {  // pinned internal node: only the pinned state survives (tree_evaluator.cpp:589-594)
+        const int ps = (int)a.pin[tile0 * 16 + sl];
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[w][r] = (16 * w + 4 * r + g == ps) ? acc[w][r] : 0.;
+      }
       double s = 0.;
 #pragma unroll
       for (int w = 0; w < NW; w++) s += (acc[w][0] + acc[w][1]) + (acc[w][2] + acc[w][3]);
@@ -818,9 +838,12 @@ __global__ __launch_bounds__(64 * WPT, NP ? 3 : HYPHY_OCC6) void prune_split4_ke
     int4 *dst = reinterpret_cast<int4 *>(codes_lds);
     for (int i = threadIdx.x; i < a.L * 2; i += 64 * WPT) dst[i] = src[i];
     __syncthreads();
+    if (a.pin_leaf >= 0 && threadIdx.x < 16) codes_lds[a.pin_leaf * 16 + threadIdx.x] = a.pin[tile0 * 16 + threadIdx.x];
+    __syncthreads();
   }
   auto leaf_code = [&](int leaf, int site) -> int {
     if (CLDS) return (int)codes_lds[leaf * 16 + site];
+    if (leaf == a.pin_leaf) return (int)a.pin[tile0 * 16 + site];
     return (int)a.codes_tile[((size_t)tile0 * a.L + leaf) * 16 + site];
   };
   auto b_elem = [](int kk) -> int { return (((kk >> 2) * 2) * 64 + 16 * (kk & 3)) * 2; };  // + blane16 bytes
@@ -1003,6 +1026,14 @@ __global__ __launch_bounds__(64 * WPT, NP ? 3 : HYPHY_OCC6) void prune_split4_ke
         // finalise the parent: publish this wave's rows and its votes, ONE LDS-only barrier, decision
         const int par2 = (op.x >> 4) & 1;
         const int slot = (op.x >> 16) & 0xff;
+        if (op.y == a.pin_inode) {  // pinned internal node: only the pinned state survives
+#pragma unroll
+          for (int J = 0; J < 4; J++) {
+            const int ps = (int)a.pin[tile0 * 16 + 4 * J + j];
+#pragma unroll
+            for (int r = 0; r < RBW; r++) acc[r][J] = (16 * (R0 + r) + q16 == ps) ? acc[r][J] : 0.;
+          }
+        }
         // votes: bit (4J + j) of `nib` = some lane of this wave holds >= 2^-64 in the column of site 4J + j;
         // hi_bad = some partial sum exceeds 2^64 / (16 WPT).  All 16 bits set in the OR over the waves and no
         // hi_bad  =>  no site of the tile needs rescaling (partial sums are non-negative).
@@ -1310,13 +1341,18 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
   double P[16];
 #pragma unroll
   for (int e = 0; e < 16; e++) P[e] = Pm[(size_t)child_of(op) * 16 + e];
-  int code = (op.x & 3) == OPK_LEAF ? (int)a.codes[(size_t)child_of(op) * S_pad + s] : 0;
+  auto code_of = [&](const int4 &o) -> int {
+    if ((o.x & 3) != OPK_LEAF) return 0;
+    const int lf = o.z & 0xffff;
+    return lf == a.pin_leaf ? (int)a.pin[s] : (int)a.codes[(size_t)lf * S_pad + s];  // (pinned leaf: its states replace the data)
+  };
+  int code = code_of(op);
   for (int oi = 0; oi < a.n_ops; oi++) {
     const int4 nxt = ops[oi + 1];
     double Pn[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) Pn[e] = Pm[(size_t)child_of(nxt) * 16 + e];
-    const int code_n = (nxt.x & 3) == OPK_LEAF ? (int)a.codes[(size_t)child_of(nxt) * S_pad + s] : 0;
+    const int code_n = code_of(nxt);
     const int kind = op.x & 3, parent = op.y;
     const bool is_leaf = kind == OPK_LEAF;
     if (!(is_leaf && ((op.x >> 8) & 0xff) == 0)) {  // (else: padding entry)
@@ -1361,6 +1397,11 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
       }
     }
     if (op.x & OPF_LAST) {
+      if (parent == a.pin_inode) {  // pinned internal node: only the pinned state survives
+        const int ps = (int)a.pin[s];
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = (i == ps) ? acc[i] : 0.;
+      }
       const double tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
       double sc;
       const int m = rescale_decision(tot, sc);

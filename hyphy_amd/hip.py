@@ -23,6 +23,7 @@ EXPORTS = [
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
+    "hyphy_hip_set_pinned_states",
     "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
@@ -85,6 +86,8 @@ def load():
     lib.hyphy_hip_prune_timings.argtypes = [vp, dp, C.c_int64]
     lib.hyphy_hip_prune_launches.restype = C.c_int
     lib.hyphy_hip_prune_launches.argtypes = [vp]
+    lib.hyphy_hip_set_pinned_states.restype = C.c_int
+    lib.hyphy_hip_set_pinned_states.argtypes = [vp, C.c_int64, lp]
     lib.hyphy_hip_branch_cache_build.restype = C.c_int
     lib.hyphy_hip_branch_cache_build.argtypes = [vp, C.c_int64, C.c_int64]
     lib.hyphy_hip_branch_cache_evaluate.restype = C.c_int
@@ -279,6 +282,15 @@ class HipPartition:
         counts = np.zeros((self.I, self.S), dtype=np.int64)
         _check(self._lib.hyphy_hip_download_partials(self._h, cat, _d(cache), _l(counts)))
         return cache, counts
+
+    def set_pinned_states(self, node=None, states=None):
+        """Fix node ``node`` (node code) to ``states[pattern]`` for the evaluations that follow; ``None`` removes it."""
+        if node is None:
+            _check(self._lib.hyphy_hip_set_pinned_states(self._h, -1, None))
+            return
+        st = np.ascontiguousarray(states, dtype=np.int64)
+        assert st.shape == (self.S,)
+        _check(self._lib.hyphy_hip_set_pinned_states(self._h, int(node), _l(st)))
 
     # -- branch cache (one-branch line searches) --------------------------------------------------
     def branch_cache_build(self, node: int, cat: int = 0):

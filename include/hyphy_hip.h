@@ -187,6 +187,15 @@ int hyphy_hip_set_stream(hyphy_hip_partition *p, void *stream);
  * out[0] = expm kernel(s), out[1] = pruning kernel, out[2] = root/site reduction. */
 int hyphy_hip_last_timings(hyphy_hip_partition *p, double out[3]);
 
+/* ---- pinned node states ---------------------------------------------------------------------
+ * ComputeBlock's branchIndex / branchValues ("setBranch": src/core/likefunc.cpp:10950-10957; leaf case
+ * src/core/tree_evaluator.cpp:163-181, internal case :583-594 and :3624): every evaluation that follows sees
+ * node `node` (node code: leaf l -> l, internal i -> L + i, the root included) fixed to states[pattern] in
+ * [0, D).  node < 0 or states == NULL removes the pin.  The caller lists the node (and, after removing the pin,
+ * lists it again) among update_nodes, as RecoverAncestralSequencesMarginal does with
+ * AddBranchToForcedRecomputeList (src/core/likefunc2.cpp:932-1040). */
+int hyphy_hip_set_pinned_states(hyphy_hip_partition *p, int64_t node, const int64_t *states /* [S] */);
+
 /* ---- branch cache ---------------------------------------------------------------------
  * Replaces _TheTree::ComputeBranchCache (src/core/tree_evaluator.cpp:4286-4845) and
  * _TheTree::ComputeLLWithBranchCache (src/core/tree.cpp:3383-3936), driven by the policy code of

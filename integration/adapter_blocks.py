@@ -108,6 +108,17 @@ static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catI
   return rc;
 }
 
+// pinned node states (branchIndex >= 0: marginal ancestral reconstruction, likefunc2.cpp:932-1040): pin, evaluate, unpin
+static int _hyphy_hip_pinned(const void *lf, long index, _TheTree *t, long catID, _SimpleList &branches, _List &matrices,
+                             long node_code, long const *states, hyFloat *siteRes, long *scc, hyFloat *result) {
+  _HyHipPart &hp = _hyhip_lfs[lf][index];
+  int rc = hyphy_hip_set_pinned_states(hp.part, node_code, (const int64_t *)states);
+  if (rc != 0) return rc > 0 ? rc : 1;
+  rc = _hyphy_hip_compute(lf, index, t, catID, branches, matrices, siteRes, scc, result);
+  hyphy_hip_set_pinned_states(hp.part, -1, nullptr);
+  return rc;
+}
+
 // branch cache (SURVEY 8f-1): device counterparts of ComputeBranchCache / ComputeLLWithBranchCache, driven by the
 // reference's own policy state machine (computedLocalUpdatePolicy, likefunc.cpp:10886-10948)
 static int _hyphy_hip_cache_build(const void *lf, long index, long catID, long node) {
@@ -155,6 +166,16 @@ TEARDOWN = r'''
 # ---- block 4: ComputeBlock, between ExponentiateMatrices and the OpenMP pruning loop -----------------
 COMPUTE = r'''
 #ifdef HYPHY_HIP
+      if (branchIndex >= 0 && branchValues && _hyphy_hip_active(this, index)) {
+        // pinned node states: internal node branchIndex, or leaf branchIndex - #internal nodes (:10953-10956)
+        hyFloat hip_result = 0.;
+        const long n_int = t->GetINodeCount();
+        const long code = branchIndex < n_int ? t->GetLeafCount() + branchIndex : branchIndex - n_int;
+        if (_hyphy_hip_pinned(this, index, t, catID, *branches, *matrices, code, branchValues->list_data, siteRes, scc,
+                              &hip_result) == 0) {
+          return hip_result;
+        }
+      }
       if (branchIndex < 0 && _hyphy_hip_active(this, index)) {
         hyFloat hip_result = 0.;
         if (doCachedComp >= 3) {  // one-branch line search: a single contraction against the device branch cache

@@ -440,6 +440,93 @@ def test_lazy_persistence_nucleotide_path():
     assert abs(c - r3) <= RTOL * abs(r3)
 
 
+def _pin_update_list(flat, code):
+    """Dirty list of an evaluation with node ``code`` pinned: DetermineNodesForUpdate with addOne = the node
+    (tree.cpp:3268-3297) lists the node, its ancestors and the direct children of every touched internal node —
+    including the pinned node's own children, so that the node itself is recomputed."""
+    L = flat.L
+    out = set()
+    if int(flat.flat_parents[code]) >= 0:
+        out.update(int(x) for x in flat.path_update_nodes(int(code)))
+    if code >= L:
+        out.update(int(c) for c in flat.children_of(code - L))
+    return np.array(sorted(out), dtype=np.int64)
+
+
+@pytest.mark.parametrize("kernel", ["0", "1", "2"])
+def test_pinned_states_reproduce_reference_marginal_support(kernel, monkeypatch):
+    """hyphy_hip_set_pinned_states (ComputeBlock's branchIndex / branchValues): the device's pinned per-pattern
+    likelihoods reproduce the support matrix of the REAL reference's ReconstructAncestors (lf, MARGINAL) —
+    partial updates along the path of the pinned node, exactly the call sequence of
+    RecoverAncestralSequencesMarginal (likefunc2.cpp:932-1040)."""
+    from hyphy_amd import tree
+    monkeypatch.setenv("HYPHY_HIP_KERNEL", kernel)
+    fx = common.load("codon_small_marginal")
+    L = int(fx["L"])
+    nodes = common.all_nodes(fx)
+    Q = common.fixture_Q(fx)
+    pi = fx["root_freqs"]
+    flat = tree.flat_from_parents(fx["flat_parents"], L)
+    I = flat.I
+    none = np.zeros(0, dtype=np.int64)
+    with _mk(fx) as part:
+        S = part.S
+        _, base, bsc = part.evaluate(nodes, nodes, Q, pi, per_site=True)
+        ours = np.zeros((I, S, 61))
+        for i in range(I):
+            un = _pin_update_list(flat, L + i)
+            for k in range(60):
+                part.set_pinned_states(L + i, np.full(S, k))
+                _, lk, sc = part.evaluate(un, none, np.zeros((0, 61, 61)), pi, per_site=True)
+                ours[i, :, k] = lk / base * np.exp(-(sc - bsc) * 64 * np.log(2.0))
+            part.set_pinned_states(None)
+            part.evaluate(un, none, np.zeros((0, 61, 61)), pi)   # restore the path (forced recompute, as the reference does)
+        ll = part.evaluate(nodes[:0], none, np.zeros((0, 61, 61)), pi)
+    ours[:, :, 60] = 1.0 - ours[:, :, :60].sum(2)
+    ref = fx["support"].reshape(I, S, 61)
+    used = set()
+    for i in range(I):
+        match = [r for r in range(I) if r not in used and np.allclose(ours[i], ref[r], rtol=1e-9, atol=1e-12)]
+        assert match, (kernel, i)
+        used.add(match[0])
+
+
+@pytest.mark.parametrize("name", ["codon_ambig", "nuc_ambig", "codon_deep"])
+def test_pinned_states_match_oracle(name):
+    """Pinned leaves and pinned internal nodes (4-state and MFMA paths, ambiguity codes, deep trees with
+    rescaling) against the CPU restatement."""
+    from hyphy_amd import tree
+    from oracle import oracle
+    fx = common.load(name)
+    L, D = int(fx["L"]), int(fx["D"])
+    nodes = common.all_nodes(fx)
+    Q = common.fixture_Q(fx)
+    pi = fx["root_freqs"]
+    flat = tree.flat_from_parents(fx["flat_parents"], L)
+    op = oracle.OraclePartition(D, fx["flat_parents"], L, fx["leaf_codes"], fx["ambig"], fx["pattern_freq"])
+    op.set_P(nodes, oracle.expm(Q, D > 4))
+    rng = np.random.default_rng(3)
+    with _mk(fx) as part:
+        S = part.S
+        part.evaluate(nodes, nodes, Q, pi)
+        op.site_block(nodes, pi)   # (per-site mode throughout: the oracle's site corrections are cumulative state)
+        for code in (1, L - 1, L + 0, L + flat.I // 2, L + flat.I - 2):
+            states = rng.integers(0, D, size=S)
+            un = _pin_update_list(flat, int(code))
+            part.set_pinned_states(code, states)
+            op.set_branch(code, states)
+            _, lk, sc = part.evaluate(un, np.zeros(0, dtype=np.int64), np.zeros((0, D, D)), pi, per_site=True)
+            rl, rs = op.site_block(un, pi)
+            part.set_pinned_states(None)
+            op.set_branch(None)
+            ok = rl > 0
+            assert np.array_equal(lk > 0, ok), (name, code)
+            assert np.allclose(np.log(lk[ok]) - sc[ok] * 64 * np.log(2.0), np.log(rl[ok]) - rs[ok] * 64 * np.log(2.0),
+                               rtol=1e-10, atol=1e-9), (name, code)
+            part.evaluate(un, np.zeros(0, dtype=np.int64), np.zeros((0, D, D)), pi)
+            op.site_block(un, pi)
+
+
 def test_categories_match_reference():
     fx = common.load("codon_cat3")
     C = len(fx["cat_weights"])
