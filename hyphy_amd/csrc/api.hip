@@ -932,9 +932,10 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     const int64_t tiles = (s.S + 15) / 16;
     int T = 1;
     if (!p->nuc) {
-      // one 16-pattern tile per workgroup keeps >= 2-3 waves per SIMD in flight (the FP64 matrix pipe
-      // needs that to saturate, tools/ubench_mfma_f64); larger T only once the grid is many waves deep
-      T = tiles <= 8 * cus ? 1 : (tiles <= 24 * cus ? 2 : 4);
+      // T = 1 everywhere the wave-per-tile kernel applies (any shard of >= 1.75 tiles per CU: measured 2.3x
+      // faster than the T = 2 workgroup kernel at 128 taxa x 100k codons, 2 718 vs 6 190 us); T > 1 only beyond
+      // the grid limit of 65 535 tiles
+      T = tiles <= 65535 ? 1 : (tiles <= 2 * 65535 ? 2 : 4);
       if (tiles_override >= 1 && tiles_override <= 4) T = tiles_override;
     }
     s.T = T;
