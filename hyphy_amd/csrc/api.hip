@@ -284,10 +284,6 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
       }
     }
     entries.back().x |= OPF_LAST | ((fin & 1) ? OPF_PARITY : 0) | (dst << 16);
-    if (!p->nuc)  // split-tile kernel: a child read from global memory is staged in this parent's destination tile
-      for (int4 &e : entries)
-        if ((e.x & 3) == OPK_INTERNAL_GLOBAL || ((e.x & 3) == OPK_LEAF && (e.x & OPF_AMBIG)))
-          e.x = (e.x & 0x00ffffff) | (dst << 24);
     if (handoff && !is_root_program && ti + 1 == nodes.size()) entries.back().x |= OPF_HANDOFF;  // fragment root
     // lazy persistence: skip the store of this node unless it is the root of a fragment (read by another
     // program) — a later consumer through the persisted copy clears the flag again
@@ -582,7 +578,6 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       ea.Prow = nullptr;
       ea.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
       ea.PTg = s.PTg + (size_t)cat * B * DP * DP;
-      ea.ptg_layout = (p->variant == 2) ? 1 : 0;
     }
     tr.lap("slots+q");
     launch_expm(ea, s.stream);
@@ -653,17 +648,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       HIPCHK(hipStreamSynchronize(s.stream));
       HIPCHK(hipMemcpy(h.data(), pa.timeline, tl_n * sizeof(long long), hipMemcpyDeviceToHost));
       hipFree(pa.timeline);
-      if (p->variant == 2) {
-        if (FILE *f = fopen(tl_path, "w")) {
-          fprintf(f, "# tile  cycles(leaf, product, pre-barrier, barrier wait, post-barrier)  counts(...)\n");
-          for (int b = 0; b < kTraceWG; b++) {
-            fprintf(f, "%d", b);
-            for (int i = 0; i < 10; i++) fprintf(f, " %lld", h[(size_t)b * 16 + i]);
-            fprintf(f, "\n");
-          }
-          fclose(f);
-        }
-      } else if (FILE *f = fopen(tl_path, "w")) {
+      if (FILE *f = fopen(tl_path, "w")) {
         fprintf(f, "# wg wave entry flags t_start t_compute_done t_after_barrier t_finalised\n");
         for (int b = 0; b < kTraceWG; b++)
           for (int w = 0; w < p->NW; w++)
@@ -814,7 +799,7 @@ int hyphy_hip_prune_launches(hyphy_hip_partition *p) { return p ? (int)std::max<
 const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p) {
   if (!p) return "";
   if (p->nuc) return "prune_nuc_kernel";
-  return p->variant == 2 ? "prune_split4_kernel" : (p->variant == 1 ? "prune_wave_kernel" : "prune_mfma_kernel");
+  return p->variant == 1 ? "prune_wave_kernel" : "prune_mfma_kernel";
 }
 
 int64_t hyphy_hip_prune_timings(hyphy_hip_partition *p, double *out_ms, int64_t n) {
@@ -948,8 +933,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       // 624) and the workgroup-per-tile kernel, which splits a tile's rows over four waves, is faster
       // (123 us at 312 tiles, 63 us at 78).
       p->variant = tiles >= (7 * (int64_t)cus) / 4 ? 1 : 0;
-      if (const char *e = getenv("HYPHY_HIP_KERNEL")) p->variant = std::min(2, std::max(0, atoi(e)));
-      if (p->variant == 2 && (p->NW & 1)) p->variant = 1;  // the split-tile kernel needs an even number of row blocks  // the split-tile kernel needs an even number of row blocks
+      if (const char *e = getenv("HYPHY_HIP_KERNEL")) p->variant = atoi(e) ? 1 : 0;  // the split-tile kernel needs an even number of row blocks
       if (T != 1) p->variant = 0;
       p->n_slots = lds_slots(T);
       if (p->variant >= 1) {
@@ -1247,7 +1231,7 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
         double *dtmp = nullptr;
         HIPCHK(hipMalloc((void **)&dtmp, (size_t)I * s.S * D * sizeof(double)));
         launch_unpack_partials_mfma(s.partials + (size_t)cat * s.partial_stride, (int)I, s.ntiles, p->NW, (int)D,
-                                    (int)s.S, (p->variant == 2) ? 1 : 0, dtmp, s.stream);
+                                    (int)s.S, dtmp, s.stream);
         hipError_t e = hipMemcpy2DAsync(inode_cache + s.s0 * D, (size_t)S * D * sizeof(double), dtmp,
                                         (size_t)s.S * D * sizeof(double), (size_t)s.S * D * sizeof(double), (size_t)I,
                                         hipMemcpyDeviceToHost, s.stream);
@@ -1262,9 +1246,7 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
                        hipMemcpyDeviceToHost));
       for (int64_t n = 0; n < I; n++)
         for (int64_t k = 0; k < s.S; k++) {
-          // the 4x4x4 kernel keeps a tile's exponents as [site & 3][site >> 2] (one int4 per lane)
-          const int64_t within = (p->variant == 2) ? (k & ~15) + (k & 3) * 4 + ((k >> 2) & 3) : k;
-          scaler_counts[n * S + s.s0 + k] = tmp[(size_t)n * s.S_pad + within];
+          scaler_counts[n * S + s.s0 + k] = tmp[(size_t)n * s.S_pad + k];
         }
     }
   }
@@ -1323,8 +1305,8 @@ static int ensure_resident(hyphy_hip_partition *p, int64_t cat) {
 
 int hyphy_hip_branch_cache_build(hyphy_hip_partition *p, int64_t cat, int64_t node) {
   if (!p) return fail("partition == NULL");
-  if (p->nuc || p->variant == 2) {
-    g_last_error = "branch cache: not available for this partition (4-state path / quad-layout kernel)";
+  if (p->nuc) {
+    g_last_error = "branch cache: not available for the 4-state path";
     return 1;
   }
   if (cat < 0) cat = 0;
@@ -1392,9 +1374,6 @@ int hyphy_hip_branch_cache_build(hyphy_hip_partition *p, int64_t cat, int64_t no
       entries.push_back(op);
     }
     entries.back().x |= OPF_LAST | ((k & 1) ? OPF_PARITY : 0) | ((k & 1) << 16);
-    for (int4 &e : entries)  // staging tile of the split-tile kernels = this node's destination
-      if ((e.x & 3) == OPK_INTERNAL_GLOBAL || ((e.x & 3) == OPK_LEAF && (e.x & OPF_AMBIG)))
-        e.x = (e.x & 0x00ffffff) | ((k & 1) << 24);
     for (const int4 &e : entries) ops.push_back(e);
   }
   int4 nop;
@@ -1464,7 +1443,6 @@ int hyphy_hip_branch_cache_evaluate(hyphy_hip_partition *p, int64_t cat, int64_t
     ea.Prow = nullptr;
     ea.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
     ea.PTg = s.PTg + (size_t)cat * B * DP * DP;
-    ea.ptg_layout = 0;
     launch_expm(ea, s.stream);
     BcArgs ba;
     ba.NW = p->NW;
@@ -1519,7 +1497,7 @@ int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_
   HIPCHK(hipMemcpy(dq, q_dense, bytes, hipMemcpyHostToDevice));
   ExpmArgs ea;
   ea.Q = dq; ea.slots = nullptr; ea.n = (int)n; ea.D = (int)D; ea.is_prob = 0;
-  ea.Prow = dp; ea.Pfrag = nullptr; ea.PTg = nullptr; ea.ptg_layout = 0; ea.prof = 0; ea.status = st;
+  ea.Prow = dp; ea.Pfrag = nullptr; ea.PTg = nullptr; ea.prof = 0; ea.status = st;
   ea.templates = nullptr; ea.coeffs = nullptr; ea.K = 0;
   launch_expm(ea, nullptr);
   int32_t hst = 0;

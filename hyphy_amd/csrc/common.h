@@ -79,8 +79,7 @@ struct PruneArgs {
   int n_prog_total;          // programs in the whole table (chained fragments: stride of frag_ctr)
   int *frag_ctr;             // [class][program][tile] arrivals of finished child fragments (zero between launches)
   int32_t *hand_cnt;         // [class][I][tile][32] exponents of fragment roots handed between workgroups
-  int variant;               // 0: workgroup-per-tile kernel (prune_mfma_kernel), 1: wave-per-tile kernel (T = 1),
-                             // 2: split-tile kernel on the 4x4x4 MFMA (quad-layout conditionals, PTg layout 1)
+  int variant;               // 0: workgroup-per-tile kernel (prune_mfma_kernel), 1: wave-per-tile kernel (T = 1)
   int n_slots;               // LDS slots the schedule was compiled for (2 exchange + parking)
   const double *Pfrag;       // [B][NW][NKK*64]      A-operand images of the transition matrices
   const double *PTg;         // [B][DP][NW][4][4]    column-gather images (leaf edges)
@@ -142,8 +141,7 @@ struct ExpmArgs {
   int is_prob;
   double *Prow;              // optional [.][D*D] row-major output (slot-indexed)
   double *Pfrag;             // optional [.][NW][NKK*64]
-  double *PTg;               // optional [.][DP][NW][16]  column-gather image (leaf edges), layout below
-  int ptg_layout;            // 0: [code][wb][g][r] = P[16wb + 4r + g][code];  1: [code][q][R] = P[16R + q][code]
+  double *PTg;               // optional [.][DP][NW][16]  column-gather image (leaf edges): [code][wb][g][r] = P[16wb + 4r + g][code]
   int32_t *status;           // [1] set to nonzero if any matrix failed (NaN / ill-conditioned)
   // optional fused rate-matrix construction: Q_m = sum_k coeffs[m][k] * templates[k]
   // off-diagonal, diagonal = -(row sum); when templates != nullptr, Q is ignored
@@ -191,7 +189,7 @@ int prune_nuc_grid(const NucArgs &a);
 void launch_mix_categories(const double *site_lik /*[C][S_pad]*/, const int32_t *site_cnt, const double *weights_dev,
                            int C, int S_pad, double *mixed_lik, int32_t *mixed_cnt, hipStream_t stream);
 void launch_build_q(const double *templates, const double *coeffs, int n, int K, int D, double *Q, hipStream_t stream);
-void launch_unpack_partials_mfma(const double *partials, int I, int ntiles, int NW, int D, int S, int tile_layout,
-                                 double *out, hipStream_t stream);
+void launch_unpack_partials_mfma(const double *partials, int I, int ntiles, int NW, int D, int S, double *out,
+                                 hipStream_t stream);
 
 }  // namespace hyhip

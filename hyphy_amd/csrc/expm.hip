@@ -343,14 +343,8 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
     double *out = a.PTg + (size_t)slot * DP * DP;
     for (int idx = tid; idx < DP * DP; idx += NTHR) {
       const int code = idx / (NT * 16), rem = idx - code * (NT * 16);
-      int rr;
-      if (a.ptg_layout == 0) {
-        const int wb = rem >> 4, gg = (rem >> 2) & 3, r = rem & 3;
-        rr = 16 * wb + 4 * r + gg;
-      } else {  // [code][q][R]  <-  P[16 R + q][code]   (4x4x4 kernel: a lane's NT row blocks contiguous)
-        const int q = rem / NT, R = rem - q * NT;
-        rr = 16 * R + q;
-      }
+      const int wb = rem >> 4, gg = (rem >> 2) & 3, r = rem & 3;
+      const int rr = 16 * wb + 4 * r + gg;
       out[idx] = (rr < D && code < D) ? Xs[rr * LD + code] : 0.0;
     }
   }

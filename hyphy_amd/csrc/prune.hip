@@ -754,458 +754,6 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
   }
 }
 
-__device__ __forceinline__ double mfma4(double a, double b, double c) {
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
-// butterfly sum over lane bits 2..5 (the 16 (b, i) lanes of a site column): bit-identical in all lanes
-__device__ __forceinline__ double col_sum16(double x) {
-  x += __shfl_xor(x, 4);
-  x += __shfl_xor(x, 8);
-  x += __shfl_xor(x, 16);
-  x += __shfl_xor(x, 32);
-  return x;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Split-tile kernel on v_mfma_f64_4x4x4_4b_f64 (T = 1, "quad layout" conditionals), HYPHY_HIP_KERNEL=2:
-// WPT waves per 16-pattern tile, each wave RBW = NW / WPT row blocks.
-//
-// Why the instruction (tools/ubench_mfma_f64, tools/probe_mfma_4x4x4): with ONE operand pair the 16x16x4 f64
-// MFMA issues every ~100 cycles per SIMD and the four-block 4x4x4 form every ~18; with distinct operand
-// registers per instruction, as in any real kernel, 16x16x4 sustains one per ~130 cycles (38-42 TFLOP/s) and
-// 4x4x4 one per 22-30 depending on the register blocking (2x4 operand grid 25-30 cycles, 4x4 grid 22-23:
-// 46-56 TFLOP/s).  Operand lanes of the 4x4x4 form (probed): A[b][i][k] <- lane i + 4b + 16k,
-// B[b][k][j] <- lane j + 4b + 16k, D[b][i][j] -> lane j + 4b + 16i (block b; no broadcast modes for f64).
-//
-// Mapping: block b = 4-row group inside a 16-row block R of the parent (row = 16R + 4b + i), so the A operand
-// of (R, k-step) is exactly the Pfrag image the 16x16x4 kernels use; the B operand of (k-step, site quad J)
-// is a 4 x 4 piece of the child's conditionals replicated over the blocks — a broadcast read of the child's
-// tile from LDS (lanes differing only in b read the same address).  D(R, J): lane (j, b, i) holds
-// parent[16R + 4b + i][site 4J + j].  Tiles (LDS and HBM) use the quad layout: element (state 16R + 4b + i,
-// site 4J + j) at ((2R + (J >> 1))*64 + j + 4i + 16b)*2 + (J & 1) — every wave store is one contiguous 1 KiB
-// line and the 16 distinct 16-byte chunks of a B read tile the 64 LDS banks exactly.
-//
-// Exchange: ping-pong tiles in LDS (each wave writes its rows), ONE LDS-only barrier per node; the rescale
-// decision comes from wave ballots published next to the tile (a site needs no rescale if some lane of its
-// column holds >= 2^-64 and none exceeds 2^64/(16 WPT); exact totals only otherwise).  Children that live in
-// global memory, and resolution vectors of ambiguous leaves, are staged in the tile the parent will be
-// finalised into.  Status: parity-green, 160 us at the headline size against 152 us for prune_wave_kernel —
-// its products run at 5.2 k cycles per edge where the operand-grid ceiling is 3.5 k (A is requested only one
-// 16-MFMA step ahead), see DESIGN.md.
-// ---------------------------------------------------------------------------------------------
-#ifndef HYPHY_OCC6
-#define HYPHY_OCC6 4
-#endif
-
-template <int NW, int WPT, int NP, bool CLDS>
-__global__ __launch_bounds__(64 * WPT, NP ? 3 : HYPHY_OCC6) void prune_split4_kernel(const int4 *__restrict__ ops,
-                                                                              const int4 *__restrict__ prog, PruneArgs a) {
-  int cur = blockIdx.x;  // grid = (leaf programs, classes, tiles), tile-major
-  {
-    const size_t cat = blockIdx.y;
-    a.frag_ctr += cat * (size_t)a.n_prog_total * a.ntiles;
-    a.hand_cnt += cat * (size_t)(a.root_inode + 1) * a.ntiles * 32;
-    a.Pfrag += cat * a.cs_P;
-    a.PTg += cat * a.cs_P;
-    a.partials += cat * a.cs_partials;
-    a.counts += cat * a.cs_counts;
-    a.site_lik += cat * a.cs_site;
-    a.site_cnt += cat * a.cs_site;
-    a.wg_sum += cat * a.cs_wg;
-    a.wg_cnt += cat * a.cs_wg;
-    a.wg_flag += cat * a.cs_wg;
-  }
-  constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = DP * 16, RBW = NW / WPT, NS2 = NKK / 2;
-  static_assert(NW % WPT == 0, "row blocks must split evenly over the waves");
-  __shared__ __align__(16) double xl[(2 + NP) * TILE];  // [0],[1]: ping-pong exchange tiles; [2..]: parked nodes (scaled)
-  __shared__ __align__(16) int xcnt[2 + NP][WPT][16];    // their 2^64-exponents, [j][J]; every wave keeps its own copy
-  __shared__ int vote[2][WPT][2];                        // per finalisation parity and wave: (lo_ok nibble, hi_bad)
-  __shared__ double tot_part[WPT][16];                   // rare path: exact per-wave site sums, [j][J]
-  __shared__ int go_on;
-  extern __shared__ __align__(16) int16_t codes_lds[];   // CLDS: [L][16]
-
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int R0 = wv * RBW;  // this wave's first row block
-  const int j = lane & 3, bq = (lane >> 2) & 3, iq = lane >> 4;
-  const int q16 = 4 * bq + iq, kB = lane >> 4, posw = j + 4 * iq + 16 * bq;
-  const unsigned lane16 = (unsigned)lane * 16u, posw16 = (unsigned)posw * 16u, blane16 = (unsigned)(4 * kB + j) * 16u;
-  const int tile0 = blockIdx.z;
-  const int S_pad = a.S_pad;
-
-  if (CLDS) {
-    const int4 *src = reinterpret_cast<const int4 *>(a.codes_tile + (size_t)tile0 * a.L * 16);
-    int4 *dst = reinterpret_cast<int4 *>(codes_lds);
-    for (int i = threadIdx.x; i < a.L * 2; i += 64 * WPT) dst[i] = src[i];
-    __syncthreads();
-    if (a.pin_leaf >= 0 && threadIdx.x < 16) codes_lds[a.pin_leaf * 16 + threadIdx.x] = a.pin[tile0 * 16 + threadIdx.x];
-    __syncthreads();
-  }
-  auto leaf_code = [&](int leaf, int site) -> int {
-    if (CLDS) return (int)codes_lds[leaf * 16 + site];
-    if (leaf == a.pin_leaf) return (int)a.pin[tile0 * 16 + site];
-    return (int)a.codes_tile[((size_t)tile0 * a.L + leaf) * 16 + site];
-  };
-  auto b_elem = [](int kk) -> int { return (((kk >> 2) * 2) * 64 + 16 * (kk & 3)) * 2; };  // + blane16 bytes
-
-  double acc[RBW][4];  // running product: rows 16(R0 + r) + q16, sites 4J + j
-  int cnt[4];
-#pragma unroll
-  for (int J = 0; J < 4; J++) {
-    cnt[J] = 0;
-#pragma unroll
-    for (int r = 0; r < RBW; r++) acc[r][J] = 1.0;
-  }
-
-  // acc(r, J) *= sum_k A(R0 + r, k) B(k, J), B = LDS tile `xi` (broadcast reads)
-  auto edge_product = [&](int branch, int xi) {
-    const double *pf = a.Pfrag + ((size_t)branch * NW + R0) * (NKK * 64);  // uniform
-    const char *src = reinterpret_cast<const char *>(xl + xi * TILE) + blane16;
-    auto bsrc = [&](int kk) -> f64x4 {
-      const f64x2 u0 = *reinterpret_cast<const f64x2 *>(src + b_elem(kk) * 8),
-                  u1 = *reinterpret_cast<const f64x2 *>(src + b_elem(kk) * 8 + 1024);
-      return (f64x4){u0[0], u0[1], u1[0], u1[1]};
-    };
-    double D[RBW][4];
-#pragma unroll
-    for (int r = 0; r < RBW; r++)
-#pragma unroll
-      for (int J = 0; J < 4; J++) D[r][J] = 0.;
-    f64x2 Ac[RBW], An[RBW];
-    f64x4 Bc[2], Bn[2];
-#pragma unroll
-    for (int r = 0; r < RBW; r++) Ac[r] = ld16(pf + r * NKK * 64, lane16);
-    Bc[0] = bsrc(0);
-    Bc[1] = bsrc(1);
-#pragma unroll
-    for (int k2 = 0; k2 < NS2; k2++) {
-      if (k2 + 1 < NS2) {
-#pragma unroll
-        for (int r = 0; r < RBW; r++) An[r] = ld16(pf + r * NKK * 64 + (k2 + 1) * 128, lane16);
-        Bn[0] = bsrc(2 * k2 + 2);
-        Bn[1] = bsrc(2 * k2 + 3);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 2; e++)
-#pragma unroll
-        for (int r = 0; r < RBW; r++)
-#pragma unroll
-          for (int J = 0; J < 4; J++) D[r][J] = mfma4(Ac[r][e], Bc[e][J], D[r][J]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < RBW; r++) Ac[r] = An[r];
-      Bc[0] = Bn[0];
-      Bc[1] = Bn[1];
-    }
-#pragma unroll
-    for (int r = 0; r < RBW; r++)
-#pragma unroll
-      for (int J = 0; J < 4; J++) acc[r][J] *= D[r][J];
-  };
-  // K4: column gather, [code][q16][R] = P[16R + q16][code]: this wave's RBW row blocks are contiguous
-  auto leaf_multiply = [&](int lf, const int (&c)[4]) {
-    const double *bl = a.PTg + (size_t)lf * DP * DP + R0;  // uniform
-#pragma unroll
-    for (int J = 0; J < 4; J++) {
-      const unsigned off = (unsigned)(((c[J] < 0 ? 0 : c[J]) * 16 + q16) * NW) * 8u;
-      if constexpr (RBW == 2) {
-        const f64x2 v = ld16(bl, off);
-        acc[0][J] *= v[0];
-        acc[1][J] *= v[1];
-      } else {
-#pragma unroll
-        for (int r = 0; r < RBW; r++) acc[r][J] *= bl[off / 8 + r];
-      }
-    }
-  };
-
-  // optional phase profile (HYPHY_HIP_TIMELINE): cycles in leaf entries / products / pre-barrier finalise /
-  // barrier wait / post-barrier finalise, first kTraceWG tiles, wave 0
-  const bool prof = a.timeline != nullptr && tile0 < kTraceWG && blockIdx.y == 0 && wv == 0;
-  long long tph[5] = {0, 0, 0, 0, 0}, tmark = prof ? clock64() : 0;
-  int nph[5] = {0, 0, 0, 0, 0};
-  auto phase_end = [&](int ph) {
-    if (!prof) return;
-    const long long t = clock64();
-    tph[ph] += t - tmark;
-    nph[ph]++;
-    tmark = t;
-  };
-  for (;;) {  // chained fragments: run program `cur`, then possibly its parent program
-    const int4 prg = prog[cur];
-    const int4 *__restrict__ pops = ops + prg.x;
-    const int n_ops = prg.y;
-    int4 op = pops[0];
-    for (int oi = 0; oi < n_ops; oi++) {
-      const int4 nxt = pops[oi + 1];
-      const int kind = op.x & 3;
-      int ep_tile = -1, ep_branch = op.z;
-      bool staged = false;
-      if (kind == OPK_LEAF) {
-        const int nl = (op.x >> 8) & 0xff;
-        const int lf0 = op.z & 0xffff, lf1 = (op.z >> 16) & 0xffff;
-        int c0[4];
-        bool amb = false;
-#pragma unroll
-        for (int J = 0; J < 4; J++) {
-          c0[J] = leaf_code(lf0, 4 * J + j);
-          amb |= c0[J] < 0;
-        }
-        if (op.x & OPF_AMBIG) {  // (the host emits a leaf with ambiguity codes as a group of its own)
-          // all waves must agree: the verdict is per tile, not per wave
-          amb = __any(amb);
-        } else {
-          amb = false;
-        }
-        if (!amb) {
-          if (nl > 0) leaf_multiply(lf0, c0);
-          if (nl > 1) {
-#pragma unroll
-            for (int J = 0; J < 4; J++) c0[J] = leaf_code(lf1, 4 * J + j);
-            leaf_multiply(lf1, c0);
-          }
-        } else {
-          // ambiguity codes in this tile: the resolution vectors become a staged child tile (each wave writes
-          // its rows), then the full product
-          const int st = (op.x >> 24) & 0xff;  // staging tile chosen by the host (this parent's destination)
-#pragma unroll
-          for (int r = 0; r < RBW; r++)
-#pragma unroll
-            for (int Jp = 0; Jp < 2; Jp++) {
-              f64x2 qv;
-#pragma unroll
-              for (int h = 0; h < 2; h++) {
-                const int c = c0[2 * Jp + h], state = 16 * (R0 + r) + q16;
-                qv[h] = (c >= 0) ? ((state == c) ? 1.0 : 0.0) : a.ambig[(size_t)(-c - 1) * DP + state];
-              }
-              *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(xl + st * TILE + ((R0 + r) * 2 + Jp) * 128) + posw16) = qv;
-            }
-          __syncthreads();
-          ep_tile = st;
-          ep_branch = lf0;
-          staged = true;
-        }
-      } else if (kind == OPK_INTERNAL) {
-        const int slot = (op.x >> 24) & 0xff;
-        ep_tile = slot;
-        const int4 cc = *reinterpret_cast<const int4 *>(&xcnt[slot][wv][4 * j]);
-        cnt[0] += cc.x, cnt[1] += cc.y, cnt[2] += cc.z, cnt[3] += cc.w;
-      } else {
-        // child tile in global memory (fragment root of another workgroup: agent-scope loads; or a persisted
-        // copy): staged by all waves together in the tile this parent will be finalised into
-        const int st = (op.x >> 24) & 0xff;
-        const double *src = a.partials + ((size_t)op.w * a.ntiles + tile0) * TILE;  // uniform
-        if (op.x & OPF_HANDOFF) {
-          const int32_t *hc = a.hand_cnt + ((size_t)op.w * a.ntiles + tile0) * 32;
-#pragma unroll
-          for (int J = 0; J < 4; J++)
-            cnt[J] += __hip_atomic_load(hc + 4 * j + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          for (int c = wv; c < TILE / 128; c += WPT)
-            *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(xl + st * TILE + c * 128) + lane16) = ld16_agent(src + c * 128, lane16);
-        } else {
-          if (op.x & OPF_GSYNC) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // every wave's stores of that node are visible in L2
-          }
-          const int4 cc = *reinterpret_cast<const int4 *>(a.counts + (size_t)op.w * S_pad + tile0 * 16 + 4 * j);
-          cnt[0] += cc.x, cnt[1] += cc.y, cnt[2] += cc.z, cnt[3] += cc.w;
-          for (int c = wv; c < TILE / 128; c += WPT)
-            *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(xl + st * TILE + c * 128) + lane16) = ld16(src + c * 128, lane16);
-        }
-        __syncthreads();
-        ep_tile = st;
-        staged = true;
-      }
-      if (ep_tile >= 0) edge_product(ep_branch, ep_tile);
-      if (staged) __syncthreads();  // the staging tile is free again (it is this node's destination)
-      if (prof) asm volatile("" ::"v"(acc[0][0]), "v"(acc[RBW - 1][3]));
-      phase_end(kind == OPK_LEAF ? 0 : 1);
-
-      if (op.x & OPF_LAST) {
-        // finalise the parent: publish this wave's rows and its votes, ONE LDS-only barrier, decision
-        const int par2 = (op.x >> 4) & 1;
-        const int slot = (op.x >> 16) & 0xff;
-        if (op.y == a.pin_inode) {  // pinned internal node: only the pinned state survives
-#pragma unroll
-          for (int J = 0; J < 4; J++) {
-            const int ps = (int)a.pin[tile0 * 16 + 4 * J + j];
-#pragma unroll
-            for (int r = 0; r < RBW; r++) acc[r][J] = (16 * (R0 + r) + q16 == ps) ? acc[r][J] : 0.;
-          }
-        }
-        // votes: bit (4J + j) of `nib` = some lane of this wave holds >= 2^-64 in the column of site 4J + j;
-        // hi_bad = some partial sum exceeds 2^64 / (16 WPT).  All 16 bits set in the OR over the waves and no
-        // hi_bad  =>  no site of the tile needs rescaling (partial sums are non-negative).
-        double part[4];
-        unsigned nib = 0;
-        unsigned long long hi_bad = 0ull;
-#pragma unroll
-        for (int J = 0; J < 4; J++) {
-          double s = acc[0][J];
-#pragma unroll
-          for (int r = 1; r < RBW; r++) s += acc[r][J];
-          part[J] = s;
-          unsigned long long m = __ballot(s >= kScalerThreshold);  // lanes of column j: j mod 4
-          m |= m >> 32;
-          m |= m >> 16;
-          m |= m >> 8;
-          m |= m >> 4;
-          nib |= (unsigned)(m & 0xf) << (4 * J);
-          hi_bad |= __ballot(!(s <= kScalerUp * (0.0625 / WPT)));
-        }
-        if (lane == 0) {
-          vote[par2][wv][0] = (int)nib;
-          vote[par2][wv][1] = hi_bad ? 1 : 0;
-        }
-        char *dst = reinterpret_cast<char *>(xl + slot * TILE) + posw16;
-#pragma unroll
-        for (int r = 0; r < RBW; r++)
-#pragma unroll
-          for (int Jp = 0; Jp < 2; Jp++)
-            *reinterpret_cast<f64x2 *>(dst + ((R0 + r) * 2 + Jp) * 1024) = (f64x2){acc[r][2 * Jp], acc[r][2 * Jp + 1]};
-        phase_end(2);
-        lds_barrier();
-        phase_end(3);
-        unsigned all_nib = 0;
-        int any_hi = 0;
-#pragma unroll
-        for (int q = 0; q < WPT; q++) {
-          all_nib |= (unsigned)vote[par2][q][0];
-          any_hi |= vote[par2][q][1];
-        }
-        if (all_nib != 0xffffu || any_hi) {  // rare: exact totals, rescale, fix the published tile in place
-          double sc[4];
-#pragma unroll
-          for (int J = 0; J < 4; J++) {
-            const double t = col_sum16(part[J]);
-            if (q16 == 0) tot_part[wv][4 * j + J] = t;
-          }
-          __syncthreads();
-          bool odd = false;
-#pragma unroll
-          for (int J = 0; J < 4; J++) {
-            double t = 0.;
-#pragma unroll
-            for (int q = 0; q < WPT; q++) t += tot_part[q][4 * j + J];
-            sc[J] = t;
-            odd |= !(t >= kScalerThreshold && t <= kScalerUp);
-          }
-          if (__any(odd)) {  // (identical totals in every wave: identical verdict)
-#pragma unroll
-            for (int J = 0; J < 4; J++) {
-              double f;
-              cnt[J] += rescale_decision(sc[J], f);
-#pragma unroll
-              for (int r = 0; r < RBW; r++) acc[r][J] *= f;
-            }
-#pragma unroll
-            for (int r = 0; r < RBW; r++)
-#pragma unroll
-              for (int Jp = 0; Jp < 2; Jp++)
-                *reinterpret_cast<f64x2 *>(dst + ((R0 + r) * 2 + Jp) * 1024) = (f64x2){acc[r][2 * Jp], acc[r][2 * Jp + 1]};
-          }
-          __syncthreads();  // tot_part reusable; the corrected tile visible
-        }
-        double *out = a.partials + ((size_t)op.y * a.ntiles + tile0) * TILE;  // uniform
-        const bool hand = op.x & OPF_HANDOFF;
-#pragma unroll
-        for (int r = 0; r < RBW; r++)
-#pragma unroll
-          for (int Jp = 0; Jp < 2; Jp++) {
-            const f64x2 qv = (f64x2){acc[r][2 * Jp], acc[r][2 * Jp + 1]};
-            const int eu = ((R0 + r) * 2 + Jp) * 128;
-            if (hand) st16_agent(out + eu, posw16, qv);
-            else if (!(op.x & OPF_NOPERSIST)) st16(out + eu, posw16, qv);
-          }
-        if (q16 == 0) *reinterpret_cast<int4 *>(&xcnt[slot][wv][4 * j]) = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);
-        if (wv == 0 && q16 == 0) {
-          const int4 cc = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);
-          if (!(op.x & OPF_NOPERSIST)) *reinterpret_cast<int4 *>(a.counts + (size_t)op.y * S_pad + tile0 * 16 + 4 * j) = cc;
-          if (hand) {
-#pragma unroll
-            for (int J = 0; J < 4; J++)
-              __hip_atomic_store(a.hand_cnt + ((size_t)op.y * a.ntiles + tile0) * 32 + 4 * j + J, cnt[J], __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-#pragma unroll
-        for (int J = 0; J < 4; J++) {
-          cnt[J] = 0;
-#pragma unroll
-          for (int r = 0; r < RBW; r++) acc[r][J] = 1.0;
-        }
-        phase_end(4);
-      }
-      op = nxt;
-    }
-    if (prof && lane == 0) {
-      long long *tl = a.timeline + ((size_t)tile0 * 16 + (blockIdx.x & 1) * 0);
-      for (int i = 0; i < 5; i++) {
-        tl[i] = tph[i];
-        tl[5 + i] = nph[i];
-      }
-    }
-    if (prg.z < 0) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int *ctr = a.frag_ctr + (size_t)prg.z * a.ntiles + tile0;
-      const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old + 1 >= prog[prg.z].w;
-      if (last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      go_on = last;
-    }
-    __syncthreads();
-    if (!go_on) return;
-    __syncthreads();
-    cur = prg.z;
-  }
-
-  if (a.do_root) {
-    __syncthreads();  // wave 0's exponent record of the root (xcnt) and every wave's rows are in LDS
-    if (wv == 0) {
-      const int sl = lane & 15, g = lane >> 4;
-      const int xi = a.root_slot;
-      const double *rootv = xl + xi * TILE + ((((sl >> 3) * 64) + (sl & 3) + 4 * g) * 2 + ((sl >> 2) & 1));
-      double s = 0.;
-#pragma unroll
-      for (int kk = 0; kk < NKK; kk++) s = fma(rootv[((kk >> 2) * 2 * 64 + 16 * (kk & 3)) * 2], a.pi[4 * kk + g], s);
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      const int rcnt = xcnt[xi][0][(sl & 3) * 4 + (sl >> 2)];
-      double wsum = 0.;
-      long long wcnt = 0;
-      int wflag = 0;
-      if (g == 0) {
-        const int site = tile0 * 16 + sl;
-        a.site_lik[site] = s;
-        a.site_cnt[site] = rcnt;
-        const double f = a.freq[site];
-        if (f != 0.) {
-          if (s != s || isinf(s)) wflag |= 2;
-          else if (s <= 0.) wflag |= 1;
-          else {
-            wsum += log(s) * f;
-            wcnt += (long long)rcnt * (long long)f;
-          }
-        }
-      }
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) {
-        wsum += __shfl_xor(wsum, off);
-        wcnt += __shfl_xor(wcnt, off);
-        wflag |= __shfl_xor(wflag, off);
-      }
-      if (lane == 0) {
-        a.wg_sum[tile0] = wsum;
-        a.wg_cnt[tile0] = wcnt;
-        a.wg_flag[tile0] = wflag;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Branch cache (device counterpart of _TheTree::ComputeBranchCache tree_evaluator.cpp:4286-4845 and
 // _TheTree::ComputeLLWithBranchCache tree.cpp:3383-3936).  While the optimiser varies ONE branch length,
@@ -1622,7 +1170,7 @@ __global__ void mix_categories_kernel(const double *__restrict__ site_lik, const
 
 // fragment layout -> reference iNodeCache layout [(node*S + pattern)*D + state]
 __global__ void unpack_partials_kernel(const double *__restrict__ partials, int I, int ntiles, int NW, int D, int S,
-                                       int tile_layout, double *__restrict__ out) {
+                                       double *__restrict__ out) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)I * S * D;
   if (idx >= total) return;
@@ -1633,10 +1181,7 @@ __global__ void unpack_partials_kernel(const double *__restrict__ partials, int 
   const int tile = pat >> 4, sl = pat & 15;
   const int kk = state >> 2, lane = (state & 3) * 16 + sl;
   const int TILE = NW * 4 * 64;
-  // tile_layout 1 = the 4x4x4 kernel's quad layout (see prune_split4_kernel)
-  const int within = tile_layout ? (((state >> 4) * 2 + (sl >> 3)) * 64 + (sl & 3) + 4 * (state & 3) + 16 * ((state >> 2) & 3)) * 2 +
-                                       ((sl >> 2) & 1)
-                                 : frag_index(kk, lane);
+  const int within = frag_index(kk, lane);
   out[idx] = partials[((size_t)node * ntiles + tile) * TILE + within];
 }
 
@@ -1645,15 +1190,6 @@ void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
   const dim3 grid(a.ntiles / a.T, a.n_cat > 0 ? a.n_cat : 1, a.n_prog > 0 ? a.n_prog : 1), block(64 * NW);
   const size_t lds = CLDS ? (size_t)a.L * a.T * 16 * sizeof(int16_t) : 0;
   const dim3 gridw(a.n_prog > 0 ? a.n_prog : 1, a.n_cat > 0 ? a.n_cat : 1, a.ntiles);  // wave kernels: tile-major
-  if constexpr (NW % 2 == 0) {
-    if (a.variant == 2 && a.T == 1) {  // split-tile kernel on the 4x4x4 MFMA: two waves per tile, quad layout
-      const dim3 block2(128);
-      const size_t lds2 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
-      if (a.n_slots <= 2) hipLaunchKernelGGL((prune_split4_kernel<NW, 2, 0, CLDS>), gridw, block2, lds2, stream, a.ops, a.prog, a);
-      else hipLaunchKernelGGL((prune_split4_kernel<NW, 2, 1, CLDS>), gridw, block2, lds2, stream, a.ops, a.prog, a);
-      return;
-    }
-  }
   if (a.variant == 1 && a.T == 1) {  // wave-per-tile kernel: one wave per workgroup
     const dim3 block1(64);
     const size_t lds1 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
@@ -1757,11 +1293,11 @@ void launch_mix_categories(const double *site_lik, const int32_t *site_cnt, cons
                      weights_dev, C, S_pad, mixed_lik, mixed_cnt);
 }
 
-void launch_unpack_partials_mfma(const double *partials, int I, int ntiles, int NW, int D, int S, int tile_layout,
-                                 double *out, hipStream_t stream) {
+void launch_unpack_partials_mfma(const double *partials, int I, int ntiles, int NW, int D, int S, double *out,
+                                 hipStream_t stream) {
   const size_t total = (size_t)I * S * D;
   hipLaunchKernelGGL(unpack_partials_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partials, I,
-                     ntiles, NW, D, S, tile_layout, out);
+                     ntiles, NW, D, S, out);
 }
 
 }  // namespace hyhip

@@ -69,19 +69,19 @@ def test_logl_and_sites_match_reference(name):
         assert sc.max() > 0  # the rescaling branch was really exercised
 
 
-@pytest.mark.parametrize("kernel", ["1", "2"])
+@pytest.mark.parametrize("kernel", ["1"])
 @pytest.mark.parametrize("name", ["codon_small", "codon_ambig", "codon_deep", "codon_wide"])
 def test_wave_kernels_match_reference(name, kernel, monkeypatch):
     """The goldens are small shards (the library would pick the workgroup-per-tile kernel): force the
-    wave-per-tile kernel (1: 16x16x4 MFMA, register hand-over) and the split-tile kernel on the 4x4x4 MFMA with
-    quad-layout conditionals (2) — through the same checks, including the downloaded conditionals of every internal node."""
+    wave-per-tile kernel (register hand-over, chained fragments) through the same checks, including the downloaded
+    conditionals of every internal node."""
     from oracle import oracle
     monkeypatch.setenv("HYPHY_HIP_KERNEL", kernel)
     fx = common.load(name)
     nodes = common.all_nodes(fx)
     Q = common.fixture_Q(fx)
     with _mk(fx) as part:
-        assert part.prune_kernel_name() == {"1": "prune_wave_kernel", "2": "prune_split4_kernel"}[kernel]
+        assert part.prune_kernel_name() == "prune_wave_kernel"
         ll, sl, sc = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
         cache, counts = part.download_partials()
     ref = float(fx["logl"])
@@ -453,7 +453,7 @@ def _pin_update_list(flat, code):
     return np.array(sorted(out), dtype=np.int64)
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "2"])
+@pytest.mark.parametrize("kernel", ["0", "1"])
 def test_pinned_states_reproduce_reference_marginal_support(kernel, monkeypatch):
     """hyphy_hip_set_pinned_states (ComputeBlock's branchIndex / branchValues): the device's pinned per-pattern
     likelihoods reproduce the support matrix of the REAL reference's ReconstructAncestors (lf, MARGINAL) —
