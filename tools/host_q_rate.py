@@ -20,8 +20,8 @@ def Q(om):
     return q
 Qs = [Q(0.3 + 0.001 * k) for k in range(8)]
 Ps = [oracle.expm(q, True) for q in Qs]
-for name, mats, prob in (("host Q (device expm)", Qs, False), ("host P (host expm, mode A)", Ps, True)):
-    for k in range(5): part.evaluate(nodes, nodes, mats[k % 8], pi, q_is_probability=prob)
+for name, mats, prob in (("host P (host expm, mode A)", Ps, True), ("host Q (device expm)", Qs, False), ("host P again", Ps, True), ("host Q again", Qs, False)):
+    for k in range(20): part.evaluate(nodes, nodes, mats[k % 8], pi, q_is_probability=prob)
     t0 = time.perf_counter(); n = 100
     for k in range(n): ll = part.evaluate(nodes, nodes, mats[k % 8], pi, q_is_probability=prob)
     dt = time.perf_counter() - t0
