@@ -284,7 +284,7 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
       }
     }
     entries.back().x |= OPF_LAST | ((fin & 1) ? OPF_PARITY : 0) | (dst << 16);
-    if (handoff && !is_root_program && ti + 1 == nodes.size()) entries.back().x |= OPF_HANDOFF;  // fragment root
+    if (handoff && !is_root_program && ti + 1 == nodes.size()) entries.back().x |= OPF_PUBLISH;  // fragment root
     // lazy persistence: skip the store of this node unless it is the root of a fragment (read by another
     // program) — a later consumer through the persisted copy clears the flag again
     if (lazy && (is_root_program || ti + 1 < nodes.size())) entries.back().x |= np_flag;
@@ -933,7 +933,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       // 624) and the workgroup-per-tile kernel, which splits a tile's rows over four waves, is faster
       // (123 us at 312 tiles, 63 us at 78).
       p->variant = tiles >= (7 * (int64_t)cus) / 4 ? 1 : 0;
-      if (const char *e = getenv("HYPHY_HIP_KERNEL")) p->variant = atoi(e) ? 1 : 0;  // the split-tile kernel needs an even number of row blocks
+      if (const char *e = getenv("HYPHY_HIP_KERNEL")) p->variant = atoi(e) ? 1 : 0;  // (diagnostic override)
       if (T != 1) p->variant = 0;
       p->n_slots = lds_slots(T);
       if (p->variant >= 1) {
@@ -950,7 +950,20 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       s.S_pad = s.ntiles * 16;
       s.partial_stride = (size_t)I * s.ntiles * 16 * DP;
     }
-#define A_(ptr, n) if (hipMalloc((void **)&(ptr), (n)) != hipSuccess) { hyphy_hip_destroy(p); return fail("hipMalloc failed (" #ptr ")"); }
+    // HYPHY_HIP_POISON=1 (tests): fill every fresh allocation with 0xff bytes (NaN / -1), so that anything read before
+    // it is written shows up even in a process whose recycled device memory happens to hold zeros
+    const bool poison = getenv("HYPHY_HIP_POISON") != nullptr;
+#define A_(ptr, n)                                                                                           \
+  {                                                                                                          \
+    if (hipMalloc((void **)&(ptr), (n)) != hipSuccess) {                                                     \
+      hyphy_hip_destroy(p);                                                                                  \
+      return fail("hipMalloc failed (" #ptr ")");                                                            \
+    }                                                                                                        \
+    if (poison && !getenv("HYPHY_HIP_NOPOISON_" #ptr)) {                                                     \
+      hipMemset((ptr), 0xff, (n));                                                                           \
+      hipDeviceSynchronize();                                                                                \
+    }                                                                                                        \
+  }
     hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking);
     s.stream = s.own_stream;
     for (auto &e : s.ev) hipEventCreate(&e);

@@ -37,15 +37,17 @@ __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1)
 //   x  bits 0-1  kind: OPK_LEAF (group of <= 2 leaf children), OPK_INTERNAL (child vector in an LDS
 //                slot), OPK_INTERNAL_GLOBAL (child vector = persisted copy in HBM)
 //      bit  2    OPF_HANDOFF (wave-per-tile kernel, chained fragments) internal-global entry: the child is the root of
-//                a fragment finished by ANOTHER workgroup of this launch — read it with agent-scope (sc1) loads;
-//                OPF_LAST entry: the finalised parent is such a fragment root — publish it with sc1 stores
+//                a fragment finished by ANOTHER workgroup of this launch — read it with agent-scope (sc1) loads
 //      bit  3    OPF_LAST    last child of its parent: finalise the parent
 //      bit  4    parity of this finalisation (which psum buffer / exchange slot pair member)
 //      bit  5    OPF_GSYNC   (internal-global) copy was written earlier in THIS launch: full fence first
 //      bit  6    OPF_AMBIG   (leaf group) some leaf of the group carries ambiguity codes in this shard
 //      bit  7    OPF_INREGS  (nucleotide kernel only) child is the node finalised by the previous entry
 //                OPF_NOPERSIST (MFMA kernels, OPF_LAST entries) lazy persistence: do not store the finalised parent
-//      bits 8-15 number of leaves in a leaf group
+//      bits 8-14 number of leaves in a leaf group
+//      bit  15   OPF_PUBLISH (wave-per-tile kernel, OPF_LAST entries) the finalised parent is the root of a fragment that
+//                another workgroup of this launch consumes — publish it with sc1 stores.  (Its own bit: the last entry
+//                of a fragment root may itself be an internal-global entry, with or without OPF_HANDOFF.)
 //      bits 16-23 destination LDS slot of the finalised parent (0/1 exchange slots, >= 2 parking)
 //      bits 24-31 source LDS slot of an OPK_INTERNAL child
 //   y  parent internal index
@@ -54,7 +56,7 @@ __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1)
 // A parent's first entry needs no flag: the running product is reset when a parent is finalised.
 enum : int { OPK_LEAF = 0, OPK_INTERNAL = 1, OPK_INTERNAL_GLOBAL = 2 };
 enum : int { OPF_HANDOFF = 4, OPF_LAST = 8, OPF_PARITY = 16, OPF_GSYNC = 32, OPF_AMBIG = 64, OPF_INREGS = 128,
-             OPF_NOPERSIST = 128, OPF_NOPERSIST_NUC = 4 /* (nucleotide kernel: bit 7 is OPF_INREGS there) */ };
+             OPF_NOPERSIST = 128, OPF_PUBLISH = 0x8000, OPF_NOPERSIST_NUC = 4 /* (nucleotide kernel: bit 7 is OPF_INREGS there) */ };
 #ifndef HYPHY_SLOTS1
 #define HYPHY_SLOTS1 5
 #endif

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
 
     if (kind == OPK_LEAF) {
       // K4: parent[k] *= P[k][state] — the columns were gathered one entry ahead
-      const int nl = (op.x >> 8) & 0xff;
+      const int nl = (op.x >> 8) & 0x7f;
       if (!(op.x & OPF_AMBIG)) {
         {
           const bool one = nl > 0;  // (nl == 0: padding entry)
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
     const int4 nxt = pops[oi + 1];
     const int kind = op.x & 3;
     if (kind == OPK_LEAF) {
-      const int nl = (op.x >> 8) & 0xff;
+      const int nl = (op.x >> 8) & 0x7f;
       for (int i = 0; i < nl; i++) {
         const int lf = (op.z >> (16 * i)) & 0xffff;
         const int c = leaf_code(lf);
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
         bch[w] = acc[w] * sc;
         acc[w] = ones;
       }
-      if (op.x & OPF_HANDOFF) {  // fragment root: another workgroup may consume it in this launch
+      if (op.x & OPF_PUBLISH) {  // fragment root: another workgroup may consume it in this launch
 #pragma unroll
         for (int w = 0; w < NW; w++) {
           st16_agent(out, (unsigned)((2 * w) * 64 + lane) * 16u, (f64x2){bch[w][0], bch[w][1]});
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
     const int code_n = code_of(nxt);
     const int kind = op.x & 3, parent = op.y;
     const bool is_leaf = kind == OPK_LEAF;
-    if (!(is_leaf && ((op.x >> 8) & 0xff) == 0)) {  // (else: padding entry)
+    if (!(is_leaf && ((op.x >> 8) & 0x7f) == 0)) {  // (else: padding entry)
     double cv[4];
     bool matvec = true;
     if (is_leaf) {

@@ -1,6 +1,7 @@
 """GPU parity tests proper: the HIP path (through the C-ABI) against the committed golden
 vectors of the real reference and against the CPU oracle on the same seeded inputs.
 Tolerance: north_star asks 1e-6 relative on logL; FP64 end to end lets us hold 1e-10."""
+import os
 import numpy as np
 import pytest
 
@@ -601,3 +602,19 @@ def test_error_paths():
     Q = np.full((1, 4, 4), np.nan)
     with pytest.raises(hip.HipError):
         hip.expm_batch(Q)
+
+
+@pytest.mark.parametrize("script,n_cases,seed", [("stress_codon.py", 30, 1), ("stress_generic.py", 50, 1)])
+def test_randomised_stress_with_poisoned_allocations(script, n_cases, seed):
+    """Random trees / sizes / kernels / fragment cuts and random sequences of full passes, partial updates, pinned
+    evaluations, branch-cache line searches and downloads against the oracle, in ONE process (recycled device memory)
+    and with every fresh device allocation filled with 0xff bytes (HYPHY_HIP_POISON): anything read before it is
+    written changes the result.  (Found: the fragment-root publish flag shared a bit with the hand-off consumer flag.)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HYPHY_HIP_POISON="1")
+    r = subprocess.run([sys.executable, os.path.join(here, script), str(n_cases), str(seed)], env=env,
+                       capture_output=True, text=True, timeout=900)
+    tail = "\n".join((r.stdout + r.stderr).strip().splitlines()[-5:])
+    assert r.returncode == 0 and "checks passed" in tail, tail
