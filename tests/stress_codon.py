@@ -26,6 +26,8 @@ for case in range(n_cases):
     os.environ["HYPHY_HIP_FRAGMENT"] = str(frag)
     os.environ["HYPHY_HIP_SLOTS"] = slots
     os.environ["HYPHY_HIP_CACHE"] = persist
+    tiles = os.environ.get("STRESS_TILES", str(int(rng.choice([1, 1, 1, 2, 4]))))
+    os.environ["HYPHY_HIP_TILES"] = tiles
     from hyphy_amd import hip
     root = tree.random_tree(taxa, rng, trifurcating_root=bool(rng.integers(0, 2)))
     syn = data.evolve(taxa, codons, 3, seed=seed0 + case, tree=root, p_change=float(rng.uniform(0.02, 0.3)))
@@ -47,7 +49,7 @@ for case in range(n_cases):
             global n_checks
             n_checks += 1
             if not (abs(got - ref) <= RTOL * abs(ref) or (got == ref)):
-                raise SystemExit(f"MISMATCH case {case} ({taxa} taxa, {codons} codons, kernel {kernel}, frag {frag}, slots {slots}, cache {persist}) {tag}: {got!r} vs {ref!r}")
+                raise SystemExit(f"MISMATCH case {case} ({taxa} taxa, {codons} codons, kernel {kernel}, frag {frag}, slots {slots}, cache {persist}, T {tiles}) {tag}: {got!r} vs {ref!r}")
         check("first", part.evaluate(nodes, nodes, Q, pi), op.compute_block(nodes, pi))
         for step in range(int(rng.integers(4, 10))):
             what = rng.choice(["full", "partial", "branch_cache", "pinned", "download"], p=[0.3, 0.3, 0.15, 0.15, 0.1])
@@ -100,5 +102,5 @@ for case in range(n_cases):
                     if not np.allclose(x[ok] / sx[ok], y[ok] / sy[ok], rtol=1e-8, atol=1e-300):
                         raise SystemExit(f"MISMATCH case {case} download node {n}")
                 n_checks += 1
-    print(f"case {case}: {taxa} taxa x {codons} codons ({pd.S} patterns), kernel {kernel}, fragment {frag}, slots {slots}, {persist}: ok", flush=True)
+    print(f"case {case}: {taxa} taxa x {codons} codons ({pd.S} patterns), kernel {kernel}, fragment {frag}, slots {slots}, {persist}, T {tiles}: ok", flush=True)
 print(f"{n_cases} cases, {n_checks} checks passed in {time.time() - t0:.0f} s")

@@ -38,7 +38,10 @@ for case in range(n_cases):
     kernel = os.environ.get("STRESS_KERNEL", str(int(rng.integers(0, 2))))
     frag = os.environ.get("STRESS_FRAGMENT", str(int(rng.choice([2, 4, 7, 11, 1000]))))
     persist = os.environ.get("STRESS_CACHE", str(rng.choice(["lazy", "always"])))
+    tiles = os.environ.get("STRESS_TILES", str(int(rng.choice([1, 1, 2, 3, 4]))))  # patterns tiles per workgroup (workgroup kernel)
+    shards = os.environ.get("STRESS_SHARDS", str(int(rng.choice([0, 0, 2, 3]))))  # pattern shards (here: all on one device)
     os.environ["HYPHY_HIP_KERNEL"], os.environ["HYPHY_HIP_FRAGMENT"], os.environ["HYPHY_HIP_CACHE"] = kernel, frag, persist
+    os.environ["HYPHY_HIP_TILES"], os.environ["HYPHY_HIP_FORCE_SHARDS"] = tiles, shards
     from hyphy_amd import hip
     root = tree.caterpillar_tree(taxa) if rng.random() < 0.25 else tree.random_tree(taxa, rng, trifurcating_root=bool(rng.integers(0, 2)))
     flat = tree.flatten(root)
@@ -59,7 +62,21 @@ for case in range(n_cases):
     rates = rng.uniform(0.2, 3.0, n_cat)
     weights = rng.dirichlet(np.full(n_cat, 3.0))
     Q1, pi = random_q(D, 1.0, np.random.default_rng(1000 + seed0 + case))
-    Q = np.stack([tb[:, None, None] * r * Q1[None] for r in rates])  # [C][B][D][D]
+    # template model (device-side Q construction): Q_b = sum_k coeff[b][k] T_k; T_0 + T_1 = offdiag(Q1)
+    templated = shards == "0" and (D > 4 or n_cat == 1) and rng.random() < 0.45  # (class batch from templates: MFMA path only)
+    offd = Q1 - np.diag(np.diag(Q1))
+    split = rng.random((D, D)) < 0.5
+    T = np.stack([offd * split, offd * ~split])
+    k1 = rng.uniform(0.3, 2.0)  # "omega"
+
+    def q_from(coeff):  # [n][2] -> [n][D][D]
+        Qn = coeff[:, 0, None, None] * T[0][None] + coeff[:, 1, None, None] * T[1][None]
+        idx = np.arange(D)
+        Qn[:, idx, idx] = -Qn.sum(2)
+        return Qn
+
+    co = np.stack([np.stack([tb * r, tb * r * k1], axis=1) for r in rates])  # [C][B][2]
+    Q = np.stack([q_from(co[c]) for c in range(n_cat)])  # [C][B][D][D]
     nodes = np.arange(B, dtype=np.int64)
     none = np.zeros(0, dtype=np.int64)
     op = oracle.OraclePartition(D, flat.flat_parents, L, codes, ambig, pd.pattern_freq, n_cat)
@@ -79,31 +96,42 @@ for case in range(n_cases):
         global n_checks
         n_checks += 1
         if not (abs(got - ref) <= RTOL * abs(ref) or got == ref):
-            raise SystemExit(f"MISMATCH case {case} (D {D}, {taxa} taxa, {pd.S} patterns, {n_cat} classes, kernel {kernel}, frag {frag}, {persist}) {tag}: {got!r} vs {ref!r}")
+            raise SystemExit(f"MISMATCH case {case} (D {D}, {taxa} taxa, {pd.S} patterns, {n_cat} classes, kernel {kernel}, frag {frag}, {persist}, T {tiles}, shards {shards}, templated {templated}) {tag}: {got!r} vs {ref!r}")
 
     for c in range(n_cat):
         op.set_P(nodes, oracle.expm(Q[c], D > 4), cat=c)
     with hip.HipPartition(D, flat.flat_parents, L, codes, ambig, pd.pattern_freq, n_cat) as part:
-        def device_value(upd, qn, q):
+        if templated:
+            part.set_q_templates(T)
+
+        def device_value(upd, qn):
+            if templated:
+                cc = np.ascontiguousarray(co[:, qn].reshape(-1, 2))  # class-major coefficient rows of the changed branches
+                if n_cat == 1:
+                    return part.prepare_built_step(upd, qn, pi, cc)()
+                return part.prepare_built_categories_step(upd, qn, weights, pi, cc)()
+            q = np.ascontiguousarray(Q[:, qn])
             if n_cat == 1:
                 return part.evaluate(upd, qn, q[0] if len(qn) else np.zeros((0, D, D)), pi)
             return part.evaluate_categories(upd, qn, q if len(qn) else np.zeros((n_cat, 0, D, D)), weights, pi)
-        check("first", device_value(nodes, nodes, Q), oracle_value(nodes))
+        check("first", device_value(nodes, nodes), oracle_value(nodes))
         for step in range(int(rng.integers(3, 8))):
             what = rng.choice(["full", "partial", "none"], p=[0.4, 0.5, 0.1])
             if what == "full":
-                Q = Q * rng.uniform(0.8, 1.25)
+                co = co * rng.uniform(0.8, 1.25)
+                Q = np.stack([q_from(co[c]) for c in range(n_cat)])
                 for c in range(n_cat):
                     op.set_P(nodes, oracle.expm(Q[c], D > 4), cat=c)
-                check("full", device_value(nodes, nodes, Q), oracle_value(nodes))
+                check("full", device_value(nodes, nodes), oracle_value(nodes))
             elif what == "partial":
                 ch = np.unique(rng.integers(0, B, size=int(rng.integers(1, 4)))).astype(np.int64)
-                Q[:, ch] = Q[:, ch] * rng.uniform(0.3, 3.0)
+                co[:, ch] = co[:, ch] * rng.uniform(0.3, 3.0)
+                Q = np.stack([q_from(co[c]) for c in range(n_cat)])
                 upd = np.unique(np.concatenate([flat.path_update_nodes(int(n)) for n in ch])).astype(np.int64)
                 for c in range(n_cat):
                     op.set_P(ch, oracle.expm(Q[c][ch], D > 4), cat=c)
-                check("partial", device_value(upd, ch, np.ascontiguousarray(Q[:, ch])), oracle_value(upd))
-            else:
-                check("nothing dirty", device_value(none, none, Q), oracle_value(none))
-    print(f"case {case}: D {D}, {taxa} taxa, {pd.S} patterns, {n_cat} classes, kernel {kernel}, fragment {frag}, {persist}: ok", flush=True)
+                check("partial", device_value(upd, ch), oracle_value(upd))
+            elif not templated:
+                check("nothing dirty", device_value(none, none), oracle_value(none))
+    print(f"case {case}: D {D}, {taxa} taxa, {pd.S} patterns, {n_cat} classes, kernel {kernel}, fragment {frag}, {persist}, T {tiles}, shards {shards}, templated {templated}: ok", flush=True)
 print(f"{n_cases} cases, {n_checks} checks passed in {time.time() - t0:.0f} s")
