@@ -109,6 +109,14 @@ struct Shard {
   uint64_t ring_count = 0;       // evaluations stamped so far
   uint64_t eval_count = 0;
   size_t partial_stride = 0;  // doubles per class
+  // per-site batched fits (hyphy_hip_site_fits_evaluate), allocated on first use
+  double *fit_Timg = nullptr, *fit_bcoef = nullptr, *fit_smult = nullptr, *fit_out = nullptr, *fit_scratch = nullptr,
+         *fit_pi = nullptr;
+  int *fit_bgroup = nullptr;
+  int32_t *fit_scratch_cnt = nullptr;
+  int4 *fit_ops = nullptr;
+  size_t fit_sets_cap = 0, fit_scratch_sets = 0;
+  bool fit_static_current = false;  // template images + schedule on the device match the host copies
 };
 
 }  // namespace
@@ -153,6 +161,11 @@ struct hyphy_hip_partition {
   bool coeffs_pending = false;               // build_q staged coefficients; the next evaluate_device(q_buffer) fuses
                                              // the rate-matrix construction into the expm kernel
   int64_t K = 0;                             // Q templates
+  std::vector<double> templates_host;        // [K][D][D] as passed to hyphy_hip_set_q_templates
+  std::vector<int4> fit_ops_host;            // per-site fits: full schedule compiled for kSiteFitParkSlots parking slots
+  int fit_n_ops = 0;
+  bool fit_spills = false;                   // ... some node goes through the scratch copy
+  double fit_kernel_ms = 0.;                 // duration of the last site-fit kernel (max over shards)
   double timings[3] = {0, 0, 0};
 };
 
@@ -166,7 +179,8 @@ void free_shard(Shard &s) {
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
                  s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.codes_tile,
-                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin};
+                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_out, s.fit_scratch,
+                 s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops};
   for (void *d : dev)
     if (d) hipFree(d);
   void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog};
@@ -1541,6 +1555,8 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
     HIPCHK(hipMemcpy(s.templates, templates, (size_t)K * D * D * sizeof(double), hipMemcpyHostToDevice));
   }
   p->K = K;
+  p->templates_host.assign(templates, templates + (size_t)K * D * D);
+  for (Shard &s : p->shards) s.fit_static_current = false;
   return 0;
 }
 
@@ -1572,6 +1588,194 @@ int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs) {
   p->coeffs_pending = fuse;
   return 0;
 }
+
+// Per-site batched fits (kernel and method: sitefit.hip).  The FEL family fits site-specific rate
+// multipliers (FEL.bf:593-605: fel.alpha_scaler, fel.beta_scaler_test, fel.beta_scaler_nuisance) with one
+// single-site likelihood function per site; this evaluates ALL patterns of the partition, each under its own
+// multipliers, for n_sets candidate parameter vectors per pattern in one launch.
+int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t n_groups, const int64_t *branch_group,
+                                 const double *branch_coeffs, const double *site_mult, const double *root_freqs,
+                                 double *site_logl_out) {
+  if (!p) return fail("partition == NULL");
+  if (p->nuc) {
+    g_last_error = "site fits: not available for the 4-state path";
+    return 1;
+  }
+  if (!p->K || p->templates_host.empty()) return fail("site fits: templates not set (hyphy_hip_set_q_templates)");
+  if (p->K > 4) {
+    g_last_error = "site fits: at most 4 templates";
+    return 1;
+  }
+  if (n_sets < 1 || n_sets > 65535 || n_groups < 1 || n_groups > 16) return fail("site fits: bad set / group count");
+  if (!branch_group || !branch_coeffs || !site_mult || !root_freqs || !site_logl_out) return fail("site fits: null argument");
+  const int64_t D = p->D, B = p->B, K = p->K, S = p->S;
+  const int L = (int)p->L, I = (int)p->I, DP = p->DP, NW = p->NW;
+  const int NKK = 4 * NW, TILE = NKK * 64;
+  for (int64_t b = 0; b < B; b++)
+    if (branch_group[b] < 0 || branch_group[b] >= n_groups) return fail("site fits: branch group out of range");
+  for (int64_t b = 0; b < B * K; b++)
+    if (!(branch_coeffs[b] >= 0.)) return fail("site fits: branch coefficients must be non-negative");
+  for (int64_t k = 0; k < n_sets * S * n_groups * K; k++)
+    if (!(site_mult[k] >= 0.)) return fail("site fits: site multipliers must be non-negative");
+
+  // schedule of a full pass, compiled for this kernel's slot budget (lazy persistence: only nodes that find no
+  // parking slot are stored, to the scratch copy)
+  if (p->fit_ops_host.empty()) {
+    std::vector<int4> keep;
+    keep.swap(p->ops_host);
+    const int n_slots0 = p->n_slots;
+    const bool persist0 = p->sched_persist;
+    p->n_slots = 2 + kSiteFitParkSlots;
+    p->sched_persist = false;
+    std::vector<int> all(I);
+    for (int n = 0; n < I; n++) all[n] = n;
+    int off = 0, n = 0;
+    emit_program(p, all, &off, &n);
+    p->fit_ops_host.swap(p->ops_host);
+    p->ops_host.swap(keep);
+    p->n_slots = n_slots0;
+    p->sched_persist = persist0;
+    p->fit_n_ops = n;
+    p->fit_spills = false;
+    for (int e = 0; e < n; e++) {
+      const int4 &op = p->fit_ops_host[e];
+      if ((op.x & OPF_LAST) && !(op.x & OPF_NOPERSIST) && op.y != I - 1) p->fit_spills = true;
+      if ((op.x & OPF_LAST) && op.y == I - 1) p->fit_ops_host[e].x |= OPF_NOPERSIST;  // the root is consumed in registers
+    }
+  }
+  // template images with diagonals, A-operand layout (cf. the image writer in expm.hip); dmax_k = max_i |T_k[i][i]|
+  SiteFitArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  std::vector<double> img;
+  {
+    std::vector<double> full((size_t)D * D);
+    img.assign((size_t)K * DP * DP, 0.0);
+    for (int64_t k = 0; k < K; k++) {
+      const double *T = p->templates_host.data() + (size_t)k * D * D;
+      double dmax = 0.;
+      for (int64_t i = 0; i < D; i++) {
+        double rs = 0.;
+        for (int64_t j = 0; j < D; j++) {
+          if (j != i && !(T[i * D + j] >= 0.)) return fail("site fits: templates must have non-negative off-diagonal entries");
+          if (j != i) rs += T[i * D + j];
+          full[i * D + j] = T[i * D + j];
+        }
+        full[i * D + i] = -rs;
+        dmax = std::max(dmax, rs);
+      }
+      fa.dmax[k] = dmax;
+      double *out = img.data() + (size_t)k * DP * DP;
+      for (int idx = 0; idx < DP * DP; idx++) {
+        const int wb = idx / TILE, rem = idx - wb * TILE;
+        const int kk2 = rem >> 7, l = (rem >> 1) & 63, kb = rem & 1, kk = 2 * kk2 + kb;
+        const int rr = 16 * wb + (l & 15), cc = 4 * kk + (l >> 4);
+        out[idx] = (rr < D && cc < D) ? full[(size_t)rr * D + cc] : 0.0;
+      }
+    }
+  }
+  std::vector<int> grp(B);
+  for (int64_t b = 0; b < B; b++) grp[b] = (int)branch_group[b];
+  std::vector<double> pi(DP, 0.0);
+  for (int64_t k = 0; k < D; k++) pi[k] = root_freqs[k];
+  const size_t GK = (size_t)n_groups * K;
+
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    if (!s.fit_Timg) {
+      HIPCHK(hipMalloc((void **)&s.fit_Timg, (size_t)4 * DP * DP * sizeof(double)));
+      HIPCHK(hipMalloc((void **)&s.fit_bcoef, (size_t)B * 4 * sizeof(double)));
+      HIPCHK(hipMalloc((void **)&s.fit_bgroup, (size_t)B * sizeof(int)));
+      HIPCHK(hipMalloc((void **)&s.fit_pi, (size_t)DP * sizeof(double)));
+      HIPCHK(hipMalloc((void **)&s.fit_ops, ops_capacity(p) * sizeof(int4)));
+    }
+    if (!s.fit_static_current) {
+      if (p->fit_ops_host.size() > ops_capacity(p)) return fail("internal: site-fit schedule overflow");
+      HIPCHK(hipMemcpy(s.fit_Timg, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(s.fit_ops, p->fit_ops_host.data(), p->fit_ops_host.size() * sizeof(int4), hipMemcpyHostToDevice));
+      s.fit_static_current = true;
+    }
+    const size_t need = (size_t)n_sets * std::max<size_t>(GK, 1);  // (doubles per pattern)
+    if (s.fit_sets_cap < need) {
+      if (s.fit_smult) hipFree(s.fit_smult);
+      if (s.fit_out) hipFree(s.fit_out);
+      s.fit_smult = s.fit_out = nullptr;
+      s.fit_sets_cap = 0;
+      HIPCHK(hipMalloc((void **)&s.fit_smult, need * s.S_pad * sizeof(double)));
+      HIPCHK(hipMalloc((void **)&s.fit_out, need * s.S_pad * sizeof(double)));
+      s.fit_sets_cap = need;
+    }
+    if (p->fit_spills && s.fit_scratch_sets < (size_t)n_sets) {
+      if (s.fit_scratch) hipFree(s.fit_scratch);
+      if (s.fit_scratch_cnt) hipFree(s.fit_scratch_cnt);
+      s.fit_scratch = nullptr;
+      s.fit_scratch_cnt = nullptr;
+      s.fit_scratch_sets = 0;
+      const size_t bytes = (size_t)n_sets * I * s.ntiles * TILE * sizeof(double);
+      size_t free_b = 0, total_b = 0;
+      hipMemGetInfo(&free_b, &total_b);
+      if (bytes > free_b / 2) {
+        g_last_error = "site fits: scratch for spilled nodes does not fit; use fewer parameter sets per call";
+        return 1;
+      }
+      HIPCHK(hipMalloc((void **)&s.fit_scratch, bytes));
+      HIPCHK(hipMalloc((void **)&s.fit_scratch_cnt, (size_t)n_sets * I * s.S_pad * sizeof(int32_t)));
+      s.fit_scratch_sets = (size_t)n_sets;
+    }
+    // site multipliers of this shard's pattern range, padded with zeros (padding sites: exp(0) = I, weightless)
+    std::vector<double> sm((size_t)n_sets * s.S_pad * GK, 0.0);
+    for (int64_t st = 0; st < n_sets; st++)
+      memcpy(sm.data() + (size_t)st * s.S_pad * GK, site_mult + ((size_t)st * S + s.s0) * GK, (size_t)s.S * GK * sizeof(double));
+    HIPCHK(hipMemcpyAsync(s.fit_smult, sm.data(), sm.size() * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    HIPCHK(hipMemcpyAsync(s.fit_bcoef, branch_coeffs, (size_t)B * K * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    HIPCHK(hipMemcpyAsync(s.fit_bgroup, grp.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, s.stream));
+    HIPCHK(hipMemcpyAsync(s.fit_pi, pi.data(), (size_t)DP * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    HIPCHK(hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream));
+    fa.ops = s.fit_ops;
+    fa.n_ops = p->fit_n_ops;
+    fa.NW = NW;
+    fa.L = L;
+    fa.I = I;
+    fa.ntiles = s.ntiles;
+    fa.S_pad = s.S_pad;
+    fa.K = (int)K;
+    fa.G = (int)n_groups;
+    fa.n_sets = (int)n_sets;
+    fa.Timg = s.fit_Timg;
+    fa.bcoef = s.fit_bcoef;
+    fa.bgroup = s.fit_bgroup;
+    fa.smult = s.fit_smult;
+    fa.codes_tile = s.codes_tile;
+    fa.ambig = s.ambig;
+    fa.pi = s.fit_pi;
+    fa.freq = s.freq;
+    fa.scratch = s.fit_scratch;
+    fa.scratch_cnt = s.fit_scratch_cnt;
+    fa.site_logl = s.fit_out;
+    fa.status = s.status;
+    HIPCHK(hipEventRecord(s.ev[0], s.stream));
+    launch_site_fit(fa, s.stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s.ev[1], s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));  // (the staging vectors go out of scope)
+    {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) p->fit_kernel_ms = std::max(&s == &p->shards[0] ? 0.0 : p->fit_kernel_ms, (double)ms);
+    }
+    std::vector<double> out((size_t)n_sets * s.S_pad);
+    int32_t st = 0;
+    HIPCHK(hipMemcpy(out.data(), s.fit_out, out.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&st, s.status, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream));
+    if (st) return fail("site fits: a site likelihood is not a number");
+    for (int64_t k = 0; k < n_sets; k++)
+      memcpy(site_logl_out + (size_t)k * S + s.s0, out.data() + (size_t)k * s.S_pad, (size_t)s.S * sizeof(double));
+  }
+  return 0;
+}
+
+
+double hyphy_hip_site_fits_kernel_ms(const hyphy_hip_partition *p) { return p ? p->fit_kernel_ms : 0.; }
 
 double *hyphy_hip_q_buffer(hyphy_hip_partition *p) { return p && !p->shards.empty() ? p->shards[0].qbuf : nullptr; }
 

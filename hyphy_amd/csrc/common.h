@@ -135,6 +135,30 @@ struct NucArgs {
   int *wg_flag;
 };
 
+constexpr int kSiteFitParkSlots = 1;  // wave-private LDS parking slots of the per-site fit kernel (8 KiB each at D = 61); nodes
+                                      // beyond that go through a scratch copy in HBM (cheap next to the series of an edge)
+
+// Per-site batched fits (sitefit.hip): one wave per (16-site tile, parameter set)
+struct SiteFitArgs {
+  const int4 *ops;           // full post-order schedule, compiled for 2 + kSiteFitParkSlots slots, lazy persistence
+  int n_ops;
+  int NW, L, I, ntiles, S_pad;
+  int K, G, n_sets;          // templates, branch groups, parameter sets (grid.y)
+  double dmax[4];            // max_i |T_k[i][i]|: the uniformisation rate of site s on branch b is sum_k x_k dmax_k
+  const double *Timg;        // [K][NW][NKK*64] A-operand images of the templates, diagonal = -(row sum)
+  const double *bcoef;       // [B][K] branch coefficients
+  const int *bgroup;         // [B]    multiplier group of each branch
+  const double *smult;       // [n_sets][S_pad][G][K] site multipliers (0 for padding sites)
+  const int16_t *codes_tile; // [ntiles][L][16]
+  const double *ambig;       // [n_ambig][DP]
+  const double *pi;          // [DP]
+  const double *freq;        // [S_pad]
+  double *scratch;           // [n_sets][I][ntiles][NKK*64] nodes that found no parking slot (may be null if none)
+  int32_t *scratch_cnt;      // [n_sets][I][S_pad]
+  double *site_logl;         // [n_sets][S_pad]
+  int32_t *status;
+};
+
 struct ExpmArgs {
   const double *Q;           // [n][D*D] row-major (rate matrices, or probabilities if is_prob)
   const int32_t *slots;      // [n] destination branch slot (node code) or nullptr -> identity
@@ -180,6 +204,7 @@ struct BcArgs {
 void launch_transpose_frag(const double *src_image, double *dst_image, const double *row_scale, int NW, hipStream_t stream);
 void launch_bc_eval(const BcArgs &a, hipStream_t stream);
 void launch_expm(const ExpmArgs &a, hipStream_t stream);
+void launch_site_fit(const SiteFitArgs &a, hipStream_t stream);
 void launch_prune_mfma(const PruneArgs &a, hipStream_t stream);
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream);
 void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,

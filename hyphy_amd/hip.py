@@ -23,7 +23,7 @@ EXPORTS = [
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
-    "hyphy_hip_set_pinned_states",
+    "hyphy_hip_set_pinned_states", "hyphy_hip_site_fits_evaluate", "hyphy_hip_site_fits_kernel_ms",
     "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
@@ -72,6 +72,10 @@ def load():
     lib.hyphy_hip_evaluate_built.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, dp]
     lib.hyphy_hip_evaluate_categories_built.restype = C.c_int
     lib.hyphy_hip_evaluate_categories_built.argtypes = [vp, lp, C.c_int64, lp, C.c_int64, dp, dp, dp]
+    lib.hyphy_hip_site_fits_evaluate.restype = C.c_int
+    lib.hyphy_hip_site_fits_evaluate.argtypes = [vp, C.c_int64, C.c_int64, lp, dp, dp, dp, dp]
+    lib.hyphy_hip_site_fits_kernel_ms.restype = C.c_double
+    lib.hyphy_hip_site_fits_kernel_ms.argtypes = [vp]
     lib.hyphy_hip_q_buffer.restype = vp
     lib.hyphy_hip_q_buffer.argtypes = [vp]
     lib.hyphy_hip_synchronize.restype = C.c_int
@@ -328,6 +332,25 @@ class HipPartition:
     def build_q(self, coeffs: np.ndarray):
         c = np.ascontiguousarray(coeffs, dtype=np.float64)
         _check(self._lib.hyphy_hip_build_q(self._h, c.shape[0], _d(c)))
+
+    def site_fits_evaluate(self, branch_group, branch_coeffs, site_mult, root_freqs) -> np.ndarray:
+        """Per-site batched fits (SURVEY 8f-4): ``site_mult`` is [n_sets, S, n_groups, K] (or [S, n_groups, K]);
+        returns the site log-likelihoods [n_sets, S] (or [S]) of every pattern under its own multipliers."""
+        bg = np.ascontiguousarray(branch_group, dtype=np.int64)
+        bc = np.ascontiguousarray(branch_coeffs, dtype=np.float64)
+        sm = np.ascontiguousarray(site_mult, dtype=np.float64)
+        single = sm.ndim == 3
+        if single:
+            sm = sm[None]
+        n_sets, S, G, K = sm.shape
+        assert S == self.S and bg.shape == (self.B,) and bc.shape == (self.B, K)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        out = np.zeros((n_sets, S))
+        _check(self._lib.hyphy_hip_site_fits_evaluate(self._h, n_sets, G, _l(bg), _d(bc), _d(sm), _d(rf), _d(out)))
+        return out[0] if single else out
+
+    def site_fits_kernel_ms(self) -> float:
+        return float(self._lib.hyphy_hip_site_fits_kernel_ms(self._h))
 
     def q_buffer(self) -> int:
         return int(self._lib.hyphy_hip_q_buffer(self._h))

@@ -164,6 +164,33 @@ int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_
 int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *templates /* [K*D*D] */);
 int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs /* host [n*K] */);
 double *hyphy_hip_q_buffer(hyphy_hip_partition *p); /* device pointer, capacity (L+I-1)*C*D*D doubles */
+
+/*
+ * Per-site batched fits.  The FEL family of analyses gives every alignment site its own rate
+ * multipliers — res/TemplateBatchFiles/SelectionAnalyses/FEL.bf:593-605 attaches the globals fel.alpha_scaler,
+ * fel.beta_scaler_test and fel.beta_scaler_nuisance to the site model, and fel.handle_a_site (FEL.bf:609+) optimises
+ * them for ONE site at a time with a single-site likelihood function: per evaluation (L+I-1) calls of
+ * _Matrix::Exponentiate (matrix.cpp:5746+) and a one-pattern pruning pass (tree_evaluator.cpp:3556+), sites fanned
+ * out over MPI (libv3/tasks/mpi.bf).  This entry point evaluates ALL S patterns of the partition, each under its own
+ * multipliers, for n_sets candidate parameter vectors per pattern (e.g. the 12-point start.grid of FEL.bf:617-680, or
+ * the simplex of a batched optimiser) in one launch:
+ *
+ *       Q_{b,s} = sum_k  site_mult[set][s][branch_group[b]][k] * branch_coeffs[b][k] * T_k       (off-diagonal)
+ *       site_logl_out[set][s] = log L(pattern s | tree, {Q_{b,s}}_b, root_freqs)     (pattern frequency NOT applied)
+ *
+ * with the templates T_k of hyphy_hip_set_q_templates (K <= 4; e.g. MG94xREV: T_0 synonymous, T_1 non-synonymous,
+ * branch_coeffs[b] = the branch's synonymous / non-synonymous lengths from the global fit, branch_group = 0 tested,
+ * 1 nuisance, site_mult[s][g] = (alpha_s, beta_s^g)).  All multipliers, coefficients and off-diagonal template
+ * entries must be >= 0.  The transition matrices are never formed: each pruning step applies exp(Q_{b,s}) to the
+ * child's conditional vector by uniformisation on the FP64 matrix cores (sitefit.hip).  The result agrees with
+ * "exponentiate, then multiply" to rounding (both are approximations of the same exact value; this one has
+ * componentwise relative accuracy).  Returns 1 (unsupported) for 4-state partitions and K > 4.
+ */
+int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t n_groups,
+                                 const int64_t *branch_group /* [L+I-1] */, const double *branch_coeffs /* [L+I-1][K] */,
+                                 const double *site_mult /* [n_sets][S][n_groups][K] */, const double *root_freqs,
+                                 double *site_logl_out /* [n_sets][S] */);
+double hyphy_hip_site_fits_kernel_ms(const hyphy_hip_partition *p); /* duration of the last site-fit kernel */
 /* Synchronous evaluation from the rate matrices staged by the last hyphy_hip_build_q() (n matrices,
  * in the order of q_nodes): template models never move a dense Q across PCIe — only the n*K
  * coefficients go down and one double comes back.  Same semantics as hyphy_hip_evaluate otherwise. */

@@ -618,3 +618,132 @@ def test_randomised_stress_with_poisoned_allocations(script, n_cases, seed):
                        capture_output=True, text=True, timeout=900)
     tail = "\n".join((r.stdout + r.stderr).strip().splitlines()[-5:])
     assert r.returncode == 0 and "checks passed" in tail, tail
+
+
+# ---- per-site batched fits --------------------------------------------------------------------------
+def _site_fit_case(D, taxa, sites, K, G, n_sets, seed, caterpillar=False, balanced=False, mult_hi=5.0, ambiguity=True):
+    from hyphy_amd import data, tree
+    rng = np.random.default_rng(seed)
+    if balanced:
+        counter = [0, 0]
+
+        def bal(n):
+            if n == 1:
+                counter[0] += 1
+                return tree.Node(name=f"T{counter[0]}")
+            counter[1] += 1
+            nd = tree.Node(name=f"N{counter[1]}", children=[bal(n // 2), bal(n - n // 2)])
+            for c in nd.children:
+                c.parent = nd
+            return nd
+        root = bal(taxa)
+    else:
+        root = tree.caterpillar_tree(taxa) if caterpillar else tree.random_tree(taxa, rng)
+    flat = tree.flatten(root)
+    L, B = flat.L, flat.n_branches
+    base = rng.integers(0, D, size=sites)
+    states = np.where(rng.random((L, sites)) < 0.3, rng.integers(0, D, size=(L, sites)), base[None, :])
+    codes = states.astype(np.int64)
+    ambig = np.zeros((0, D))
+    if ambiguity:
+        ambig = (rng.random((2, D)) < 0.5).astype(np.float64)
+        ambig[:, 0] = 1.0
+        ambig[1, :] = 1.0  # fully missing
+        hit = rng.random(codes.shape) < 0.05
+        codes[hit] = -(rng.integers(0, 2, size=int(hit.sum())) + 1)
+    pi = rng.dirichlet(np.full(D, 5.0))
+    T = np.zeros((K, D, D))
+    for k in range(K):
+        R = rng.uniform(0.1, 2.0, (D, D)) * (rng.random((D, D)) < 0.4)
+        R = np.maximum(R, R.T) + np.diag(np.full(D - 1, 0.05), 1) + np.diag(np.full(D - 1, 0.05), -1)
+        T[k] = R * pi[None, :]
+        np.fill_diagonal(T[k], 0.0)
+    T /= max(float((T.sum(0).sum(1) * pi).sum()), 1e-9)  # ~ one expected substitution per unit coefficient
+    bgroup = rng.integers(0, G, size=B)
+    bcoef = rng.uniform(0.01, 0.5, (B, K))
+    bcoef[rng.integers(0, B)] = 0.0  # a zero-length branch
+    smult = np.exp(rng.uniform(np.log(0.01), np.log(mult_hi), (n_sets, sites, G, K)))
+    smult[0, :3] = 0.0          # sites whose every rate is zero
+    smult[-1, 3:6, :, 0] = 0.0  # alpha = 0
+    return flat, codes, ambig, pi, T, bgroup, bcoef, smult
+
+
+def _site_fit_reference(D, flat, codes, ambig, pi, T, bgroup, bcoef, smult):
+    """The reference's way (FEL.bf:609+): one single-site likelihood function per site — exponentiate every branch's
+    own rate matrix (oracle restatement of _Matrix::Exponentiate), then prune that one pattern."""
+    from oracle import oracle
+    n_sets, S, G, K = smult.shape
+    B = flat.n_branches
+    nodes = np.arange(B, dtype=np.int64)
+    out = np.zeros((n_sets, S))
+    idx = np.arange(D)
+    for st in range(n_sets):
+        for s in range(S):
+            x = smult[st, s][bgroup] * bcoef  # [B][K]
+            Q = np.einsum("bk,kij->bij", x, T)
+            Q[:, idx, idx] = -Q.sum(2)
+            op = oracle.OraclePartition(D, flat.flat_parents, flat.L, codes[:, s:s + 1], ambig, np.ones(1, dtype=np.int64))
+            op.set_P(nodes, oracle.expm(Q, True))
+            out[st, s] = op.site_log_likelihoods(nodes, pi)[0]
+    return out
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("codon_random", dict(D=61, taxa=14, sites=40, K=2, G=2, n_sets=3, seed=1)),
+    ("codon_caterpillar", dict(D=61, taxa=24, sites=20, K=2, G=2, n_sets=2, seed=2, caterpillar=True)),
+    ("codon_balanced_spills", dict(D=61, taxa=32, sites=18, K=2, G=3, n_sets=2, seed=3, balanced=True)),
+    ("protein_one_template", dict(D=20, taxa=10, sites=50, K=1, G=1, n_sets=2, seed=4)),
+    ("states_48_three_templates", dict(D=48, taxa=9, sites=17, K=3, G=2, n_sets=1, seed=5)),
+    ("codon_fast_sites", dict(D=61, taxa=8, sites=16, K=2, G=2, n_sets=2, seed=6, mult_hi=800.0)),
+])
+def test_site_fits_match_per_site_reference(name, kw):
+    """hyphy_hip_site_fits_evaluate (exp(Q) applied by uniformisation, matrices never formed) against one oracle
+    likelihood function per site with explicitly exponentiated matrices.  Tolerance 1e-9 relative on the site log-L."""
+    hip = _hip()
+    D = kw["D"]
+    flat, codes, ambig, pi, T, bgroup, bcoef, smult = _site_fit_case(**kw)
+    ref = _site_fit_reference(D, flat, codes, ambig, pi, T, bgroup, bcoef, smult)
+    with hip.HipPartition(D, flat.flat_parents, flat.L, codes, ambig, np.ones(codes.shape[1], dtype=np.int64)) as part:
+        part.set_q_templates(T)
+        got = part.site_fits_evaluate(bgroup, bcoef, smult, pi)
+        again = part.site_fits_evaluate(bgroup, bcoef, smult[0], pi)
+    assert got.shape == ref.shape
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin), name
+    assert np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))) < 1e-9, name
+    assert np.array_equal(again, got[0])
+
+
+def test_site_fits_with_unit_multipliers_equal_the_ordinary_evaluation():
+    """All multipliers 1: every site sees the same matrices, so the result must agree with the per-site output of
+    hyphy_hip_evaluate on the same partition (device against device, different kernels and algorithms)."""
+    hip = _hip()
+    flat, codes, ambig, pi, T, bgroup, bcoef, smult = _site_fit_case(D=61, taxa=20, sites=200, K=2, G=2, n_sets=1, seed=11)
+    B = flat.n_branches
+    nodes = np.arange(B, dtype=np.int64)
+    Q = np.einsum("bk,kij->bij", bcoef, T)
+    idx = np.arange(61)
+    Q[:, idx, idx] = -Q.sum(2)
+    with hip.HipPartition(61, flat.flat_parents, flat.L, codes, ambig, np.ones(200, dtype=np.int64)) as part:
+        part.set_q_templates(T)
+        got = part.site_fits_evaluate(bgroup, bcoef, np.ones((200, 2, 2)), pi)
+        ll, lik, sc = part.evaluate(nodes, nodes, Q, pi, per_site=True)
+    ref = np.log(lik) - sc * 64 * np.log(2.0)
+    assert np.max(np.abs(got - ref) / np.abs(ref)) < 1e-10
+    assert abs(got.sum() - ll) < 1e-9 * abs(ll)
+
+
+def test_site_fits_error_paths():
+    hip = _hip()
+    fx = common.load("nuc_small")
+    with _mk(fx) as part:
+        part.set_q_templates(np.ones((1, 4, 4)))
+        with pytest.raises(hip.HipUnsupported):
+            part.site_fits_evaluate(np.zeros(part.B, dtype=np.int64), np.ones((part.B, 1)), np.ones((part.S, 1, 1)), fx["root_freqs"])
+    flat, codes, ambig, pi, T, bgroup, bcoef, smult = _site_fit_case(D=20, taxa=5, sites=8, K=1, G=1, n_sets=1, seed=3)
+    with hip.HipPartition(20, flat.flat_parents, flat.L, codes, ambig, np.ones(8, dtype=np.int64)) as part:
+        with pytest.raises(hip.HipError):  # templates not set
+            part.site_fits_evaluate(bgroup, bcoef, smult, pi)
+        part.set_q_templates(T)
+        with pytest.raises(hip.HipError):  # negative multiplier
+            part.site_fits_evaluate(bgroup, bcoef, -smult, pi)
