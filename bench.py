@@ -122,6 +122,88 @@ def cpu_port_baseline(pd, flat, Q, pi, sparse):
                 sample="1 full evaluation (expm of every branch + full pruning pass) by oracle/hyphy_oracle.c, scalar C"), ll
 
 
+def site_fit_terms(mu):
+    """Series length of sitefit.hip for a tile whose largest uniformisation rate (per sub-step) is mu."""
+    mu = float(mu)
+    if mu <= 0.:
+        return 0
+    n_sub = int(np.ceil(mu / 64.0))
+    m = mu / n_sub
+    wgt, j = np.exp(-m), 0
+    while True:
+        j += 1
+        wgt *= m / j
+        r = m / (j + 1)
+        if r < 0.5 and wgt * r / (1.0 - r) < 1e-18:
+            return j * n_sub
+
+
+def time_site_fits(part, args, wl, pd, flat, T, pi, tb):
+    """FEL-style per-site fits: every pattern has its own (alpha, beta_test, beta_nuisance); one launch evaluates
+    SETS candidate vectors per pattern.  Reports site-evaluations/s, the MFMA rate of the kernel (flops counted from
+    the series lengths the kernel uses) and the reference's way timed on this host: one single-site likelihood
+    function per site = (L+I-1) matrix exponentials + a one-pattern pruning pass (oracle restatement, 1 core)."""
+    from oracle import oracle
+    rng = np.random.default_rng(7)
+    S, B, D = part.S, part.B, part.D
+    n_sets = args.site_fits
+    bgroup = (rng.random(B) < 0.25).astype(np.int64)           # a quarter of the branches "tested"
+    bcoef = np.stack([tb, 0.3 * tb], axis=1)                    # synonymous / non-synonymous lengths of the global fit
+    smult = np.exp(rng.uniform(np.log(0.1), np.log(5.0), (n_sets, S, 2, 2)))   # (alpha_s, beta_s) per group, log-uniform
+    smult[:, :, 1, 0] = smult[:, :, 0, 0]                      # alpha is shared by the two groups
+    part.site_fits_evaluate(bgroup, bcoef, smult, pi)          # warm-up (allocations, schedule)
+    reps = max(1, min(args.steps, 10))
+    t0 = time.perf_counter()
+    kern = 0.0
+    for _ in range(reps):
+        out = part.site_fits_evaluate(bgroup, bcoef, smult, pi)
+        kern += part.site_fits_kernel_ms()
+    dt = (time.perf_counter() - t0) / reps
+    kern /= reps
+    # flops: per (set, tile, branch) terms x K templates x NW*NKK MFMAs x 2048
+    dmax = np.array([T[k].sum(1).max() for k in range(T.shape[0])])
+    S_pad = (S + 15) // 16 * 16
+    x = np.zeros((n_sets, S_pad, B, 2))
+    x[:, :S] = smult[:, :, bgroup, :] * bcoef[None, None]
+    mu_tile = (x @ dmax).reshape(n_sets, S_pad // 16, 16, B).max(2)
+    mus, inv = np.unique(np.round(mu_tile, 6), return_inverse=True)
+    terms = np.array([site_fit_terms(m) for m in mus])[inv.reshape(-1)]
+    NW = (D + 15) // 16
+    mfma = int(terms.sum()) * T.shape[0] * NW * 4 * NW
+    flops = mfma * 2048.0
+    # the reference's way on one host core, a few sites
+    n_cpu = 6
+    nodes = np.arange(B, dtype=np.int64)
+    idx = np.arange(D)
+    t1 = time.perf_counter()
+    worst = 0.0
+    for s_ in range(n_cpu):
+        xs = smult[0, s_][bgroup] * bcoef
+        Q = np.einsum("bk,kij->bij", xs, T)
+        Q[:, idx, idx] = 0.0
+        Q[:, idx, idx] = -Q.sum(2)
+        op = oracle.OraclePartition(D, flat.flat_parents, flat.L, pd.leaf_codes[:, s_:s_ + 1], None, np.ones(1, dtype=np.int64))
+        op.set_P(nodes, oracle.expm(Q, True))
+        ref = op.site_log_likelihoods(nodes, pi)[0]
+        worst = max(worst, abs(out[0, s_] - ref) / abs(ref))
+    cpu_rate = n_cpu / (time.perf_counter() - t1)
+    fel_fit = None
+    if args.fel:
+        from hyphy_amd import fel
+        t2 = time.perf_counter()
+        res = fel.fel(part, bgroup == 0, bcoef[:, 0], bcoef[:, 1], pi, max_iter=300)
+        fel_fit = {"seconds": time.perf_counter() - t2, "launches": res.launches, "patterns": int(S),
+                   "median_alpha": float(np.median(res.alpha)), "median_beta": float(np.median(res.beta)),
+                   "sites_p_below_0.1": int((res.p_value < 0.1).sum()), "sum_logl_alt": float(res.logl_alt.sum()),
+                   "sum_logl_null": float(res.logl_null.sum())}
+    return {**({"fel_fit": fel_fit} if fel_fit else {}), "sets_per_launch": n_sets, "patterns": int(S), "site_evals_per_s": n_sets * S / dt, "ms_per_launch": 1e3 * dt,
+            "kernel_ms": kern, "kernel_site_evals_per_s": n_sets * S / (kern * 1e-3), "mean_series_terms": float(terms.mean()),
+            "mfma_tflops": flops / (kern * 1e-3) / 1e12, "mfma_frac_of_peak": flops / (kern * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "cpu_reference_way": {"site_evals_per_s": cpu_rate, "cores": 1, "kind": "port",
+                                  "sample": f"{n_cpu} sites: {B} matrix exponentials + one-pattern pruning each"},
+            "max_rel_err_vs_cpu_sample": worst}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +215,12 @@ def main():
     ap.add_argument("--pipelined", action="store_true", help="also report throughput with no per-step host sync")
     ap.add_argument("--branch-cache", action="store_true",
                     help="also time one-branch line-search evaluations through the device branch cache (SURVEY 8f-1)")
+    ap.add_argument("--site-fits", type=int, default=0, metavar="SETS",
+                    help="also time per-site batched fits (SURVEY 8f-4): every pattern under its own (alpha, beta), "
+                         "SETS candidate parameter vectors per pattern and launch")
+    ap.add_argument("--fel", action="store_true",
+                    help="with --site-fits: also run the whole FEL-style analysis (alternative + null fit of every "
+                         "pattern, hyphy_amd/fel.py) and report its wall time")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -258,6 +346,10 @@ def main():
                         "build_ms": build_ms, "logl_full": full, "logl_cached_same_length": same,
                         "rel_err_vs_full": abs(same - full) / abs(full), "logl_last": lastb}
 
+    site_fits = None
+    if args.site_fits > 0 and n_classes == 1 and N == 1 and D > 4:
+        site_fits = time_site_fits(part, args, wl, pd_all, flat, T, pi, tb)
+
     pipelined = None
     if args.pipelined and n_classes == 1:
         torch.cuda.synchronize()
@@ -323,6 +415,7 @@ def main():
             "logl_first": ll0, "logl_last": last,
             "roofline": roof,
             **({"branch_cache": branch_cache} if branch_cache else {}),
+            **({"site_fits": site_fits} if site_fits else {}),
         }
         if pipelined:
             out["value_pipelined_no_host_sync"] = pipelined

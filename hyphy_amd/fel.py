@@ -1,0 +1,204 @@
+"""FEL-style per-site fits on top of ``hyphy_hip_site_fits_evaluate``.
+
+Host-side mirror of what ``fel.handle_a_site`` does for ONE site
+(/root/reference/res/TemplateBatchFiles/SelectionAnalyses/FEL.bf:609-900): evaluate the starting grid
+(FEL.bf:617-760), optimise the site's rate multipliers under the alternative model (alpha, beta_test,
+beta_nuisance free), then under the null (beta_test := alpha), and form the likelihood-ratio test.  The
+reference runs one single-site likelihood function per site through ``Optimize`` and farms sites out over
+MPI (libv3/tasks/mpi.bf); here ALL sites advance in lockstep through a batched Nelder-Mead whose every
+iteration is one device launch with four candidate parameter vectors per site (reflection, expansion and
+the two contractions), so a whole alignment is fitted in a few hundred launches.
+
+This module is host logic (numpy): the arithmetic of the likelihoods happens in the HIP library.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Optional, Sequence
+
+import numpy as np
+
+# FEL.bf:617-680 (site-rate-variation grid: alpha scaler included) as (alpha, beta) multiples
+START_GRID = np.array([
+    (0.01, 0.1), (1.0, 0.1), (1.0, 0.5), (1.0, 1.0), (1.0, 5.0), (10.0, 0.1),
+    (0.01, 0.5), (0.01, 5.0), (10.0, 0.5), (10.0, 1.0), (10.0, 50.0), (100.0, 1.0),
+])
+
+
+@dataclasses.dataclass
+class SiteFit:
+    theta: np.ndarray        # [S, P] maximum-likelihood multipliers
+    logl: np.ndarray         # [S] site log-likelihood at theta
+    iterations: int
+    launches: int
+    converged: np.ndarray    # [S] bool
+
+
+def _multipliers(theta: np.ndarray, param_map: np.ndarray) -> np.ndarray:
+    """theta [..., S, P] -> site_mult [..., S, G, K]; param_map[g][k] = index into theta or -1 (fixed at 1)."""
+    pm = np.asarray(param_map)
+    out = np.ones(theta.shape[:-1] + pm.shape)
+    for g in range(pm.shape[0]):
+        for k in range(pm.shape[1]):
+            if pm[g, k] >= 0:
+                out[..., g, k] = theta[..., pm[g, k]]
+    return out
+
+
+def fit_sites(part, branch_group, branch_coeffs, root_freqs, param_map, start_points: np.ndarray,
+              max_iter: int = 400, tol: float = 1e-9, upper: float = 1e4, x_init: Optional[np.ndarray] = None,
+              active: Optional[np.ndarray] = None) -> SiteFit:
+    """Maximise every site's log-likelihood over its own parameter vector theta (P entries, all >= 0).
+
+    ``start_points`` [n_start, P]: every site starts from the best of these (one launch).  Lockstep Nelder-Mead in
+    u = sqrt(theta) (keeps theta >= 0 without constraints, boundary optima theta = 0 are reachable).
+    ``x_init`` [S, P]: an extra per-site starting point.  ``active`` [S] bool: only these sites are fitted — the others
+    are evaluated with all-zero multipliers (the kernel skips zero-rate tiles) and come back with logl = nan."""
+    pm = np.asarray(param_map, dtype=np.int64)
+    S = part.S
+    P = int(pm.max()) + 1
+    launches = 0
+
+    def evaluate(U):  # U [n, S, P] -> logL [n, S]
+        nonlocal launches
+        launches += 1
+        theta = np.minimum(U * U, upper)
+        if active is not None:
+            theta = np.where(active[None, :, None], theta, 0.0)
+        return part.site_fits_evaluate(branch_group, branch_coeffs, _multipliers(theta, pm), root_freqs)
+
+    sp = np.sqrt(np.asarray(start_points, dtype=np.float64))            # [n_start, P]
+    f0 = evaluate(np.broadcast_to(sp[:, None, :], (sp.shape[0], S, P)).copy())
+    best = np.argmax(f0, axis=0)
+    x0 = sp[best]                                                        # [S, P]
+    f_best = f0[best, np.arange(S)]
+    if x_init is not None:
+        xi = np.sqrt(np.asarray(x_init, dtype=np.float64))
+        fi = evaluate(xi[None])[0]
+        use = fi > f_best
+        x0 = np.where(use[:, None], xi, x0)
+        f_best = np.where(use, fi, f_best)
+    # initial simplex: x0 and x0 with one coordinate stretched
+    X = np.repeat(x0[:, None, :], P + 1, axis=1)                         # [S, P+1, P]
+    for k in range(P):
+        X[:, k + 1, k] = X[:, k + 1, k] * 1.6 + 0.05
+    F = np.empty((S, P + 1))
+    F[:, 0] = f_best
+    F[:, 1:] = evaluate(np.ascontiguousarray(np.transpose(X[:, 1:, :], (1, 0, 2)))).T
+    F = np.where(np.isnan(F), -np.inf, F)
+    rows = np.arange(S)
+    it = 0
+    converged = np.zeros(S, dtype=bool)
+    for it in range(1, max_iter + 1):
+        order = np.argsort(-F, axis=1)                                   # best first (maximisation)
+        F = np.take_along_axis(F, order, axis=1)
+        X = np.take_along_axis(X, order[:, :, None], axis=1)
+        spread = F[:, 0] - F[:, -1]
+        size = np.max(np.abs(X[:, 1:, :] - X[:, :1, :]), axis=(1, 2))
+        converged = ((spread < tol) & (size < 1e-5)) | ~np.isfinite(F[:, 0])
+        if active is not None:
+            converged |= ~active
+        if converged.all():
+            break
+        c = X[:, :-1, :].mean(axis=1)                                    # centroid of all but the worst
+        w = X[:, -1, :]
+        cand = np.stack([c + (c - w), c + 2.0 * (c - w), c + 0.5 * (c - w), c - 0.5 * (c - w)])   # r, e, oc, ic
+        fc = evaluate(cand)
+        fc = np.where(np.isnan(fc), -np.inf, fc)
+        fr, fe, foc, fic = fc
+        fb, fsw, fw = F[:, 0], F[:, -2], F[:, -1]
+        newx = w.copy()
+        newf = fw.copy()
+        shrink = np.zeros(S, dtype=bool)
+        m_exp = fr > fb
+        take_e = m_exp & (fe > fr)
+        take_r = (m_exp & ~take_e) | (~m_exp & (fr > fsw))
+        m_oc = ~m_exp & ~(fr > fsw) & (fr > fw)
+        m_ic = ~m_exp & ~(fr > fsw) & ~(fr > fw)
+        for mask, idx, fv in ((take_e, 1, fe), (take_r, 0, fr)):
+            newx[mask] = cand[idx][mask]
+            newf[mask] = fv[mask]
+        ok_oc = m_oc & (foc >= fr)
+        ok_ic = m_ic & (fic > fw)
+        newx[ok_oc] = cand[2][ok_oc]
+        newf[ok_oc] = foc[ok_oc]
+        newx[ok_ic] = cand[3][ok_ic]
+        newf[ok_ic] = fic[ok_ic]
+        shrink = (m_oc & ~ok_oc) | (m_ic & ~ok_ic)
+        shrink &= ~converged
+        X[:, -1, :] = newx
+        F[:, -1] = newf
+        if shrink.any():
+            Xs = X[:, :1, :] + 0.5 * (X - X[:, :1, :])
+            fs = evaluate(np.ascontiguousarray(np.transpose(Xs[:, 1:, :], (1, 0, 2)))).T
+            fs = np.where(np.isnan(fs), -np.inf, fs)
+            X[shrink, 1:, :] = Xs[shrink, 1:, :]
+            F[shrink, 1:] = fs[shrink]
+    order = np.argmax(F, axis=1)
+    theta = np.minimum(X[rows, order] ** 2, upper)
+    logl = F[rows, order]
+    if active is not None:
+        logl = np.where(active, logl, np.nan)
+    return SiteFit(theta=theta, logl=logl, iterations=it, launches=launches, converged=converged)
+
+
+@dataclasses.dataclass
+class FelResult:
+    alpha: np.ndarray
+    beta: np.ndarray          # tested branches
+    beta_nuisance: np.ndarray
+    logl_alt: np.ndarray
+    logl_null: np.ndarray
+    lrt: np.ndarray
+    p_value: np.ndarray
+    launches: int
+
+
+def fel(part, tested: Sequence[bool], syn_lengths, nonsyn_lengths, root_freqs, max_iter: int = 400,
+        pattern_of_site: Optional[np.ndarray] = None) -> FelResult:
+    """Per-site alpha / beta fits and the LRT for beta_test != alpha, for every pattern of ``part`` (whose templates
+    must be (synonymous, non-synonymous), e.g. ``bench.templates_for(3)``).  ``tested[b]``: branch b belongs to the
+    tested set; syn/nonsyn_lengths [B]: the branch's coefficients from the global fit (FEL.bf:560-590).  Returns
+    per-pattern vectors, or per-site ones when ``pattern_of_site`` is given."""
+    from scipy.stats import chi2
+    tested = np.asarray(tested, dtype=bool)
+    group = np.where(tested, 0, 1).astype(np.int64)
+    bc = np.stack([np.asarray(syn_lengths, dtype=np.float64), np.asarray(nonsyn_lengths, dtype=np.float64)], axis=1)
+    has_nuisance = bool((~tested).any())
+    if has_nuisance:
+        alt_map, null_map = np.array([[0, 1], [0, 2]]), np.array([[0, 0], [0, 1]])
+        alt_start = np.array([(a, b, b) for a, b in START_GRID])
+        null_start = np.array([(a, b) for a, b in START_GRID])
+    else:
+        alt_map, null_map = np.array([[0, 1], [0, 1]]), np.array([[0, 0], [0, 0]])
+        alt_start = START_GRID.copy()
+        null_start = np.unique(START_GRID[:, :1], axis=0)
+    alt = fit_sites(part, group, bc, root_freqs, alt_map, alt_start, max_iter=max_iter)
+    # the null is nested in the alternative: also start it from the alternative's optimum projected onto beta_test = alpha
+    proj = np.stack([alt.theta[:, 0], alt.theta[:, 2]], axis=1) if has_nuisance else alt.theta[:, :1]
+    null = fit_sites(part, group, bc, root_freqs, null_map, null_start, max_iter=max_iter)
+    null_p = part.site_fits_evaluate(group, bc, _multipliers(proj, null_map), root_freqs)
+    better = null_p > null.logl
+    null.theta[better] = proj[better]
+    null.logl[better] = null_p[better]
+    launches = alt.launches + null.launches + 1
+    # ... and the alternative contains the null: where the independent null fit ended above the alternative's (a
+    # local optimum on a multi-modal surface), refit those sites' alternative from the embedded null optimum
+    worse = null.logl > alt.logl + 1e-9
+    if worse.any():
+        emb = (np.stack([null.theta[:, 0], null.theta[:, 0], null.theta[:, 1]], axis=1) if has_nuisance
+               else np.stack([null.theta[:, 0], null.theta[:, 0]], axis=1))
+        again = fit_sites(part, group, bc, root_freqs, alt_map, alt_start[:1], max_iter=max_iter, x_init=emb, active=worse)
+        launches += again.launches
+        take = worse & (again.logl > alt.logl)
+        alt.theta[take] = again.theta[take]
+        alt.logl[take] = again.logl[take]
+    lrt = np.maximum(0.0, 2.0 * (alt.logl - null.logl))
+    res = FelResult(alpha=alt.theta[:, 0], beta=alt.theta[:, 1], beta_nuisance=alt.theta[:, 2] if has_nuisance else alt.theta[:, 1],
+                    logl_alt=alt.logl, logl_null=null.logl, lrt=lrt, p_value=chi2.sf(lrt, 1),
+                    launches=launches)
+    if pattern_of_site is not None:
+        idx = np.asarray(pattern_of_site)
+        res = FelResult(**{f.name: (getattr(res, f.name)[idx] if f.name != "launches" else res.launches)
+                           for f in dataclasses.fields(FelResult)})
+    return res

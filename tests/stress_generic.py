@@ -133,5 +133,22 @@ for case in range(n_cases):
                 check("partial", device_value(upd, ch), oracle_value(upd))
             elif not templated:
                 check("nothing dirty", device_value(none, none), oracle_value(none))
+        if templated and D > 4 and n_cat == 1 and rng.random() < 0.6:
+            # per-site batched fits on a few patterns: every pattern under its own multipliers, against one
+            # oracle likelihood function per pattern with explicitly exponentiated matrices
+            G = int(rng.integers(1, 4))
+            bgroup = rng.integers(0, G, size=B)
+            bcoef = co[0] * rng.uniform(0.5, 2.0)
+            n_sets = int(rng.integers(1, 4))
+            smult = np.exp(rng.uniform(np.log(0.02), np.log(30.0), (n_sets, pd.S, G, 2)))
+            got = part.site_fits_evaluate(bgroup, bcoef, smult, pi)
+            for st, s_ in zip(rng.integers(0, n_sets, size=5), rng.integers(0, pd.S, size=5)):
+                Qs = q_from(smult[st, s_][bgroup] * bcoef)
+                o1 = oracle.OraclePartition(D, flat.flat_parents, L, codes[:, s_:s_ + 1], ambig, np.ones(1, dtype=np.int64))
+                o1.set_P(nodes, oracle.expm(Qs, True))
+                ref = o1.site_log_likelihoods(nodes, pi)[0]
+                n_checks += 1
+                if not (abs(got[st, s_] - ref) <= 1e-9 * max(1.0, abs(ref)) or got[st, s_] == ref):
+                    raise SystemExit(f"MISMATCH case {case} site fits (D {D}, {taxa} taxa, set {st}, pattern {s_}): {got[st, s_]!r} vs {ref!r}")
     print(f"case {case}: D {D}, {taxa} taxa, {pd.S} patterns, {n_cat} classes, kernel {kernel}, fragment {frag}, {persist}, T {tiles}, shards {shards}, templated {templated}: ok", flush=True)
 print(f"{n_cases} cases, {n_checks} checks passed in {time.time() - t0:.0f} s")

@@ -1,0 +1,88 @@
+"""Host logic of the FEL-style driver (hyphy_amd/fel.py) without a GPU: the lockstep Nelder-Mead and the
+alternative / null bookkeeping, run against a small numpy stand-in for hyphy_hip_site_fits_evaluate (same
+argument meaning: site_mult [sets, S, G, K], log-likelihood of every pattern under its own multipliers)."""
+import numpy as np
+import scipy.linalg
+import scipy.optimize
+
+from hyphy_amd import fel, tree
+
+
+class _NumpySiteFits:
+    """Stand-in with the interface of HipPartition.site_fits_evaluate (tests only; tiny 4-state trees)."""
+
+    def __init__(self, flat, codes, T):
+        self.flat, self.codes, self.T = flat, codes, T
+        self.S, self.B, self.D = codes.shape[1], flat.n_branches, T.shape[1]
+
+    def site_fits_evaluate(self, branch_group, branch_coeffs, site_mult, root_freqs):
+        sm = np.asarray(site_mult, dtype=np.float64)
+        single = sm.ndim == 3
+        if single:
+            sm = sm[None]
+        out = np.zeros(sm.shape[:2])
+        L, I, D = self.flat.L, self.flat.I, self.D
+        idx = np.arange(D)
+        for st in range(sm.shape[0]):
+            for s in range(self.S):
+                x = sm[st, s][np.asarray(branch_group)] * np.asarray(branch_coeffs)
+                Q = np.einsum("bk,kij->bij", x, self.T)
+                Q[:, idx, idx] = 0.0
+                Q[:, idx, idx] = -Q.sum(2)
+                P = np.stack([scipy.linalg.expm(q) for q in Q])
+                cond = np.ones((I, D))
+                for node in range(L + I - 1):
+                    par = int(self.flat.flat_parents[node])
+                    v = np.eye(D)[self.codes[node, s]] if node < L else cond[node - L]
+                    cond[par] *= P[node] @ v
+                out[st, s] = np.log(cond[I - 1] @ np.asarray(root_freqs))
+        return out[0] if single else out
+
+
+def _toy(seed=0, taxa=5, sites=10):
+    rng = np.random.default_rng(seed)
+    flat = tree.flatten(tree.random_tree(taxa, rng))
+    D = 4
+    pi = np.array([0.3, 0.2, 0.25, 0.25])
+    T = np.zeros((2, D, D))
+    T[0, 0, 2] = T[0, 2, 0] = T[0, 1, 3] = T[0, 3, 1] = 1.0           # "synonymous": transitions
+    T[1] = 1.0 - np.eye(D) - T[0]                                      # "non-synonymous": transversions
+    T = T * pi[None, None, :]
+    base = rng.integers(0, D, size=sites)
+    codes = np.where(rng.random((flat.L, sites)) < 0.2, rng.integers(0, D, size=(flat.L, sites)), base[None, :])
+    codes[:, 0] = base[0]                                              # an invariable site: both rates -> 0
+    return flat, codes, T, pi, rng
+
+
+def test_lockstep_nelder_mead_reaches_the_per_site_optima():
+    flat, codes, T, pi, rng = _toy()
+    part = _NumpySiteFits(flat, codes, T)
+    B = flat.n_branches
+    group = np.zeros(B, dtype=np.int64)
+    bc = np.stack([np.full(B, 0.2), np.full(B, 0.1)], axis=1)
+    fit = fel.fit_sites(part, group, bc, pi, np.array([[0, 1]]), fel.START_GRID, max_iter=300)
+    assert fit.theta.shape == (part.S, 2) and (fit.theta >= 0).all()
+    for s in range(part.S):
+        def neg(u, s=s):
+            sm = np.ones((part.S, 1, 2))
+            sm[s, 0] = u * u
+            return -part.site_fits_evaluate(group, bc, sm, pi)[s]
+        best = min((scipy.optimize.minimize(neg, np.sqrt(x0), method="Nelder-Mead",
+                                            options=dict(xatol=1e-8, fatol=1e-12, maxiter=2000)) for x0 in fel.START_GRID[[1, 3, 7, 10]]),
+                   key=lambda r: r.fun)
+        assert fit.logl[s] >= -best.fun - 1e-6, (s, fit.logl[s], -best.fun)
+    # the invariable site: every substitution only lowers the likelihood
+    assert fit.theta[0].max() < 1e-3
+
+
+def test_fel_alternative_contains_the_null():
+    flat, codes, T, pi, rng = _toy(seed=3, taxa=6, sites=8)
+    part = _NumpySiteFits(flat, codes, T)
+    B = flat.n_branches
+    tested = rng.random(B) < 0.5
+    tested[0], tested[1] = True, False
+    res = fel.fel(part, tested, np.full(B, 0.15), np.full(B, 0.1), pi, max_iter=250, pattern_of_site=np.arange(part.S)[::-1])
+    assert res.alpha.shape == (part.S,)
+    assert (res.logl_alt >= res.logl_null - 1e-7).all()
+    assert ((res.p_value >= 0) & (res.p_value <= 1)).all()
+    assert np.allclose(res.lrt, np.maximum(0, 2 * (res.logl_alt - res.logl_null)))

@@ -747,3 +747,26 @@ def test_site_fits_error_paths():
         part.set_q_templates(T)
         with pytest.raises(hip.HipError):  # negative multiplier
             part.site_fits_evaluate(bgroup, bcoef, -smult, pi)
+
+
+def test_fel_driver_on_the_device():
+    """hyphy_amd/fel.py over the HIP entry point: alternative contains the null, optima at least as good as every
+    grid point, and the fitted log-likelihoods reproduce through an independent evaluation."""
+    hip = _hip()
+    from hyphy_amd import fel
+    flat, codes, ambig, pi, T, bgroup, bcoef, smult = _site_fit_case(D=61, taxa=10, sites=48, K=2, G=2, n_sets=1, seed=21,
+                                                                     ambiguity=False)
+    tested = bgroup == 0
+    tested[0], tested[1] = True, False
+    with hip.HipPartition(61, flat.flat_parents, flat.L, codes, ambig, np.ones(48, dtype=np.int64)) as part:
+        part.set_q_templates(T)
+        res = fel.fel(part, tested, bcoef[:, 0], bcoef[:, 1], pi, max_iter=200)
+        group = np.where(tested, 0, 1)
+        theta = np.stack([res.alpha, res.beta, res.beta_nuisance], axis=1)
+        again = part.site_fits_evaluate(group, bcoef, fel._multipliers(theta, np.array([[0, 1], [0, 2]])), pi)
+        grid = part.site_fits_evaluate(group, bcoef, fel._multipliers(
+            np.broadcast_to(np.array([(a, b, b) for a, b in fel.START_GRID])[:, None, :], (12, 48, 3)), np.array([[0, 1], [0, 2]])), pi)
+    assert np.allclose(again, res.logl_alt, rtol=0, atol=1e-9)
+    assert (res.logl_alt >= grid.max(0) - 1e-9).all()
+    assert (res.logl_alt >= res.logl_null - 1e-7).all()
+    assert ((res.p_value >= 0) & (res.p_value <= 1)).all()
