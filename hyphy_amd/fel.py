@@ -93,7 +93,8 @@ def fit_sites(part, branch_group, branch_coeffs, root_freqs, param_map, start_po
         order = np.argsort(-F, axis=1)                                   # best first (maximisation)
         F = np.take_along_axis(F, order, axis=1)
         X = np.take_along_axis(X, order[:, :, None], axis=1)
-        spread = F[:, 0] - F[:, -1]
+        with np.errstate(invalid="ignore"):
+            spread = F[:, 0] - F[:, -1]
         size = np.max(np.abs(X[:, 1:, :] - X[:, :1, :]), axis=(1, 2))
         converged = ((spread < tol) & (size < 1e-5)) | ~np.isfinite(F[:, 0])
         if active is not None:
