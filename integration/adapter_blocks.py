@@ -17,9 +17,30 @@ struct _HyHipPart {
   std::vector<double> pbuf;
   std::vector<int64_t> qnodes;
   std::vector<char> cat_seen;
+  // mode B (device exponentials, INTEGRATION.md): rate matrices the host queued for exponentiation, kept dense
+  std::vector<std::vector<double>> qstash;   // per class: [B][D*D]
+  std::vector<std::vector<char>> q_pending;  // ... not yet handed to the device
+  std::vector<std::vector<char>> host_stale; // ... the node's host-side compExp does not reflect it yet
+  std::vector<long> cat_arg;                 // the catID ComputeBlock used for the class (-1 without categories)
+  long n_stale = 0;
 };
 static std::map<const void *, std::vector<_HyHipPart>> _hyhip_lfs;
-long _hyhip_calls = 0L, _hyhip_cached_calls = 0L;
+static std::map<const void *, std::pair<const void *, long>> _hyhip_tree_owner;  // _TheTree* -> (lf, partition index)
+long _hyhip_calls = 0L, _hyhip_cached_calls = 0L, _hyhip_deferred = 0L;
+// > 0: ExponentiateMatrices hands the queued rate matrices to the adapter instead of exponentiating them on the host.
+// On while Optimize runs (nothing but ComputeBlock reads the transition matrices there; they are brought up to date
+// on the host when it returns); HYPHY_HIP_DEVICE_EXPM=0 keeps mode A, =always forces it (LFCompute benchmarks only:
+// ancestral reconstruction and simulation read the host matrices between evaluations).
+static int _hyhip_defer_depth = 0;
+extern bool (*_hyhip_defer_expm_hook)(_TheTree *, long, _List &, _List &, _SimpleList &);  // tree.cpp copy
+static int _hyphy_hip_expm_mode(void) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *v = getenv("HYPHY_HIP_DEVICE_EXPM");
+    mode = !v ? 1 : (!strcmp(v, "0") ? 0 : (!strcmp(v, "always") ? 2 : 1));
+  }
+  return mode;
+}
 
 static bool _hyphy_hip_enabled(void) {
   static int state = -1;
@@ -35,8 +56,12 @@ static void _hyphy_hip_teardown(const void *lf) {
   if (it == _hyhip_lfs.end()) return;
   for (auto &hp : it->second) hyphy_hip_destroy(hp.part);
   _hyhip_lfs.erase(it);
-  if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %ld ComputeBlock evaluations ran on the device so far (+ %ld through the branch cache)\n", _hyhip_calls, _hyhip_cached_calls);
+  for (auto o = _hyhip_tree_owner.begin(); o != _hyhip_tree_owner.end();)
+    o = o->second.first == lf ? _hyhip_tree_owner.erase(o) : std::next(o);
+  if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %ld ComputeBlock evaluations ran on the device so far (+ %ld through the branch cache); %ld matrix exponentials moved to the device\n", _hyhip_calls, _hyhip_cached_calls, _hyhip_deferred);
 }
+
+static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue, _SimpleList &parallel);
 
 static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_parts, _TheTree *cT,
                              _DataSetFilter const *theFilter, long const *leaf_codes, _Vector *ambigs) {
@@ -65,12 +90,81 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   }
   hp.code_of.clear();
   for (long code = 0; code < L + I; code++) hp.code_of[cT->GetNodeFromFlatIndex(code)] = code;
-  hp.cat_seen.assign(cT->categoryCount > 0 ? cT->categoryCount : 1, 0);
+  const long n_cat = cT->categoryCount > 0 ? cT->categoryCount : 1;
+  hp.cat_seen.assign(n_cat, 0);
+  hp.qstash.assign(n_cat, std::vector<double>());
+  hp.q_pending.assign(n_cat, std::vector<char>(L + I, 0));
+  hp.host_stale.assign(n_cat, std::vector<char>(L + I, 0));
+  hp.cat_arg.assign(n_cat, -1L);
+  hp.n_stale = 0;
+  _hyhip_tree_owner[cT] = std::make_pair(lf, (long)i);
+  if (_hyphy_hip_expm_mode() > 0) {
+    _hyhip_defer_expm_hook = _hyphy_hip_defer_handler;
+    if (_hyphy_hip_expm_mode() == 2 && _hyhip_defer_depth == 0) _hyhip_defer_depth = 1;
+  }
 }
 
 static bool _hyphy_hip_active(const void *lf, long index) {
   auto it = _hyhip_lfs.find(lf);
   return it != _hyhip_lfs.end() && index < (long)it->second.size() && it->second[index].part != nullptr;
+}
+
+// ---- mode B: the host's ExponentiateMatrices hands its queue over instead of exponentiating (tree.cpp copy) ----
+static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue, _SimpleList &parallel) {
+  if (_hyhip_defer_depth <= 0) return false;
+  auto own = _hyhip_tree_owner.find(t);
+  if (own == _hyhip_tree_owner.end()) return false;
+  auto it = _hyhip_lfs.find(own->second.first);
+  if (it == _hyhip_lfs.end() || own->second.second >= (long)it->second.size()) return false;
+  _HyHipPart &hp = it->second[own->second.second];
+  if (!hp.part) return false;
+  const long D = t->GetCodeBase(), DD = D * D, cat = catID < 0 ? 0 : catID;
+  if (cat >= (long)hp.qstash.size()) return false;
+  for (unsigned long id = 0; id < parallel.lLength; id++) {  // validate first: all or nothing
+    _Matrix *m = (_Matrix *)matrixQueue(parallel.get(id));
+    if (!m || !m->is_numeric() || m->GetHDim() != D || m->GetVDim() != D || !m->theData) return false;
+    if (hp.code_of.find(nodesToDo(parallel.get(id))) == hp.code_of.end()) return false;
+  }
+  if (hp.qstash[cat].empty()) hp.qstash[cat].assign((size_t)(hp.code_of.size()) * DD, 0.);
+  hp.cat_arg[cat] = catID;
+  for (unsigned long id = 0; id < parallel.lLength; id++) {
+    const long mid = parallel.get(id);
+    _Matrix *m = (_Matrix *)matrixQueue(mid);
+    const long code = hp.code_of.at(nodesToDo(mid));
+    double *dst = hp.qstash[cat].data() + (size_t)code * DD;
+    if (m->is_dense()) {
+      memcpy(dst, m->theData, sizeof(double) * DD);
+    } else {
+      memset(dst, 0, sizeof(double) * DD);
+      for (long k = 0; k < m->lDim; k++) {
+        const long idx = m->theIndex[k];
+        if (idx >= 0 && idx < DD) dst[idx] = m->theData[k];
+      }
+    }
+    hp.q_pending[cat][code] = 1;
+    if (!hp.host_stale[cat][code]) {
+      hp.host_stale[cat][code] = 1;
+      hp.n_stale++;
+    }
+  }
+  _hyhip_deferred += parallel.lLength;
+  return true;
+}
+
+// bring the host-side transition matrices of one partition up to date (host exponentials of the stashed matrices)
+static void _hyphy_hip_flush_part(_HyHipPart &hp, _TheTree *t) {
+  if (hp.n_stale == 0) return;
+  const long D = t->GetCodeBase(), DD = D * D;
+  for (size_t cat = 0; cat < hp.host_stale.size(); cat++)
+    for (size_t code = 0; code < hp.host_stale[cat].size(); code++)
+      if (hp.host_stale[cat][code]) {
+        _Matrix q(D, D, false, true);
+        memcpy(q.theData, hp.qstash[cat].data() + code * DD, sizeof(double) * DD);
+        ((_CalcNode *)t->GetNodeFromFlatIndex(code))->SetCompExp(&q, hp.cat_arg[cat], true);
+        hp.host_stale[cat][code] = 0;
+        hp.q_pending[cat][code] = 0;  // (the device receives the probabilities if it has not seen this matrix yet:
+      }                               //  _hyphy_hip_compute resends every matrix the host lists)
+  hp.n_stale = 0;
 }
 
 // one ComputeBlock evaluation on the device; returns 0 when *result is valid
@@ -85,22 +179,37 @@ static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catI
   if (first) n_q = B;  // first evaluation of a rate class: hand over every transition matrix
   hp.pbuf.resize((size_t)n_q * D * D);
   hp.qnodes.resize(n_q);
+  long n_pending = 0;
   for (long k = 0; k < n_q; k++) {
+    hp.qnodes[k] = first ? k : hp.code_of.at(matrices(k));
+    n_pending += hp.q_pending[cat][hp.qnodes[k]];
+  }
+  if (n_pending > 0 && n_pending < n_q) {  // mixed (rare): exponentiate the stashed ones on the host, send probabilities
+    _hyphy_hip_flush_part(hp, t);
+    n_pending = 0;
+  }
+  const bool rate_matrices = n_pending > 0;
+  for (long k = 0; k < n_q; k++) {
+    if (rate_matrices) {
+      memcpy(hp.pbuf.data() + (size_t)k * D * D, hp.qstash[cat].data() + (size_t)hp.qnodes[k] * D * D, sizeof(double) * D * D);
+      continue;
+    }
     _CalcNode *n = first ? (_CalcNode *)t->GetNodeFromFlatIndex(k) : (_CalcNode *)matrices(k);
     _Matrix *P = n->GetCompExp(catID);
     if (!P || !P->theData) return 1;
     memcpy(hp.pbuf.data() + (size_t)k * D * D, P->theData, sizeof(double) * D * D);
-    hp.qnodes[k] = first ? k : hp.code_of.at(n);
   }
   double ll = 0.;
   int rc = hyphy_hip_evaluate(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength,
-                              hp.qnodes.data(), n_q, hp.pbuf.data(), /* q_is_probability = */ 1, t->GetProbs(),
-                              &ll, siteRes, (int64_t *)scc);
+                              hp.qnodes.data(), n_q, hp.pbuf.data(), /* q_is_probability = */ rate_matrices ? 0 : 1,
+                              t->GetProbs(), &ll, siteRes, (int64_t *)scc);
   if (rc < 0) {
     HandleApplicationError(_String("hyphy_hip_evaluate: ") & hyphy_hip_last_error());
     return rc;
   }
   if (rc == 0) {
+    if (rate_matrices)
+      for (long k = 0; k < n_q; k++) hp.q_pending[cat][hp.qnodes[k]] = 0;
     hp.cat_seen[cat] = 1;
     _hyhip_calls++;
     *result = ll;
@@ -130,12 +239,20 @@ static int _hyphy_hip_cache_build(const void *lf, long index, long catID, long n
 static int _hyphy_hip_cached(const void *lf, long index, _TheTree *t, long catID, long node, hyFloat *siteRes,
                              long *scc, hyFloat *result) {
   _HyHipPart &hp = _hyhip_lfs[lf][index];
-  _CalcNode *n = (_CalcNode *)t->GetNodeFromFlatIndex(node);
-  _Matrix *P = n->GetCompExp(catID);
-  if (!P || !P->theData) return 1;
+  const long cat = catID < 0 ? 0 : catID, DD = t->GetCodeBase() * t->GetCodeBase();
+  const bool rate_matrix = hp.q_pending[cat][node];  // (mode B: the line search's new matrix was handed over, not exponentiated)
+  const double *mx = nullptr;
+  if (rate_matrix) {
+    mx = hp.qstash[cat].data() + (size_t)node * DD;
+  } else {
+    _Matrix *P = ((_CalcNode *)t->GetNodeFromFlatIndex(node))->GetCompExp(catID);
+    if (!P || !P->theData) return 1;
+    mx = P->theData;
+  }
   double ll = 0.;
-  int rc = hyphy_hip_branch_cache_evaluate(hp.part, catID, node, P->theData, /* q_is_probability = */ 1, &ll, siteRes,
+  int rc = hyphy_hip_branch_cache_evaluate(hp.part, catID, node, mx, /* q_is_probability = */ rate_matrix ? 0 : 1, &ll, siteRes,
                                            (int64_t *)scc);
+  if (rc == 0 && rate_matrix) hp.q_pending[cat][node] = 0;
   if (rc < 0) {
     HandleApplicationError(_String("hyphy_hip_branch_cache_evaluate: ") & hyphy_hip_last_error());
     return rc;
@@ -146,6 +263,23 @@ static int _hyphy_hip_cached(const void *lf, long index, _TheTree *t, long catID
   }
   return rc;
 }
+
+static void _hyphy_hip_flush(_LikelihoodFunction *lf) {
+  auto it = _hyhip_lfs.find(lf);
+  if (it == _hyhip_lfs.end()) return;
+  for (size_t i = 0; i < it->second.size(); i++)
+    if (it->second[i].part) _hyphy_hip_flush_part(it->second[i], lf->GetIthTree(i));
+}
+struct _HyHipOptimizeScope {  // Optimize: device exponentials inside, host matrices brought up to date on the way out
+  _LikelihoodFunction *lf;
+  bool on;
+  explicit _HyHipOptimizeScope(_LikelihoodFunction *l) : lf(l), on(_hyphy_hip_enabled() && _hyphy_hip_expm_mode() == 1) {
+    if (on) _hyhip_defer_depth++;
+  }
+  ~_HyHipOptimizeScope() {
+    if (on && --_hyhip_defer_depth == 0) _hyphy_hip_flush(lf);
+  }
+};
 #endif
 '''
 
@@ -200,7 +334,31 @@ COMPUTE = r'''
         // This call stays on the CPU (pinned node states for marginal ancestral reconstruction, branchIndex >= 0,
         // or an "unsupported" return): the host caches were never filled by the device evaluations before it, so
         // the pass must recompute every node, like the first evaluation after a setup (:10964-10966).
+        _hyphy_hip_flush(this);
         branches->Populate(t->GetINodeCount() + t->GetLeafCount() - 1, 0, 1);
       }
+#endif
+'''
+
+# ---- block 5: Optimize, first statement ----------------------------------------------------------------------------
+OPTIMIZE = r'''
+#ifdef HYPHY_HIP
+  _HyHipOptimizeScope _hyhip_scope(this);
+#endif
+'''
+
+# ---- tree.cpp copy: the hook and its call site in ExponentiateMatrices (mode B) -----------------------------------
+TREE_HOOK_DEF = r'''
+#ifdef HYPHY_HIP
+// set by the likelihood-function adapter (likefunc.cpp copy); returns true when it took the queued rate matrices
+bool (*_hyhip_defer_expm_hook)(_TheTree *, long, _List &, _List &, _SimpleList &) = nullptr;
+#endif
+'''
+TREE_HOOK_CALL = r'''
+#ifdef HYPHY_HIP
+  if (_hyhip_defer_expm_hook && !hasExpForm && serial.lLength == 0UL && parallel.lLength &&
+      _hyhip_defer_expm_hook(this, catID, nodesToDo, matrixQueue, parallel)) {
+    parallel.Clear();  // the device exponentiates these; nothing left for the OpenMP loop below
+  }
 #endif
 '''

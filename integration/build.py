@@ -2,7 +2,7 @@
 """Builds integration/_build/hyphy_hip: the reference HyPhy with its ComputeBlock routed through
 libhyphy_hip.so.  Needs /root/reference (build container only); the result is a binary (git-ignored)
 that travels to the GPU box.  Re-uses the reference objects already compiled by oracle/Makefile.ref —
-only likefunc.cpp is recompiled, from a patched COPY that lives in integration/_build/."""
+only likefunc.cpp and tree.cpp are recompiled, from patched COPIES that live in integration/_build/."""
 import os
 import subprocess
 import sys
@@ -43,8 +43,15 @@ def main():
     # (AB.COMPUTE).  The host-side scaling-factor backup/restore around it is harmless: the device path keeps
     # no sticky scalers.
     lf = splice(lf, "      hyFloat sum = 0.;\n\n      if (doCachedComp >= 3) {", AB.COMPUTE, before=True)
+    lf = splice(lf, "_Matrix *_LikelihoodFunction::Optimize(_AssociativeList const *options) {\n", AB.OPTIMIZE)
     src = os.path.join(OUT, "likefunc_hip.cpp")
     open(src, "w").write(lf)
+    # tree.cpp copy: ExponentiateMatrices offers its queue to the adapter before the OpenMP exponentiation loop (mode B)
+    tr = open(os.path.join(REF, "src/core/tree.cpp")).read()
+    tr = splice(tr, "using namespace hyphy_global_objects;\n", AB.TREE_HOOK_DEF)
+    tr = splice(tr, "  if (parallel.lLength) {\n    if (parallel.lLength == 1) {", AB.TREE_HOOK_CALL, before=True)
+    tsrc = os.path.join(OUT, "tree_hip.cpp")
+    open(tsrc, "w").write(tr)
     # 3. compile that one file with the reference's flags (oracle/Makefile.ref) + -DHYPHY_HIP
     refobj = os.path.join(ROOT, "oracle", "_ref", "obj")
     if not os.path.isdir(refobj):
@@ -54,11 +61,14 @@ def main():
              f"-D_HYPHY_LIBDIRECTORY_=\"/nonexistent\" -I{OUT}/include -I{ROOT}/include "
              f"-I{REF}/src/core/include -I{REF}/src/contrib -I{REF}/src/lib/Link -I{REF}/src/new/include").split()
     obj = os.path.join(OUT, "likefunc_hip.o")
-    subprocess.check_call(["g++"] + flags + ["-c", src, "-o", obj])
-    objs = []
+    tobj = os.path.join(OUT, "tree_hip.o")
+    procs = [subprocess.Popen(["g++"] + flags + ["-c", src, "-o", obj]), subprocess.Popen(["g++"] + flags + ["-c", tsrc, "-o", tobj])]
+    if any(p.wait() != 0 for p in procs):
+        raise SystemExit("compilation of the patched copies failed")
+    objs = [tobj]
     for dp, _, files in os.walk(refobj):
         for f in files:
-            if f.endswith(".o") and not (f == "likefunc.o" and dp.endswith("core")):
+            if f.endswith(".o") and not (f in ("likefunc.o", "tree.o") and dp.endswith("core")):
                 objs.append(os.path.join(dp, f))
     libdir = os.path.join(ROOT, "hyphy_amd", "lib")
     exe = os.path.join(OUT, "hyphy_hip")

@@ -147,3 +147,46 @@ def test_hbl_ancestral_reconstruction_through_adapter_matches_cpu(mode):
     # MARGINAL: one pinned device evaluation per internal node and state (6 x 60 here) on top of the baseline
     assert _device_calls(stdout) > (300 if mode == "marginal" else 0)
     assert len(cpu) > 100 and cpu == gpu
+
+
+def _deferred(stdout):
+    m = re.findall(r"(\d+) matrix exponentials moved to the device", stdout)
+    return max(int(x) for x in m) if m else 0
+
+
+def test_hbl_optimize_exponentiates_on_the_device_and_leaves_host_matrices_current():
+    """Mode B: while Optimize runs, ExponentiateMatrices hands its queue of rate matrices to the
+    adapter (device expm) instead of exponentiating on the host; when Optimize returns the host-side transition
+    matrices are brought up to date, so a consumer that reads them directly — joint ancestral reconstruction inside
+    the same LF_START_COMPUTE bracket — sees the fitted model.  Compared with the same binary in mode A
+    (HYPHY_HIP_DEVICE_EXPM=0: host exponentials) and with the unmodified reference."""
+    _need_binaries()
+    import tempfile
+    from oracle import hbl
+    case = _case("codon", 8, 40, 11)
+
+    def run(binary, env):
+        tmp = tempfile.mkdtemp(prefix="modeb_")
+        fasta, outp, ancp = (os.path.join(tmp, n) for n in ("aln.fasta", "out.txt", "anc.txt"))
+        hbl.write_fasta(fasta, case["names"], case["seqs"])
+        txt = hbl.build_script(fasta=fasta, newick=case["newick"], unit=case["unit"], model_block=case["model_block"],
+                               model_name=case["model_name"], globals_=case["globals_"], branch_t=case["branch_t"],
+                               out_path=outp, per_site=False)
+        tail = ("OPTIMIZATION_PRECISION = 0.001; VERBOSITY_LEVEL = -1;\nOptimize (m2_, lf);\n"
+                f'fprintf ("{outp}", "OPT_LOGL ", Format (m2_[1][0], 30, 17), "\\n");\n'
+                "DataSet anc = ReconstructAncestors (lf);\nDataSetFilter af = CreateFilter (anc, 1);\nDATA_FILE_PRINT_FORMAT = 9;\n"
+                f'fprintf ("{ancp}", CLEAR_FILE, af);\n'
+                "LFCompute (lf, LF_DONE_COMPUTE);\n")
+        assert txt.count("LFCompute (lf, LF_DONE_COMPUTE);\n") == 1
+        txt = txt.replace("LFCompute (lf, LF_DONE_COMPUTE);\n", tail)
+        out = hbl.run_script(txt, tmp, binary=binary, extra_env=env)
+        return open(ancp).read(), hbl.parse_output(outp), out
+
+    anc_cpu, res_cpu, _ = run(None, None)
+    anc_a, res_a, out_a = run(HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="0"))
+    anc_b, res_b, out_b = run(HIP_BIN, ENV)
+    assert _deferred(out_a) == 0
+    assert _deferred(out_b) > 100, out_b[-400:]
+    assert _device_calls(out_b) > 50
+    assert abs(res_b["opt_logl"] - res_cpu["opt_logl"]) <= 2e-3 and abs(res_a["opt_logl"] - res_cpu["opt_logl"]) <= 2e-3
+    assert len(anc_cpu) > 100 and anc_b == anc_a == anc_cpu
