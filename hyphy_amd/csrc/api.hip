@@ -109,6 +109,9 @@ struct Shard {
   uint64_t ring_count = 0;       // evaluations stamped so far
   uint64_t eval_count = 0;
   size_t partial_stride = 0;  // doubles per class
+  // completion of the synchronous entry points: the reduction kernel writes a sequence number behind the result
+  // record in host-mapped memory and the host spins on it (hipStreamSynchronize costs several microseconds more)
+  double seq_next = 1., seq_wait = 0.;
   // per-site batched fits (hyphy_hip_site_fits_evaluate), allocated on first use
   double *fit_Timg = nullptr, *fit_bcoef = nullptr, *fit_smult = nullptr, *fit_out = nullptr, *fit_scratch = nullptr,
          *fit_pi = nullptr;
@@ -470,6 +473,18 @@ int upload_small(Shard &s, const double *src, size_t n, double *dst) {
   return 0;
 }
 
+// Sequence number for the result record of a synchronous evaluation (0: the caller must wait for the stream).
+double next_seq(Shard &s, bool host_record) {
+  static const bool spin = !(getenv("HYPHY_HIP_SPIN") && atoi(getenv("HYPHY_HIP_SPIN")) == 0);
+  if (!spin || !host_record || !s.d_hout) {
+    s.seq_wait = 0.;
+    return 0.;
+  }
+  s.seq_wait = s.seq_next;
+  s.seq_next += 1.;
+  return s.seq_wait;
+}
+
 // Everything in a PruneArgs that does not depend on the schedule being launched.
 PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch) {
   const int64_t B = p->B;
@@ -686,10 +701,11 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     double *rec = s.d_hout ? s.d_hout : s.out;
     double *o0 = d_logl_out ? d_logl_out : rec, *o1 = d_logl_out ? s.out + 1 : rec + 1;
     const int *st = d_logl_out ? nullptr : s.status;
+    const double seq = next_seq(s, !d_logl_out);
     if (n_ops > 0 && !floor_log)  // the pruning kernel left per-workgroup partial sums
-      launch_wg_reduce(s.wg_sum, s.wg_cnt, s.wg_flag, n_wg, o0, o1, st, s.stream);
+      launch_wg_reduce(s.wg_sum, s.wg_cnt, s.wg_flag, n_wg, o0, o1, st, s.stream, seq);
     else  // nothing was recomputed (or category mode): reduce the stored per-pattern values
-      launch_site_reduce(site_lik, site_cnt, s.freq, s.S_pad, floor_log ? 1 : 0, o0, o1, st, s.stream);
+      launch_site_reduce(site_lik, site_cnt, s.freq, s.S_pad, floor_log ? 1 : 0, o0, o1, st, s.stream, seq);
   }
   if (p->all_timings) HIPCHK(hipEventRecord(s.ev[3], s.stream));
   HIPCHK(hipGetLastError());
@@ -737,7 +753,27 @@ int collect_status(hyphy_hip_partition *p) {
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
     if (!s.d_hout) HIPCHK(hipMemcpyAsync(s.h_out, s.out, 3 * sizeof(double), hipMemcpyDeviceToHost, s.stream));
-    HIPCHK(hipStreamSynchronize(s.stream));
+    if (s.seq_wait != 0. && s.d_hout && !expm_prof) {
+      // the last kernel of the evaluation publishes the sequence number after the record (system-scope fence)
+      volatile double *flag = s.h_out + 3;
+      bool seen = false;
+      for (long spins = 1; !seen; spins++) {
+        seen = *flag == s.seq_wait;
+        if (!seen && (spins & 0x3fff) == 0) {  // every few tens of microseconds: has the stream died or finished?
+          const hipError_t q = hipStreamQuery(s.stream);
+          if (q == hipSuccess) {
+            seen = *flag == s.seq_wait;
+            break;
+          }
+          if (q != hipErrorNotReady) return fail(std::string("stream failed: ") + hipGetErrorString(q));
+        }
+      }
+      s.seq_wait = 0.;
+      if (!seen) HIPCHK(hipStreamSynchronize(s.stream));
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
+      HIPCHK(hipStreamSynchronize(s.stream));
+    }
     if (expm_prof) {
       long long t[8];
       expm_read_profile(t);
@@ -1039,6 +1075,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     }
     hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream);
     if (hipHostGetDevicePointer((void **)&s.d_hout, s.h_out, 0) != hipSuccess) s.d_hout = nullptr;
+    for (int k = 0; k < 4; k++) s.h_out[k] = 0.;
     hipMemsetAsync(s.partials, 0, (size_t)C * s.partial_stride * sizeof(double), s.stream);
     hipMemsetAsync(s.counts, 0, (size_t)C * I * s.S_pad * sizeof(int32_t), s.stream);
     hipMemsetAsync(s.site_lik, 0, (size_t)C * s.S_pad * sizeof(double), s.stream);
@@ -1198,7 +1235,7 @@ int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_
     if (upload_small(s, weights, (size_t)p->C, s.weights)) return -1;
     launch_mix_categories(s.site_lik, s.site_cnt, s.weights, (int)p->C, s.S_pad, s.mixed_lik, s.mixed_cnt, s.stream);
     double *rec = s.d_hout ? s.d_hout : s.out;
-    launch_site_reduce(s.mixed_lik, s.mixed_cnt, s.freq, s.S_pad, 1, rec, rec + 1, s.status, s.stream);
+    launch_site_reduce(s.mixed_lik, s.mixed_cnt, s.freq, s.S_pad, 1, rec, rec + 1, s.status, s.stream, next_seq(s, rec == s.d_hout));
   }
   if (collect_status(p)) return -1;
   for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
@@ -1227,7 +1264,7 @@ int hyphy_hip_evaluate_categories_built(hyphy_hip_partition *p, const int64_t *u
   launch_mix_categories(s.site_lik, s.site_cnt, s.weights, (int)p->C, s.S_pad, s.mixed_lik, s.mixed_cnt, s.stream);
   {
     double *rec = s.d_hout ? s.d_hout : s.out;
-    launch_site_reduce(s.mixed_lik, s.mixed_cnt, s.freq, s.S_pad, 1, rec, rec + 1, s.status, s.stream);
+    launch_site_reduce(s.mixed_lik, s.mixed_cnt, s.freq, s.S_pad, 1, rec, rec + 1, s.status, s.stream, next_seq(s, rec == s.d_hout));
   }
   if (collect_status(p)) return -1;
   if (logl_out) *logl_out = s.h_out[0];
@@ -1495,7 +1532,7 @@ int hyphy_hip_branch_cache_evaluate(hyphy_hip_partition *p, int64_t cat, int64_t
     ba.wg_flag = s.wg_flag;
     launch_bc_eval(ba, s.stream);
     double *rec = s.d_hout ? s.d_hout : s.out;
-    launch_wg_reduce(s.wg_sum, s.wg_cnt, s.wg_flag, s.ntiles, rec, rec + 1, s.status, s.stream);
+    launch_wg_reduce(s.wg_sum, s.wg_cnt, s.wg_flag, s.ntiles, rec, rec + 1, s.status, s.stream, next_seq(s, rec == s.d_hout));
     HIPCHK(hipGetLastError());
   }
   if (collect_status(p)) return -1;

@@ -208,9 +208,9 @@ void launch_site_fit(const SiteFitArgs &a, hipStream_t stream);
 void launch_prune_mfma(const PruneArgs &a, hipStream_t stream);
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream);
 void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,
-                        double *out_logl, double *out_cnt, const int *status, hipStream_t stream);
+                        double *out_logl, double *out_cnt, const int *status, hipStream_t stream, double seq = 0.);
 void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *wg_flag, int n, double *out_logl,
-                      double *out_cnt, const int *status, hipStream_t stream);
+                      double *out_cnt, const int *status, hipStream_t stream, double seq = 0.);
 int prune_mfma_grid(const PruneArgs &a);
 int prune_nuc_grid(const NucArgs &a);
 void launch_mix_categories(const double *site_lik /*[C][S_pad]*/, const int32_t *site_cnt, const double *weights_dev,

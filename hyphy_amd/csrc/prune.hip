@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(1024) void site_reduce_kernel(const double *__restr
                                                            const double *__restrict__ freq, int S_pad,
                                                            int floor_log, double *__restrict__ out,
                                                            double *__restrict__ out_cnt,
-                                                           const int *__restrict__ status) {
+                                                           const int *__restrict__ status, double seq) {
   __shared__ double ssum[1024];
   __shared__ double scomp[1024];
   __shared__ long long scnt[1024];
@@ -1086,6 +1086,10 @@ __global__ __launch_bounds__(1024) void site_reduce_kernel(const double *__restr
     out[0] = r;
     out_cnt[0] = (double)scnt[0];
     out_cnt[1] = status ? (double)*status : 0.;  // [log-L, scaler sum, expm status]: one host-visible record
+    if (seq != 0.) {  // host spins on this word instead of waiting for the stream (record complete before it)
+      __threadfence_system();
+      reinterpret_cast<volatile double *>(out_cnt)[2] = seq;
+    }
   }
 }
 
@@ -1095,7 +1099,7 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const double *__restrict
                                                         const long long *__restrict__ wg_cnt,
                                                         const int *__restrict__ wg_flag, int n,
                                                         double *__restrict__ out, double *__restrict__ out_cnt,
-                                                        const int *__restrict__ status) {
+                                                        const int *__restrict__ status, double seq) {
   __shared__ double ssum[256];
   __shared__ double scomp[256];
   __shared__ long long scnt[256];
@@ -1137,6 +1141,10 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const double *__restrict
     out[0] = r;
     out_cnt[0] = (double)scnt[0];
     out_cnt[1] = status ? (double)*status : 0.;  // [log-L, scaler sum, expm status]: one host-visible record
+    if (seq != 0.) {  // host spins on this word instead of waiting for the stream (record complete before it)
+      __threadfence_system();
+      reinterpret_cast<volatile double *>(out_cnt)[2] = seq;
+    }
   }
 }
 
@@ -1260,15 +1268,15 @@ void launch_prune_nuc(const NucArgs &a, hipStream_t stream) {
 }
 
 void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,
-                        double *out, double *out_cnt, const int *status, hipStream_t stream) {
+                        double *out, double *out_cnt, const int *status, hipStream_t stream, double seq) {
   hipLaunchKernelGGL(site_reduce_kernel, dim3(1), dim3(1024), 0, stream, site_lik, site_cnt, freq, S_pad, floor_log,
-                     out, out_cnt, status);
+                     out, out_cnt, status, seq);
 }
 
 void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *wg_flag, int n, double *out_logl,
-                      double *out_cnt, const int *status, hipStream_t stream) {
+                      double *out_cnt, const int *status, hipStream_t stream, double seq) {
   hipLaunchKernelGGL(wg_reduce_kernel, dim3(1), dim3(256), 0, stream, wg_sum, wg_cnt, wg_flag, n, out_logl, out_cnt,
-                     status);
+                     status, seq);
 }
 
 int prune_mfma_grid(const PruneArgs &a) { return a.ntiles / a.T; }
