@@ -770,3 +770,19 @@ def test_fel_driver_on_the_device():
     assert (res.logl_alt >= grid.max(0) - 1e-9).all()
     assert (res.logl_alt >= res.logl_null - 1e-7).all()
     assert ((res.p_value >= 0) & (res.p_value <= 1)).all()
+
+
+def test_site_fits_on_a_sharded_partition(monkeypatch):
+    """device_count > 1 semantics (pattern shards) for the per-site entry point, all shards mapped to device 0."""
+    hip = _hip()
+    flat, codes, ambig, pi, T, bgroup, bcoef, smult = _site_fit_case(D=61, taxa=12, sites=75, K=2, G=2, n_sets=2, seed=31)
+    freq = np.ones(75, dtype=np.int64)
+    with hip.HipPartition(61, flat.flat_parents, flat.L, codes, ambig, freq) as part:
+        part.set_q_templates(T)
+        one = part.site_fits_evaluate(bgroup, bcoef, smult, pi)
+    monkeypatch.setenv("HYPHY_HIP_FORCE_SHARDS", "3")
+    with hip.HipPartition(61, flat.flat_parents, flat.L, codes, ambig, freq) as part:
+        part.set_q_templates(T)
+        three = part.site_fits_evaluate(bgroup, bcoef, smult, pi)
+    monkeypatch.delenv("HYPHY_HIP_FORCE_SHARDS")
+    assert np.array_equal(one, three)
