@@ -2,7 +2,8 @@
 """Builds integration/_build/hyphy_hip: the reference HyPhy with its ComputeBlock routed through
 libhyphy_hip.so.  Needs /root/reference (build container only); the result is a binary (git-ignored)
 that travels to the GPU box.  Re-uses the reference objects already compiled by oracle/Makefile.ref —
-only likefunc.cpp and tree.cpp are recompiled, from patched COPIES that live in integration/_build/."""
+only likefunc.cpp and tree.cpp are recompiled, from patched copies that are written to integration/_build/ and deleted
+again after linking (HYPHY_HIP_KEEP_PATCHED=1 keeps them for debugging)."""
 import os
 import subprocess
 import sys
@@ -27,7 +28,7 @@ def splice(text, anchor, block, before=False, count=1):
 
 
 def main():
-    os.makedirs(os.path.join(OUT, "include"), exist_ok=True)
+    os.makedirs(OUT, exist_ok=True)
     # likefunc.cpp copy with the four adapter blocks.  _TheTree::flatParents is protected and
     # _LikelihoodFunction is not a friend; an upstream patch would add a one-line public accessor to
     # tree.h.  Headers are found next to their includers first, so a shadow copy of
@@ -58,7 +59,7 @@ def main():
         subprocess.check_call(["make", "-f", os.path.join(ROOT, "oracle", "Makefile.ref"), "-j8"])
     flags = ("-std=c++17 -fsigned-char -O3 -fopenmp -w -mavx -mavx2 -mfma -D_SLKP_USE_AVX_INTRINSICS "
              "-D_SLKP_USE_FMA3_INTRINSICS -D__AFYP_REWRITE_BGM__ -D__UNIX__ -D__MP__ -D__MP2__ -DHYPHY_HIP "
-             f"-D_HYPHY_LIBDIRECTORY_=\"/nonexistent\" -I{OUT}/include -I{ROOT}/include "
+             f"-D_HYPHY_LIBDIRECTORY_=\"/nonexistent\" -I{ROOT}/include "
              f"-I{REF}/src/core/include -I{REF}/src/contrib -I{REF}/src/lib/Link -I{REF}/src/new/include").split()
     obj = os.path.join(OUT, "likefunc_hip.o")
     tobj = os.path.join(OUT, "tree_hip.o")
@@ -75,6 +76,10 @@ def main():
     subprocess.check_call(["g++", "-fopenmp", "-o", exe, obj] + sorted(objs) +
                           [f"-L{libdir}", "-lhyphy_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,$ORIGIN/../../hyphy_amd/lib",
                            "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-ldl"])
+    if not os.environ.get("HYPHY_HIP_KEEP_PATCHED"):
+        # the patched copies are intermediate files: nothing derived from the reference's sources stays in the tree
+        for f in (src, tsrc, obj, tobj):
+            os.remove(f)
     print("built", exe)
 
 

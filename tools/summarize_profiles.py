@@ -17,7 +17,9 @@ def kname(full):
 for f in ("bench.json", "bench_alltimings.json"):
     shutil.copy(os.path.join(src, f), os.path.join(out, f"{tag}_{f}"))
 for f, dst in (("ubench_mfma_f64.txt", f"{tag}_ubench_mfma_f64.txt"),
-               ("kernel_choice_by_shard_size.txt", f"{tag}_kernel_choice_by_shard_size.txt")):
+               ("kernel_choice_by_shard_size.txt", f"{tag}_kernel_choice_by_shard_size.txt"),
+               ("all_workloads.txt", f"{tag}_all_workloads.txt"), ("adapter_rate.jsonl", f"{tag}_adapter_rate.jsonl"),
+               ("stress.txt", f"{tag}_stress.txt")):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(out, dst))
 st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
