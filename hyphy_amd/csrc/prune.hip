@@ -872,6 +872,8 @@ __global__ __launch_bounds__(64) void bc_eval_kernel(BcArgs a) {
 // ---------------------------------------------------------------------------------------------
 // (ops and P are separate __restrict__ kernel arguments: schedule entries and transition matrices then come
 //  through scalar loads; as members of the by-value argument struct they were 30 vector loads per entry)
+template <bool PIN>  // PIN: a node's states are pinned (hyphy_hip_set_pinned_states); compiled apart — the extra
+                      // select per leaf entry costs the HBM-bound kernel 30 % (54 vs 41 us at gtr_32x50k)
 __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__ ops, const double *__restrict__ Pm,
                                                         NucArgs a) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;  // S_pad is a multiple of the block size
@@ -892,7 +894,8 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
   auto code_of = [&](const int4 &o) -> int {
     if ((o.x & 3) != OPK_LEAF) return 0;
     const int lf = o.z & 0xffff;
-    return lf == a.pin_leaf ? (int)a.pin[s] : (int)a.codes[(size_t)lf * S_pad + s];  // (pinned leaf: its states replace the data)
+    if (PIN && lf == a.pin_leaf) return (int)a.pin[s];  // (pinned leaf: its states replace the data)
+    return (int)a.codes[(size_t)lf * S_pad + s];
   };
   int code = code_of(op);
   for (int oi = 0; oi < a.n_ops; oi++) {
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
       }
     }
     if (op.x & OPF_LAST) {
-      if (parent == a.pin_inode) {  // pinned internal node: only the pinned state survives
+      if (PIN && parent == a.pin_inode) {  // pinned internal node: only the pinned state survives
         const int ps = (int)a.pin[s];
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i] = (i == ps) ? acc[i] : 0.;
@@ -1264,7 +1267,8 @@ void launch_prune_mfma(const PruneArgs &a, hipStream_t stream) {
 
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream) {
   if (a.n_ops <= 0) return;
-  hipLaunchKernelGGL(prune_nuc_kernel, dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a.ops, a.P, a);
+  if (a.pin_leaf >= 0 || a.pin_inode >= 0) hipLaunchKernelGGL(prune_nuc_kernel<true>, dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a.ops, a.P, a);
+  else hipLaunchKernelGGL(prune_nuc_kernel<false>, dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a.ops, a.P, a);
 }
 
 void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,
