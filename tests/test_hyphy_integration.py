@@ -190,3 +190,18 @@ def test_hbl_optimize_exponentiates_on_the_device_and_leaves_host_matrices_curre
     assert _device_calls(out_b) > 50
     assert abs(res_b["opt_logl"] - res_cpu["opt_logl"]) <= 2e-3 and abs(res_a["opt_logl"] - res_cpu["opt_logl"]) <= 2e-3
     assert len(anc_cpu) > 100 and anc_b == anc_a == anc_cpu
+
+
+def test_hbl_optimize_with_rate_categories_through_device():
+    """Optimize of a model with 3 rate classes: ComputeBlock runs once per class (catID >= 0), so mode B stashes the
+    rate matrices per class; the fit must land on the CPU optimum."""
+    _need_binaries()
+    from oracle import hbl
+    cat = dict(name="rc", weights=[0.7, 0.25, 0.05], values=[0.1, 1.0, 5.0])
+    case = _case("codon", 8, 40, 11, category=cat)
+    cpu = hbl.evaluate(optimize=True, per_site=False, **case)
+    gpu = hbl.evaluate(optimize=True, per_site=False, binary=HIP_BIN, extra_env=ENV, **case)
+    assert _device_calls(gpu["stdout"]) > 50
+    assert _deferred(gpu["stdout"]) > 100
+    assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3
+    assert abs(gpu["logl"] - cpu["logl"]) <= 1e-10 * abs(cpu["logl"])
