@@ -1712,6 +1712,29 @@ int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t
   }
   std::vector<int> grp(B);
   for (int64_t b = 0; b < B; b++) grp[b] = (int)branch_group[b];
+  {
+    // The series length of an edge grows linearly with its uniformisation rate mu = sum_k x_k dmax_k (sitefit.hip);
+    // refuse parameter vectors that would keep a wave busy for seconds (rates this large mean "saturated" anyway).
+    std::vector<double> cmax((size_t)n_groups * K, 0.0);  // per group and template: largest branch coefficient x dmax
+    for (int64_t b = 0; b < B; b++)
+      for (int64_t k = 0; k < K; k++)
+        cmax[grp[b] * K + k] = std::max(cmax[grp[b] * K + k], branch_coeffs[b * K + k] * fa.dmax[k]);
+    double mu_max = 0.;
+    const size_t gk = (size_t)n_groups * K;
+    for (int64_t r = 0; r < n_sets * S; r++)
+      for (int64_t g = 0; g < n_groups; g++) {
+        double mu = 0.;
+        for (int64_t k = 0; k < K; k++) mu += site_mult[r * gk + g * K + k] * cmax[g * K + k];
+        mu_max = std::max(mu_max, mu);
+      }
+    if (!(mu_max <= kSiteFitMaxRate)) {
+      char msg[160];
+      snprintf(msg, sizeof msg, "site fits: uniformisation rate %.3g of some site and branch exceeds the limit %.3g "
+               "(multipliers too large for this entry point)", mu_max, kSiteFitMaxRate);
+      g_last_error = msg;
+      return 1;
+    }
+  }
   std::vector<double> pi(DP, 0.0);
   for (int64_t k = 0; k < D; k++) pi[k] = root_freqs[k];
   const size_t GK = (size_t)n_groups * K;

@@ -138,6 +138,8 @@ struct NucArgs {
 constexpr int kSiteFitParkSlots = 1;  // wave-private LDS parking slots of the per-site fit kernel (8 KiB each at D = 61); nodes
                                       // beyond that go through a scratch copy in HBM (cheap next to the series of an edge)
 
+constexpr double kSiteFitMaxRate = 4096.0;  // largest uniformisation rate hyphy_hip_site_fits_evaluate accepts (64 sub-series)
+
 // Per-site batched fits (sitefit.hip): one wave per (16-site tile, parameter set)
 struct SiteFitArgs {
   const int4 *ops;           // full post-order schedule, compiled for 2 + kSiteFitParkSlots slots, lazy persistence

@@ -46,12 +46,13 @@ def _multipliers(theta: np.ndarray, param_map: np.ndarray) -> np.ndarray:
 
 
 def fit_sites(part, branch_group, branch_coeffs, root_freqs, param_map, start_points: np.ndarray,
-              max_iter: int = 400, tol: float = 1e-9, upper: float = 1e4, x_init: Optional[np.ndarray] = None,
+              max_iter: int = 400, tol: float = 1e-9, upper: float = 1e3, x_init: Optional[np.ndarray] = None,
               active: Optional[np.ndarray] = None) -> SiteFit:
     """Maximise every site's log-likelihood over its own parameter vector theta (P entries, all >= 0).
 
     ``start_points`` [n_start, P]: every site starts from the best of these (one launch).  Lockstep Nelder-Mead in
-    u = sqrt(theta) (keeps theta >= 0 without constraints, boundary optima theta = 0 are reachable).
+    u = sqrt(theta) (keeps theta >= 0 without constraints, boundary optima theta = 0 are reachable); theta is capped at
+    ``upper`` (the cost of an evaluation grows linearly with the rates, and the entry point refuses total rates > 4096).
     ``x_init`` [S, P]: an extra per-site starting point.  ``active`` [S] bool: only these sites are fitted — the others
     are evaluated with all-zero multipliers (the kernel skips zero-rate tiles) and come back with logl = nan."""
     pm = np.asarray(param_map, dtype=np.int64)

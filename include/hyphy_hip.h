@@ -184,7 +184,9 @@ double *hyphy_hip_q_buffer(hyphy_hip_partition *p); /* device pointer, capacity 
  * entries must be >= 0.  The transition matrices are never formed: each pruning step applies exp(Q_{b,s}) to the
  * child's conditional vector by uniformisation on the FP64 matrix cores (sitefit.hip).  The result agrees with
  * "exponentiate, then multiply" to rounding (both are approximations of the same exact value; this one has
- * componentwise relative accuracy).  Returns 1 (unsupported) for 4-state partitions and K > 4.
+ * componentwise relative accuracy).  Cost per edge grows linearly with the site's total rate on that branch
+ * (sum_k multiplier * coefficient * max_i |T_k[i][i]|); rates above 4096 are refused.  Returns 1 (unsupported) for
+ * 4-state partitions, K > 4 and such rates.
  */
 int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t n_groups,
                                  const int64_t *branch_group /* [L+I-1] */, const double *branch_coeffs /* [L+I-1][K] */,

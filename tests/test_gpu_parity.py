@@ -747,6 +747,8 @@ def test_site_fits_error_paths():
         part.set_q_templates(T)
         with pytest.raises(hip.HipError):  # negative multiplier
             part.site_fits_evaluate(bgroup, bcoef, -smult, pi)
+        with pytest.raises(hip.HipUnsupported):  # total rate beyond the entry point's limit (series length ~ rate)
+            part.site_fits_evaluate(bgroup, bcoef, smult * 1e7, pi)
 
 
 def test_fel_driver_on_the_device():
