@@ -113,8 +113,8 @@ struct Shard {
   // record in host-mapped memory and the host spins on it (hipStreamSynchronize costs several microseconds more)
   double seq_next = 1., seq_wait = 0.;
   // per-site batched fits (hyphy_hip_site_fits_evaluate), allocated on first use
-  double *fit_Timg = nullptr, *fit_bcoef = nullptr, *fit_smult = nullptr, *fit_out = nullptr, *fit_scratch = nullptr,
-         *fit_pi = nullptr;
+  double *fit_Timg = nullptr, *fit_bcoef = nullptr, *fit_smult = nullptr, *fit_smix = nullptr, *fit_out = nullptr,
+         *fit_scratch = nullptr, *fit_pi = nullptr;
   int *fit_bgroup = nullptr;
   int32_t *fit_scratch_cnt = nullptr;
   int4 *fit_ops = nullptr;
@@ -182,7 +182,7 @@ void free_shard(Shard &s) {
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
                  s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.codes_tile,
-                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_out, s.fit_scratch,
+                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops};
   for (void *d : dev)
     if (d) hipFree(d);
@@ -1630,9 +1630,9 @@ int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs) {
 // multipliers (FEL.bf:593-605: fel.alpha_scaler, fel.beta_scaler_test, fel.beta_scaler_nuisance) with one
 // single-site likelihood function per site; this evaluates ALL patterns of the partition, each under its own
 // multipliers, for n_sets candidate parameter vectors per pattern in one launch.
-int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t n_groups, const int64_t *branch_group,
-                                 const double *branch_coeffs, const double *site_mult, const double *root_freqs,
-                                 double *site_logl_out) {
+static int site_fits_common(hyphy_hip_partition *p, int64_t n_sets, int64_t n_groups, int64_t n_mix,
+                            const int64_t *branch_group, const double *branch_coeffs, const double *site_mult,
+                            const double *site_weights, const double *root_freqs, double *site_logl_out) {
   if (!p) return fail("partition == NULL");
   if (p->nuc) {
     g_last_error = "site fits: not available for the 4-state path";
@@ -1643,8 +1643,10 @@ int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t
     g_last_error = "site fits: at most 4 templates";
     return 1;
   }
-  if (n_sets < 1 || n_sets > 65535 || n_groups < 1 || n_groups > 16) return fail("site fits: bad set / group count");
-  if (!branch_group || !branch_coeffs || !site_mult || !root_freqs || !site_logl_out) return fail("site fits: null argument");
+  if (n_sets < 1 || n_sets > 65535 || n_groups < 1 || n_groups > 16 || n_mix < 1 || n_mix > 8)
+    return fail("site fits: bad set / group / mixture-component count");
+  if (!branch_group || !branch_coeffs || !site_mult || !root_freqs || !site_logl_out || (n_mix > 1 && !site_weights))
+    return fail("site fits: null argument");
   const int64_t D = p->D, B = p->B, K = p->K, S = p->S;
   const int L = (int)p->L, I = (int)p->I, DP = p->DP, NW = p->NW;
   const int NKK = 4 * NW, TILE = NKK * 64;
@@ -1652,8 +1654,11 @@ int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t
     if (branch_group[b] < 0 || branch_group[b] >= n_groups) return fail("site fits: branch group out of range");
   for (int64_t b = 0; b < B * K; b++)
     if (!(branch_coeffs[b] >= 0.)) return fail("site fits: branch coefficients must be non-negative");
-  for (int64_t k = 0; k < n_sets * S * n_groups * K; k++)
+  for (int64_t k = 0; k < n_sets * S * n_mix * n_groups * K; k++)
     if (!(site_mult[k] >= 0.)) return fail("site fits: site multipliers must be non-negative");
+  if (n_mix > 1)
+    for (int64_t k = 0; k < n_sets * S * n_mix; k++)
+      if (!(site_weights[k] >= 0.)) return fail("site fits: mixture weights must be non-negative");
 
   // schedule of a full pass, compiled for this kernel's slot budget (lazy persistence: only nodes that find no
   // parking slot are stored, to the scratch copy)
@@ -1721,7 +1726,7 @@ int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t
         cmax[grp[b] * K + k] = std::max(cmax[grp[b] * K + k], branch_coeffs[b * K + k] * fa.dmax[k]);
     double mu_max = 0.;
     const size_t gk = (size_t)n_groups * K;
-    for (int64_t r = 0; r < n_sets * S; r++)
+    for (int64_t r = 0; r < n_sets * S * n_mix; r++)
       for (int64_t g = 0; g < n_groups; g++) {
         double mu = 0.;
         for (int64_t k = 0; k < K; k++) mu += site_mult[r * gk + g * K + k] * cmax[g * K + k];
@@ -1737,7 +1742,7 @@ int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t
   }
   std::vector<double> pi(DP, 0.0);
   for (int64_t k = 0; k < D; k++) pi[k] = root_freqs[k];
-  const size_t GK = (size_t)n_groups * K;
+  const size_t GK = (size_t)n_mix * n_groups * K;  // multipliers per (set, pattern)
 
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
@@ -1761,8 +1766,11 @@ int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t
       if (s.fit_out) hipFree(s.fit_out);
       s.fit_smult = s.fit_out = nullptr;
       s.fit_sets_cap = 0;
+      if (s.fit_smix) hipFree(s.fit_smix);
+      s.fit_smix = nullptr;
       HIPCHK(hipMalloc((void **)&s.fit_smult, need * s.S_pad * sizeof(double)));
       HIPCHK(hipMalloc((void **)&s.fit_out, need * s.S_pad * sizeof(double)));
+      HIPCHK(hipMalloc((void **)&s.fit_smix, need * s.S_pad * sizeof(double)));
       s.fit_sets_cap = need;
     }
     if (p->fit_spills && s.fit_scratch_sets < (size_t)n_sets) {
@@ -1787,6 +1795,13 @@ int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t
     for (int64_t st = 0; st < n_sets; st++)
       memcpy(sm.data() + (size_t)st * s.S_pad * GK, site_mult + ((size_t)st * S + s.s0) * GK, (size_t)s.S * GK * sizeof(double));
     HIPCHK(hipMemcpyAsync(s.fit_smult, sm.data(), sm.size() * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    std::vector<double> wm;
+    if (n_mix > 1) {  // mixture weights, same padding (they share the multipliers' allocation: need >= n_sets * n_mix)
+      wm.assign((size_t)n_sets * s.S_pad * n_mix, 0.0);
+      for (int64_t st = 0; st < n_sets; st++)
+        memcpy(wm.data() + (size_t)st * s.S_pad * n_mix, site_weights + ((size_t)st * S + s.s0) * n_mix, (size_t)s.S * n_mix * sizeof(double));
+      HIPCHK(hipMemcpyAsync(s.fit_smix, wm.data(), wm.size() * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    }
     HIPCHK(hipMemcpyAsync(s.fit_bcoef, branch_coeffs, (size_t)B * K * sizeof(double), hipMemcpyHostToDevice, s.stream));
     HIPCHK(hipMemcpyAsync(s.fit_bgroup, grp.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, s.stream));
     HIPCHK(hipMemcpyAsync(s.fit_pi, pi.data(), (size_t)DP * sizeof(double), hipMemcpyHostToDevice, s.stream));
@@ -1805,6 +1820,8 @@ int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t
     fa.bcoef = s.fit_bcoef;
     fa.bgroup = s.fit_bgroup;
     fa.smult = s.fit_smult;
+    fa.n_mix = (int)n_mix;
+    fa.smix = s.fit_smix;
     fa.codes_tile = s.codes_tile;
     fa.ambig = s.ambig;
     fa.pi = s.fit_pi;
@@ -1834,6 +1851,21 @@ int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t
   return 0;
 }
 
+
+int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t n_groups, const int64_t *branch_group,
+                                 const double *branch_coeffs, const double *site_mult, const double *root_freqs,
+                                 double *site_logl_out) {
+  return site_fits_common(p, n_sets, n_groups, 1, branch_group, branch_coeffs, site_mult, nullptr, root_freqs, site_logl_out);
+}
+
+// Branch-site mixtures per site (MEME / BS-REL style "explicit form" models): on every branch the transition
+// matrix of site s is P = sum_m site_weights[s][m] exp(Q^(m)_{b,s}); the series runs once per component (sitefit.hip).
+int hyphy_hip_site_fits_evaluate_mixture(hyphy_hip_partition *p, int64_t n_sets, int64_t n_groups, int64_t n_mix,
+                                         const int64_t *branch_group, const double *branch_coeffs, const double *site_mult,
+                                         const double *site_weights, const double *root_freqs, double *site_logl_out) {
+  return site_fits_common(p, n_sets, n_groups, n_mix, branch_group, branch_coeffs, site_mult, site_weights, root_freqs,
+                          site_logl_out);
+}
 
 double hyphy_hip_site_fits_kernel_ms(const hyphy_hip_partition *p) { return p ? p->fit_kernel_ms : 0.; }
 

@@ -150,7 +150,9 @@ struct SiteFitArgs {
   const double *Timg;        // [K][NW][NKK*64] A-operand images of the templates, diagonal = -(row sum)
   const double *bcoef;       // [B][K] branch coefficients
   const int *bgroup;         // [B]    multiplier group of each branch
-  const double *smult;       // [n_sets][S_pad][G][K] site multipliers (0 for padding sites)
+  const double *smult;       // [n_sets][S_pad][n_mix][G][K] site multipliers (0 for padding sites)
+  int n_mix;                 // mixture components per site (1: plain per-site fits)
+  const double *smix;        // [n_sets][S_pad][n_mix] mixture weights (n_mix > 1)
   const int16_t *codes_tile; // [ntiles][L][16]
   const double *ambig;       // [n_ambig][DP]
   const double *pi;          // [DP]

@@ -65,13 +65,16 @@ __device__ __forceinline__ int rescale_decision(double tot, double &sc) {
 constexpr double kMuStep = 64.0;      // uniformisation rate handled by one Poisson series (e^-64 is a normal double)
 constexpr double kTailEps = 1e-18;    // neglected Poisson mass (relative to total mass 1)
 
-template <int NW, int NP>
+template <int NW, int NP, bool MIX>
 __global__ __launch_bounds__(64, 2) void site_fit_kernel(const int4 *__restrict__ ops, const double *__restrict__ Timg,
                                                          const double *__restrict__ bcoef, const int *__restrict__ bgroup,
                                                          SiteFitArgs a) {
   constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
   __shared__ __align__(16) double park[NP * TILE];
   __shared__ __align__(16) double accl[TILE];  // running product of the current parent (registers are needed for the series)
+  // MIX (branch-site mixtures: P_b = sum_m w_m exp(Q_b^(m)) per site, MEME / BS-REL style): the edge's operand vector,
+  // kept while the series runs once per mixture component
+  __shared__ __align__(16) double vsave[MIX ? TILE : 2];
   __shared__ int park_cnt[NP][16];
   extern __shared__ __align__(16) int16_t codes_lds[];  // [L][16]
 
@@ -85,7 +88,9 @@ __global__ __launch_bounds__(64, 2) void site_fit_kernel(const int4 *__restrict_
     __syncthreads();
   }
   // this lane's site: multipliers [G][K] of the set
-  const double *sm = a.smult + ((size_t)set * a.S_pad + (size_t)tile0 * 16 + sl) * (size_t)(a.G * K);
+  const int n_mix = MIX ? a.n_mix : 1;
+  const double *sm0 = a.smult + ((size_t)set * a.S_pad + (size_t)tile0 * 16 + sl) * (size_t)(n_mix * a.G * K);
+  const double *wmix = MIX ? a.smix + ((size_t)set * a.S_pad + (size_t)tile0 * 16 + sl) * (size_t)n_mix : nullptr;
 
   const f64x4 ones = (f64x4){1., 1., 1., 1.}, zeros = (f64x4){0., 0., 0., 0.};
   f64x4 bch[NW];  // the node finalised last (scaled)
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(64, 2) void site_fit_kernel(const int4 *__restrict_
 
   // acc *= exp(Q_{branch, site}) v   for the 16 sites of the tile (v: [NW] C/D-image registers = B-operand image)
   f64x4 term[NW];  // the edge's operand vector on entry (filled by the schedule entry), the series' running term inside
-  auto apply_edge = [&](int branch) {
+  auto series = [&](int branch, const double *sm) {  // term <- exp(Q_{branch, site}) term
     const int grp = bgroup[branch];
     // per-site coefficients of the (<= 4) templates; named scalars: a runtime-indexed array would live in scratch
     const double x0 = sm[grp * K] * bcoef[branch * K];
@@ -120,10 +125,7 @@ __global__ __launch_bounds__(64, 2) void site_fit_kernel(const int4 *__restrict_
     const double x3 = K > 3 ? sm[grp * K + 3] * bcoef[branch * K + 3] : 0.;
     const double mu = fma(x0, a.dmax[0], fma(x1, a.dmax[1], fma(x2, a.dmax[2], x3 * a.dmax[3])));
     const double mu_max = wave_max(mu);
-    if (!(mu_max > 0.)) {  // zero-length branch for every site of the tile: exp(Q) = I
-      acc_multiply(term);
-      return;
-    }
+    if (!(mu_max > 0.)) return;  // zero-length branch for every site of the tile: exp(Q) = I
     const int n_sub = (int)ceil(mu_max / kMuStep);
     const double mu_sub = mu / (double)n_sub, mu_sub_max = mu_max / (double)n_sub;
     const double inv_mu = mu > 0. ? 1.0 / mu : 0.;
@@ -178,7 +180,37 @@ __global__ __launch_bounds__(64, 2) void site_fit_kernel(const int4 *__restrict_
 #pragma unroll
       for (int w = 0; w < NW; w++) term[w] = sum[w];
     }
-    acc_multiply(term);
+  };
+  auto apply_edge = [&](int branch) {
+    if (!MIX) {
+      series(branch, sm0);
+      acc_multiply(term);
+      return;
+    }
+    // mixture: the node finalised last (bch) is dead from here to the next finalisation — the schedule reads it only
+    // in the FIRST entry of the next parent, which has copied it into `term` already — so its registers accumulate
+    // sum_m w_m exp(Q^(m)) v
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      *reinterpret_cast<f64x2 *>(vsave + ((2 * w) * 64 + lane) * 2) = (f64x2){term[w][0], term[w][1]};
+      *reinterpret_cast<f64x2 *>(vsave + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){term[w][2], term[w][3]};
+      bch[w] = zeros;
+    }
+    for (int m = 0; m < n_mix; m++) {
+      if (m > 0) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          const f64x2 lo = *reinterpret_cast<const f64x2 *>(vsave + ((2 * w) * 64 + lane) * 2);
+          const f64x2 hi = *reinterpret_cast<const f64x2 *>(vsave + ((2 * w + 1) * 64 + lane) * 2);
+          term[w] = (f64x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+      }
+      series(branch, sm0 + (size_t)m * a.G * K);
+      const double wm = wmix[m];
+#pragma unroll
+      for (int w = 0; w < NW; w++) bch[w] += term[w] * wm;
+    }
+    acc_multiply(bch);
   };
 
   int4 op = ops[0];
@@ -301,7 +333,8 @@ template <int NW>
 void launch_site_fit_NW(const SiteFitArgs &a, hipStream_t stream) {
   const dim3 grid(a.ntiles, a.n_sets), block(64);
   const size_t lds = (size_t)a.L * 16 * sizeof(int16_t);
-  hipLaunchKernelGGL((site_fit_kernel<NW, kSiteFitParkSlots>), grid, block, lds, stream, a.ops, a.Timg, a.bcoef, a.bgroup, a);
+  if (a.n_mix > 1) hipLaunchKernelGGL((site_fit_kernel<NW, kSiteFitParkSlots, true>), grid, block, lds, stream, a.ops, a.Timg, a.bcoef, a.bgroup, a);
+  else hipLaunchKernelGGL((site_fit_kernel<NW, kSiteFitParkSlots, false>), grid, block, lds, stream, a.ops, a.Timg, a.bcoef, a.bgroup, a);
 }
 
 }  // namespace

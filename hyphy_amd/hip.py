@@ -23,7 +23,7 @@ EXPORTS = [
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
-    "hyphy_hip_set_pinned_states", "hyphy_hip_site_fits_evaluate", "hyphy_hip_site_fits_kernel_ms",
+    "hyphy_hip_set_pinned_states", "hyphy_hip_site_fits_evaluate", "hyphy_hip_site_fits_evaluate_mixture", "hyphy_hip_site_fits_kernel_ms",
     "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
@@ -74,6 +74,8 @@ def load():
     lib.hyphy_hip_evaluate_categories_built.argtypes = [vp, lp, C.c_int64, lp, C.c_int64, dp, dp, dp]
     lib.hyphy_hip_site_fits_evaluate.restype = C.c_int
     lib.hyphy_hip_site_fits_evaluate.argtypes = [vp, C.c_int64, C.c_int64, lp, dp, dp, dp, dp]
+    lib.hyphy_hip_site_fits_evaluate_mixture.restype = C.c_int
+    lib.hyphy_hip_site_fits_evaluate_mixture.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, lp, dp, dp, dp, dp, dp]
     lib.hyphy_hip_site_fits_kernel_ms.restype = C.c_double
     lib.hyphy_hip_site_fits_kernel_ms.argtypes = [vp]
     lib.hyphy_hip_q_buffer.restype = vp
@@ -347,6 +349,23 @@ class HipPartition:
         rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
         out = np.zeros((n_sets, S))
         _check(self._lib.hyphy_hip_site_fits_evaluate(self._h, n_sets, G, _l(bg), _d(bc), _d(sm), _d(rf), _d(out)))
+        return out[0] if single else out
+
+    def site_fits_evaluate_mixture(self, branch_group, branch_coeffs, site_mult, site_weights, root_freqs) -> np.ndarray:
+        """Branch-site mixture per site: ``site_mult`` [n_sets, S, n_mix, n_groups, K], ``site_weights`` [n_sets, S, n_mix]
+        (or both without the leading n_sets axis); returns site log-likelihoods [n_sets, S] (or [S])."""
+        bg = np.ascontiguousarray(branch_group, dtype=np.int64)
+        bc = np.ascontiguousarray(branch_coeffs, dtype=np.float64)
+        sm = np.ascontiguousarray(site_mult, dtype=np.float64)
+        sw = np.ascontiguousarray(site_weights, dtype=np.float64)
+        single = sm.ndim == 4
+        if single:
+            sm, sw = sm[None], sw[None]
+        n_sets, S, M, G, K = sm.shape
+        assert S == self.S and sw.shape == (n_sets, S, M) and bg.shape == (self.B,) and bc.shape == (self.B, K)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        out = np.zeros((n_sets, S))
+        _check(self._lib.hyphy_hip_site_fits_evaluate_mixture(self._h, n_sets, G, M, _l(bg), _d(bc), _d(sm), _d(sw), _d(rf), _d(out)))
         return out[0] if single else out
 
     def site_fits_kernel_ms(self) -> float:

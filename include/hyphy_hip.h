@@ -192,6 +192,19 @@ int hyphy_hip_site_fits_evaluate(hyphy_hip_partition *p, int64_t n_sets, int64_t
                                  const int64_t *branch_group /* [L+I-1] */, const double *branch_coeffs /* [L+I-1][K] */,
                                  const double *site_mult /* [n_sets][S][n_groups][K] */, const double *root_freqs,
                                  double *site_logl_out /* [n_sets][S] */);
+/*
+ * The same with a branch-site MIXTURE per site (the "explicit form" models of SURVEY §3.4: MEME's two omega classes per
+ * site, `res/TemplateBatchFiles/SelectionAnalyses/MEME.bf`; BS-REL, `libv3/models/codon/BS_REL.bf:34-60`, where
+ * `tree.cpp:3047-3090` forms P = sum_m w_m exp(Q_m) on every branch): site s evolves on branch b with
+ *       P_{b,s} = sum_m site_weights[set][s][m] * exp(Q^(m)_{b,s}),
+ *       Q^(m)_{b,s} = sum_k site_mult[set][s][m][branch_group[b]][k] * branch_coeffs[b][k] * T_k.
+ * n_mix <= 8; weights >= 0 (normally summing to 1).
+ */
+int hyphy_hip_site_fits_evaluate_mixture(hyphy_hip_partition *p, int64_t n_sets, int64_t n_groups, int64_t n_mix,
+                                         const int64_t *branch_group, const double *branch_coeffs,
+                                         const double *site_mult /* [n_sets][S][n_mix][n_groups][K] */,
+                                         const double *site_weights /* [n_sets][S][n_mix] */, const double *root_freqs,
+                                         double *site_logl_out /* [n_sets][S] */);
 double hyphy_hip_site_fits_kernel_ms(const hyphy_hip_partition *p); /* duration of the last site-fit kernel */
 /* Synchronous evaluation from the rate matrices staged by the last hyphy_hip_build_q() (n matrices,
  * in the order of q_nodes): template models never move a dense Q across PCIe — only the n*K

@@ -788,3 +788,49 @@ def test_site_fits_on_a_sharded_partition(monkeypatch):
         three = part.site_fits_evaluate(bgroup, bcoef, smult, pi)
     monkeypatch.delenv("HYPHY_HIP_FORCE_SHARDS")
     assert np.array_equal(one, three)
+
+
+@pytest.mark.parametrize("name,kw,n_mix", [
+    ("codon_two_classes", dict(D=61, taxa=12, sites=36, K=2, G=2, n_sets=2, seed=41), 2),
+    ("codon_three_classes_spills", dict(D=61, taxa=24, sites=20, K=2, G=1, n_sets=1, seed=42, balanced=True), 3),
+    ("protein_two_classes", dict(D=20, taxa=9, sites=33, K=1, G=2, n_sets=1, seed=43), 2),
+])
+def test_site_fits_branch_site_mixture_matches_explicit_form_reference(name, kw, n_mix):
+    """hyphy_hip_site_fits_evaluate_mixture against the reference's explicit-form route restated with the oracle: per site,
+    P_b = sum_m w_m Exp(Q_b^(m)) (tree.cpp:3047-3090) and a one-pattern pruning pass.  1e-9 relative on the site log-L."""
+    hip = _hip()
+    from oracle import oracle
+    D = kw["D"]
+    flat, codes, ambig, pi, T, bgroup, bcoef, smult = _site_fit_case(**kw)
+    rng = np.random.default_rng(kw["seed"] + 100)
+    n_sets, S, G, K = smult.shape
+    sm = np.exp(rng.uniform(np.log(0.02), np.log(8.0), (n_sets, S, n_mix, G, K)))
+    sm[0, :2] = 0.0                       # every rate zero in every component
+    sm[-1, 2:5, 0] = 0.0                  # one component without substitutions
+    sw = rng.dirichlet(np.full(n_mix, 2.0), size=(n_sets, S))
+    sw[0, 5] = np.eye(n_mix)[0]           # degenerate mixture
+    B = flat.n_branches
+    nodes = np.arange(B, dtype=np.int64)
+    idx = np.arange(D)
+    ref = np.zeros((n_sets, S))
+    for st in range(n_sets):
+        for s in range(S):
+            P = np.zeros((B, D, D))
+            for m in range(n_mix):
+                Q = np.einsum("bk,kij->bij", sm[st, s, m][bgroup] * bcoef, T)
+                Q[:, idx, idx] = -Q.sum(2)
+                P += sw[st, s, m] * oracle.expm(Q, True)
+            op = oracle.OraclePartition(D, flat.flat_parents, flat.L, codes[:, s:s + 1], ambig, np.ones(1, dtype=np.int64))
+            op.set_P(nodes, P)
+            ref[st, s] = op.site_log_likelihoods(nodes, pi)[0]
+    with hip.HipPartition(D, flat.flat_parents, flat.L, codes, ambig, np.ones(S, dtype=np.int64)) as part:
+        part.set_q_templates(T)
+        got = part.site_fits_evaluate_mixture(bgroup, bcoef, sm, sw, pi)
+        plain = part.site_fits_evaluate(bgroup, bcoef, sm[:, :, 0], pi)
+        degenerate = part.site_fits_evaluate_mixture(bgroup, bcoef, sm, np.broadcast_to(np.eye(n_mix)[0], sw.shape).copy(), pi)
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin), name
+    assert np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))) < 1e-9, name
+    ok = np.isfinite(plain)
+    assert np.array_equal(np.isfinite(degenerate), ok)
+    assert np.max(np.abs(degenerate[ok] - plain[ok]) / np.maximum(1.0, np.abs(plain[ok]))) < 1e-12
