@@ -196,6 +196,12 @@ def time_site_fits(part, args, wl, pd, flat, T, pi, tb):
                    "median_alpha": float(np.median(res.alpha)), "median_beta": float(np.median(res.beta)),
                    "sites_p_below_0.1": int((res.p_value < 0.1).sum()), "sum_logl_alt": float(res.logl_alt.sum()),
                    "sum_logl_null": float(res.logl_null.sum())}
+        t3 = time.perf_counter()
+        mres = fel.meme(part, bgroup == 0, bcoef[:, 0], bcoef[:, 1], pi, max_iter=150)
+        fel_fit["meme_seconds"] = time.perf_counter() - t3
+        fel_fit["meme_launches"] = mres.launches
+        fel_fit["meme_sites_p_below_0.1"] = int((mres.p_value < 0.1).sum())
+        fel_fit["meme_sum_logl_alt"] = float(mres.logl_alt.sum())
     return {**({"fel_fit": fel_fit} if fel_fit else {}), "sets_per_launch": n_sets, "patterns": int(S), "site_evals_per_s": n_sets * S / dt, "ms_per_launch": 1e3 * dt,
             "kernel_ms": kern, "kernel_site_evals_per_s": n_sets * S / (kern * 1e-3), "mean_series_terms": float(terms.mean()),
             "mfma_tflops": flops / (kern * 1e-3) / 1e12, "mfma_frac_of_peak": flops / (kern * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,

@@ -39,6 +39,28 @@ class _NumpySiteFits:
         return out[0] if single else out
 
 
+    def site_fits_evaluate_mixture(self, branch_group, branch_coeffs, site_mult, site_weights, root_freqs):
+        sm, sw = np.asarray(site_mult, dtype=np.float64), np.asarray(site_weights, dtype=np.float64)
+        out = np.zeros(sm.shape[:2])
+        L, I, D = self.flat.L, self.flat.I, self.D
+        idx = np.arange(D)
+        for st in range(sm.shape[0]):
+            for s in range(self.S):
+                P = 0.0
+                for m in range(sm.shape[2]):
+                    Q = np.einsum("bk,kij->bij", sm[st, s, m][np.asarray(branch_group)] * np.asarray(branch_coeffs), self.T)
+                    Q[:, idx, idx] = 0.0
+                    Q[:, idx, idx] = -Q.sum(2)
+                    P = P + sw[st, s, m] * np.stack([scipy.linalg.expm(q) for q in Q])
+                cond = np.ones((I, D))
+                for node in range(L + I - 1):
+                    par = int(self.flat.flat_parents[node])
+                    v = np.eye(D)[self.codes[node, s]] if node < L else cond[node - L]
+                    cond[par] *= P[node] @ v
+                out[st, s] = np.log(cond[I - 1] @ np.asarray(root_freqs))
+        return out
+
+
 def _toy(seed=0, taxa=5, sites=10):
     rng = np.random.default_rng(seed)
     flat = tree.flatten(tree.random_tree(taxa, rng))
@@ -86,3 +108,26 @@ def test_fel_alternative_contains_the_null():
     assert (res.logl_alt >= res.logl_null - 1e-7).all()
     assert ((res.p_value >= 0) & (res.p_value <= 1)).all()
     assert np.allclose(res.lrt, np.maximum(0, 2 * (res.logl_alt - res.logl_null)))
+
+
+def test_meme_driver_bookkeeping():
+    flat, codes, T, pi, rng = _toy(seed=5, taxa=5, sites=5)
+    part = _NumpySiteFits(flat, codes, T)
+    B = flat.n_branches
+    tested = np.ones(B, dtype=bool)
+    tested[-1] = False
+    res = fel.meme(part, tested, np.full(B, 0.2), np.full(B, 0.1), pi, max_iter=120)
+    assert res.alpha.shape == (part.S,)
+    assert (res.beta_minus <= res.alpha + 1e-12).all() and ((res.weight_minus >= 0) & (res.weight_minus <= 1)).all()
+    assert (res.logl_alt >= res.logl_null - 1e-7).all()
+    assert ((res.p_value >= 0) & (res.p_value <= 1)).all()
+    # the reported optimum reproduces through an independent evaluation of the mixture entry point
+    group = np.where(tested, 0, 1)
+    sm = np.empty((part.S, 2, 2, 2))
+    sm[..., 0] = res.alpha[:, None, None]
+    sm[:, 0, 0, 1], sm[:, 1, 0, 1] = res.beta_minus, res.beta_plus
+    sm[:, :, 1, 1] = res.beta_nuisance[:, None]
+    sw = np.stack([res.weight_minus, 1 - res.weight_minus], axis=1)
+    bc = np.stack([np.full(B, 0.2), np.full(B, 0.1)], axis=1)
+    again = part.site_fits_evaluate_mixture(group, bc, sm[None], sw[None], pi)[0]
+    assert np.allclose(again, res.logl_alt, rtol=0, atol=1e-9)

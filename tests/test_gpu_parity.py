@@ -834,3 +834,28 @@ def test_site_fits_branch_site_mixture_matches_explicit_form_reference(name, kw,
     ok = np.isfinite(plain)
     assert np.array_equal(np.isfinite(degenerate), ok)
     assert np.max(np.abs(degenerate[ok] - plain[ok]) / np.maximum(1.0, np.abs(plain[ok]))) < 1e-12
+
+
+def test_meme_driver_on_the_device():
+    """hyphy_amd/fel.py::meme over hyphy_hip_site_fits_evaluate_mixture: nesting, parameter ranges, and the reported
+    optimum reproduces through an independent evaluation."""
+    hip = _hip()
+    from hyphy_amd import fel
+    flat, codes, ambig, pi, T, bgroup, bcoef, smult = _site_fit_case(D=61, taxa=8, sites=32, K=2, G=2, n_sets=1, seed=51,
+                                                                     ambiguity=False)
+    tested = bgroup == 0
+    tested[0], tested[1] = True, False
+    with hip.HipPartition(61, flat.flat_parents, flat.L, codes, ambig, np.ones(32, dtype=np.int64)) as part:
+        part.set_q_templates(T)
+        res = fel.meme(part, tested, bcoef[:, 0], bcoef[:, 1], pi, max_iter=150)
+        group = np.where(tested, 0, 1)
+        sm = np.empty((32, 2, 2, 2))
+        sm[..., 0] = res.alpha[:, None, None]
+        sm[:, 0, 0, 1], sm[:, 1, 0, 1] = res.beta_minus, res.beta_plus
+        sm[:, :, 1, 1] = res.beta_nuisance[:, None]
+        sw = np.stack([res.weight_minus, 1 - res.weight_minus], axis=1)
+        again = part.site_fits_evaluate_mixture(group, bcoef, sm, sw, pi)
+    assert np.allclose(again, res.logl_alt, rtol=0, atol=1e-8)
+    assert (res.beta_minus <= res.alpha + 1e-12).all()
+    assert (res.logl_alt >= res.logl_null - 1e-7).all()
+    assert ((res.p_value >= 0) & (res.p_value <= 1)).all()
