@@ -77,12 +77,16 @@ def nuc_model_block(freqs, rate_expr: str = "t") -> str:
 def build_script(*, fasta: str, newick: str, unit: int, model_block: str, model_name: str,
                  globals_: Dict[str, float], branch_t: Dict[str, float],
                  out_path: str, sweep: Optional[Dict] = None, threads: int = 0,
-                 category: Optional[Dict] = None, per_site: bool = True, optimize: bool = False) -> str:
+                 category: Optional[Dict] = None, per_site: bool = True, optimize: bool = False,
+                 constraints: Optional[Dict[str, str]] = None) -> str:
     """One self-contained batch file.  ``sweep`` = {"param": "R", "start": .3, "step": .001,
     "n": N} runs the SURVEY A.8 timing loop and reports wall-clock seconds via Time(1)."""
     L: List[str] = ["VERBOSITY_LEVEL = -1;", "PRINT_DIGITS = 17;"]
     for k, v in globals_.items():
-        L.append(f"global {k} = {_fmt(v)};")
+        if constraints and k in constraints:
+            L.append(f"global {k} := {constraints[k]};")   # (tied parameter, e.g. CG := AT)
+        else:
+            L.append(f"global {k} = {_fmt(v)};")
     if category:
         w = ",".join(_fmt(x) for x in category["weights"])
         v = ",".join(_fmt(x) for x in category["values"])
@@ -172,7 +176,7 @@ def parse_output(path: str) -> Dict:
 
 def evaluate(*, names, seqs, newick, unit, model_block, model_name, globals_, branch_t,
              sweep=None, threads=0, category=None, per_site=True, workdir=None, timeout=3600.0,
-             binary=None, extra_env=None, optimize=False) -> Dict:
+             binary=None, extra_env=None, optimize=False, constraints=None) -> Dict:
     """Write fasta + script into a scratch dir, run the reference, parse the results."""
     own = workdir is None
     tmp = tempfile.mkdtemp(prefix="hyref_") if own else workdir
@@ -182,7 +186,7 @@ def evaluate(*, names, seqs, newick, unit, model_block, model_name, globals_, br
     txt = build_script(fasta=fasta, newick=newick, unit=unit, model_block=model_block,
                        model_name=model_name, globals_=globals_, branch_t=branch_t,
                        out_path=outp, sweep=sweep, threads=threads, category=category,
-                       per_site=per_site, optimize=optimize)
+                       per_site=per_site, optimize=optimize, constraints=constraints)
     stdout = run_script(txt, tmp, cpus=max(1, threads), timeout=timeout, binary=binary, extra_env=extra_env)
     res = parse_output(outp)
     res["stdout"] = stdout

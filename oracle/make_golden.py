@@ -17,6 +17,7 @@ Cases (SURVEY §8c "Fixtures to commit"):
   nuc_ambig     GTR with ambiguities
   nuc_deep      300-taxon ladder, rescaling in the 4-state path
   expm_*        P = Exp(Q) through _Matrix::Exponentiate for 4/20/61-state Q at several scales
+  ref_smallcodon  the reference's own known-answer test SimpleOptimizations/SmallCodon.bf (data + expected log L)
 """
 from __future__ import annotations
 
@@ -152,6 +153,55 @@ def marginal_support_case(name="codon_small_marginal", n_taxa=8, n_codons=40, se
     print(f"{name}: support matrix {vals.shape}, row sums (first pattern) {vals[:, :61].sum(1)[:3]}")
 
 
+def reference_test_case(name="ref_smallcodon"):
+    """The reference's OWN known-answer test for this path: tests/hbltests/SimpleOptimizations/SmallCodon.bf — an HIV-1 RT
+    alignment (8 sequences x 440 codons) fitted with MG94x012232 (AC, AT = CG = GT, CT free; AG = 1), position-specific
+    frequency constants, expected maximised log L = -3189.516375 (`_expectedLL`, :37; tolerance of the reference's
+    harness: 2 x OPTIMIZATION_PRECISION).  The fixture takes DATA from that file (alignment, tree, expected value); the
+    model is rebuilt by our own generator (the test file's constants are the 6-digit position frequencies of the
+    alignment, which we recompute).  Stored: everything the other codon fixtures have, evaluated at the test's start
+    point (all rates 1, branch parameters 0.1), plus the fit of the unmodified binary driven by OUR script."""
+    import re
+    path = "/root/reference/tests/hbltests/SimpleOptimizations/SmallCodon.bf"
+    txt = open(path).read()
+    block = re.search(r"MATRIX\s*(.*?)\nEND;", txt, re.S).group(1)
+    names, seqs = [], []
+    for row in block.strip().splitlines():
+        m = re.match(r"\s*'([^']+)'\s+([ACGT]+)", row)
+        if m:
+            names.append(m.group(1))
+            seqs.append(m.group(2))
+    newick = re.search(r"TREE tree = (.*?);", txt).group(1)
+    expected = float(re.search(r"_expectedLL\s*=\s*(-?[0-9.]+)", txt).group(1))
+    cnt = np.zeros((3, 4))
+    for sq in seqs:
+        for i, ch in enumerate(sq):
+            cnt[i % 3, "ACGT".index(ch)] += 1
+    pf = cnt / cnt.sum(1, keepdims=True)
+    pf_model = np.array([[float("%.6g" % v) for v in row] for row in pf])   # the constants as the test file prints them
+    root = tree.parse_newick(newick + ";")
+    flat = tree.flatten(root)
+    order = [names.index(n) for n in flat.leaf_names]
+    seqs_flat = [seqs[k] for k in order]
+    bt = {n: 0.1 for n in flat.branch_names()}
+    pi = models.f3x4_codon_freqs(pf)
+    g = dict(R=1.0, AC=1.0, AT=1.0, CG=1.0, CT=1.0, GT=1.0)
+    common_args = dict(names=flat.leaf_names, seqs=seqs_flat, newick=tree.to_newick(root), unit=3,
+                       model_block=hbl.codon_model_block(models.mg94rev_template(pf_model), pi), model_name="MGM",
+                       globals_=g, branch_t=bt, constraints=dict(CG="AT", GT="AT"))
+    res = hbl.evaluate(**common_args)                                   # start point: log L + per-site log L
+    res["opt_logl"] = hbl.evaluate(optimize=True, per_site=False, **common_args)["opt_logl"]   # the fit
+    pd = data.compress(seqs_flat, 3)
+    fx = dict(kind="codon", D=61, L=flat.L, flat_parents=flat.flat_parents, leaf_codes=pd.leaf_codes,
+              ambig=pd.ambig, pattern_freq=pd.pattern_freq, site_to_pattern=pd.site_to_pattern,
+              t=np.array([bt[n] for n in flat.branch_names()]), omega=1.0,
+              rev=np.array([1.0, 1.0, 1.0, 1.0, 1.0]), pos_freqs=pf_model, root_freqs=pi, logl=res["logl"],
+              site_logl=res["site_logl"], names=np.array(flat.leaf_names), seqs=np.array(seqs_flat),
+              newick=np.array(tree.to_newick(root)), expected_opt_logl=expected, ref_opt_logl=res["opt_logl"])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(f"{name}: start logL = {res['logl']!r}  fitted = {res['opt_logl']!r}  reference test expects {expected!r}  S = {pd.S}")
+
+
 def main():
     if not hbl.have_reference():
         raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
@@ -168,6 +218,7 @@ def main():
     nuc_case("nuc_deep", 300, 40, seed=23, ladder=True, tlo=0.1, thi=0.5, p_change=0.25)
     expm_cases()
     marginal_support_case()
+    reference_test_case()
 
 
 if __name__ == "__main__":

@@ -10,7 +10,8 @@ from tests import common
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-10
-CASES = ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "nuc_small", "nuc_ambig", "nuc_deep", "nuc_wide"]
+CASES = ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "nuc_small", "nuc_ambig", "nuc_deep", "nuc_wide",
+         "ref_smallcodon"]  # (the last one: data of the reference's own test SimpleOptimizations/SmallCodon.bf)
 
 
 def _hip():

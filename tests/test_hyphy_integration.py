@@ -205,3 +205,24 @@ def test_hbl_optimize_with_rate_categories_through_device():
     assert _deferred(gpu["stdout"]) > 100
     assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3
     assert abs(gpu["logl"] - cpu["logl"]) <= 1e-10 * abs(cpu["logl"])
+
+
+def test_reference_known_answer_smallcodon_through_device():
+    """The reference's own known-answer test SimpleOptimizations/SmallCodon.bf (HIV-1 RT, 8 x 440 codons, MG94x012232,
+    expected maximised log L = -3189.516375) fitted through the adapter: every ComputeBlock on the device, exponentials
+    on the device, line searches through the device branch cache.  Tolerance = the reference harness's own
+    (2 x OPTIMIZATION_PRECISION)."""
+    _need_binaries()
+    from oracle import hbl
+    from hyphy_amd import models, tree
+    fx = common.load("ref_smallcodon")
+    flat = tree.flatten(tree.parse_newick(str(fx["newick"]) + ";"))
+    res = hbl.evaluate(binary=HIP_BIN, extra_env=ENV, names=[str(x) for x in fx["names"]], seqs=[str(x) for x in fx["seqs"]],
+                       newick=str(fx["newick"]), unit=3,
+                       model_block=hbl.codon_model_block(models.mg94rev_template(fx["pos_freqs"]), fx["root_freqs"]),
+                       model_name="MGM", globals_=dict(R=1.0, AC=1.0, AT=1.0, CG=1.0, CT=1.0, GT=1.0),
+                       branch_t={n: 0.1 for n in flat.branch_names()}, optimize=True, per_site=False,
+                       constraints=dict(CG="AT", GT="AT"))
+    assert _device_calls(res["stdout"]) > 50 and _deferred(res["stdout"]) > 100
+    assert abs(res["opt_logl"] - float(fx["expected_opt_logl"])) <= 2e-3
+    assert abs(res["logl"] - float(fx["logl"])) <= 1e-10 * abs(float(fx["logl"]))

@@ -6,7 +6,8 @@ import pytest
 from oracle import oracle
 from tests import common
 
-CASES = ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "nuc_small", "nuc_ambig", "nuc_deep", "nuc_wide"]
+CASES = ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "nuc_small", "nuc_ambig", "nuc_deep", "nuc_wide",
+         "ref_smallcodon"]  # (the last one: data of the reference's own test SimpleOptimizations/SmallCodon.bf)
 
 
 def _partition(fx, C=1):
@@ -135,3 +136,26 @@ def test_oracle_pinned_states_match_reference_marginal_support():
         match = [r for r in range(I) if r not in used and np.allclose(ours[i], ref[r], rtol=1e-9, atol=1e-12)]
         assert match, i
         used.add(match[0])
+
+
+def test_reference_known_answer_smallcodon():
+    """tests/hbltests/SimpleOptimizations/SmallCodon.bf (the reference's own known-answer test for this path): the
+    unmodified binary, driven by OUR generated batch file on the test's alignment and tree, lands on the test's expected
+    maximised log-likelihood within the reference harness's own tolerance (2 x OPTIMIZATION_PRECISION) — recorded in the
+    fixture by oracle/make_golden.py, and re-run here when the reference binary is available."""
+    fx = common.load("ref_smallcodon")
+    assert abs(float(fx["ref_opt_logl"]) - float(fx["expected_opt_logl"])) <= 2e-3
+    from oracle import hbl
+    if not hbl.have_reference():
+        return
+    from hyphy_amd import models
+    pf = fx["pos_freqs"]
+    flat_names = [str(x) for x in fx["names"]]
+    from hyphy_amd import tree
+    flat = tree.flatten(tree.parse_newick(str(fx["newick"]) + ";"))
+    res = hbl.evaluate(names=flat_names, seqs=[str(x) for x in fx["seqs"]], newick=str(fx["newick"]), unit=3,
+                       model_block=hbl.codon_model_block(models.mg94rev_template(pf), fx["root_freqs"]), model_name="MGM",
+                       globals_=dict(R=1.0, AC=1.0, AT=1.0, CG=1.0, CT=1.0, GT=1.0), branch_t={n: 0.1 for n in flat.branch_names()},
+                       optimize=True, per_site=False, constraints=dict(CG="AT", GT="AT"))
+    assert abs(res["opt_logl"] - float(fx["expected_opt_logl"])) <= 2e-3
+    assert abs(res["logl"] - float(fx["logl"])) <= 1e-9 * abs(float(fx["logl"]))
