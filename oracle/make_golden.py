@@ -18,6 +18,7 @@ Cases (SURVEY §8c "Fixtures to commit"):
   nuc_deep      300-taxon ladder, rescaling in the 4-state path
   expm_*        P = Exp(Q) through _Matrix::Exponentiate for 4/20/61-state Q at several scales
   ref_smallcodon  the reference's own known-answer test SimpleOptimizations/SmallCodon.bf (data + expected log L)
+  ref_fluHA       real data of SimpleOptimizations/IntermediateNuc.bf (HKY85, 349 influenza sequences: the 4-state path)
 """
 from __future__ import annotations
 
@@ -202,6 +203,55 @@ def reference_test_case(name="ref_smallcodon"):
     print(f"{name}: start logL = {res['logl']!r}  fitted = {res['opt_logl']!r}  reference test expects {expected!r}  S = {pd.S}")
 
 
+def reference_test_case_nuc(name="ref_fluHA"):
+    """Real data for the 4-state path from the reference's test tests/hbltests/SimpleOptimizations/IntermediateNuc.bf: HKY85
+    on an Influenza A HA alignment, 349 sequences x 967 nucleotides (tests/hbltests/data/fluHA.nex).  DATA taken from the
+    reference: alignment, tree with its branch lengths, the model's equilibrium frequencies; the model block is our
+    generator's (HKY85 = REV with AC = AT = CG = GT = TVTS, CT = 1).  Evaluated at TVTS = 0.25 (the test's start) with
+    branch parameters = the tree file's lengths (floored at 1e-4).  Not used as an optimisation known answer: the test's
+    `_expectedLL` (-11389.4544) is not reproduced by the reference itself (its own script ends at -11389.8206 with this
+    build and fails its assertion; the default optimiser started from the tree's lengths reaches -11369.5648)."""
+    import re
+    base = "/root/reference/tests/hbltests"
+    bf = open(os.path.join(base, "SimpleOptimizations", "IntermediateNuc.bf")).read()
+    freqs = np.array([float(x) for x in re.findall(r"\{\s*([0-9.]+)\}", bf[bf.index("flu_part2_Freqs"):bf.index("Model flu_part2")])])
+    assert freqs.shape == (4,) and abs(freqs.sum() - 1) < 1e-9
+    txt = open(os.path.join(base, "data", "fluHA.nex")).read()
+    block = txt[txt.index("MATRIX") + 6: txt.index("END;", txt.index("MATRIX"))]
+    names, seqs = [], []
+    for row in block.splitlines():
+        m = re.match(r"\s*'([^']+)'\s+([ACGT]+)", row)
+        if m:
+            names.append(m.group(1))
+            seqs.append(m.group(2))
+    newick = re.search(r"TREE tree = (.*?);", txt, re.S).group(1)
+    root = tree.parse_newick(newick + ";")
+    flat = tree.flatten(root)
+    seqs_flat = [seqs[names.index(n)] for n in flat.leaf_names]
+    lengths = {}
+
+    def walk(n):
+        for c in n.children:
+            walk(c)
+        if n.parent is not None:
+            lengths[n.name] = max(float(n.length or 0.0), 1e-4)
+    walk(root)
+    bt = {n: lengths[n] for n in flat.branch_names()}
+    g = dict(TVTS=0.25, AC=0.25, AT=0.25, CG=0.25, CT=1.0, GT=0.25)
+    cons = dict(AC="TVTS", AT="TVTS", CG="TVTS", GT="TVTS", CT="1")
+    common_args = dict(names=flat.leaf_names, seqs=seqs_flat, newick=tree.to_newick(root), unit=1,
+                       model_block=hbl.nuc_model_block(freqs), model_name="NM", globals_=g, branch_t=bt, constraints=cons)
+    res = hbl.evaluate(**common_args)
+    pd = data.compress(seqs_flat, 1)
+    fx = dict(kind="nuc", D=4, L=flat.L, flat_parents=flat.flat_parents, leaf_codes=pd.leaf_codes,
+              ambig=pd.ambig, pattern_freq=pd.pattern_freq, site_to_pattern=pd.site_to_pattern,
+              t=np.array([bt[n] for n in flat.branch_names()]), rev=np.array([0.25, 0.25, 0.25, 1.0, 0.25]),
+              root_freqs=freqs, logl=res["logl"], site_logl=res["site_logl"], names=np.array(flat.leaf_names),
+              seqs=np.array(seqs_flat), newick=np.array(tree.to_newick(root)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(f"{name}: logL = {res['logl']!r}  S = {pd.S}")
+
+
 def main():
     if not hbl.have_reference():
         raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
@@ -219,6 +269,7 @@ def main():
     expm_cases()
     marginal_support_case()
     reference_test_case()
+    reference_test_case_nuc()
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-10
 CASES = ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "nuc_small", "nuc_ambig", "nuc_deep", "nuc_wide",
-         "ref_smallcodon"]  # (the last one: data of the reference's own test SimpleOptimizations/SmallCodon.bf)
+         "ref_smallcodon", "ref_fluHA"]  # (the last two: real data of the reference's own tests SimpleOptimizations/SmallCodon.bf, IntermediateNuc.bf)
 
 
 def _hip():

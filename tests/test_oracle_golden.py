@@ -7,7 +7,7 @@ from oracle import oracle
 from tests import common
 
 CASES = ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "nuc_small", "nuc_ambig", "nuc_deep", "nuc_wide",
-         "ref_smallcodon"]  # (the last one: data of the reference's own test SimpleOptimizations/SmallCodon.bf)
+         "ref_smallcodon", "ref_fluHA"]  # (the last two: real data of the reference's own tests SimpleOptimizations/SmallCodon.bf, IntermediateNuc.bf)
 
 
 def _partition(fx, C=1):
