@@ -388,7 +388,7 @@ def main():
             # profiles/r01_ubench_mfma_f64.txt): v_mfma_f64_16x16x4_f64 sustains ~49 TFLOP/s chip-wide at 2.39 GHz
             # (one per ~100 cycles per SIMD); `peak` stays the datasheet figure
             roof["instruction"] = "v_mfma_f64_16x16x4_f64"
-            roof["instruction_peak_measured"] = 49.2   # one operand pair; 38-42 with distinct operand registers
+            roof["instruction_peak_measured"] = 49.2   # microbenchmark, one operand pair; site_fit_kernel sustains 48.7 in a real kernel
         # forest scheduling: the pruning pass of ONE evaluation is `launches_per_step` launches of the same
         # kernel (levels of subtree fragments).  achieved = (algorithmic work of the pass / launches) / (mean
         # launch duration) = work of the pass / time of the pass; rocprofv3's per-launch average x launches
