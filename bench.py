@@ -84,29 +84,53 @@ def alg_work(D, S, L, I):
     return flops, bytes_
 
 
-def cpu_baseline(wl, syn, omega0, t_branch, n_threads, budget_s=25.0):
-    """Reference CPU path timed on this host: the real hyphy binary (oracle/_ref) when present,
-    else the scalar C restatement.  Bounded sample of the same workload."""
+def cpu_baseline(wl, syn, omega0, t_branch, n_threads, steps, budget_s=32.0):
+    """Reference CPU path timed on this host: the real hyphy binary (oracle/_ref).  Bounded sample of the same
+    workload: the LFCompute sweep of SURVEY A.8 at ONE thread and at `n_threads` (the best count of the sweep in
+    profiles/), each timed as the difference of two runs of different length (wall clock of the whole process:
+    start-up, data reading and the thread-benchmark Optimize cancel out) with >= ~30 s between them.  The long
+    best-thread run also records the log-likelihood of every point the GPU loop evaluates, the one-thread run the
+    per-site log-likelihoods at the first point."""
     from oracle import hbl
     from hyphy_amd import tree as htree
-    if hbl.have_reference() and wl["unit"] == 3:
-        tmpl = models.mg94rev_template(POS_FREQS)
-        pi = models.f3x4_codon_freqs(POS_FREQS)
-        g = dict(R=omega0, **REV)
-        bt = {n: t_branch for n in syn.flat.branch_names()}
-        # ~0.36 s / eval / thread at 64 x 10k (SURVEY §6); scale to the budget
-        per_eval = 0.36 * (syn.flat.L / 64.0) * (syn.states.shape[1] / 10000.0) / max(1, min(n_threads, 8)) * 1.6
-        n = int(max(4, min(400, budget_s / max(per_eval, 1e-3))))
-        res = hbl.evaluate(names=syn.flat.leaf_names, seqs=syn.seqs, newick=htree.to_newick(syn.tree), unit=3,
-                           model_block=hbl.codon_model_block(tmpl, pi), model_name="MGM", globals_=g, branch_t=bt,
-                           sweep=dict(param="R", start=omega0, step=0.001, n=n), threads=n_threads, per_site=False,
-                           timeout=900.0)
-        secs = max(res.get("sweep_seconds", 0.0), 1.0)   # Time(1) has 1 s resolution
-        return dict(value=n / secs, unit="evals/s", cores=n_threads, kind="reference",
-                    sample=f"{n} LFCompute calls with R swept (HBL Time(1), 1 s resolution) on the same alignment/tree, "
-                           f"reference hyphy 2.5.100 built by oracle/Makefile.ref, NUMBER_THREADS={n_threads}"), \
-            res["logl"], res.get("sweep_last")
-    return None, None, None
+    if not (hbl.have_reference() and wl["unit"] == 3):
+        return None, None
+    tmpl = models.mg94rev_template(POS_FREQS)
+    pi = models.f3x4_codon_freqs(POS_FREQS)
+    g = dict(R=omega0, **REV)
+    bt = {n: t_branch for n in syn.flat.branch_names()}
+    scale = (syn.flat.L / 64.0) * (syn.states.shape[1] / 10000.0)   # cost of one evaluation relative to the headline workload
+    out = {}
+    ref = {}
+    for thr, rate0 in ((1, 10.0), (n_threads, 75.0)):
+        if thr in out:
+            continue
+        n_long = int(max(12, min(20000, budget_s * rate0 / scale)))
+        n_short = max(2, n_long // 10)
+        secs = {}
+        for n in (n_short, n_long):
+            rec = min(steps, n) if (thr == n_threads and n == n_long) else 0
+            t0 = time.perf_counter()
+            res = hbl.evaluate(names=syn.flat.leaf_names, seqs=syn.seqs, newick=htree.to_newick(syn.tree), unit=3,
+                               model_block=hbl.codon_model_block(tmpl, pi), model_name="MGM", globals_=g, branch_t=bt,
+                               sweep=dict(param="R", start=omega0, step=0.001, n=n, record=rec), threads=thr,
+                               per_site=(thr == 1), timeout=1800.0)
+            secs[n] = time.perf_counter() - t0
+            ref["logl"] = res["logl"]
+            if rec:
+                ref["sweep_values"] = res.get("sweep_values")
+            if thr == 1 and "site_logl" in res:
+                ref["site_logl"] = res["site_logl"]
+        dt = max(secs[n_long] - secs[n_short], 1e-3)
+        out[thr] = dict(value=(n_long - n_short) / dt, cores=thr, evals=n_long - n_short, seconds=dt)
+    best = out[n_threads]
+    cb = dict(value=best["value"], unit="evals/s", cores=n_threads, kind="reference",
+              sample=f"{best['evals']} LFCompute calls with R swept in {best['seconds']:.1f} s (difference of two runs of "
+                     f"the same script with different loop lengths, process wall clock) on the same alignment/tree, reference "
+                     f"hyphy 2.5.100 built by oracle/Makefile.ref, NUMBER_THREADS={n_threads} (best of the thread sweep in profiles/)",
+              seconds=best["seconds"],
+              one_thread=dict(value=out[1]["value"], unit="evals/s", cores=1, evals=out[1]["evals"], seconds=out[1]["seconds"]))
+    return cb, ref
 
 
 def cpu_port_baseline(pd, flat, Q, pi, sparse):
@@ -304,8 +328,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
+    timed_values = [0.0] * args.steps
     for k in range(args.steps):
-        last = step(k + 1)
+        last = timed_values[k] = step(k + 1)
     if N > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -314,9 +339,19 @@ def main():
     # pruning launches of every evaluation, read back only now (querying inside the loop perturbs it)
     pt = part.prune_timings(min(max(1, args.steps // TIMING_EVERY), 1024))
     t_prune = float(pt.sum()) * (args.steps / max(1, len(pt)))
-    if os.environ.get("HYPHY_HIP_ALL_TIMINGS"):
-        tm = part.last_timings()
-        t_exp, t_red = tm[0] * args.steps, tm[2] * args.steps
+    t_exp = t_red = None
+    if n_classes == 1:
+        # expm (incl. the fused rate-matrix build) and reduction kernels: event-timed on a few extra steps AFTER the
+        # timed region (two more event records per step would perturb it)
+        part.set_all_timings(True)
+        te, tr_ = [], []
+        for k in range(8):
+            step(args.steps + 1 + k)
+            tm = part.last_timings()
+            te.append(tm[0])
+            tr_.append(tm[2])
+        part.set_all_timings(False)
+        t_exp, t_red = float(np.median(te)), float(np.median(tr_))
     if N > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -398,8 +433,8 @@ def main():
         roof["kernel_ms_per_launch"] = prune_ms / nl
         roof["kernel_ms"] = prune_ms
         roof["timed_steps_sampled"] = f"1 in {TIMING_EVERY}"
-        roof["expm_ms"] = t_exp / args.steps
-        roof["reduce_ms"] = t_red / args.steps
+        roof["expm_ms"] = t_exp       # median of 8 event-timed steps after the timed region; None: not measured
+        roof["reduce_ms"] = t_red
         roof["alg_flops_per_step"] = flops
         roof["alg_bytes_per_step"] = bytes_
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -430,18 +465,33 @@ def main():
             out["value_pipelined_no_host_sync"] = pipelined
         if not args.no_cpu_baseline and N == 1 and n_classes == 1:
             nthr = args.cpu_threads or min(os.cpu_count() or 1, 16)   # 16 = best of the 1..128 sweep (profiles/)
-            cb = None
+            cb = ref = None
             try:
-                cb, ref_ll, _ = cpu_baseline(wl, syn, omega0, t_branch, nthr)
+                cb, ref = cpu_baseline(wl, syn, omega0, t_branch, nthr, args.steps)
             except Exception as e:  # reference binary missing / failed: fall back to the C restatement
                 sys.stderr.write(f"[bench] reference baseline unavailable: {e}\n")
             if cb is None:
                 Q0 = (models.mg94rev_Q_batch(tb, omega0, REV, POS_FREQS) if D > 4 else
                       np.stack([models.nuc_rev_Q(t_branch, models.hky85_rev(0.35), NUC_FREQS)] * B))
                 cb, ref_ll = cpu_port_baseline(pd_all, flat, Q0, pi, D > 4)
+                ref = dict(logl=ref_ll)
             out["cpu_baseline"] = cb
-            out["parity"] = {"logl_gpu": ll0, "logl_cpu": ref_ll, "rel_err": abs(ll0 - ref_ll) / abs(ref_ll),
-                             "tolerance": 1e-6}
+            par = {"logl_gpu": ll0, "logl_cpu": ref["logl"], "rel_err": abs(ll0 - ref["logl"]) / abs(ref["logl"]),
+                   "tolerance": 1e-6}
+            sv = ref.get("sweep_values")
+            if sv is not None and len(sv):   # every timed parameter point the reference also evaluated
+                n = min(len(sv), args.steps)
+                rel = np.abs(np.array(timed_values[:n]) - sv[:n]) / np.abs(sv[:n])
+                par["timed_points_checked"] = int(n)
+                par["timed_points_max_rel_err"] = float(rel.max())
+            if ref.get("site_logl") is not None and D > 4:
+                # per-site log-likelihoods at the first point: GPU per-pattern (l_s, c_s) -> log L_s, mapped to sites
+                Q0 = models.mg94rev_Q_batch(tb, omega0, REV, POS_FREQS)
+                _, sl, sc = part.evaluate(nodes, nodes, Q0, pi, per_site=True)
+                gpu_site = (np.log(sl) - 64.0 * np.log(2.0) * sc)[pd_all.site_to_pattern]
+                par["per_site_max_abs_dlogl"] = float(np.max(np.abs(gpu_site - ref["site_logl"])))
+                par["per_site_sites"] = int(len(gpu_site))
+            out["parity"] = par
         print(json.dumps(out))
     part.close()
     if N > 1:

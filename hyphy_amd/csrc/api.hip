@@ -81,6 +81,9 @@ struct Shard {
   double *bc_q = nullptr;
   int4 *prog = nullptr;       // program table (forest scheduling): (offset, entries, parent program, child programs)
   int4 *h_prog = nullptr;
+  int4 *jn = nullptr;         // chain schedules: per internal node (parent, arrivals needed | child sum << 8, trunk entries offset, count)
+  int4 *h_jn = nullptr;
+  double *deposits = nullptr; // chain schedules: [C][I][ntiles][TILE] edge products of non-last arrivers (allocated on first use)
   int *frag_ctr = nullptr;    // [classes][programs][tiles] arrivals of child fragments (wave-per-tile kernel)
   int32_t *hand_cnt = nullptr;  // [classes][I][tiles][32] 2^64-exponents of fragment roots (own 128-byte line each)
   double *pi = nullptr;       // [DP]
@@ -102,6 +105,14 @@ struct Shard {
   double *d_hcoeffs = nullptr; // ... as the device sees it (host-mapped): the fused expm kernel reads it directly
   const double *coeffs_cur = nullptr;  // coefficients of the pending fused build (device-visible pointer)
   unsigned coeff_turn = 0;
+  // The fused expm kernel reads a ring slot over PCIe when it EXECUTES.  On the asynchronous path
+  // (hyphy_hip_evaluate_device) the host may run ahead of the device: an event recorded behind the consuming launch
+  // guards the slot, and hyphy_hip_build_q waits for it before rewriting the slot.
+  hipEvent_t coeff_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool coeff_busy[4] = {false, false, false, false};
+  int coeff_slot = -1;                 // ring slot of the staged coefficients
+  int64_t coeff_rows = 0;              // rows staged by the last hyphy_hip_build_q (0: nothing staged)
+  bool qbuf_built = false;             // ... and materialised in qbuf (HYPHY_HIP_MATERIALIZE_Q)
   double *h_small = nullptr;  // pi / weights staging
   size_t h_small_cap = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -155,6 +166,13 @@ struct hyphy_hip_partition {
   int variant = 0;                           // pruning kernel variant (common.h PruneArgs::variant)
   int n_slots = 0;                           // LDS slots the schedules are compiled for (0: lds_slots(T))
   struct Prog { int off, n, parent = -1, need = 0; };
+  bool chain = false;                        // the current schedule is a chain schedule (common.h PruneArgs::chain)
+  bool kernel_forced = false;                // HYPHY_HIP_KERNEL / T > 1: the tuner must not switch kernels
+  int n_slots_wave = 3;                      // LDS slot budget of the wave-per-tile kernel's schedules
+  int chain_m_forced = 0;                    // cut chosen by the schedule tuner: > 0 source size limit m, -1 level-peeled fragments, 0 heuristic
+  int64_t tuned_for = 0;                     // batch_classes the tuner ran for (0: not yet)
+  std::string tune_report;                   // what the tuner measured (hyphy_hip_schedule_info)
+  std::vector<int4> jn_host;                 // ... its per-node join table
   struct Level { int first, count; };
   std::vector<Prog> programs;                // (offset, padded entry count) into ops_host
   std::vector<Level> levels;                 // launches: programs [first, first+count) run concurrently
@@ -182,16 +200,18 @@ void free_shard(Shard &s) {
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
                  s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.codes_tile,
-                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
+                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops};
   for (void *d : dev)
     if (d) hipFree(d);
-  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog};
+  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn};
   for (void *h : host)
     if (h) hipHostFree(h);
   for (auto &e : s.ev)
     if (e) hipEventDestroy(e);
   for (auto &e : s.ring)
+    if (e) hipEventDestroy(e);
+  for (auto &e : s.coeff_ev)
     if (e) hipEventDestroy(e);
   if (s.own_stream) hipStreamDestroy(s.own_stream);
   s = Shard();
@@ -369,6 +389,115 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
     if (const char *e = getenv("HYPHY_HIP_FRAGMENT")) max_frag = std::max(1, atoi(e));
     else if (wgs < target) max_frag = (int)std::max<long>(4, (long)I * wgs / target);
   }
+  p->chain = false;
+  p->jn_host.clear();
+  // ---- chain schedules (wave-per-tile kernel, full passes) -------------------------------------------------
+  // Bottom subtrees of at most `m` internal nodes become SOURCE programs (walked serially by one wave, exactly like a
+  // fragment); every node above them is a TRUNK node, reached by chains: a wave that finishes node c computes the
+  // edge product towards the parent and arrives there, the last arriver finalises the parent and goes on (prune.hip).
+  // The critical path of a tile is then the height of the tree (not the size of its largest fragment), and the grid is
+  // dispatched source-major with the sources sorted by their distance to the root, so that every tile's critical path
+  // starts first and the short chains that join near the root fill the end of the launch (tools/flow_sim.py).
+  // (HYPHY_HIP_CUT=levels or an explicit HYPHY_HIP_FRAGMENT keep the level-peeled fragments; HYPHY_HIP_CHAIN_M sets m)
+  const bool want_levels = (getenv("HYPHY_HIP_CUT") && !strcmp(getenv("HYPHY_HIP_CUT"), "levels")) ||
+                           (getenv("HYPHY_HIP_FRAGMENT") && !getenv("HYPHY_HIP_CHAIN_M")) ||
+                           (p->chain_m_forced < 0 && !getenv("HYPHY_HIP_CHAIN_M"));
+  if (full && !p->nuc && p->variant >= 1 && !p->shards.empty() && !want_levels) {
+    const Shard &s0 = p->shards[0];
+    std::vector<int> size(I, 1), height(I, 1), to_root(I, 0);
+    std::vector<std::vector<int>> ich(I);
+    for (int n = 0; n < I; n++)
+      for (int c : p->children[n])
+        if (c >= L) {
+          ich[n].push_back(c - L);
+          size[n] += size[c - L];
+          height[n] = std::max(height[n], height[c - L] + 1);
+        }
+    for (int n = I - 2; n >= 0; n--) to_root[n] = to_root[(int)p->parents[L + n]] + 1;
+    auto count_sources = [&](int m) {
+      int k = 0;
+      for (int n = 0; n < I; n++)
+        if (size[n] <= m && (n == I - 1 || size[(int)p->parents[L + n]] > m)) k++;
+      return k;
+    };
+    const long wgs = std::max(1, s0.ntiles) * (long)std::max<int64_t>(1, p->batch_classes);
+    const long target = 24L * s0.cus;  // >= 3 rounds of the 8 resident waves per CU
+    int m = 1;
+    if (const char *e = getenv("HYPHY_HIP_CHAIN_M")) m = std::max(1, atoi(e));
+    else if (p->chain_m_forced > 0) m = p->chain_m_forced;
+    else {
+      if (wgs >= target) m = I;  // enough tiles: one wave walks the whole tree
+      else
+        for (int t = 2; t <= 8; t++)
+          if ((long)count_sources(t) * wgs >= target) m = t;
+    }
+    if (m < I) {
+      struct Src { int root, prio; };
+      std::vector<Src> srcs;
+      std::vector<char> in_source(I, 0);
+      for (int n = I - 1; n >= 0; n--) {
+        const int par = (int)p->parents[L + n];
+        if (par >= 0 && in_source[par]) in_source[n] = 1;
+        else if (size[n] <= m) {
+          in_source[n] = 1;
+          srcs.push_back({n, to_root[n] + height[n]});
+        }
+      }
+      std::stable_sort(srcs.begin(), srcs.end(), [](const Src &x, const Src &y) { return x.prio > y.prio || (x.prio == y.prio && x.root < y.root); });
+      p->jn_host.assign(I, make_int4(-1, 0, 0, 0));
+      for (const Src &sr : srcs) {
+        std::vector<int> nodes;  // the subtree below sr.root, ascending = post-order
+        std::vector<int> stack(1, sr.root);
+        while (!stack.empty()) {
+          const int n = stack.back();
+          stack.pop_back();
+          nodes.push_back(n);
+          for (int c : ich[n]) stack.push_back(c);
+        }
+        std::sort(nodes.begin(), nodes.end());
+        int off, n;
+        const int rs = emit_program(p, nodes, &off, &n, false, true);
+        hyphy_hip_partition::Prog pr{off, n};
+        pr.parent = sr.root == I - 1 ? -1 : 0;
+        pr.need = sr.root;  // (chain schedules: w = the source's root node)
+        p->programs.push_back(pr);
+        if (sr.root == I - 1) p->root_slot = rs;
+      }
+      const bool lazy = !p->sched_persist;
+      for (int n = 0; n < I; n++) {
+        int sum = 0;
+        for (int c : ich[n]) sum += c;
+        int4 j = make_int4(n == I - 1 ? -1 : (int)p->parents[L + n], (int)ich[n].size() | (sum << 8), 0, 0);
+        if (!in_source[n]) {  // trunk node: its leaf groups, one OPK_DEP entry per internal child, finalisation flags
+          j.z = (int)p->ops_host.size();
+          std::vector<int> leaves;
+          for (int c : p->children[n])
+            if (c < L) leaves.push_back(c);
+          for (size_t k = 0; k < leaves.size();) {
+            int nl = 1;
+            const bool amb0 = p->leaf_has_ambig[leaves[k]];
+            if (!amb0 && k + 1 < leaves.size() && !p->leaf_has_ambig[leaves[k + 1]]) nl = 2;
+            const unsigned l0 = (unsigned)leaves[k], l1 = nl > 1 ? (unsigned)leaves[k + 1] : l0;
+            p->ops_host.push_back(make_int4(OPK_LEAF | (amb0 ? OPF_AMBIG : 0) | (nl << 8) | (0xff << 24), n, (int)(l0 | (l1 << 16)), 0));
+            k += nl;
+          }
+          for (int c : ich[n]) p->ops_host.push_back(make_int4(OPK_DEP | (0xff << 24), n, L + c, c));
+          p->ops_host.back().x |= OPF_LAST | (lazy ? OPF_NOPERSIST : 0);
+          j.w = (int)p->ops_host.size() - j.z;
+        }
+        p->jn_host[n] = j;
+      }
+      p->ops_host.push_back(make_int4(OPK_LEAF | (0xff << 24), 0, 0, 0));  // (the interpreter reads one entry ahead)
+      p->levels.push_back({0, (int)p->programs.size()});
+      p->chain = true;
+      if (getenv("HYPHY_HIP_VERBOSE")) {
+        fprintf(stderr, "[hyphy_hip] chain schedule: m = %d, %zu sources (root node / distance):", m, srcs.size());
+        for (const Src &sr : srcs) fprintf(stderr, " %d/%d", sr.root, sr.prio);
+        fprintf(stderr, "\n");
+      }
+      return;
+    }
+  }
   if (max_frag >= I || !full) {  // one program (also: every partial update)
     int off, n;
     p->root_slot = emit_program(p, touched_list, &off, &n);
@@ -533,8 +662,14 @@ PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
   pa.frag_ctr = s.frag_ctr;
   pa.hand_cnt = s.hand_cnt;
   pa.n_prog_total = 1;
+  pa.chain = 0;
+  pa.jn = nullptr;
+  pa.deposits = nullptr;
   return pa;
 }
+
+// "use the shard's own Q buffer" (filled / staged by hyphy_hip_build_q on every shard)
+const double kOwnQBuffer = 0.;
 
 // Enqueue everything for one rate class on one shard.  q may be a host or device pointer.
 int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, bool sched_changed, bool pi_changed,
@@ -543,6 +678,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
                  bool reduce, bool floor_log) {
   Trace tr("enqueue");
   HIPCHK(hipSetDevice(s.device));
+  if (q == &kOwnQBuffer) q = s.qbuf;
   const int64_t D = p->D, B = p->B;
   const int DP = p->DP;
   tr.lap("setdevice");
@@ -553,6 +689,18 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     for (size_t k = 0; k < p->programs.size(); k++)
       s.h_prog[k] = make_int4(p->programs[k].off, p->programs[k].n, p->programs[k].parent, p->programs[k].need);
     HIPCHK(hipMemcpyAsync(s.prog, s.h_prog, p->programs.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+    if (p->chain) {
+      memcpy(s.h_jn, p->jn_host.data(), p->jn_host.size() * sizeof(int4));
+      HIPCHK(hipMemcpyAsync(s.jn, s.h_jn, p->jn_host.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+    }
+  }
+  if (p->chain && !s.deposits) {  // edge products of non-last arrivers: one tile per (class, node, tile), like `partials`
+    const size_t bytes = (size_t)p->C * s.partial_stride * sizeof(double);
+    HIPCHK(hipMalloc((void **)&s.deposits, bytes));
+    if (getenv("HYPHY_HIP_POISON")) {
+      HIPCHK(hipMemset(s.deposits, 0xff, bytes));
+      HIPCHK(hipDeviceSynchronize());
+    }
   }
   // root frequencies, zero padded (uploaded only when they change)
   if (pi_changed) {
@@ -579,6 +727,12 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     }
     const double *dq = q;
     const bool q_from_templates = q_on_device && q == s.qbuf && p->coeffs_pending && !q_is_prob;
+    if (q_on_device && q == s.qbuf && !q_is_prob) {
+      // the partition's own Q buffer is only meaningful behind hyphy_hip_build_q: either the staged coefficients
+      // (fused construction) or the materialised matrices, with exactly the rows this evaluation consumes
+      if (!q_from_templates && !s.qbuf_built) return fail("evaluate from the Q buffer: no rate matrices staged (call hyphy_hip_build_q first)");
+      if (s.coeff_rows != n_mat) return fail("evaluate from the Q buffer: hyphy_hip_build_q staged a different number of matrices than this evaluation consumes");
+    }
     if (!q_on_device) {
       HIPCHK(hipMemcpyAsync(s.qbuf, q, (size_t)n_mat * D * D * sizeof(double), hipMemcpyHostToDevice, s.stream));
       dq = s.qbuf;
@@ -610,6 +764,10 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     }
     tr.lap("slots+q");
     launch_expm(ea, s.stream);
+    if (q_from_templates && d_logl_out && s.coeff_slot >= 0) {  // asynchronous caller: guard the ring slot until the kernel has run
+      HIPCHK(hipEventRecord(s.coeff_ev[s.coeff_slot], s.stream));
+      s.coeff_busy[s.coeff_slot] = true;
+    }
     tr.lap("launch_expm");
   }
   // kernel-duration stamps: every evaluation by default; HYPHY_HIP_TIMING_EVERY=n keeps one in n
@@ -665,7 +823,10 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     n_wg = prune_mfma_grid(pa);
     pa.frag_ctr = s.frag_ctr;
     pa.hand_cnt = s.hand_cnt;
-    pa.n_prog_total = (int)p->programs.size();
+    pa.n_prog_total = p->chain ? (int)p->I : (int)p->programs.size();
+    pa.chain = p->chain ? 1 : 0;
+    pa.jn = s.jn;
+    pa.deposits = s.deposits;
     for (size_t lv = 0; lv < p->levels.size(); lv++) {  // one launch per level of subtree fragments
       pa.prog = s.prog + p->levels[lv].first;
       pa.n_prog = p->levels[lv].count;
@@ -982,14 +1143,22 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       // at 624 tiles; below that its 64-MFMA-per-edge chains are pure latency (167 us at 312 tiles as at
       // 624) and the workgroup-per-tile kernel, which splits a tile's rows over four waves, is faster
       // (123 us at 312 tiles, 63 us at 78).
-      p->variant = tiles >= (7 * (int64_t)cus) / 4 ? 1 : 0;
-      if (const char *e = getenv("HYPHY_HIP_KERNEL")) p->variant = atoi(e) ? 1 : 0;  // (diagnostic override)
-      if (T != 1) p->variant = 0;
-      p->n_slots = lds_slots(T);
-      if (p->variant >= 1) {
-        p->n_slots = 3;  // two "exchange" ids (register hand-over) + one wave-private LDS parking slot
-        if (const char *e = getenv("HYPHY_HIP_SLOTS")) p->n_slots = atoi(e) == 2 ? 2 : 3;
+      // (r02: with chain schedules the wave-per-tile kernel also wins at a rank's share of the headline workload —
+      //  89 vs 118 us at 312 tiles, 52 vs 61 us at 78; below ~a quarter tile per CU the row-split workgroup kernel
+      //  keeps its shorter critical path.  The schedule tuner re-checks the choice on the first steady-state pass.)
+      p->variant = tiles >= (int64_t)cus / 4 ? 1 : 0;
+      p->kernel_forced = false;
+      if (const char *e = getenv("HYPHY_HIP_KERNEL")) {  // (diagnostic override)
+        p->variant = atoi(e) ? 1 : 0;
+        p->kernel_forced = true;
       }
+      if (T != 1) {
+        p->variant = 0;
+        p->kernel_forced = true;
+      }
+      p->n_slots_wave = 3;  // two "exchange" ids (register hand-over) + one wave-private LDS parking slot
+      if (const char *e = getenv("HYPHY_HIP_SLOTS")) p->n_slots_wave = atoi(e) == 2 ? 2 : 3;
+      p->n_slots = p->variant >= 1 ? p->n_slots_wave : lds_slots(T);
     }
     if (p->nuc) {
       s.S_pad = (int)((s.S + 255) / 256 * 256);
@@ -1050,6 +1219,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     A_(s.slots, (size_t)C * B * sizeof(int32_t));
     A_(s.ops, ops_capacity(p) * sizeof(int4));
     A_(s.prog, (size_t)(I + 2) * sizeof(int4));
+    A_(s.jn, (size_t)(I + 2) * sizeof(int4));
     if (!p->nuc) {
       A_(s.frag_ctr, (size_t)C * (I + 2) * s.ntiles * sizeof(int));
       hipMemset(s.frag_ctr, 0, (size_t)C * (I + 2) * s.ntiles * sizeof(int));
@@ -1067,6 +1237,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     s.h_small_cap = (size_t)std::max<int64_t>(std::max<int64_t>(DP, C), 64);
     if (hipHostMalloc((void **)&s.h_ops, ops_capacity(p) * sizeof(int4)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_prog, (size_t)(I + 2) * sizeof(int4)) != hipSuccess ||
+        hipHostMalloc((void **)&s.h_jn, (size_t)(I + 2) * sizeof(int4)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_out, 4 * sizeof(double)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_slots, (size_t)C * B * sizeof(int32_t)) != hipSuccess ||
         hipHostMalloc((void **)&s.h_small, s.h_small_cap * sizeof(double)) != hipSuccess) {
@@ -1108,6 +1279,106 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
   return 0;
 }
 
+// Upload the current schedule to one shard and launch its pruning kernel(s) (no expm, no reduction): the body of an
+// evaluation's pruning step, shared with the schedule tuner.
+static int upload_schedule(hyphy_hip_partition *p, Shard &s) {
+  HIPCHK(hipSetDevice(s.device));
+  HIPCHK(hipStreamSynchronize(s.stream));
+  if (p->ops_host.empty()) return 0;
+  memcpy(s.h_ops, p->ops_host.data(), p->ops_host.size() * sizeof(int4));
+  HIPCHK(hipMemcpyAsync(s.ops, s.h_ops, p->ops_host.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+  for (size_t k = 0; k < p->programs.size(); k++)
+    s.h_prog[k] = make_int4(p->programs[k].off, p->programs[k].n, p->programs[k].parent, p->programs[k].need);
+  HIPCHK(hipMemcpyAsync(s.prog, s.h_prog, p->programs.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+  if (p->chain) {
+    memcpy(s.h_jn, p->jn_host.data(), p->jn_host.size() * sizeof(int4));
+    HIPCHK(hipMemcpyAsync(s.jn, s.h_jn, p->jn_host.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+    if (!s.deposits) {
+      const size_t bytes = (size_t)p->C * s.partial_stride * sizeof(double);
+      HIPCHK(hipMalloc((void **)&s.deposits, bytes));
+      if (getenv("HYPHY_HIP_POISON")) {
+        HIPCHK(hipMemset(s.deposits, 0xff, bytes));
+        HIPCHK(hipDeviceSynchronize());
+      }
+    }
+  }
+  return 0;
+}
+
+static void launch_prune_current(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch) {
+  PruneArgs pa = base_prune_args(p, s, cat, n_cat_batch);
+  int n_ops = 0;
+  for (const auto &pr : p->programs) n_ops = std::max(n_ops, pr.n);
+  pa.ops = s.ops;
+  pa.n_ops = n_ops;
+  pa.n_prog_total = p->chain ? (int)p->I : (int)p->programs.size();
+  pa.chain = p->chain ? 1 : 0;
+  pa.jn = s.jn;
+  pa.deposits = s.deposits;
+  for (size_t lv = 0; lv < p->levels.size(); lv++) {
+    pa.prog = s.prog + p->levels[lv].first;
+    pa.n_prog = p->levels[lv].count;
+    pa.do_root = (lv + 1 == p->levels.size()) ? 1 : 0;
+    launch_prune_mfma(pa, s.stream);
+  }
+}
+
+// Schedule tuner.  How a full pass is best cut (level-peeled fragments, or chains with sources of at most m nodes)
+// depends on the tree's shape, the shard size and the number of classes in the launch; the pruning pass is idempotent,
+// so on the first steady-state full pass (lazy persistence: nothing but the root is stored) the library simply runs
+// the pass under each candidate cut on the resident transition matrices, times it with an event pair and keeps the
+// fastest (a few milliseconds, once per partition and class-batch mode).  HYPHY_HIP_TUNE=0 or any explicit cut
+// (HYPHY_HIP_CHAIN_M / HYPHY_HIP_CUT / HYPHY_HIP_FRAGMENT) disables it.
+static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
+  p->tuned_for = p->batch_classes;
+  const int I = (int)p->I;
+  Shard &s = p->shards[0];
+  std::vector<int> cand = {-1};
+  for (int m : {3, 5, 8, 12, 16, 24, 40, 64})
+    if (m < I) cand.push_back(m);
+  const int T0 = s.T;
+  if (!p->kernel_forced && T0 == 1 && s.ntiles < 2 * s.cus) cand.push_back(-2);  // the row-split workgroup kernel (small shards)
+  auto set_kernel = [&](int v) {
+    p->variant = v;
+    p->n_slots = v >= 1 ? p->n_slots_wave : lds_slots(T0);
+  };
+  double best_ms = 1e30;
+  int best = 0;
+  char buf[64];
+  p->tune_report.clear();
+  for (int c : cand) {
+    p->chain_m_forced = c == -2 ? 0 : c;
+    set_kernel(c == -2 ? 0 : 1);
+    build_schedule(p, nullptr, 0, true);
+    if (p->ops_host.size() > ops_capacity(p)) continue;
+    if (c > 0 && !p->chain) continue;  // (m >= I: the same as no cut)
+    if (upload_schedule(p, s)) return -1;
+    float ms = 0.f, ms2 = 0.f;
+    launch_prune_current(p, s, cat, n_cat_batch);  // warm-up (instruction cache, schedule in L2)
+    HIPCHK(hipEventRecord(s.ev[0], s.stream));
+    launch_prune_current(p, s, cat, n_cat_batch);
+    HIPCHK(hipEventRecord(s.ev[1], s.stream));
+    launch_prune_current(p, s, cat, n_cat_batch);
+    HIPCHK(hipEventRecord(s.ev[2], s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipGetLastError());
+    if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) != hipSuccess || hipEventElapsedTime(&ms2, s.ev[1], s.ev[2]) != hipSuccess) continue;
+    ms = std::min(ms, ms2);
+    snprintf(buf, sizeof buf, "%s%s%d:%.1fus", p->tune_report.empty() ? "" : " ", c == -2 ? "wg-kernel" : (c < 0 ? "levels" : "m"), c < 0 ? 0 : c, 1e3 * ms);
+    p->tune_report += buf;
+    if (ms < best_ms) {
+      best_ms = ms;
+      best = c;
+    }
+  }
+  p->chain_m_forced = best == -2 ? 0 : best;
+  set_kernel(best == -2 ? 0 : 1);
+  snprintf(buf, sizeof buf, " -> %s%d", best == -2 ? "wg-kernel" : (best < 0 ? "levels" : "m"), best < 0 ? 0 : best);
+  p->tune_report += buf;
+  if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] schedule tuner (%d classes per launch): %s\n", n_cat_batch, p->tune_report.c_str());
+  return 0;
+}
+
 static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                        const int64_t *q_nodes, int64_t n_q, const double *q, bool q_on_device, int q_is_probability,
                        const double *root_freqs, double *d_logl_out, bool reduce, bool floor_log, bool batch = false,
@@ -1129,6 +1400,14 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   if (n_q > p->B) return fail("more matrices than branches");
   if (!p->initialized[cat] && n_q < p->B)
     return fail("first evaluation of a rate class must supply all L+I-1 transition matrices");
+  {  // validate the matrix list BEFORE any host cache is touched (a failed call must not leave a half-committed state)
+    std::vector<char> seen(p->B, 0);
+    for (int64_t k = 0; k < n_q; k++) {
+      if (q_nodes[k] < 0 || q_nodes[k] >= p->B) return fail("q_nodes entry out of range");
+      if (seen[q_nodes[k]]) return fail("q_nodes lists a branch twice");
+      seen[q_nodes[k]] = 1;
+    }
+  }
   bool changed = false;
   const int64_t bc = batch ? p->C : 1;
   if (bc != p->batch_classes) {
@@ -1136,6 +1415,17 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
     p->cached_valid = 0;  // fragment sizing depends on how many classes share the launch
   }
   if (prepare_schedule(p, (int)cat, update_nodes, n_update, &changed, force_persist)) return -1;
+  {
+    const bool tune_on = p->tuned_for != p->batch_classes && !(getenv("HYPHY_HIP_TUNE") && atoi(getenv("HYPHY_HIP_TUNE")) == 0) && !getenv("HYPHY_HIP_CHAIN_M") &&
+                                !getenv("HYPHY_HIP_CUT") && !getenv("HYPHY_HIP_FRAGMENT");
+    if (tune_on && !p->nuc && (p->variant >= 1 || (p->tuned_for != 0 && !p->kernel_forced)) && p->sched_full && !p->sched_persist &&
+        p->tuned_for != p->batch_classes && p->initialized[cat]) {
+      if (tune_schedule(p, (int)cat, batch ? (int)p->C : 1)) return -1;
+      build_schedule(p, update_nodes, n_update, true);  // the chosen cut
+      if (p->ops_host.size() > ops_capacity(p)) return fail("internal: schedule overflow");
+      changed = true;
+    }
+  }
   bool pi_changed = p->cached_pi.size() != (size_t)p->D || memcmp(p->cached_pi.data(), root_freqs, p->D * sizeof(double));
   if (pi_changed) p->cached_pi.assign(root_freqs, root_freqs + p->D);
   if (p->cached_slots.size() != (size_t)p->C) p->cached_slots.assign(p->C, std::vector<int64_t>());
@@ -1146,8 +1436,15 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   p->slots_batch_mode = batch ? 1 : 0;
   for (Shard &s : p->shards)
     if (enqueue_eval(p, s, (int)cat, batch ? (int)p->C : 1, changed, pi_changed, slots_changed, q_nodes, n_q, q,
-                     q_on_device, q_is_probability, root_freqs, d_logl_out, reduce, floor_log))
+                     q_on_device, q_is_probability, root_freqs, d_logl_out, reduce, floor_log)) {
+      // some shard may hold a stale schedule / slot table / frequency vector now: rebuild everything next time
+      p->cached_valid = 0;
+      p->cached_pi.clear();
+      for (auto &v : p->cached_slots) v.clear();
+      p->slots_batch_mode = -1;
+      p->initialized[cat] = 0;
       return -1;
+    }
   if (batch)
     for (int64_t c = 0; c < p->C; c++) {
       p->initialized[c] = 1;
@@ -1156,8 +1453,7 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
     }
   p->initialized[cat] = 1;
   if (p->sched_full) p->resident[cat] = p->sched_persist ? 1 : 0;
-  if (q_on_device) p->coeffs_pending = false;
-  return 0;
+  return 0;  // (coefficients staged by hyphy_hip_build_q stay valid — and pending — until the next hyphy_hip_build_q)
 }
 
 int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
@@ -1180,19 +1476,20 @@ int hyphy_hip_evaluate_built(hyphy_hip_partition *p, int64_t cat, const int64_t 
                              const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out) {
   if (!p) return fail("partition == NULL");
   if (!p->K) return fail("evaluate_built: templates not set");
-  // q = each shard's own Q buffer (filled / staged by build_q)
-  if (p->shards.size() == 1) {
-    if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, p->shards[0].qbuf, true, 0, root_freqs, nullptr, true,
-                    false))
-      return -1;
-  } else {
-    return fail("evaluate_built: multi-device partitions use hyphy_hip_evaluate");
-  }
-  Shard &s = p->shards[0];
+  // q = each shard's own Q buffer (filled / staged by build_q on every shard)
+  if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, &kOwnQBuffer, true, 0, root_freqs, nullptr, true, false))
+    return -1;
   Trace tr("evaluate_built");
   if (collect_status(p)) return -1;
   tr.lap("wait");
-  if (logl_out) *logl_out = s.h_out[0];
+  if (logl_out) {
+    if (p->shards.size() == 1) *logl_out = p->shards[0].h_out[0];
+    else {
+      std::vector<double> parts;
+      for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
+      *logl_out = combine(parts);
+    }
+  }
   return 0;
 }
 
@@ -1230,6 +1527,7 @@ int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_
     }
   }
   std::vector<double> parts;
+  p->cached_weights.assign(weights, weights + p->C);
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
     if (upload_small(s, weights, (size_t)p->C, s.weights)) return -1;
@@ -1249,25 +1547,29 @@ int hyphy_hip_evaluate_categories_built(hyphy_hip_partition *p, const int64_t *u
                                         const double *root_freqs, double *logl_out) {
   if (!p) return fail("partition == NULL");
   if (!p->K) return fail("evaluate_categories_built: templates not set");
-  if (p->nuc || p->shards.size() != 1) return fail("evaluate_categories_built: single-device MFMA partitions only");
+  if (p->nuc) return fail("evaluate_categories_built: MFMA partitions only (4-state: hyphy_hip_evaluate_categories)");
   if (!weights) return fail("weights == NULL");
-  Shard &s = p->shards[0];
-  if (eval_common(p, 0, update_nodes, n_update, q_nodes, n_q, s.qbuf, true, 0, root_freqs, nullptr, false, true, true))
+  if (eval_common(p, 0, update_nodes, n_update, q_nodes, n_q, &kOwnQBuffer, true, 0, root_freqs, nullptr, false, true, true))
     return -1;
-  HIPCHK(hipSetDevice(s.device));
   const bool w_changed = p->cached_weights.size() != (size_t)p->C ||
                          memcmp(p->cached_weights.data(), weights, p->C * sizeof(double));
-  if (w_changed) {
-    p->cached_weights.assign(weights, weights + p->C);
-    if (upload_small(s, weights, (size_t)p->C, s.weights)) return -1;
-  }
-  launch_mix_categories(s.site_lik, s.site_cnt, s.weights, (int)p->C, s.S_pad, s.mixed_lik, s.mixed_cnt, s.stream);
-  {
+  if (w_changed) p->cached_weights.assign(weights, weights + p->C);
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    if (w_changed && upload_small(s, weights, (size_t)p->C, s.weights)) {
+      p->cached_weights.clear();
+      return -1;
+    }
+    launch_mix_categories(s.site_lik, s.site_cnt, s.weights, (int)p->C, s.S_pad, s.mixed_lik, s.mixed_cnt, s.stream);
     double *rec = s.d_hout ? s.d_hout : s.out;
     launch_site_reduce(s.mixed_lik, s.mixed_cnt, s.freq, s.S_pad, 1, rec, rec + 1, s.status, s.stream, next_seq(s, rec == s.d_hout));
   }
   if (collect_status(p)) return -1;
-  if (logl_out) *logl_out = s.h_out[0];
+  if (logl_out) {
+    std::vector<double> parts;
+    for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
+    *logl_out = combine(parts);
+  }
   return 0;
 }
 
@@ -1589,6 +1891,13 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
     HIPCHK(hipHostMalloc((void **)&s.h_coeffs, (size_t)4 * p->C * p->B * K * sizeof(double)));
     if (hipHostGetDevicePointer((void **)&s.d_hcoeffs, s.h_coeffs, 0) != hipSuccess) s.d_hcoeffs = nullptr;
     s.coeffs_cur = nullptr;
+    s.coeff_rows = 0;
+    s.coeff_slot = -1;
+    s.qbuf_built = false;
+    for (int k = 0; k < 4; k++) {
+      s.coeff_busy[k] = false;
+      if (!s.coeff_ev[k]) HIPCHK(hipEventCreateWithFlags(&s.coeff_ev[k], hipEventDisableTiming));
+    }
     HIPCHK(hipMemcpy(s.templates, templates, (size_t)K * D * D * sizeof(double), hipMemcpyHostToDevice));
   }
   p->K = K;
@@ -1608,8 +1917,16 @@ int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs) {
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
     const size_t nbytes = (size_t)n * p->K * sizeof(double);
-    double *stage = s.h_coeffs + (size_t)(s.coeff_turn++ & 3) * (size_t)p->C * p->B * p->K;  // pinned ring of 4
+    const int slot = (int)(s.coeff_turn++ & 3);  // pinned ring of 4
+    if (s.coeff_busy[slot]) {  // a queued expm launch may still read this slot
+      HIPCHK(hipEventSynchronize(s.coeff_ev[slot]));
+      s.coeff_busy[slot] = false;
+    }
+    double *stage = s.h_coeffs + (size_t)slot * (size_t)p->C * p->B * p->K;
     memcpy(stage, coeffs, nbytes);
+    s.coeff_slot = slot;
+    s.coeff_rows = n;
+    s.qbuf_built = !fuse;
     if (fuse && s.d_hcoeffs) {
       // the fused expm kernel reads the (few hundred) coefficients straight from the pinned ring slot over
       // PCIe: no copy kernel, no extra dependency in the stream
@@ -1891,6 +2208,14 @@ int hyphy_hip_set_stream(hyphy_hip_partition *p, void *stream) {
 }
 
 void *hyphy_hip_stream(hyphy_hip_partition *p) { return p && !p->shards.empty() ? (void *)p->shards[0].stream : nullptr; }
+
+const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p) { return p ? p->tune_report.c_str() : ""; }
+
+int hyphy_hip_set_timing_detail(hyphy_hip_partition *p, int on) {
+  if (!p) return fail("partition == NULL");
+  p->all_timings = on != 0;
+  return 0;
+}
 
 int hyphy_hip_last_timings(hyphy_hip_partition *p, double out[3]) {
   if (!p || !out) return fail("null argument");

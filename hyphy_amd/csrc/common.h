@@ -35,7 +35,8 @@ __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1)
 
 // Host-compiled schedule entry (int4), built by build_schedule() in api.hip:
 //   x  bits 0-1  kind: OPK_LEAF (group of <= 2 leaf children), OPK_INTERNAL (child vector in an LDS
-//                slot), OPK_INTERNAL_GLOBAL (child vector = persisted copy in HBM)
+//                slot), OPK_INTERNAL_GLOBAL (child vector = persisted copy in HBM), OPK_DEP (chain schedules of the
+//                wave-per-tile kernel: the edge product of internal child w was deposited by the wave that computed it)
 //      bit  2    OPF_HANDOFF (wave-per-tile kernel, chained fragments) internal-global entry: the child is the root of
 //                a fragment finished by ANOTHER workgroup of this launch — read it with agent-scope (sc1) loads
 //      bit  3    OPF_LAST    last child of its parent: finalise the parent
@@ -54,7 +55,7 @@ __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1)
 //   z  internal: child node code (= transition-matrix slot);  leaf group: leaf0 | leaf1 << 16
 //   w  internal: child internal index
 // A parent's first entry needs no flag: the running product is reset when a parent is finalised.
-enum : int { OPK_LEAF = 0, OPK_INTERNAL = 1, OPK_INTERNAL_GLOBAL = 2 };
+enum : int { OPK_LEAF = 0, OPK_INTERNAL = 1, OPK_INTERNAL_GLOBAL = 2, OPK_DEP = 3 };
 enum : int { OPF_HANDOFF = 4, OPF_LAST = 8, OPF_PARITY = 16, OPF_GSYNC = 32, OPF_AMBIG = 64, OPF_INREGS = 128,
              OPF_NOPERSIST = 128, OPF_PUBLISH = 0x8000, OPF_NOPERSIST_NUC = 4 /* (nucleotide kernel: bit 7 is OPF_INREGS there) */ };
 #ifndef HYPHY_SLOTS1
@@ -82,6 +83,15 @@ struct PruneArgs {
   int *frag_ctr;             // [class][program][tile] arrivals of finished child fragments (zero between launches)
   int32_t *hand_cnt;         // [class][I][tile][32] exponents of fragment roots handed between workgroups
   int variant;               // 0: workgroup-per-tile kernel (prune_mfma_kernel), 1: wave-per-tile kernel (T = 1)
+  // chain schedules (wave-per-tile kernel, full passes): the tree is cut into SOURCE programs (small bottom subtrees,
+  // walked serially) and a TRUNK of join nodes above them.  A wave starts at a source, computes the edge product
+  // towards the parent and arrives at it; the LAST arriver of a node multiplies the deposited products of its
+  // siblings in, finalises the node and goes on upwards, everybody else deposits its product and retires.
+  int chain;                 // 1: grid = (tiles, classes, sources), programs sorted by distance to the root
+  const int4 *jn;            // [I] per internal node: (parent internal index or -1, arrivals needed | sum of internal child
+                             //     indices << 8, offset of the node's trunk entries in ops, number of entries)
+  double *deposits;          // [I][ntiles][NKK*64] edge product of (node -> parent), written by non-last arrivers
+                             //     (exponents: hand_cnt; arrival counters: frag_ctr indexed by node)
   int n_slots;               // LDS slots the schedule was compiled for (2 exchange + parking)
   const double *Pfrag;       // [B][NW][NKK*64]      A-operand images of the transition matrices
   const double *PTg;         // [B][DP][NW][4][4]    column-gather images (leaf edges)

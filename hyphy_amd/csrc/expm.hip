@@ -310,8 +310,13 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
       done = true;
     }
     if (!done) {
+      // No valid transition matrix (the reference raises "Failed to compute a valid transition matrix" here).  Besides the
+      // sticky status word, the matrix images are poisoned with NaN: the log-likelihood of THIS evaluation becomes NaN
+      // — also on the asynchronous device path, where nobody reads the status word before an all-reduce — instead of
+      // being computed with the previous, stale matrix of the slot.
       if (tid == 0) atomicOr(a.status, 1);
-      return;
+#pragma unroll
+      for (int c = 0; c < NTW; c++) R.t[c] = (f64x4){NAN, NAN, NAN, NAN};
     }
     if (prof) g_expm_prof[4] = clock64();
     __syncthreads();
@@ -467,9 +472,10 @@ __global__ void expm_nuc_kernel(ExpmArgs a) {
       }
       done = true;
     }
-    if (!done) {
+    if (!done) {  // (as in the MFMA kernel: sticky status + NaN matrix, so that this evaluation's log-L is NaN)
       atomicOr(a.status, 1);
-      return;
+#pragma unroll
+      for (int k = 0; k < 16; k++) R[k] = NAN;
     }
   }
   if (a.Prow) {
@@ -513,7 +519,11 @@ void launch_expm(const ExpmArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(expm_nuc_kernel, dim3((a.n + 63) / 64), dim3(64), 0, stream, a);
     return;
   }
-  static bool attr_done[5] = {false, false, false, false, false};  // per process; one device kind only
+  // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of the function: the single-process
+  // multi-device path (hyphy_hip_create with device_count > 1) launches on every device of the node
+  static bool attr_done[64][5];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   const int NT = (a.D + 15) / 16;
   const int DP = 16 * NT, LD = DP + 2;
   const size_t lds = (size_t)(3 * DP * LD + 2 * DP + 8 + 2 * DP) * sizeof(double);
@@ -525,18 +535,18 @@ void launch_expm(const ExpmArgs &a, hipStream_t stream) {
       hipLaunchKernelGGL((expm_mfma_kernel<2, 2>), dim3(a.n), dim3(256), lds, stream, a);
       break;
     case 3:
-      if (!attr_done[3]) {
+      if (!attr_done[dev][3]) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<3, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done[3] = true;
+        attr_done[dev][3] = true;
       }
       hipLaunchKernelGGL((expm_mfma_kernel<3, 1>), dim3(a.n), dim3(192), lds, stream, a);
       break;
     default:
-      if (!attr_done[4]) {
+      if (!attr_done[dev][4]) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(expm_mfma_kernel<4, 2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done[4] = true;
+        attr_done[dev][4] = true;
       }
       hipLaunchKernelGGL((expm_mfma_kernel<4, 2>), dim3(a.n), dim3(512), lds, stream, a);
       break;

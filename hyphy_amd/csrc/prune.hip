@@ -494,10 +494,12 @@ __device__ __forceinline__ double row_sum4(double x) {
 
 template <int NW, int NP, bool CLDS>
 __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *__restrict__ ops, const int4 *__restrict__ prog,
-                                                                             PruneArgs a) {
-  // grid = (leaf programs, classes, tiles): tile-major dispatch order, so that a tile's chained parent
-  // programs start while other tiles still run their leaf fragments (no low-occupancy tail)
-  int cur = blockIdx.x;  // program (subtree fragment) this wave starts with
+                                                                             const int4 *__restrict__ jn, PruneArgs a) {
+  // legacy grid = (leaf programs, classes, tiles): tile-major dispatch order, so that a tile's chained parent
+  // programs start while other tiles still run their leaf fragments (no low-occupancy tail);
+  // chain grid = (tiles, classes, sources), sources sorted by their distance to the root: every tile's critical path
+  // is dispatched first, the short chains that join close to the root fill the end of the launch
+  int cur = a.chain ? blockIdx.z : blockIdx.x;  // program (subtree fragment / source) this wave starts with
   {
     const size_t cat = blockIdx.y;
     a.frag_ctr += cat * (size_t)a.n_prog_total * a.ntiles;
@@ -505,6 +507,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
     a.Pfrag += cat * a.cs_P;
     a.PTg += cat * a.cs_P;
     a.partials += cat * a.cs_partials;
+    a.deposits += cat * a.cs_partials;
     a.counts += cat * a.cs_counts;
     a.site_lik += cat * a.cs_site;
     a.site_cnt += cat * a.cs_site;
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
   extern __shared__ __align__(16) int16_t codes_lds[];  // CLDS: [L][16]
 
   const int lane = threadIdx.x, g = lane >> 4, sl = lane & 15;
-  const int tile0 = blockIdx.z;
+  const int tile0 = a.chain ? blockIdx.x : blockIdx.z;
   const int S_pad = a.S_pad;
 
   if (CLDS) {  // the tile's leaf codes: one contiguous run of 32 L bytes in the tile-major table
@@ -538,15 +541,20 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
 
   const f64x4 ones = (f64x4){1., 1., 1., 1.}, zeros = (f64x4){0., 0., 0., 0.};
   f64x4 acc[NW], bch[NW];  // running product of the current parent / the node finalised last (scaled)
+  f64x2 dreg[NKK / 2];     // chain schedules: a sibling's deposited edge product, fetched while this wave's own product runs
   int cnt = 0, bcnt = 0;
 #pragma unroll
   for (int w = 0; w < NW; w++) acc[w] = ones, bch[w] = zeros;
+#pragma unroll
+  for (int k = 0; k < NKK / 2; k++) dreg[k] = (f64x2){0., 0.};
 
   // acc[w'] *= sum_kk A[w'][kk] * B[kk]: `bsrc(k2)` yields the B operands of k-steps 2*k2, 2*k2 + 1.
   // Explicit two-stage software pipeline: the operands of step k2 + 1 are requested before the MFMAs of
   // step k2 are issued (sched_barrier: left alone, the scheduler sinks the loads below the MFMAs to save
   // registers and then waits for them with vmcnt(0) — eight exposed L2 round trips per edge).
-  auto edge_product = [&](int branch, auto bsrc) {
+  // `pre` != nullptr (wave-uniform): one 16-byte agent-scope load of a sibling's deposit rides along with every step.
+  int polled = 0;  // (lane 0) arrival counter sampled near the end of an edge product, see the trunk loop
+  auto edge_product = [&](int branch, auto bsrc, const double *pre, const int *poll = nullptr) {
     const double *pf = a.Pfrag + (size_t)branch * NW * TILE;  // uniform
     f64x4 D[NW];
 #pragma unroll
@@ -562,6 +570,8 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
         for (int w = 0; w < NW; w++) An[w] = ld16(pf, (unsigned)((w * TILE + ((k2 + 1) * 64 + lane) * 2) * 8));
         bn = bsrc(k2 + 1);
       }
+      if (pre) dreg[k2] = ld16_agent(pre, (unsigned)(k2 * 64 + lane) * 16u);
+      if (poll && k2 == NKK / 2 - 2 && lane == 0) polled = __hip_atomic_load(poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int w = 0; w < NW; w++) D[w] = mfma(Ac[w][0], bc[0], D[w]);
@@ -585,11 +595,9 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
     }
   };
 
-
- for (;;) {  // chained fragments: run program `cur`, then possibly its parent program
-  const int4 prg = prog[cur];  // (scalar load: uniform control flow, schedule entries in SGPRs)
-  const int4 *__restrict__ pops = ops + prg.x;
-  const int n_ops = prg.y;
+  // Interpreter of one run of schedule entries.  `own`: (trunk nodes of a chain schedule) internal index of the child
+  // whose edge product this wave holds in `acc` already; `have_pre`: the deposit of the first OTHER child is in dreg.
+  auto run_ops = [&](const int4 *__restrict__ pops, int n_ops, int own, bool have_pre, int pre_cnt) {
   int4 op = pops[0];
   for (int oi = 0; oi < n_ops; oi++) {
     const int4 nxt = pops[oi + 1];
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
             b[0] = (c >= 0) ? ((8 * k2 + g == c) ? 1.0 : 0.0) : av[8 * k2 + g];
             b[1] = (c >= 0) ? ((8 * k2 + 4 + g == c) ? 1.0 : 0.0) : av[8 * k2 + 4 + g];
             return b;
-          });
+          }, nullptr);
         }
       }
     } else if (kind == OPK_INTERNAL) {
@@ -616,15 +624,33 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
       if (slot < 2) {  // the node finalised by the previous entry: operand straight from registers
         edge_product(op.z, [&](int k2) -> f64x2 {
           return (f64x2){bch[k2 >> 1][(k2 & 1) * 2], bch[k2 >> 1][(k2 & 1) * 2 + 1]};
-        });
+        }, nullptr);
         cnt += bcnt;
       } else {
         const double *src = park + (slot - 2) * TILE;
         const int ccnt = park_cnt[slot - 2][sl];
         edge_product(op.z, [&](int k2) -> f64x2 {
           return *reinterpret_cast<const f64x2 *>(src + (k2 * 64 + lane) * 2);
-        });
+        }, nullptr);
         cnt += ccnt;
+      }
+    } else if (kind == OPK_DEP) {
+      // trunk node of a chain schedule: the product of the edge from internal child op.w was deposited (agent-scope
+      // stores, drained before its arrival was counted) by the wave that computed it — unless that wave is this one
+      if (op.w != own) {
+        const double *src = a.deposits + ((size_t)op.w * a.ntiles + tile0) * TILE;  // uniform
+        int dcnt = pre_cnt;
+        if (!have_pre) {
+          dcnt = __hip_atomic_load(a.hand_cnt + ((size_t)op.w * a.ntiles + tile0) * 32 + sl, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int k2 = 0; k2 < NKK / 2; k2++) dreg[k2] = ld16_agent(src, (unsigned)(k2 * 64 + lane) * 16u);
+        }
+        have_pre = false;
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+          acc[w] *= (f64x4){dreg[2 * w][0], dreg[2 * w][1], dreg[2 * w + 1][0], dreg[2 * w + 1][1]};
+        cnt += dcnt;
       }
     } else {
       // The child's tile is in global memory — the root of a child fragment finished by another workgroup
@@ -646,7 +672,8 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
         for (int k2 = 0; k2 < NKK / 2; k2++)
           *reinterpret_cast<f64x2 *>(stage + (k2 * 64 + lane) * 2) = ld16(src, (unsigned)(k2 * 64 + lane) * 16u);
       }
-      edge_product(op.z, [&](int k2) -> f64x2 { return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2); });
+      edge_product(op.z, [&](int k2) -> f64x2 { return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2); },
+                   nullptr);
       cnt += ccnt;
     }
 
@@ -704,7 +731,13 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
     }
     op = nxt;
   }
-  if (prg.z < 0) break;  // the root program (or a stand-alone one)
+  };
+
+ int4 prg;
+ for (;;) {  // chained fragments: run program `cur`, then possibly its parent program
+  prg = prog[cur];  // (scalar load: uniform control flow, schedule entries in SGPRs)
+  run_ops(ops + prg.x, prg.y, -1, false, 0);
+  if (a.chain || prg.z < 0) break;  // a chain source / the root program (or a stand-alone one)
   // arrival at the parent program: the wave that completes the parent's last child fragment (for this
   // tile) continues with the parent; every other wave retires.  Payload stores were write-through.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -712,10 +745,81 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
   int old = 0;
   if (lane == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = __builtin_amdgcn_readfirstlane(old);
+  asm volatile("" ::: "memory");
   if (old + 1 < prog[prg.z].w) return;
   if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
   cur = prg.z;
  }
+
+  if (a.chain) {
+    // The trunk: `c` = internal index of the node whose (scaled) conditionals are in bch.  Per level: the edge product
+    // towards the parent p, the arrival at p, and — for the last arriver only — p's remaining children and its
+    // finalisation.  A wave that finds every sibling already arrived (relaxed read of the arrival counter BEFORE its
+    // own product) knows it will be last: it skips its own deposit and streams the sibling's deposit in under its
+    // MFMAs, so that a join costs the critical path one counter read instead of a ~4 us hand-off.
+    int c = prg.w;
+    int early = -1;  // arrival counter of c's parent, sampled (lane 0) while c itself was still being finalised
+    for (;;) {
+      const int4 jc = jn[c];
+      if (jc.x < 0) break;  // c is the root: epilogue below
+      const int p = jc.x;
+      const int4 jp = jn[p];
+      const int need = jp.y & 0xff;
+      int *ctr = a.frag_ctr + (size_t)p * a.ntiles + tile0;
+      bool last = need <= 1;
+      const double *pre = nullptr;
+      int pre_cnt = 0;
+      if (!last) {
+        int seen = early;
+        if (seen < 0 && lane == 0) seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen = __builtin_amdgcn_readfirstlane(seen);
+        asm volatile("" ::: "memory");
+        if (seen == need - 1) {
+          last = true;
+          if (need == 2) {  // the one sibling: its deposit streams in under this wave's own product
+            const int sib = (jp.y >> 8) - c;
+            pre = a.deposits + ((size_t)sib * a.ntiles + tile0) * TILE;
+            pre_cnt = __hip_atomic_load(a.hand_cnt + ((size_t)sib * a.ntiles + tile0) * 32 + sl, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      edge_product(a.L + c, [&](int k2) -> f64x2 {
+        return (f64x2){bch[k2 >> 1][(k2 & 1) * 2], bch[k2 >> 1][(k2 & 1) * 2 + 1]};
+      }, pre, last ? nullptr : ctr);
+      cnt = bcnt;
+      if (!last) {
+        // (the counter was sampled two k-steps before the end of the product: its round trip is covered)
+        const int seen = __builtin_amdgcn_readfirstlane(polled);
+        asm volatile("" ::: "memory");
+        if (seen != need - 1) {
+          // deposit the product (write-through), drain, count the arrival
+          double *out = a.deposits + ((size_t)c * a.ntiles + tile0) * TILE;  // uniform
+#pragma unroll
+          for (int w = 0; w < NW; w++) {
+            st16_agent(out, (unsigned)((2 * w) * 64 + lane) * 16u, (f64x2){acc[w][0], acc[w][1]});
+            st16_agent(out, (unsigned)((2 * w + 1) * 64 + lane) * 16u, (f64x2){acc[w][2], acc[w][3]});
+          }
+          if (g == 0)
+            __hip_atomic_store(a.hand_cnt + ((size_t)c * a.ntiles + tile0) * 32 + sl, cnt, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          int old = 0;
+          if (lane == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          old = __builtin_amdgcn_readfirstlane(old);
+          asm volatile("" ::: "memory");
+          if (old + 1 < need) return;  // somebody else will finish p
+        }
+      }
+      if (need > 1 && lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+      // sample the NEXT level's arrival counter now: the round trip hides behind p's leaves, deposits and finalisation
+      early = -1;
+      if (jp.x >= 0 && (jn[jp.x].y & 0xff) > 1 && lane == 0)
+        early = __hip_atomic_load(a.frag_ctr + (size_t)jp.x * a.ntiles + tile0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      run_ops(ops + jp.z, jp.w, c, pre != nullptr, pre_cnt);
+      c = p;
+    }
+  }
 
   if (a.do_root) {
     // root: L_s = sum_k root[s][k] pi[k]; bch holds the (scaled) root conditionals, bcnt its exponent
@@ -1200,12 +1304,13 @@ template <int NW, bool CLDS>
 void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
   const dim3 grid(a.ntiles / a.T, a.n_cat > 0 ? a.n_cat : 1, a.n_prog > 0 ? a.n_prog : 1), block(64 * NW);
   const size_t lds = CLDS ? (size_t)a.L * a.T * 16 * sizeof(int16_t) : 0;
-  const dim3 gridw(a.n_prog > 0 ? a.n_prog : 1, a.n_cat > 0 ? a.n_cat : 1, a.ntiles);  // wave kernels: tile-major
+  const dim3 gridw = a.chain ? dim3(a.ntiles, a.n_cat > 0 ? a.n_cat : 1, a.n_prog > 0 ? a.n_prog : 1)   // chains: source-major
+                             : dim3(a.n_prog > 0 ? a.n_prog : 1, a.n_cat > 0 ? a.n_cat : 1, a.ntiles);  // fragments: tile-major
   if (a.variant == 1 && a.T == 1) {  // wave-per-tile kernel: one wave per workgroup
     const dim3 block1(64);
     const size_t lds1 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
-    if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<NW, 0, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a);
-    else hipLaunchKernelGGL((prune_wave_kernel<NW, 1, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a);
+    if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<NW, 0, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+    else hipLaunchKernelGGL((prune_wave_kernel<NW, 1, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
     return;
   }
   if (a.timeline) {  // tracing build of the kernel (HYPHY_HIP_TIMELINE), T = 1 only

@@ -24,7 +24,7 @@ EXPORTS = [
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
     "hyphy_hip_set_pinned_states", "hyphy_hip_site_fits_evaluate", "hyphy_hip_site_fits_evaluate_mixture", "hyphy_hip_site_fits_kernel_ms",
-    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_last_error",
+    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
 
@@ -88,6 +88,10 @@ def load():
     lib.hyphy_hip_set_stream.argtypes = [vp, vp]
     lib.hyphy_hip_last_timings.restype = C.c_int
     lib.hyphy_hip_last_timings.argtypes = [vp, dp]
+    lib.hyphy_hip_schedule_info.restype = C.c_char_p
+    lib.hyphy_hip_schedule_info.argtypes = [vp]
+    lib.hyphy_hip_set_timing_detail.restype = C.c_int
+    lib.hyphy_hip_set_timing_detail.argtypes = [vp, C.c_int]
     lib.hyphy_hip_prune_timings.restype = C.c_int64
     lib.hyphy_hip_prune_timings.argtypes = [vp, dp, C.c_int64]
     lib.hyphy_hip_prune_launches.restype = C.c_int
@@ -395,6 +399,13 @@ class HipPartition:
 
     def prune_kernel_name(self) -> str:
         return self._lib.hyphy_hip_prune_kernel_name(self._h).decode()
+
+    def schedule_info(self) -> str:
+        return self._lib.hyphy_hip_schedule_info(self._h).decode()
+
+    def set_all_timings(self, on: bool):
+        """Also stamp the expm and reduction kernels of the evaluations that follow (``last_timings()[0]``, ``[2]``)."""
+        _check(self._lib.hyphy_hip_set_timing_detail(self._h, 1 if on else 0))
 
     def last_timings(self) -> np.ndarray:
         out = np.zeros(3)

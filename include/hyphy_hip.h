@@ -228,6 +228,9 @@ int hyphy_hip_set_stream(hyphy_hip_partition *p, void *stream);
 /* Per-call device timers of the last evaluation, milliseconds (SURVEY §5 tracing row):
  * out[0] = expm kernel(s), out[1] = pruning kernel, out[2] = root/site reduction. */
 int hyphy_hip_last_timings(hyphy_hip_partition *p, double out[3]);
+/* out[0] and out[2] are only stamped while the detail switch is on (two more event records per evaluation; the
+ * environment variable HYPHY_HIP_ALL_TIMINGS sets its initial state); out[1] comes from the ring below. */
+int hyphy_hip_set_timing_detail(hyphy_hip_partition *p, int on);
 
 /* ---- pinned node states ---------------------------------------------------------------------
  * ComputeBlock's branchIndex / branchValues ("setBranch": src/core/likefunc.cpp:10950-10957; leaf case
@@ -268,6 +271,11 @@ int hyphy_hip_prune_launches(hyphy_hip_partition *p);
 /* Name of the pruning kernel this partition's evaluations launch (chosen by shard size and state count;
  * as it appears in a rocprofv3 kernel trace).  Static string. */
 const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p);
+
+/* What the schedule tuner measured for this partition ("" before it ran): on the first steady-state full pass the
+ * library times the (idempotent) pruning pass under each candidate cut of the tree — level-peeled fragments, or chains
+ * with source subtrees of at most m internal nodes — and keeps the fastest.  HYPHY_HIP_TUNE=0 disables it. */
+const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p);
 
 const char *hyphy_hip_last_error(void);
 const char *hyphy_hip_version(void);

@@ -116,9 +116,16 @@ def build_script(*, fasta: str, newick: str, unit: int, model_block: str, model_
     L.append(f'fprintf ("{out_path}", CLEAR_FILE, "LOGL ", Format (res0, 30, 17), "\\n");')
     if sweep:
         p = sweep["param"]
+        rec = int(sweep.get("record", 0))   # keep the log-likelihoods of the first `record` points (parity at every timed point)
+        if rec > 0:
+            L.append(f"swv_ = {{{rec},1}};")
+        keep = f" if (k_ < {rec}) {{ swv_[k_] = res_; }}" if rec > 0 else ""
         L.append("t0_ = Time (1);")
-        L.append(f"for (k_ = 0; k_ < {int(sweep['n'])}; k_ += 1) {{ {p} = {_fmt(sweep['start'])} + {_fmt(sweep['step'])}*(k_+1); LFCompute (lf, res_); }}")
+        L.append(f"for (k_ = 0; k_ < {int(sweep['n'])}; k_ += 1) {{ {p} = {_fmt(sweep['start'])} + {_fmt(sweep['step'])}*(k_+1); LFCompute (lf, res_);{keep} }}")
         L.append("t1_ = Time (1);")
+        if rec > 0:
+            L.append(f'fprintf ("{out_path}", "SWEEP_VALUES ", {min(rec, int(sweep["n"]))}, "\\n");')
+            L.append(f'for (k_ = 0; k_ < {min(rec, int(sweep["n"]))}; k_ += 1) {{ fprintf ("{out_path}", Format (swv_[k_], 30, 17), "\\n"); }}')
         L.append(f'fprintf ("{out_path}", "SWEEP_SECONDS ", Format (t1_-t0_, 20, 6), "\\n", "SWEEP_LAST ", Format (res_, 30, 17), "\\n");')
         L.append(f"{p} = {_fmt(globals_[p])};")
     L.append("LFCompute (lf, LF_DONE_COMPUTE);")
@@ -166,6 +173,10 @@ def parse_output(path: str) -> Dict:
             out["sweep_seconds"] = float(ln.split()[1])
         elif ln.startswith("SWEEP_LAST "):
             out["sweep_last"] = float(ln.split()[1])
+        elif ln.startswith("SWEEP_VALUES "):
+            n = int(ln.split()[1])
+            out["sweep_values"] = np.array([float(x) for x in lines[i + 1:i + 1 + n]])
+            i += n
         elif ln.startswith("SITES "):
             n = int(ln.split()[1])
             out["site_logl"] = np.array([float(x) for x in lines[i + 1:i + 1 + n]])

@@ -21,7 +21,12 @@ for case in range(n_cases):
     kernel = str(int(rng.integers(0, 2)))
     frag = int(rng.choice([2, 3, 5, 8, 13, 1000]))
     slots, persist = str(int(rng.choice([2, 3]))), str(rng.choice(["lazy", "always"]))
-    kernel, frag, slots, persist = (os.environ.get("STRESS_" + k, v) for k, v in (("KERNEL", kernel), ("FRAGMENT", frag), ("SLOTS", slots), ("CACHE", persist)))
+    chain_m = str(int(rng.choice([0, 1, 2, 3, 5])))   # wave-per-tile kernel: chain schedule with sources of <= m nodes (0: level-peeled fragments)
+    kernel, frag, slots, persist, chain_m = (os.environ.get("STRESS_" + k, v) for k, v in (("KERNEL", kernel), ("FRAGMENT", frag), ("SLOTS", slots), ("CACHE", persist), ("CHAIN_M", chain_m)))
+    if int(chain_m) > 0:
+        os.environ["HYPHY_HIP_CHAIN_M"] = str(chain_m)
+    else:
+        os.environ.pop("HYPHY_HIP_CHAIN_M", None)
     os.environ["HYPHY_HIP_KERNEL"] = str(kernel)
     os.environ["HYPHY_HIP_FRAGMENT"] = str(frag)
     os.environ["HYPHY_HIP_SLOTS"] = slots
@@ -49,7 +54,7 @@ for case in range(n_cases):
             global n_checks
             n_checks += 1
             if not (abs(got - ref) <= RTOL * abs(ref) or (got == ref)):
-                raise SystemExit(f"MISMATCH case {case} ({taxa} taxa, {codons} codons, kernel {kernel}, frag {frag}, slots {slots}, cache {persist}, T {tiles}) {tag}: {got!r} vs {ref!r}")
+                raise SystemExit(f"MISMATCH case {case} ({taxa} taxa, {codons} codons, kernel {kernel}, frag {frag}, chain_m {chain_m}, slots {slots}, cache {persist}, T {tiles}) {tag}: {got!r} vs {ref!r}")
         check("first", part.evaluate(nodes, nodes, Q, pi), op.compute_block(nodes, pi))
         for step in range(int(rng.integers(4, 10))):
             what = rng.choice(["full", "partial", "branch_cache", "pinned", "download"], p=[0.3, 0.3, 0.15, 0.15, 0.1])
@@ -102,5 +107,5 @@ for case in range(n_cases):
                     if not np.allclose(x[ok] / sx[ok], y[ok] / sy[ok], rtol=1e-8, atol=1e-300):
                         raise SystemExit(f"MISMATCH case {case} download node {n}")
                 n_checks += 1
-    print(f"case {case}: {taxa} taxa x {codons} codons ({pd.S} patterns), kernel {kernel}, fragment {frag}, slots {slots}, {persist}, T {tiles}: ok", flush=True)
+    print(f"case {case}: {taxa} taxa x {codons} codons ({pd.S} patterns), kernel {kernel}, fragment {frag}, chain_m {chain_m}, slots {slots}, {persist}, T {tiles}: ok", flush=True)
 print(f"{n_cases} cases, {n_checks} checks passed in {time.time() - t0:.0f} s")

@@ -40,6 +40,11 @@ for case in range(n_cases):
     persist = os.environ.get("STRESS_CACHE", str(rng.choice(["lazy", "always"])))
     tiles = os.environ.get("STRESS_TILES", str(int(rng.choice([1, 1, 2, 3, 4]))))  # patterns tiles per workgroup (workgroup kernel)
     shards = os.environ.get("STRESS_SHARDS", str(int(rng.choice([0, 0, 2, 3]))))  # pattern shards (here: all on one device)
+    chain_m = os.environ.get("STRESS_CHAIN_M", str(int(rng.choice([0, 1, 2, 4]))))  # wave kernel: chain schedule (0: level-peeled fragments)
+    if int(chain_m) > 0:
+        os.environ["HYPHY_HIP_CHAIN_M"] = chain_m
+    else:
+        os.environ.pop("HYPHY_HIP_CHAIN_M", None)
     os.environ["HYPHY_HIP_KERNEL"], os.environ["HYPHY_HIP_FRAGMENT"], os.environ["HYPHY_HIP_CACHE"] = kernel, frag, persist
     os.environ["HYPHY_HIP_TILES"], os.environ["HYPHY_HIP_FORCE_SHARDS"] = tiles, shards
     from hyphy_amd import hip
@@ -96,7 +101,7 @@ for case in range(n_cases):
         global n_checks
         n_checks += 1
         if not (abs(got - ref) <= RTOL * abs(ref) or got == ref):
-            raise SystemExit(f"MISMATCH case {case} (D {D}, {taxa} taxa, {pd.S} patterns, {n_cat} classes, kernel {kernel}, frag {frag}, {persist}, T {tiles}, shards {shards}, templated {templated}) {tag}: {got!r} vs {ref!r}")
+            raise SystemExit(f"MISMATCH case {case} (D {D}, {taxa} taxa, {pd.S} patterns, {n_cat} classes, kernel {kernel}, frag {frag}, chain_m {chain_m}, {persist}, T {tiles}, shards {shards}, templated {templated}) {tag}: {got!r} vs {ref!r}")
 
     for c in range(n_cat):
         op.set_P(nodes, oracle.expm(Q[c], D > 4), cat=c)
@@ -150,5 +155,5 @@ for case in range(n_cases):
                 n_checks += 1
                 if not (abs(got[st, s_] - ref) <= 1e-9 * max(1.0, abs(ref)) or got[st, s_] == ref):
                     raise SystemExit(f"MISMATCH case {case} site fits (D {D}, {taxa} taxa, set {st}, pattern {s_}): {got[st, s_]!r} vs {ref!r}")
-    print(f"case {case}: D {D}, {taxa} taxa, {pd.S} patterns, {n_cat} classes, kernel {kernel}, fragment {frag}, {persist}, T {tiles}, shards {shards}, templated {templated}: ok", flush=True)
+    print(f"case {case}: D {D}, {taxa} taxa, {pd.S} patterns, {n_cat} classes, kernel {kernel}, fragment {frag}, chain_m {chain_m}, {persist}, T {tiles}, shards {shards}, templated {templated}: ok", flush=True)
 print(f"{n_cases} cases, {n_checks} checks passed in {time.time() - t0:.0f} s")
