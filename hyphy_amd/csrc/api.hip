@@ -815,7 +815,9 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     pa.ablate = 0;
     if (const char *ab = getenv("HYPHY_HIP_ABLATE")) pa.ablate = atoi(ab);
     const char *tl_path = getenv("HYPHY_HIP_TIMELINE");
-    const size_t tl_n = (size_t)kTraceWG * p->NW * std::max(1, n_ops) * 4;
+    const bool tl_wave = p->variant >= 1;  // wave-per-tile kernel: one record of 8 words per wave of the grid
+    const size_t tl_waves = (size_t)s.ntiles * std::max(1, n_cat_batch) * std::max<size_t>(1, p->programs.size());
+    const size_t tl_n = tl_wave ? tl_waves * 8 : (size_t)kTraceWG * p->NW * std::max(1, n_ops) * 4;
     if (tl_path && n_ops > 0 && s.T == 1) {
       HIPCHK(hipMalloc((void **)&pa.timeline, tl_n * sizeof(long long)));
       HIPCHK(hipMemsetAsync(pa.timeline, 0, tl_n * sizeof(long long), s.stream));
@@ -838,7 +840,17 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       HIPCHK(hipStreamSynchronize(s.stream));
       HIPCHK(hipMemcpy(h.data(), pa.timeline, tl_n * sizeof(long long), hipMemcpyDeviceToHost));
       hipFree(pa.timeline);
-      if (FILE *f = fopen(tl_path, "w")) {
+      if (tl_wave) {
+        if (FILE *f = fopen(tl_path, "w")) {
+          fprintf(f, "# wave t_start t_prologue t_program t_end levels how hw_id xcc_id   (100 MHz ticks; grid = %s)\n",
+                  p->chain ? "tiles x classes x sources" : "programs x classes x tiles");
+          for (size_t k = 0; k < tl_waves; k++) {
+            const long long *r = &h[k * 8];
+            fprintf(f, "%zu %lld %lld %lld %lld %lld %lld %lld %lld\n", k, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+          }
+          fclose(f);
+        }
+      } else if (FILE *f = fopen(tl_path, "w")) {
         fprintf(f, "# wg wave entry flags t_start t_compute_done t_after_barrier t_finalised\n");
         for (int b = 0; b < kTraceWG; b++)
           for (int w = 0; w < p->NW; w++)
@@ -1315,6 +1327,7 @@ static void launch_prune_current(hyphy_hip_partition *p, Shard &s, int cat, int 
   pa.chain = p->chain ? 1 : 0;
   pa.jn = s.jn;
   pa.deposits = s.deposits;
+  if (const char *ab = getenv("HYPHY_HIP_ABLATE")) pa.ablate = atoi(ab);
   for (size_t lv = 0; lv < p->levels.size(); lv++) {
     pa.prog = s.prog + p->levels[lv].first;
     pa.n_prog = p->levels[lv].count;

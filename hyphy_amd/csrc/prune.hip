@@ -492,9 +492,28 @@ __device__ __forceinline__ double row_sum4(double x) {
 #define HYPHY_OCC3 2
 #endif
 
-template <int NW, int NP, bool CLDS>
+// TRACE (HYPHY_HIP_TIMELINE, a separate diagnostic instantiation): per wave [start, prologue done, source program done,
+// end] in 100 MHz ticks, trunk levels walked (+100 per prefetched join, +1000 per join won after depositing), how it
+// ended (0 deposited and retired, 1 reached the root, 2 retired at a fragment hand-off), HW_ID and XCC_ID; it also honours
+// HYPHY_HIP_ABLATE bits 256 / 512 (no deposit stores / no deposit reads: results invalid).
+#define HYPHY_TRACE_STAMP(k) \
+  if constexpr (TRACE) tr_t[k] = wall_clock64();
+#define HYPHY_TRACE_FINISH(how)                                                                                          \
+  if constexpr (TRACE) {                                                                                                 \
+    if (a.timeline && threadIdx.x == 0) {                                                                                \
+      long long *r_ = a.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;         \
+      r_[0] = tr_t[0], r_[1] = tr_t[1], r_[2] = tr_t[2], r_[3] = wall_clock64(), r_[4] = tr_levels, r_[5] = (how);      \
+      r_[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                                                 \
+      r_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                                                \
+    }                                                                                                                    \
+  }
+
+template <int NW, int NP, bool CLDS, bool TRACE = false>
 __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *__restrict__ ops, const int4 *__restrict__ prog,
                                                                              const int4 *__restrict__ jn, PruneArgs a) {
+  [[maybe_unused]] long long tr_t[3] = {0, 0, 0};
+  [[maybe_unused]] int tr_levels = 0;
+  HYPHY_TRACE_STAMP(0)
   // legacy grid = (leaf programs, classes, tiles): tile-major dispatch order, so that a tile's chained parent
   // programs start while other tiles still run their leaf fragments (no low-occupancy tail);
   // chain grid = (tiles, classes, sources), sources sorted by their distance to the root: every tile's critical path
@@ -539,6 +558,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
     return (int)a.codes_tile[((size_t)tile0 * a.L + leaf) * 16 + sl];
   };
 
+  HYPHY_TRACE_STAMP(1)
   const f64x4 ones = (f64x4){1., 1., 1., 1.}, zeros = (f64x4){0., 0., 0., 0.};
   f64x4 acc[NW], bch[NW];  // running product of the current parent / the node finalised last (scaled)
   f64x2 dreg[NKK / 2];     // chain schedules: a sibling's deposited edge product, fetched while this wave's own product runs
@@ -640,7 +660,9 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
       if (op.w != own) {
         const double *src = a.deposits + ((size_t)op.w * a.ntiles + tile0) * TILE;  // uniform
         int dcnt = pre_cnt;
-        if (!have_pre) {
+        bool skip_load = have_pre;
+        if constexpr (TRACE) skip_load = skip_load || (a.ablate & 512) != 0;
+        if (!skip_load) {
           dcnt = __hip_atomic_load(a.hand_cnt + ((size_t)op.w * a.ntiles + tile0) * 32 + sl, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
@@ -746,10 +768,14 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
   if (lane == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = __builtin_amdgcn_readfirstlane(old);
   asm volatile("" ::: "memory");
-  if (old + 1 < prog[prg.z].w) return;
+  if (old + 1 < prog[prg.z].w) {
+    HYPHY_TRACE_FINISH(2)
+    return;
+  }
   if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
   cur = prg.z;
  }
+  HYPHY_TRACE_STAMP(2)
 
   if (a.chain) {
     // The trunk: `c` = internal index of the node whose (scaled) conditionals are in bch.  Per level: the edge product
@@ -795,6 +821,9 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
         if (seen != need - 1) {
           // deposit the product (write-through), drain, count the arrival
           double *out = a.deposits + ((size_t)c * a.ntiles + tile0) * TILE;  // uniform
+          bool skip_store = false;
+          if constexpr (TRACE) skip_store = (a.ablate & 256) != 0;
+          if (!skip_store)
 #pragma unroll
           for (int w = 0; w < NW; w++) {
             st16_agent(out, (unsigned)((2 * w) * 64 + lane) * 16u, (f64x2){acc[w][0], acc[w][1]});
@@ -808,7 +837,11 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
           if (lane == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           old = __builtin_amdgcn_readfirstlane(old);
           asm volatile("" ::: "memory");
-          if (old + 1 < need) return;  // somebody else will finish p
+          if (old + 1 < need) {  // somebody else will finish p
+            HYPHY_TRACE_FINISH(0)
+            return;
+          }
+          if constexpr (TRACE) tr_levels += 1000;
         }
       }
       if (need > 1 && lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
@@ -817,6 +850,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
       if (jp.x >= 0 && (jn[jp.x].y & 0xff) > 1 && lane == 0)
         early = __hip_atomic_load(a.frag_ctr + (size_t)jp.x * a.ntiles + tile0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       run_ops(ops + jp.z, jp.w, c, pre != nullptr, pre_cnt);
+      if constexpr (TRACE) tr_levels += 1 + (pre ? 100 : 0);
       c = p;
     }
   }
@@ -856,6 +890,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
       a.wg_flag[tile0] = wflag;
     }
   }
+  HYPHY_TRACE_FINISH(1)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1309,6 +1344,10 @@ void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
   if (a.variant == 1 && a.T == 1) {  // wave-per-tile kernel: one wave per workgroup
     const dim3 block1(64);
     const size_t lds1 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
+    if (a.timeline && NW == 4 && CLDS) {  // tracing build (HYPHY_HIP_TIMELINE)
+      hipLaunchKernelGGL((prune_wave_kernel<4, 1, true, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      return;
+    }
     if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<NW, 0, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
     else hipLaunchKernelGGL((prune_wave_kernel<NW, 1, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
     return;
