@@ -169,6 +169,10 @@ struct hyphy_hip_partition {
   bool chain = false;                        // the current schedule is a chain schedule (common.h PruneArgs::chain)
   bool kernel_forced = false;                // HYPHY_HIP_KERNEL / T > 1: the tuner must not switch kernels
   int n_slots_wave = 3;                      // LDS slot budget of the wave-per-tile kernel's schedules
+  double *h_qstage = nullptr;                // pinned copy of the caller's matrices for hyphy_hip_evaluate_async
+  size_t h_qstage_cap = 0;
+  bool async_pending = false;                // an asynchronous evaluation has not been collected yet
+  int64_t async_cat = 0;
   int chain_m_forced = 0;                    // cut chosen by the schedule tuner: > 0 source size limit m, -1 level-peeled fragments, 0 heuristic
   int64_t tuned_for = 0;                     // batch_classes the tuner ran for (0: not yet)
   std::string tune_report;                   // what the tuner measured (hyphy_hip_schedule_info)
@@ -1051,6 +1055,7 @@ int hyphy_hip_device_count(void) {
 void hyphy_hip_destroy(hyphy_hip_partition *p) {
   if (!p) return;
   for (Shard &s : p->shards) free_shard(s);
+  if (p->h_qstage) hipHostFree(p->h_qstage);
   delete p;
 }
 
@@ -1399,6 +1404,14 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   if (!p) return fail("partition == NULL");
   if (cat < 0) cat = 0;
   if (cat >= p->C) return fail("rate class out of range");
+  if (p->async_pending) {  // (an uncollected asynchronous evaluation: its result record is about to be overwritten)
+    for (Shard &s : p->shards) {
+      HIPCHK(hipSetDevice(s.device));
+      HIPCHK(hipStreamSynchronize(s.stream));
+      s.seq_wait = 0.;
+    }
+    p->async_pending = false;
+  }
   if (batch) {  // all classes in one launch: bookkeeping is shared, keyed on class 0
     if (p->nuc) return fail("internal: class batching is for the MFMA path");
     cat = 0;
@@ -1482,6 +1495,51 @@ int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   if (logl_out) *logl_out = combine(parts);
   if (site_lik_out || site_scaler_out)
     return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
+  return 0;
+}
+
+/* Asynchronous pair (partitions of one likelihood function on different devices / streams overlap: the host enqueues
+ * every partition's evaluation before it waits for the first — the reference's partition loop, likefunc.cpp:2524-2589,
+ * is serial).  The matrices are copied to a pinned staging buffer, so the caller's array is free on return. */
+int hyphy_hip_evaluate_async(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                             const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
+                             const double *root_freqs) {
+  if (!p) return fail("partition == NULL");
+  if (p->async_pending && hyphy_hip_synchronize(p)) return -1;
+  p->async_pending = false;
+  const size_t n = (size_t)std::max<int64_t>(0, n_q) * p->D * p->D;
+  if (n > 0) {
+    if (!q_dense) return fail("null matrix list");
+    if (p->h_qstage_cap < n) {
+      if (hyphy_hip_synchronize(p)) return -1;
+      if (p->h_qstage) hipHostFree(p->h_qstage);
+      p->h_qstage = nullptr;
+      p->h_qstage_cap = 0;
+      const size_t cap = std::max(n, (size_t)p->B * p->D * p->D);
+      HIPCHK(hipHostMalloc((void **)&p->h_qstage, cap * sizeof(double)));
+      p->h_qstage_cap = cap;
+    }
+    // (the previous asynchronous evaluation was collected or synchronised above: the staging buffer is free)
+    memcpy(p->h_qstage, q_dense, n * sizeof(double));
+  }
+  if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, n > 0 ? p->h_qstage : nullptr, false, q_is_probability,
+                  root_freqs, nullptr, true, false))
+    return -1;
+  p->async_pending = true;
+  p->async_cat = cat < 0 ? 0 : cat;
+  return 0;
+}
+
+int hyphy_hip_collect(hyphy_hip_partition *p, double *logl_out, double *site_lik_out, int64_t *site_scaler_out) {
+  if (!p) return fail("partition == NULL");
+  if (!p->async_pending) return fail("collect: no asynchronous evaluation pending");
+  p->async_pending = false;
+  if (collect_status(p)) return -1;
+  std::vector<double> parts;
+  for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
+  record_timings(p);
+  if (logl_out) *logl_out = combine(parts);
+  if (site_lik_out || site_scaler_out) return gather_sites(p, (int)p->async_cat, site_lik_out, site_scaler_out, false);
   return 0;
 }
 

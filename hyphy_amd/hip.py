@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("HYPHY_HIP_LIB") or os.path.join(HERE, "lib", "libhyph
 
 EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
-    "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
+    "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
@@ -56,6 +56,10 @@ def load():
     lib.hyphy_hip_destroy.argtypes = [vp]
     lib.hyphy_hip_evaluate.restype = C.c_int
     lib.hyphy_hip_evaluate.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp, dp, dp, lp]
+    lib.hyphy_hip_evaluate_async.restype = C.c_int
+    lib.hyphy_hip_evaluate_async.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp]
+    lib.hyphy_hip_collect.restype = C.c_int
+    lib.hyphy_hip_collect.argtypes = [vp, dp, dp, lp]
     lib.hyphy_hip_evaluate_device.restype = C.c_int
     lib.hyphy_hip_evaluate_device.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, vp, C.c_int, dp, vp]
     lib.hyphy_hip_evaluate_categories.restype = C.c_int
@@ -191,6 +195,23 @@ class HipPartition:
         sc = np.zeros(self.S, dtype=np.int64) if per_site else None
         _check(self._lib.hyphy_hip_evaluate(self._h, cat, _l(un), len(un), _l(qn), len(qn), _d(q),
                                             int(q_is_probability), _d(rf), C.byref(out), _d(sl), _l(sc)))
+        return (out.value, sl, sc) if per_site else out.value
+
+    def evaluate_async(self, update_nodes, q_nodes, q_dense, root_freqs, cat: int = -1, q_is_probability: bool = False):
+        """Enqueue an evaluation and return at once (``collect`` waits for it): lets the partitions of one
+        likelihood function overlap on different devices / streams."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        q = np.ascontiguousarray(q_dense, dtype=np.float64) if len(qn) else None
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        _check(self._lib.hyphy_hip_evaluate_async(self._h, cat, _l(un), len(un), _l(qn), len(qn), _d(q),
+                                                  int(q_is_probability), _d(rf)))
+
+    def collect(self, per_site: bool = False):
+        out = C.c_double(0.0)
+        sl = np.zeros(self.S) if per_site else None
+        sc = np.zeros(self.S, dtype=np.int64) if per_site else None
+        _check(self._lib.hyphy_hip_collect(self._h, C.byref(out), _d(sl), _l(sc)))
         return (out.value, sl, sc) if per_site else out.value
 
     def evaluate_device(self, update_nodes, q_nodes, d_q_ptr: int, root_freqs, d_logl_ptr: int, cat: int = -1,

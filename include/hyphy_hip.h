@@ -104,6 +104,20 @@ int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
                        int64_t *site_scaler_out);
 
 /*
+ * The same evaluation split in two, so that the partitions of one likelihood function overlap (different devices, or
+ * different streams of one device): enqueue every partition, then collect.  The reference's partition loop in
+ * _LikelihoodFunction::Compute (src/core/likefunc.cpp:2524-2589) calls ComputeBlock(partID) serially and its MPI
+ * partition mode (:2708-2768) farms the partitions out; the adapter's pre-pass does the former on
+ * N devices.  evaluate_async copies the matrices to a pinned staging buffer (host arrays are free on return) and
+ * returns as soon as everything is enqueued; collect waits and returns what hyphy_hip_evaluate returns.  Any other
+ * evaluation entry point called in between finishes the pending evaluation first.
+ */
+int hyphy_hip_evaluate_async(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                             const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
+                             const double *root_freqs);
+int hyphy_hip_collect(hyphy_hip_partition *p, double *logl_out, double *site_lik_out, int64_t *site_scaler_out);
+
+/*
  * Same evaluation with device-resident inputs/outputs, enqueued asynchronously on the
  * partition's stream (device_count must be 1): d_q is a DEVICE pointer [n_q*D*D];
  * d_logl_out a DEVICE pointer to one double that receives this shard's partial

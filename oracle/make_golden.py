@@ -252,7 +252,116 @@ def reference_test_case_nuc(name="ref_fluHA"):
     print(f"{name}: logL = {res['logl']!r}  S = {pd.S}")
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configurations at their STATED sizes ("no -m gpu test runs any BASELINE config at its
+# stated size").  The alignments are the synthetic ones bench.py uses (hyphy_amd.data.evolve with bench.py's seeds:
+# regenerated from the seed on the GPU box, checked against the CRC stored here), evaluated by the unmodified
+# reference at bench.py's first parameter point (all branch parameters 0.05, omega 0.3).  Stored: scalar log L and
+# per-site log L (all sites up to 10 000 codons, 2 000 sampled sites beyond).
+#     python -m oracle.make_golden fullsize
+# ---------------------------------------------------------------------------------------------------------------
+def _crc(a):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff
+
+
+def _site_sample(n_sites, seed):
+    if n_sites <= 10000:
+        return np.arange(n_sites)
+    return np.sort(np.random.default_rng(seed).choice(n_sites, size=2000, replace=False))
+
+
+def fullsize_codon(name, taxa, codons, seed, classes=None, threads=8):
+    syn = data.evolve(taxa, codons, 3, seed=seed, p_change=0.04)
+    flat = syn.flat
+    bt = {n: 0.05 for n in flat.branch_names()}
+    tmpl = models.mg94rev_template(POS_FREQS)
+    pi = models.f3x4_codon_freqs(POS_FREQS)
+    g = dict(R=0.3, **REV)
+    category = None
+    omega_expr = "R"
+    if classes:   # BUSTED-style: 3 omega classes mixed per site (weighted-sum category mode), omega_c = R * cc
+        category = dict(name="cc", weights=classes["weights"], values=classes["values"])
+        omega_expr = "R*cc"
+    res = hbl.evaluate(names=flat.leaf_names, seqs=syn.seqs, newick=tree.to_newick(syn.tree), unit=3,
+                       model_block=hbl.codon_model_block(tmpl, pi, omega=omega_expr), model_name="MGM", globals_=g, branch_t=bt,
+                       category=category, threads=threads, timeout=3600.0)
+    idx = _site_sample(codons, seed)
+    fx = dict(kind="codon_full", taxa=taxa, sites=codons, seed=seed, p_change=0.04, states_crc=_crc(syn.states.astype(np.int16)),
+              t=0.05, omega=0.3, rev=np.array([REV[k] for k in ("AC", "AT", "CG", "CT", "GT")]), pos_freqs=POS_FREQS,
+              logl=res["logl"], site_index=idx, site_logl=res["site_logl"][idx])
+    if classes:
+        fx["cat_weights"] = np.array(classes["weights"])
+        fx["cat_values"] = np.array(classes["values"])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(f"{name}: logL = {res['logl']!r}  sites stored {len(idx)}")
+
+
+def fullsize_partitions(name="full_gtr_32x50k_x8", taxa=32, sites=50000, n_part=8, seed0=5, threads=8):
+    """configs[4]: GARD-style multi-partition GTR — 8 partitions of 32 taxa x 50 000 sites, each with its own tree and
+    alignment, ONE likelihood function over all of them (syntax precedent: res/TemplateBatchFiles/REL/MultiplePartitions.bf
+    builds `LikelihoodFunction lf = (filter_1, tree_1, filter_2, tree_2, ...)`).  Stored: the total log L, every
+    partition's own log L (single-partition functions) and sampled per-site values of partition 0."""
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="hygold_")
+    outp = os.path.join(tmp, "out.txt")
+    rev = dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4)
+    L = ["VERBOSITY_LEVEL = -1;", "PRINT_DIGITS = 17;"] + [f"global {k} = {v!r};" for k, v in rev.items()]
+    L.append(hbl.nuc_model_block(NUC_FREQS))
+    L.append("UseModel (NM);")
+    crcs, part_ll = [], []
+    pairs = []
+    for k in range(n_part):
+        syn = data.evolve(taxa, sites, 1, seed=seed0 + k, p_change=0.25)
+        crcs.append(_crc(syn.states.astype(np.int16)))
+        fasta = os.path.join(tmp, f"p{k}.fasta")
+        hbl.write_fasta(fasta, syn.flat.leaf_names, syn.seqs)
+        L.append(f"Tree t{k} = {tree.to_newick(syn.tree)};")
+        L.append(f'DataSet ds{k} = ReadDataFile ("{fasta}");')
+        L.append(f"DataSetFilter f{k} = CreateFilter (ds{k},1);")
+        for n in syn.flat.branch_names():
+            L.append(f"t{k}.{n}.t = 0.05;")
+        pairs.append(f"f{k}, t{k}")
+        if k == 0:
+            site0 = syn
+    L.append(f"LikelihoodFunction lf = ({', '.join(pairs)});")
+    L.append(f"NUMBER_THREADS = {threads};")
+    L.append("LFCompute (lf, LF_START_COMPUTE); LFCompute (lf, res0); LFCompute (lf, LF_DONE_COMPUTE);")
+    L.append(f'fprintf ("{outp}", CLEAR_FILE, "LOGL ", Format (res0, 30, 17), "\n");')
+    for k in range(n_part):
+        L.append(f"LikelihoodFunction lf{k} = (f{k}, t{k}); LFCompute (lf{k}, LF_START_COMPUTE); LFCompute (lf{k}, r{k}); LFCompute (lf{k}, LF_DONE_COMPUTE);")
+        L.append(f'fprintf ("{outp}", "PART ", Format (r{k}, 30, 17), "\n");')
+    L.append("ConstructCategoryMatrix (sl_, lf0, SITE_LOG_LIKELIHOODS);")
+    L.append(f'fprintf ("{outp}", "SITES ", Columns (sl_), "\n");')
+    L.append(f'for (k_ = 0; k_ < Columns (sl_); k_ += 1) {{ fprintf ("{outp}", Format (sl_[k_], 30, 17), "\n"); }}')
+    hbl.run_script("\n".join(L) + "\n", tmp, cpus=threads, timeout=3600.0)
+    res = hbl.parse_output(outp)
+    with open(outp) as fh:
+        part_ll = [float(ln.split()[1]) for ln in fh if ln.startswith("PART ")]
+    idx = _site_sample(sites, seed0)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="nuc_partitions", taxa=taxa, sites=sites, n_part=n_part,
+                        seed0=seed0, p_change=0.25, states_crc=np.array(crcs), t=0.05,
+                        rev=np.array([rev[k] for k in ("AC", "AT", "CG", "CT", "GT")]), root_freqs=NUC_FREQS,
+                        logl=res["logl"], part_logl=np.array(part_ll), site_index=idx, site_logl_part0=res["site_logl"][idx])
+    print(f"{name}: logL = {res['logl']!r}  sum of partitions = {sum(part_ll)!r}")
+
+
+def fullsize_cases():
+    fullsize_codon("full_mg94_32x5k", 32, 5000, seed=2)            # configs[1]
+    fullsize_codon("full_mg94_64x10k", 64, 10000, seed=3)          # the headline metric's workload
+    fullsize_codon("full_busted3_64x10k", 64, 10000, seed=3,       # configs[2]
+                   classes=dict(weights=[0.7, 0.25, 0.05], values=[0.1 / 0.3, 1.0 / 0.3, 5.0 / 0.3]))
+    fullsize_codon("full_mg94_128x100k", 128, 100000, seed=4)      # configs[3] (all 100 000 codons on one device in the test)
+    fullsize_partitions()                                          # configs[4]
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
+        if not hbl.have_reference():
+            raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
+        os.makedirs(OUT, exist_ok=True)
+        fullsize_cases()
+        return
     if not hbl.have_reference():
         raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
     os.makedirs(OUT, exist_ok=True)
