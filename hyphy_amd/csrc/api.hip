@@ -1543,6 +1543,14 @@ int hyphy_hip_collect(hyphy_hip_partition *p, double *logl_out, double *site_lik
   return 0;
 }
 
+int hyphy_hip_evaluate_built_sites(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                                   const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out,
+                                   double *site_lik_out, int64_t *site_scaler_out) {
+  if (hyphy_hip_evaluate_built(p, cat, update_nodes, n_update, q_nodes, n_q, root_freqs, logl_out)) return -1;
+  if (site_lik_out || site_scaler_out) return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
+  return 0;
+}
+
 int hyphy_hip_evaluate_built(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                              const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out) {
   if (!p) return fail("partition == NULL");
@@ -1974,6 +1982,27 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
   p->K = K;
   p->templates_host.assign(templates, templates + (size_t)K * D * D);
   for (Shard &s : p->shards) s.fit_static_current = false;
+  return 0;
+}
+
+/* Replace the VALUES of the K templates (same K as hyphy_hip_set_q_templates): in-stream, no reallocation.  For hosts
+ * whose templates depend on the global parameters of the current evaluation (template mode of the
+ * adapter: Q_b = sum_k x_bk M_k(globals), M_k re-derived at every evaluation from K probe branches). */
+int hyphy_hip_update_q_templates(hyphy_hip_partition *p, int64_t K, const double *templates) {
+  if (!p || K < 1 || !templates) return fail("invalid templates");
+  if (K != p->K) return hyphy_hip_set_q_templates(p, K, templates);
+  const int64_t D = p->D;
+  const size_t n = (size_t)K * D * D;
+  if (p->templates_host.size() == n && !memcmp(p->templates_host.data(), templates, n * sizeof(double))) return 0;
+  p->templates_host.assign(templates, templates + n);
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    // (staged through the pinned coefficient ring's allocation would race with queued kernels; a small synchronous
+    //  wait on the stream keeps it simple: the previous evaluation has been collected by the time a host adapter gets here)
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipMemcpyAsync(s.templates, p->templates_host.data(), n * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    s.fit_static_current = false;
+  }
   return 0;
 }
 

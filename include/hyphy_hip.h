@@ -177,6 +177,10 @@ int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_
  */
 int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *templates /* [K*D*D] */);
 int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs /* host [n*K] */);
+/* New VALUES for the K templates (K unchanged: no reallocation): for hosts whose templates depend on the global
+ * parameters of the current evaluation — the HyPhy adapter derives M_k(globals) from K probe branches per
+ * ExponentiateMatrices call and sends Q_b = sum_k x_bk M_k as K coefficients per branch. */
+int hyphy_hip_update_q_templates(hyphy_hip_partition *p, int64_t K, const double *templates /* [K*D*D] */);
 double *hyphy_hip_q_buffer(hyphy_hip_partition *p); /* device pointer, capacity (L+I-1)*C*D*D doubles */
 
 /*
@@ -225,6 +229,11 @@ double hyphy_hip_site_fits_kernel_ms(const hyphy_hip_partition *p); /* duration 
  * coefficients go down and one double comes back.  Same semantics as hyphy_hip_evaluate otherwise. */
 int hyphy_hip_evaluate_built(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                              const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out);
+
+/* hyphy_hip_evaluate_built + the per-pattern outputs of hyphy_hip_evaluate (storageVec / siteCorrections). */
+int hyphy_hip_evaluate_built_sites(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                                   const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out,
+                                   double *site_lik_out, int64_t *site_scaler_out);
 
 /* Blocks until all work enqueued for the partition has finished. */
 int hyphy_hip_synchronize(hyphy_hip_partition *p);

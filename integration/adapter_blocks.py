@@ -23,6 +23,26 @@ struct _HyHipPart {
   std::vector<std::vector<char>> host_stale; // ... the node's host-side compExp does not reflect it yet
   std::vector<long> cat_arg;                 // the catID ComputeBlock used for the class (-1 without categories)
   long n_stale = 0;
+  // asynchronous pre-pass of _LikelihoodFunction::Compute (all device partitions are enqueued before the first is collected)
+  bool pending = false, pre_done = false;
+  double pre_value = 0.;
+  // template mode (SURVEY 8f-3 through the real host): Q_b = sum_k x_bk M_k(globals), x_b = the branch's independent local
+  // parameters.  Per rate class: 0 not analysed yet, 1 enabled, -1 disabled (the model is not linear in its local parameters)
+  std::vector<int> tmpl_state;
+  long tmpl_K = 0;
+  _SimpleList tmpl_refs;                     // template-variable references every conforming node must show (iVariables odd entries)
+  long tmpl_model = -1;
+  std::vector<std::vector<double>> tmpl_M;   // per class: [K][D*D] current templates (off-diagonal entries are what counts)
+  std::vector<std::vector<double>> tmpl_x;   // per class: [B][K] latest local-parameter rows
+  std::vector<char> tmpl_uploaded;           // per class: tmpl_M is what the device holds
+  long tmpl_device_cat = -1;                 // class whose templates were uploaded last
+  struct Call {                              // one ExponentiateMatrices call in template mode
+    bool active = false;
+    long cat = 0;
+    std::vector<long> probe, skipped;        // node codes
+    long verify = -1;
+  } call;
+  long n_template_evals = 0, n_skipped = 0;
 };
 static std::map<const void *, std::vector<_HyHipPart>> _hyhip_lfs;
 static std::map<const void *, std::pair<const void *, long>> _hyhip_tree_owner;  // _TheTree* -> (lf, partition index)
@@ -33,6 +53,8 @@ long _hyhip_calls = 0L, _hyhip_cached_calls = 0L, _hyhip_deferred = 0L;
 // ancestral reconstruction and simulation read the host matrices between evaluations).
 static int _hyhip_defer_depth = 0;
 extern bool (*_hyhip_defer_expm_hook)(_TheTree *, long, _List &, _List &, _SimpleList &);  // tree.cpp copy
+extern bool (*_hyhip_skip_recompute_hook)(_TheTree *, long, _CalcNode *, unsigned long, unsigned long);  // tree.cpp copy
+static int _hyhip_async_phase = 0;  // > 0: ComputeBlock enqueues the device evaluation and returns (pre-pass of Compute)
 static int _hyphy_hip_expm_mode(void) {
   static int mode = -1;
   if (mode < 0) {
@@ -54,7 +76,12 @@ static bool _hyphy_hip_enabled(void) {
 static void _hyphy_hip_teardown(const void *lf) {
   auto it = _hyhip_lfs.find(lf);
   if (it == _hyhip_lfs.end()) return;
-  for (auto &hp : it->second) hyphy_hip_destroy(hp.part);
+  for (auto &hp : it->second) {
+    if (hp.part && getenv("HYPHY_HIP_VERBOSE") && hp.n_template_evals)
+      fprintf(stderr, "[hyphy_hip] template mode: %ld evaluations took their rate matrices as coefficients (K = %ld), %ld RecomputeMatrix calls skipped\n",
+              hp.n_template_evals, hp.tmpl_K, hp.n_skipped);
+    hyphy_hip_destroy(hp.part);
+  }
   _hyhip_lfs.erase(it);
   for (auto o = _hyhip_tree_owner.begin(); o != _hyhip_tree_owner.end();)
     o = o->second.first == lf ? _hyhip_tree_owner.erase(o) : std::next(o);
@@ -62,6 +89,7 @@ static void _hyphy_hip_teardown(const void *lf) {
 }
 
 static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue, _SimpleList &parallel);
+static bool _hyphy_hip_skip_handler(_TheTree *t, long catID, _CalcNode *node, unsigned long nodeID, unsigned long n_nodes);
 
 static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_parts, _TheTree *cT,
                              _DataSetFilter const *theFilter, long const *leaf_codes, _Vector *ambigs) {
@@ -80,9 +108,34 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   for (long s = 0; s < S; s++) freq[s] = theFilter->theFrequencies.get(s);
   for (size_t k = 0; k < (size_t)L * S; k++) codes[k] = leaf_codes[k];
   const long n_amb = (long)ambigs->get_used() / D;
-  const char *dv = getenv("HYPHY_HIP_DEVICE");
+  // Partition -> device(s).  HYPHY_HIP_DEVICES=a-b (or HYPHY_HIP_DEVICE=a, or every visible device): a likelihood
+  // function with several partitions puts partition i on device a + i mod n (config "multi-partition -> N GPUs",
+  // the evaluations are enqueued together by the pre-pass in Compute); a single partition is site-sharded over
+  // the whole range (hyphy_hip_create's device_count, config "site-sharded across N GPUs").
+  int dev_first = 0, dev_n = 1;
+  {
+    const int ndev = hyphy_hip_device_count();
+    if (const char *dr = getenv("HYPHY_HIP_DEVICES")) {
+      int a = 0, b = -1;
+      if (sscanf(dr, "%d-%d", &a, &b) < 2) b = a;
+      if (a < 0) a = 0;
+      if (b >= ndev) b = ndev - 1;
+      if (b < a) b = a;
+      dev_first = a;
+      dev_n = b - a + 1;
+    } else if (const char *dv = getenv("HYPHY_HIP_DEVICE")) {
+      dev_first = atoi(dv);
+    } else if (n_parts > 1) {
+      dev_n = ndev > 0 ? ndev : 1;
+    }
+  }
+  const int my_first = n_parts > 1 ? dev_first + (int)(i % (unsigned long)dev_n) : dev_first;
+  const int my_count = n_parts > 1 ? 1 : dev_n;
   int rc = hyphy_hip_create(&hp.part, D, S, L, I, cT->categoryCount, parents.data(), codes.data(),
-                            n_amb ? ambigs->theData : nullptr, n_amb, freq.data(), dv ? atoi(dv) : 0, 1);
+                            n_amb ? ambigs->theData : nullptr, n_amb, freq.data(), my_first, my_count);
+  if (rc == 0 && getenv("HYPHY_HIP_VERBOSE"))
+    fprintf(stderr, "[hyphy_hip] partition %lu of %lu -> device %d%s (%ld states, %ld patterns, %ld leaves)\n", i, n_parts, my_first,
+            my_count > 1 ? " (+ site shards on the following devices)" : "", D, S, L);
   if (rc != 0) {  // > 0: unsupported here -> the CPU path keeps working; < 0: report and use the CPU path
     hp.part = nullptr;
     ReportWarning(_String("hyphy_hip_create: ") & hyphy_hip_last_error());
@@ -97,9 +150,20 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   hp.host_stale.assign(n_cat, std::vector<char>(L + I, 0));
   hp.cat_arg.assign(n_cat, -1L);
   hp.n_stale = 0;
+  hp.pending = hp.pre_done = false;
+  hp.tmpl_state.assign(n_cat, getenv("HYPHY_HIP_TEMPLATES") && !strcmp(getenv("HYPHY_HIP_TEMPLATES"), "0") ? -1 : 0);
+  hp.tmpl_K = 0;
+  hp.tmpl_refs.Clear();
+  hp.tmpl_model = -1;
+  hp.tmpl_M.assign(n_cat, std::vector<double>());
+  hp.tmpl_x.assign(n_cat, std::vector<double>());
+  hp.tmpl_uploaded.assign(n_cat, 0);
+  hp.tmpl_device_cat = -1;
+  hp.call = _HyHipPart::Call();
   _hyhip_tree_owner[cT] = std::make_pair(lf, (long)i);
   if (_hyphy_hip_expm_mode() > 0) {
     _hyhip_defer_expm_hook = _hyphy_hip_defer_handler;
+    _hyhip_skip_recompute_hook = _hyphy_hip_skip_handler;
     if (_hyphy_hip_expm_mode() == 2 && _hyhip_defer_depth == 0) _hyhip_defer_depth = 1;
   }
 }
@@ -107,6 +171,177 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
 static bool _hyphy_hip_active(const void *lf, long index) {
   auto it = _hyhip_lfs.find(lf);
   return it != _hyhip_lfs.end() && index < (long)it->second.size() && it->second[index].part != nullptr;
+}
+
+// ---- template mode (mode B only): Q_b = sum_k x_bk M_k(globals) ------------------------------------------------
+// For the usual models every entry of the rate matrix is (a function of the global parameters) x (ONE independent
+// local parameter of the branch) — MG94xREV: t; local MG94: synonymous / non-synonymous rate — i.e. the numeric
+// matrix _CalcNode::RecomputeMatrix evaluates entry by entry (calcnode.cpp:526-704, ~526 formulas per codon branch,
+// serial loop tree.cpp:2944-2969) is LINEAR and homogeneous in the branch's local parameters x_b.  The adapter checks
+// that numerically (never symbolically) and then lets only K + 1 branches per ExponentiateMatrices call go through
+// RecomputeMatrix: K probes give the templates M_k of THIS evaluation, one more verifies them (1e-11 relative), all the
+// others are skipped and reach the device as K coefficients (hyphy_hip_build_q).  A failed verification recomputes
+// the skipped matrices the normal way and switches the mode off for the rate class.
+static bool _hyhip_conforms(const _HyHipPart &hp, _CalcNode *n) {
+  if (n->HasExplicitFormModel() || n->GetModelIndex() != hp.tmpl_model) return false;
+  if (n->dVariables && n->dVariables->lLength) return false;
+  if (!n->iVariables || (long)n->iVariables->lLength != 2 * hp.tmpl_K) return false;
+  for (long k = 0; k < hp.tmpl_K; k++)
+    if (n->iVariables->list_data[2 * k + 1] != hp.tmpl_refs.list_data[k]) return false;
+  return true;
+}
+static void _hyhip_local_row(_CalcNode *n, long K, double *x) {
+  for (long k = 0; k < K; k++) x[k] = LocateVar(n->iVariables->list_data[2 * k])->Compute()->Value();
+}
+// rows [r][K] -> inverse of the K x K matrix (Gauss-Jordan, partial pivoting); false if (numerically) singular
+static bool _hyhip_invert(const double *rows, long K, double *inv) {
+  double a[16], b[16];
+  for (long i = 0; i < K; i++)
+    for (long j = 0; j < K; j++) {
+      a[i * K + j] = rows[i * K + j];
+      b[i * K + j] = i == j ? 1. : 0.;
+    }
+  double scale = 0.;
+  for (long i = 0; i < K * K; i++) scale = fmax(scale, fabs(a[i]));
+  if (!(scale > 0.)) return false;
+  for (long c = 0; c < K; c++) {
+    long piv = c;
+    for (long r = c + 1; r < K; r++)
+      if (fabs(a[r * K + c]) > fabs(a[piv * K + c])) piv = r;
+    if (fabs(a[piv * K + c]) < 1e-8 * scale) return false;
+    for (long j = 0; j < K; j++) {
+      std::swap(a[c * K + j], a[piv * K + j]);
+      std::swap(b[c * K + j], b[piv * K + j]);
+    }
+    const double d = 1. / a[c * K + c];
+    for (long j = 0; j < K; j++) {
+      a[c * K + j] *= d;
+      b[c * K + j] *= d;
+    }
+    for (long r = 0; r < K; r++)
+      if (r != c) {
+        const double f = a[r * K + c];
+        for (long j = 0; j < K; j++) {
+          a[r * K + j] -= f * a[c * K + j];
+          b[r * K + j] -= f * b[c * K + j];
+        }
+      }
+  }
+  for (long i = 0; i < K * K; i++) inv[i] = b[i];
+  return true;
+}
+static void _hyhip_dense_copy(_Matrix *m, long DD, double *dst) {
+  if (m->is_dense()) {
+    memcpy(dst, m->theData, sizeof(double) * DD);
+  } else {
+    memset(dst, 0, sizeof(double) * DD);
+    for (long k = 0; k < m->lDim; k++) {
+      const long idx = m->theIndex[k];
+      if (idx >= 0 && idx < DD) dst[idx] = m->theData[k];
+    }
+  }
+}
+// Q_b = sum_k x_bk M_k with the diagonal set to -(row sum), as the numeric matrix the host would have queued
+static void _hyhip_template_dense(const _HyHipPart &hp, long cat, long code, long D, double *dst) {
+  const long K = hp.tmpl_K, DD = D * D;
+  const double *x = hp.tmpl_x[cat].data() + (size_t)code * K, *M = hp.tmpl_M[cat].data();
+  for (long e = 0; e < DD; e++) {
+    double v = 0.;
+    for (long k = 0; k < K; k++) v += x[k] * M[k * DD + e];
+    dst[e] = v;
+  }
+  for (long i = 0; i < D; i++) {
+    double d = 0.;
+    for (long j = 0; j < D; j++)
+      if (j != i) d -= dst[i * D + j];
+    dst[i * D + i] = d;
+  }
+}
+// templates from probes (rows X_p, matrices Q_p): M = X_p^-1 Q_p; returns false when the probes are dependent
+static bool _hyhip_solve_templates(long K, long DD, const double *Xp, const std::vector<const double *> &Qp, std::vector<double> &M) {
+  double inv[16];
+  if (!_hyhip_invert(Xp, K, inv)) return false;
+  M.assign((size_t)K * DD, 0.);
+  for (long k = 0; k < K; k++)
+    for (long i = 0; i < K; i++) {
+      const double f = inv[k * K + i];
+      if (f == 0.) continue;
+      const double *q = Qp[i];
+      double *m = M.data() + (size_t)k * DD;
+      for (long e = 0; e < DD; e++) m[e] += f * q[e];
+    }
+  return true;
+}
+static double _hyhip_template_error(long K, long D, const double *x, const std::vector<double> &M, const double *q) {
+  const long DD = D * D;
+  double err = 0., scale = 0.;
+  for (long e = 0; e < DD; e++) {
+    if (e / D == e % D) continue;  // (the diagonal follows from the row)
+    double v = 0.;
+    for (long k = 0; k < K; k++) v += x[k] * M[(size_t)k * DD + e];
+    err = fmax(err, fabs(v - q[e]));
+    scale = fmax(scale, fabs(q[e]));
+  }
+  return scale > 0. ? err / scale : (err > 0. ? 1. : 0.);
+}
+
+static _HyHipPart *_hyhip_part_of_tree(_TheTree *t) {
+  auto own = _hyhip_tree_owner.find(t);
+  if (own == _hyhip_tree_owner.end()) return nullptr;
+  auto it = _hyhip_lfs.find(own->second.first);
+  if (it == _hyhip_lfs.end() || own->second.second >= (long)it->second.size()) return nullptr;
+  _HyHipPart &hp = it->second[own->second.second];
+  return hp.part ? &hp : nullptr;
+}
+
+// called for every node of ExponentiateMatrices' first loop (tree.cpp copy): true = do not call RecomputeMatrix
+static bool _hyphy_hip_skip_handler(_TheTree *t, long catID, _CalcNode *node, unsigned long nodeID, unsigned long n_nodes) {
+  if (_hyhip_defer_depth <= 0) return false;
+  _HyHipPart *php = _hyhip_part_of_tree(t);
+  if (!php) return false;
+  _HyHipPart &hp = *php;
+  const long cat = catID < 0 ? 0 : catID;
+  if (nodeID == 0) {
+    hp.call = _HyHipPart::Call();
+    hp.call.cat = cat;
+    hp.call.active = cat < (long)hp.tmpl_state.size() && hp.tmpl_state[cat] == 1 && (long)n_nodes >= hp.tmpl_K + 6;
+  }
+  if (!hp.call.active || hp.call.cat != cat) return false;
+  auto itc = hp.code_of.find(node);
+  if (itc == hp.code_of.end() || !_hyhip_conforms(hp, node)) return false;  // (goes the dense way)
+  const long code = itc->second, K = hp.tmpl_K;
+  std::vector<double> &X = hp.tmpl_x[cat];
+  if (X.empty()) X.assign(hp.code_of.size() * K, 0.);
+  _hyhip_local_row(node, K, X.data() + (size_t)code * K);
+  if ((long)hp.call.probe.size() < K) {  // a probe, if independent of the probes so far
+    double rows[16], inv[16];
+    const long np = (long)hp.call.probe.size();
+    // complete the candidate set with unit rows orthogonal enough only for K = 1 .. 4: test the rank by trial inversion of
+    // the (np + 1) x (np + 1) leading block in the candidate's own coordinates is overkill here — K is tiny: use the
+    // Gram determinant of the candidate rows
+    for (long i = 0; i < np; i++)
+      for (long k = 0; k < K; k++) rows[i * K + k] = X[(size_t)hp.call.probe[i] * K + k];
+    for (long k = 0; k < K; k++) rows[np * K + k] = X[(size_t)code * K + k];
+    double gram[16];
+    for (long i = 0; i <= np; i++)
+      for (long j = 0; j <= np; j++) {
+        double g = 0.;
+        for (long k = 0; k < K; k++) g += rows[i * K + k] * rows[j * K + k];
+        gram[i * (np + 1) + j] = g;
+      }
+    if (_hyhip_invert(gram, np + 1, inv)) {
+      hp.call.probe.push_back(code);
+      return false;
+    }
+    return false;  // dependent on the probes so far and no basis yet: the dense way
+  }
+  if (hp.call.verify < 0) {
+    hp.call.verify = code;
+    return false;
+  }
+  hp.call.skipped.push_back(code);
+  hp.n_skipped++;
+  return true;
 }
 
 // ---- mode B: the host's ExponentiateMatrices hands its queue over instead of exponentiating (tree.cpp copy) ----
@@ -127,27 +362,119 @@ static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, 
   }
   if (hp.qstash[cat].empty()) hp.qstash[cat].assign((size_t)(hp.code_of.size()) * DD, 0.);
   hp.cat_arg[cat] = catID;
-  for (unsigned long id = 0; id < parallel.lLength; id++) {
+  auto mark = [&](long code, char how) {  // how: 1 dense matrix in qstash, 2 template row in tmpl_x
+    hp.q_pending[cat][code] = how;
+    if (!hp.host_stale[cat][code]) hp.n_stale++;
+    hp.host_stale[cat][code] = how;
+  };
+  for (unsigned long id = 0; id < parallel.lLength; id++) {  // everything that went through RecomputeMatrix: dense
     const long mid = parallel.get(id);
-    _Matrix *m = (_Matrix *)matrixQueue(mid);
     const long code = hp.code_of.at(nodesToDo(mid));
-    double *dst = hp.qstash[cat].data() + (size_t)code * DD;
-    if (m->is_dense()) {
-      memcpy(dst, m->theData, sizeof(double) * DD);
-    } else {
-      memset(dst, 0, sizeof(double) * DD);
-      for (long k = 0; k < m->lDim; k++) {
-        const long idx = m->theIndex[k];
-        if (idx >= 0 && idx < DD) dst[idx] = m->theData[k];
-      }
-    }
-    hp.q_pending[cat][code] = 1;
-    if (!hp.host_stale[cat][code]) {
-      hp.host_stale[cat][code] = 1;
-      hp.n_stale++;
-    }
+    _hyhip_dense_copy((_Matrix *)matrixQueue(mid), DD, hp.qstash[cat].data() + (size_t)code * DD);
+    mark(code, 1);
   }
   _hyhip_deferred += parallel.lLength;
+  const long K = hp.tmpl_K;
+  if (hp.call.active && hp.call.cat == cat) {
+    // template call: K probes + one verification node were recomputed, hp.call.skipped were not
+    bool ok = (long)hp.call.probe.size() == K && hp.call.verify >= 0;
+    std::vector<double> M;
+    if (ok) {
+      double Xp[16];
+      std::vector<const double *> Qp;
+      for (long i = 0; i < K; i++) {
+        for (long k = 0; k < K; k++) Xp[i * K + k] = hp.tmpl_x[cat][(size_t)hp.call.probe[i] * K + k];
+        Qp.push_back(hp.qstash[cat].data() + (size_t)hp.call.probe[i] * DD);
+      }
+      ok = _hyhip_solve_templates(K, DD, Xp, Qp, M) &&
+           _hyhip_template_error(K, D, hp.tmpl_x[cat].data() + (size_t)hp.call.verify * K, M,
+                                 hp.qstash[cat].data() + (size_t)hp.call.verify * DD) < 1e-11;
+    }
+    if (ok) {
+      hp.tmpl_M[cat].swap(M);
+      hp.tmpl_uploaded[cat] = 0;
+      for (long code : hp.call.probe) mark(code, 2);
+      mark(hp.call.verify, 2);
+      for (long code : hp.call.skipped) mark(code, 2);
+      _hyhip_deferred += (long)hp.call.skipped.size();
+    } else {
+      // not linear after all (or no usable probes): the skipped matrices the normal way, and never again for this class
+      hp.tmpl_state[cat] = -1;
+      ReportWarning("hyphy_hip: rate matrices are not linear in the branch parameters; template mode switched off");
+      for (long code : hp.call.skipped) {
+        _List lq;
+        _SimpleList lt;
+        _CalcNode *nd = (_CalcNode *)t->GetNodeFromFlatIndex(code);
+        nd->RecomputeMatrix(catID, t->categoryCount, nil, &lq, &lt);
+        if (lq.lLength != 1) return false;
+        _hyhip_dense_copy((_Matrix *)lq(0), DD, hp.qstash[cat].data() + (size_t)code * DD);
+        mark(code, 1);
+      }
+    }
+    hp.call = _HyHipPart::Call();
+  } else if (cat < (long)hp.tmpl_state.size() && hp.tmpl_state[cat] == 0 && parallel.lLength >= 12) {
+    // first large call of this class: is the model linear in the branches' local parameters?  (all matrices are dense here)
+    _CalcNode *first = (_CalcNode *)nodesToDo(parallel.get(0));
+    int verdict = -1;
+    const long K0 = first->iVariables ? (long)first->iVariables->lLength / 2 : 0;
+    if (!first->HasExplicitFormModel() && K0 >= 1 && K0 <= 3 && (hp.tmpl_K == 0 || hp.tmpl_K == K0)) {
+      if (hp.tmpl_K == 0) {
+        hp.tmpl_K = K0;
+        hp.tmpl_model = first->GetModelIndex();
+        hp.tmpl_refs.Clear();
+        for (long k = 0; k < K0; k++) hp.tmpl_refs << first->iVariables->list_data[2 * k + 1];
+      }
+      std::vector<long> codes;
+      bool all_conform = true;
+      for (unsigned long id = 0; id < parallel.lLength && all_conform; id++) {
+        _CalcNode *nd = (_CalcNode *)nodesToDo(parallel.get(id));
+        all_conform = _hyhip_conforms(hp, nd);
+        codes.push_back(hp.code_of.at(nd));
+      }
+      if (all_conform) {
+        std::vector<double> &X = hp.tmpl_x[cat];
+        if (X.empty()) X.assign(hp.code_of.size() * K0, 0.);
+        for (unsigned long id = 0; id < parallel.lLength; id++)
+          _hyhip_local_row((_CalcNode *)nodesToDo(parallel.get(id)), K0, X.data() + (size_t)codes[id] * K0);
+        // greedy choice of K0 independent probes
+        std::vector<long> probe;
+        for (long code : codes) {
+          if ((long)probe.size() == K0) break;
+          double rows[16], gram[16], inv[16];
+          const long np = (long)probe.size();
+          for (long i = 0; i < np; i++)
+            for (long k = 0; k < K0; k++) rows[i * K0 + k] = X[(size_t)probe[i] * K0 + k];
+          for (long k = 0; k < K0; k++) rows[np * K0 + k] = X[(size_t)code * K0 + k];
+          for (long i = 0; i <= np; i++)
+            for (long j = 0; j <= np; j++) {
+              double g = 0.;
+              for (long k = 0; k < K0; k++) g += rows[i * K0 + k] * rows[j * K0 + k];
+              gram[i * (np + 1) + j] = g;
+            }
+          if (_hyhip_invert(gram, np + 1, inv)) probe.push_back(code);
+        }
+        if ((long)probe.size() == K0) {
+          double Xp[16];
+          std::vector<const double *> Qp;
+          for (long i = 0; i < K0; i++) {
+            for (long k = 0; k < K0; k++) Xp[i * K0 + k] = X[(size_t)probe[i] * K0 + k];
+            Qp.push_back(hp.qstash[cat].data() + (size_t)probe[i] * DD);
+          }
+          std::vector<double> M;
+          if (_hyhip_solve_templates(K0, DD, Xp, Qp, M)) {
+            double worst = 0.;
+            for (long code : codes)
+              worst = fmax(worst, _hyhip_template_error(K0, D, X.data() + (size_t)code * K0, M, hp.qstash[cat].data() + (size_t)code * DD));
+            verdict = worst < 1e-11 ? 1 : -1;
+            if (getenv("HYPHY_HIP_VERBOSE"))
+              fprintf(stderr, "[hyphy_hip] template analysis, class %ld: K = %ld local parameter(s), %ld branches, worst relative deviation from linearity %.2e -> %s\n",
+                      cat, K0, (long)codes.size(), worst, verdict == 1 ? "template mode" : "dense matrices");
+          } else verdict = 0;  // (dependent probes, e.g. every branch length equal to zero: try again next time)
+        } else verdict = 0;
+      }
+    }
+    hp.tmpl_state[cat] = verdict;
+  }
   return true;
 }
 
@@ -159,6 +486,7 @@ static void _hyphy_hip_flush_part(_HyHipPart &hp, _TheTree *t) {
     for (size_t code = 0; code < hp.host_stale[cat].size(); code++)
       if (hp.host_stale[cat][code]) {
         _Matrix q(D, D, false, true);
+        if (hp.host_stale[cat][code] == 2) _hyhip_template_dense(hp, (long)cat, (long)code, D, hp.qstash[cat].data() + code * DD);
         memcpy(q.theData, hp.qstash[cat].data() + code * DD, sizeof(double) * DD);
         ((_CalcNode *)t->GetNodeFromFlatIndex(code))->SetCompExp(&q, hp.cat_arg[cat], true);
         hp.host_stale[cat][code] = 0;
@@ -167,42 +495,86 @@ static void _hyphy_hip_flush_part(_HyHipPart &hp, _TheTree *t) {
   hp.n_stale = 0;
 }
 
-// one ComputeBlock evaluation on the device; returns 0 when *result is valid
+// one ComputeBlock evaluation on the device; returns 0 when *result is valid (or, with go_async, when it was enqueued:
+// _hyphy_hip_prepass_result collects it)
 static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catID, _SimpleList &branches,
-                              _List &matrices, hyFloat *siteRes, long *scc, hyFloat *result) {
+                              _List &matrices, hyFloat *siteRes, long *scc, hyFloat *result, bool go_async = false) {
   _HyHipPart &hp = _hyhip_lfs[lf][index];
-  const long D = t->GetCodeBase();
+  const long D = t->GetCodeBase(), DD = D * D;
   const long B = t->GetLeafCount() + t->GetINodeCount() - 1;
   const long cat = catID < 0 ? 0 : catID;
   long n_q = matrices.lLength;
   const bool first = !hp.cat_seen[cat];
   if (first) n_q = B;  // first evaluation of a rate class: hand over every transition matrix
-  hp.pbuf.resize((size_t)n_q * D * D);
   hp.qnodes.resize(n_q);
-  long n_pending = 0;
+  long n_pending = 0, n_template = 0;
   for (long k = 0; k < n_q; k++) {
     hp.qnodes[k] = first ? k : hp.code_of.at(matrices(k));
-    n_pending += hp.q_pending[cat][hp.qnodes[k]];
+    n_pending += hp.q_pending[cat][hp.qnodes[k]] != 0;
+    n_template += hp.q_pending[cat][hp.qnodes[k]] == 2;
   }
+  double ll = 0.;
+  int rc = 0;
+  if (n_q > 0 && n_template == n_q && !go_async) {
+    // template mode: K coefficients per branch instead of D*D matrix entries; the device builds and exponentiates
+    const long K = hp.tmpl_K;
+    if (!hp.tmpl_uploaded[cat] || hp.tmpl_device_cat != cat) {
+      rc = hyphy_hip_update_q_templates(hp.part, K, hp.tmpl_M[cat].data());
+      hp.tmpl_uploaded[cat] = 1;
+      hp.tmpl_device_cat = cat;
+    }
+    hp.pbuf.resize((size_t)n_q * K);
+    for (long k = 0; k < n_q; k++)
+      for (long j = 0; j < K; j++) hp.pbuf[(size_t)k * K + j] = hp.tmpl_x[cat][(size_t)hp.qnodes[k] * K + j];
+    if (rc == 0) rc = hyphy_hip_build_q(hp.part, n_q, hp.pbuf.data());
+    if (rc == 0)
+      rc = hyphy_hip_evaluate_built_sites(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(),
+                                          n_q, t->GetProbs(), &ll, siteRes, (int64_t *)scc);
+    if (rc < 0) {
+      HandleApplicationError(_String("hyphy_hip (template mode): ") & hyphy_hip_last_error());
+      return rc;
+    }
+    if (rc == 0) {
+      for (long k = 0; k < n_q; k++) hp.q_pending[cat][hp.qnodes[k]] = 0;
+      hp.cat_seen[cat] = 1;
+      hp.n_template_evals++;
+      _hyhip_calls++;
+      *result = ll;
+    }
+    return rc;
+  }
+  if (n_template > 0)  // mixed (or asynchronous): template rows become dense rate matrices
+    for (long k = 0; k < n_q; k++)
+      if (hp.q_pending[cat][hp.qnodes[k]] == 2) {
+        _hyhip_template_dense(hp, cat, hp.qnodes[k], D, hp.qstash[cat].data() + (size_t)hp.qnodes[k] * DD);
+        hp.q_pending[cat][hp.qnodes[k]] = 1;
+        if (hp.host_stale[cat][hp.qnodes[k]]) hp.host_stale[cat][hp.qnodes[k]] = 1;
+      }
   if (n_pending > 0 && n_pending < n_q) {  // mixed (rare): exponentiate the stashed ones on the host, send probabilities
     _hyphy_hip_flush_part(hp, t);
     n_pending = 0;
   }
   const bool rate_matrices = n_pending > 0;
+  hp.pbuf.resize((size_t)n_q * DD);
   for (long k = 0; k < n_q; k++) {
     if (rate_matrices) {
-      memcpy(hp.pbuf.data() + (size_t)k * D * D, hp.qstash[cat].data() + (size_t)hp.qnodes[k] * D * D, sizeof(double) * D * D);
+      memcpy(hp.pbuf.data() + (size_t)k * DD, hp.qstash[cat].data() + (size_t)hp.qnodes[k] * DD, sizeof(double) * DD);
       continue;
     }
     _CalcNode *n = first ? (_CalcNode *)t->GetNodeFromFlatIndex(k) : (_CalcNode *)matrices(k);
     _Matrix *P = n->GetCompExp(catID);
     if (!P || !P->theData) return 1;
-    memcpy(hp.pbuf.data() + (size_t)k * D * D, P->theData, sizeof(double) * D * D);
+    memcpy(hp.pbuf.data() + (size_t)k * DD, P->theData, sizeof(double) * DD);
   }
-  double ll = 0.;
-  int rc = hyphy_hip_evaluate(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength,
-                              hp.qnodes.data(), n_q, hp.pbuf.data(), /* q_is_probability = */ rate_matrices ? 0 : 1,
-                              t->GetProbs(), &ll, siteRes, (int64_t *)scc);
+  if (go_async) {
+    rc = hyphy_hip_evaluate_async(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(), n_q,
+                                  hp.pbuf.data(), rate_matrices ? 0 : 1, t->GetProbs());
+    if (rc == 0) hp.pending = true;
+  } else {
+    rc = hyphy_hip_evaluate(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(), n_q,
+                            hp.pbuf.data(), /* q_is_probability = */ rate_matrices ? 0 : 1, t->GetProbs(), &ll, siteRes,
+                            (int64_t *)scc);
+  }
   if (rc < 0) {
     HandleApplicationError(_String("hyphy_hip_evaluate: ") & hyphy_hip_last_error());
     return rc;
@@ -215,6 +587,36 @@ static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catI
     *result = ll;
   }
   return rc;
+}
+
+// pre-pass of _LikelihoodFunction::Compute: every device partition is enqueued before the first result is waited for
+static void _hyphy_hip_note_prepass(const void *lf, long index, hyFloat value) {
+  _HyHipPart &hp = _hyhip_lfs[lf][index];
+  if (!hp.pending) {  // ComputeBlock finished synchronously (branch cache, CPU path ...): keep what it returned
+    hp.pre_done = true;
+    hp.pre_value = value;
+  }
+}
+static bool _hyphy_hip_prepass_result(const void *lf, long index, hyFloat *value) {
+  auto it = _hyhip_lfs.find(lf);
+  if (it == _hyhip_lfs.end() || index >= (long)it->second.size()) return false;
+  _HyHipPart &hp = it->second[index];
+  if (hp.pending) {
+    hp.pending = false;
+    double ll = 0.;
+    if (hyphy_hip_collect(hp.part, &ll, nullptr, nullptr) != 0) {
+      HandleApplicationError(_String("hyphy_hip_collect: ") & hyphy_hip_last_error());
+      return false;
+    }
+    *value = ll;
+    return true;
+  }
+  if (hp.pre_done) {
+    hp.pre_done = false;
+    *value = hp.pre_value;
+    return true;
+  }
+  return false;
 }
 
 // pinned node states (branchIndex >= 0: marginal ancestral reconstruction, likefunc2.cpp:932-1040): pin, evaluate, unpin
@@ -240,6 +642,11 @@ static int _hyphy_hip_cached(const void *lf, long index, _TheTree *t, long catID
                              long *scc, hyFloat *result) {
   _HyHipPart &hp = _hyhip_lfs[lf][index];
   const long cat = catID < 0 ? 0 : catID, DD = t->GetCodeBase() * t->GetCodeBase();
+  if (hp.q_pending[cat][node] == 2) {  // (a template row: make it the dense rate matrix)
+    _hyhip_template_dense(hp, cat, node, t->GetCodeBase(), hp.qstash[cat].data() + (size_t)node * DD);
+    hp.q_pending[cat][node] = 1;
+    if (hp.host_stale[cat][node]) hp.host_stale[cat][node] = 1;
+  }
   const bool rate_matrix = hp.q_pending[cat][node];  // (mode B: the line search's new matrix was handed over, not exponentiated)
   const double *mx = nullptr;
   if (rate_matrix) {
@@ -313,12 +720,16 @@ COMPUTE = r'''
       if (branchIndex < 0 && _hyphy_hip_active(this, index)) {
         hyFloat hip_result = 0.;
         if (doCachedComp >= 3) {  // one-branch line search: a single contraction against the device branch cache
-          if (_hyphy_hip_cached(this, index, t, catID, doCachedComp - 3, siteRes, scc, &hip_result) == 0) {
+          const int crc = _hyphy_hip_cached(this, index, t, catID, doCachedComp - 3, siteRes, scc, &hip_result);
+          if (crc == 0) {
             return hip_result;
           }
-          return -INFINITY;  // (the error was reported; the host caches were never filled)
+          if (crc > 0)  // "unsupported here" from the cached entry point: say so (an error, crc < 0, was reported already)
+            ReportWarning(_String("hyphy_hip_branch_cache_evaluate declined (") & hyphy_hip_last_error() & "); this evaluation returns -infinity");
+          return -INFINITY;  // (the host caches were never filled)
         }
-        if (_hyphy_hip_compute(this, index, t, catID, *branches, *matrices, siteRes, scc, &hip_result) == 0) {
+        const bool go_async = _hyhip_async_phase > 0 && !siteRes && doCachedComp == 0;
+        if (_hyphy_hip_compute(this, index, t, catID, *branches, *matrices, siteRes, scc, &hip_result, go_async) == 0) {
           if (doCachedComp < 0) {  // the policy asked for a cache of this branch after the normal pass
             const long nd = -doCachedComp - 1;
             if (_hyphy_hip_cache_build(this, index, catID, nd) == 0) {
@@ -336,9 +747,43 @@ COMPUTE = r'''
         // the pass must recompute every node, like the first evaluation after a setup (:10964-10966).
         _hyphy_hip_flush(this);
         branches->Populate(t->GetINodeCount() + t->GetLeafCount() - 1, 0, 1);
+        // ... and the per-pattern exponents the device wrote into the siteCorrections slice are ABSOLUTE values, while the
+        // reference's pruning code accumulates changes (+= didScale) on top of what it finds and keeps the matching
+        // total in overallScalingFactors: start the CPU pass of this partition from a clean slate
+        if (scc) {
+          const long pc = df->GetPatternCount();
+          for (long s_ = 0; s_ < pc; s_++) scc[s_] = 0;
+        }
+        if (currentRateClass < 1) overallScalingFactors.list_data[index] = 0;
       }
 #endif
 '''
+
+# ---- block 6: _LikelihoodFunction::Compute, in front of the partition loop (likefunc.cpp:2524) -----------------------
+PREPASS = r'''
+#ifdef HYPHY_HIP
+    if (theTrees.lLength > 1UL && _hyphy_hip_enabled()) {
+      // The reference evaluates its partitions one after the other (ComputeBlock is synchronous); on the device the
+      // partitions live on different GPUs / streams, so: enqueue every one of them first, collect in the loop below.
+      _hyhip_async_phase = 1;
+      for (unsigned long partID = 0; partID < theTrees.lLength; partID++)
+        if (!blockDependancies.list_data[partID] && _hyphy_hip_active(this, partID)) {
+          const hyFloat r_ = ComputeBlock(partID);
+          _hyphy_hip_note_prepass(this, partID, r_);
+        }
+      _hyhip_async_phase = 0;
+    }
+#endif
+'''
+# ... and the loop's own call, which must not run ComputeBlock a second time for those partitions
+LOOPCALL_OLD = "        hyFloat blockResult = ComputeBlock(partID);\n        if (blockMatrix) {"
+LOOPCALL_NEW = r'''#ifdef HYPHY_HIP
+        hyFloat blockResult = 0.;
+        if (!_hyphy_hip_prepass_result(this, partID, &blockResult)) blockResult = ComputeBlock(partID);
+#else
+        hyFloat blockResult = ComputeBlock(partID);
+#endif
+        if (blockMatrix) {'''
 
 # ---- block 5: Optimize, first statement ----------------------------------------------------------------------------
 OPTIMIZE = r'''
@@ -352,8 +797,19 @@ TREE_HOOK_DEF = r'''
 #ifdef HYPHY_HIP
 // set by the likelihood-function adapter (likefunc.cpp copy); returns true when it took the queued rate matrices
 bool (*_hyhip_defer_expm_hook)(_TheTree *, long, _List &, _List &, _SimpleList &) = nullptr;
+// template mode: asked for every node of ExponentiateMatrices' first loop; true = the adapter derives this node's rate
+// matrix from the probes of this call, do not run RecomputeMatrix for it
+bool (*_hyhip_skip_recompute_hook)(_TheTree *, long, _CalcNode *, unsigned long, unsigned long) = nullptr;
 #endif
 '''
+TREE_SKIP_OLD = "    if (thisNode->RecomputeMatrix(catID, categoryCount, nil, &matrixQueue,\n                                  &isExplicitForm)) {"
+TREE_SKIP_NEW = r'''#ifdef HYPHY_HIP
+    if (_hyhip_skip_recompute_hook && _hyhip_skip_recompute_hook(this, catID, thisNode, nodeID, expNodes.lLength)) {
+      // (template mode: nothing queued for this node)
+    } else
+#endif
+    if (thisNode->RecomputeMatrix(catID, categoryCount, nil, &matrixQueue,
+                                  &isExplicitForm)) {'''
 TREE_HOOK_CALL = r'''
 #ifdef HYPHY_HIP
   if (_hyhip_defer_expm_hook && !hasExpForm && serial.lLength == 0UL && parallel.lLength &&

@@ -27,6 +27,12 @@ def splice(text, anchor, block, before=False, count=1):
     return text[:idx] + block + text[idx:]
 
 
+def replace_once(text, old, new):
+    if text.count(old) != 1:
+        raise SystemExit(f"anchor not unique ({text.count(old)}x): {old!r}")
+    return text.replace(old, new)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     # likefunc.cpp copy with the four adapter blocks.  _TheTree::flatParents is protected and
@@ -45,12 +51,17 @@ def main():
     # no sticky scalers.
     lf = splice(lf, "      hyFloat sum = 0.;\n\n      if (doCachedComp >= 3) {", AB.COMPUTE, before=True)
     lf = splice(lf, "_Matrix *_LikelihoodFunction::Optimize(_AssociativeList const *options) {\n", AB.OPTIMIZE)
+    # Compute(): all device partitions are enqueued before the first is collected (pre-pass + the loop's own call)
+    lf = splice(lf, "    for (unsigned long partID = 0; partID < theTrees.lLength; partID++) {\n      if (blockDependancies.list_data[partID]) {\n        // has category variables",
+                AB.PREPASS, before=True)
+    lf = replace_once(lf, AB.LOOPCALL_OLD, AB.LOOPCALL_NEW)
     src = os.path.join(OUT, "likefunc_hip.cpp")
     open(src, "w").write(lf)
     # tree.cpp copy: ExponentiateMatrices offers its queue to the adapter before the OpenMP exponentiation loop (mode B)
     tr = open(os.path.join(REF, "src/core/tree.cpp")).read()
     tr = splice(tr, "using namespace hyphy_global_objects;\n", AB.TREE_HOOK_DEF)
     tr = splice(tr, "  if (parallel.lLength) {\n    if (parallel.lLength == 1) {", AB.TREE_HOOK_CALL, before=True)
+    tr = replace_once(tr, AB.TREE_SKIP_OLD, AB.TREE_SKIP_NEW)
     tsrc = os.path.join(OUT, "tree_hip.cpp")
     open(tsrc, "w").write(tr)
     # 3. compile that one file with the reference's flags (oracle/Makefile.ref) + -DHYPHY_HIP

@@ -78,7 +78,7 @@ def build_script(*, fasta: str, newick: str, unit: int, model_block: str, model_
                  globals_: Dict[str, float], branch_t: Dict[str, float],
                  out_path: str, sweep: Optional[Dict] = None, threads: int = 0,
                  category: Optional[Dict] = None, per_site: bool = True, optimize: bool = False,
-                 constraints: Optional[Dict[str, str]] = None) -> str:
+                 constraints: Optional[Dict[str, str]] = None, extra_partitions: Optional[List[Dict]] = None) -> str:
     """One self-contained batch file.  ``sweep`` = {"param": "R", "start": .3, "step": .001,
     "n": N} runs the SURVEY A.8 timing loop and reports wall-clock seconds via Time(1)."""
     L: List[str] = ["VERBOSITY_LEVEL = -1;", "PRINT_DIGITS = 17;"]
@@ -101,7 +101,20 @@ def build_script(*, fasta: str, newick: str, unit: int, model_block: str, model_
         L.append("DataSetFilter filteredData = CreateFilter (ds,1);")
     for name, t in branch_t.items():
         L.append(f"givenTree.{name}.t = {_fmt(t)};")
-    L.append("LikelihoodFunction lf = (filteredData, givenTree);")
+    pairs = ["filteredData, givenTree"]
+    # further partitions of the same likelihood function, each with its own alignment and tree (syntax precedent:
+    # res/TemplateBatchFiles/REL/MultiplePartitions.bf builds `LikelihoodFunction lf = (filter_1, tree_1, filter_2, tree_2, ...)`)
+    for k, part in enumerate(extra_partitions or [], start=1):
+        L.append(f"Tree givenTree{k} = {part['newick']};")
+        L.append(f'DataSet ds{k} = ReadDataFile ("{part["fasta"]}");')
+        if unit == 3:
+            L.append(f'DataSetFilter filteredData{k} = CreateFilter (ds{k},3,"","","TAA,TAG,TGA");')
+        else:
+            L.append(f"DataSetFilter filteredData{k} = CreateFilter (ds{k},1);")
+        for name, t in part["branch_t"].items():
+            L.append(f"givenTree{k}.{name}.t = {_fmt(t)};")
+        pairs.append(f"filteredData{k}, givenTree{k}")
+    L.append(f"LikelihoodFunction lf = ({', '.join(pairs)});")
     if threads and threads > 1:
         # SURVEY A.8 / BASELINE.md §3: a fresh LF is single-threaded until Optimize runs
         # BenchmarkThreads (likefunc.cpp:223-227); do a throw-away 1-iteration Optimize.
@@ -111,6 +124,9 @@ def build_script(*, fasta: str, newick: str, unit: int, model_block: str, model_
             L.append(f"{k} = {_fmt(v)};")
         for name, t in branch_t.items():
             L.append(f"givenTree.{name}.t = {_fmt(t)};")
+        for k, part in enumerate(extra_partitions or [], start=1):
+            for name, t in part["branch_t"].items():
+                L.append(f"givenTree{k}.{name}.t = {_fmt(t)};")
     L.append("LFCompute (lf, LF_START_COMPUTE);")
     L.append("LFCompute (lf, res0);")
     L.append(f'fprintf ("{out_path}", CLEAR_FILE, "LOGL ", Format (res0, 30, 17), "\\n");')
@@ -187,14 +203,19 @@ def parse_output(path: str) -> Dict:
 
 def evaluate(*, names, seqs, newick, unit, model_block, model_name, globals_, branch_t,
              sweep=None, threads=0, category=None, per_site=True, workdir=None, timeout=3600.0,
-             binary=None, extra_env=None, optimize=False, constraints=None) -> Dict:
+             binary=None, extra_env=None, optimize=False, constraints=None, extra_partitions=None) -> Dict:
     """Write fasta + script into a scratch dir, run the reference, parse the results."""
     own = workdir is None
     tmp = tempfile.mkdtemp(prefix="hyref_") if own else workdir
     fasta = os.path.join(tmp, "aln.fasta")
     outp = os.path.join(tmp, "out.txt")
     write_fasta(fasta, names, seqs)
-    txt = build_script(fasta=fasta, newick=newick, unit=unit, model_block=model_block,
+    xparts = []
+    for k, part in enumerate(extra_partitions or [], start=1):   # dicts with names, seqs, newick, branch_t
+        fk = os.path.join(tmp, f"aln{k}.fasta")
+        write_fasta(fk, part["names"], part["seqs"])
+        xparts.append(dict(fasta=fk, newick=part["newick"], branch_t=part["branch_t"]))
+    txt = build_script(fasta=fasta, newick=newick, unit=unit, model_block=model_block, extra_partitions=xparts,
                        model_name=model_name, globals_=globals_, branch_t=branch_t,
                        out_path=outp, sweep=sweep, threads=threads, category=category,
                        per_site=per_site, optimize=optimize, constraints=constraints)

@@ -21,7 +21,7 @@ HIP_BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 for thr in threads:
     for label, binary, env, count in (("adapter", HIP_BIN, dict(HYPHY_HIP="1", **{k: v for k, v in os.environ.items() if k.startswith("HYPHY_HIP_")}), n),
                                       ("reference", None, None, max(8, n // 40))):
-        if label == "reference" and thr not in (16,):
+        if label == "reference" and (thr not in (16,) or os.environ.get("NO_REFERENCE")):
             continue
         t0 = time.time()
         res = hbl.evaluate(names=syn.flat.leaf_names, seqs=syn.seqs, newick=htree.to_newick(syn.tree), unit=3,

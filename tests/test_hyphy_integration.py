@@ -226,3 +226,61 @@ def test_reference_known_answer_smallcodon_through_device():
     assert _device_calls(res["stdout"]) > 50 and _deferred(res["stdout"]) > 100
     assert abs(res["opt_logl"] - float(fx["expected_opt_logl"])) <= 2e-3
     assert abs(res["logl"] - float(fx["logl"])) <= 1e-10 * abs(float(fx["logl"]))
+
+
+def _template_evals(stdout):
+    m = re.findall(r"template mode: (\d+) evaluations took their rate matrices as coefficients \(K = (\d+)\), (\d+) RecomputeMatrix calls skipped", stdout)
+    return (max(int(x[0]) for x in m), int(m[-1][1]), max(int(x[2]) for x in m)) if m else (0, 0, 0)
+
+
+def test_hbl_optimize_in_template_mode():
+    """Template mode of the adapter (SURVEY 8f-3 through the real host): while Optimize runs, the host evaluates the rate
+    matrix of K + 1 branches per ExponentiateMatrices call (K = 1 local parameter: t), the adapter derives the templates of
+    that evaluation from them, verifies on one more branch and sends every other branch as K coefficients
+    (hyphy_hip_build_q).  Same optimum as the CPU reference and as the adapter with HYPHY_HIP_TEMPLATES=0."""
+    _need_binaries()
+    from oracle import hbl
+    case = _case("codon", 16, 60, 31)
+    cpu = hbl.evaluate(optimize=True, **case)
+    gpu = hbl.evaluate(optimize=True, binary=HIP_BIN, extra_env=ENV, **case)
+    off = hbl.evaluate(optimize=True, binary=HIP_BIN, extra_env=dict(ENV, HYPHY_HIP_TEMPLATES="0"), **case)
+    n_eval, K, n_skip = _template_evals(gpu["stdout"])
+    assert K == 1 and n_eval > 10 and n_skip > 10 * n_eval, gpu["stdout"][-800:]
+    assert _template_evals(off["stdout"])[0] == 0
+    assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3
+    assert abs(off["opt_logl"] - cpu["opt_logl"]) <= 2e-3
+    assert abs(gpu["logl"] - cpu["logl"]) <= 1e-10 * abs(cpu["logl"])
+
+
+def test_hbl_lfcompute_sweep_in_template_mode_matches_reference_at_every_point():
+    """The benchmark's own loop through the real host: R swept, every branch's matrix changes at every point, mode B
+    forced (HYPHY_HIP_DEVICE_EXPM=always) -> template mode after the first evaluation.  Every value of the sweep against
+    the unmodified binary."""
+    _need_binaries()
+    from oracle import hbl
+    case = _case("codon", 24, 80, 33)
+    sweep = dict(param="R", start=0.3, step=0.01, n=25, record=25)
+    cpu = hbl.evaluate(sweep=sweep, per_site=False, **case)
+    gpu = hbl.evaluate(sweep=sweep, per_site=False, binary=HIP_BIN, extra_env=dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), **case)
+    n_eval, K, _ = _template_evals(gpu["stdout"])
+    assert K == 1 and n_eval >= 20, gpu["stdout"][-800:]
+    assert np.max(np.abs(gpu["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10
+
+
+def test_hbl_two_partitions_on_the_device():
+    """A likelihood function with two partitions (own alignment and tree each; REL/MultiplePartitions.bf syntax): both go
+    to the device (partition i -> device i mod n), Compute() enqueues both before it collects the first; LFCompute value,
+    per-site values and a complete Optimize against the unmodified binary."""
+    _need_binaries()
+    from oracle import hbl
+    a, b = _case("codon", 8, 40, 11), _case("codon", 10, 30, 12)
+    xp = [dict(names=b["names"], seqs=b["seqs"], newick=b["newick"], branch_t=b["branch_t"])]
+    cpu = hbl.evaluate(extra_partitions=xp, **a)                       # value and per-site values at the start point
+    gpu = hbl.evaluate(extra_partitions=xp, binary=HIP_BIN, extra_env=ENV, **a)
+    assert "partition 0 of 2 -> device" in gpu["stdout"] and "partition 1 of 2 -> device" in gpu["stdout"], gpu["stdout"][-800:]
+    assert abs(gpu["logl"] - cpu["logl"]) <= 1e-10 * abs(cpu["logl"])
+    assert np.max(np.abs(gpu["site_logl"] - cpu["site_logl"]) / np.abs(cpu["site_logl"])) < 1e-10
+    cpu = hbl.evaluate(extra_partitions=xp, optimize=True, per_site=False, **a)   # a complete fit
+    gpu = hbl.evaluate(extra_partitions=xp, optimize=True, per_site=False, binary=HIP_BIN, extra_env=ENV, **a)
+    assert _device_calls(gpu["stdout"]) > 50
+    assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3
