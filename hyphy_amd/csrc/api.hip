@@ -81,6 +81,9 @@ struct Shard {
   double *bc_q = nullptr;
   int4 *prog = nullptr;       // program table (forest scheduling): (offset, entries, parent program, child programs)
   int4 *h_prog = nullptr;
+  double *mix_q = nullptr, *mix_p = nullptr, *mix_w = nullptr;  // branch-site mixtures: component rate matrices, their exponentials, weights
+  int *mix_off = nullptr;
+  size_t mix_cap = 0, mix_nq_cap = 0;
   int4 *jn = nullptr;         // chain schedules: per internal node (parent, arrivals needed | child sum << 8, trunk entries offset, count)
   int4 *h_jn = nullptr;
   double *deposits = nullptr; // chain schedules: [C][I][ntiles][TILE] edge products of non-last arrivers (allocated on first use)
@@ -204,7 +207,7 @@ void free_shard(Shard &s) {
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
                  s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.codes_tile,
-                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
+                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.mix_q, s.mix_p, s.mix_w, s.mix_off, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops};
   for (void *d : dev)
     if (d) hipFree(d);
@@ -675,11 +678,18 @@ PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
 // "use the shard's own Q buffer" (filled / staged by hyphy_hip_build_q on every shard)
 const double kOwnQBuffer = 0.;
 
+// branch-site mixture: matrix k of the evaluation is sum_m weights[off_k + m] exp(q[off_k + m]), count[k] components
+struct MixSpec {
+  const int64_t *count;
+  const double *weights;
+  int64_t n_tot;
+};
+
 // Enqueue everything for one rate class on one shard.  q may be a host or device pointer.
 int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, bool sched_changed, bool pi_changed,
                  bool slots_changed, const int64_t *q_nodes, int64_t n_q,
                  const double *q, bool q_on_device, int q_is_prob, const double *root_freqs, double *d_logl_out,
-                 bool reduce, bool floor_log) {
+                 bool reduce, bool floor_log, const MixSpec *mix = nullptr) {
   Trace tr("enqueue");
   HIPCHK(hipSetDevice(s.device));
   if (q == &kOwnQBuffer) q = s.qbuf;
@@ -729,6 +739,48 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
         }
       HIPCHK(hipMemcpyAsync(d_slots, h_slots, n_mat * sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
     }
+    if (mix) {
+      // explicit-form branch-site mixtures: exponentiate every component, then mix into the branch's matrix images
+      if (q_on_device || q_is_prob || n_cat_batch != 1) return fail("mixture evaluation: host rate matrices, one class at a time");
+      const size_t n_tot = (size_t)mix->n_tot, DD = (size_t)D * D;
+      if (s.mix_cap < n_tot || s.mix_nq_cap < (size_t)n_q) {
+        HIPCHK(hipStreamSynchronize(s.stream));
+        for (void *d : {(void *)s.mix_q, (void *)s.mix_p, (void *)s.mix_w, (void *)s.mix_off})
+          if (d) hipFree(d);
+        s.mix_q = s.mix_p = s.mix_w = nullptr;
+        s.mix_off = nullptr;
+        s.mix_cap = std::max(n_tot, (size_t)(2 * B));
+        s.mix_nq_cap = (size_t)B;
+        HIPCHK(hipMalloc((void **)&s.mix_q, s.mix_cap * DD * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&s.mix_p, s.mix_cap * DD * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&s.mix_w, s.mix_cap * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&s.mix_off, (s.mix_nq_cap + 1) * sizeof(int)));
+      }
+      std::vector<int> off((size_t)n_q + 1, 0);
+      for (int64_t k = 0; k < n_q; k++) off[k + 1] = off[k] + (int)mix->count[k];
+      HIPCHK(hipMemcpyAsync(s.mix_q, q, n_tot * DD * sizeof(double), hipMemcpyHostToDevice, s.stream));
+      HIPCHK(hipMemcpyAsync(s.mix_w, mix->weights, n_tot * sizeof(double), hipMemcpyHostToDevice, s.stream));
+      HIPCHK(hipMemcpyAsync(s.mix_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, s.stream));
+      HIPCHK(hipStreamSynchronize(s.stream));  // (pageable sources; `off` goes out of scope)
+      ExpmArgs ea;
+      ea.Q = s.mix_q;
+      ea.slots = nullptr;
+      ea.n = (int)n_tot;
+      ea.D = (int)D;
+      ea.is_prob = 0;
+      ea.status = s.status;
+      ea.templates = nullptr;
+      ea.coeffs = nullptr;
+      ea.K = 0;
+      ea.prof = 0;
+      ea.Prow = s.mix_p;
+      ea.Pfrag = nullptr;
+      ea.PTg = nullptr;
+      launch_expm(ea, s.stream);
+      launch_mix_images(s.mix_p, s.mix_off, s.mix_w, d_slots, (int)n_q, (int)D,
+                        p->nuc ? nullptr : s.Pfrag + (size_t)cat * B * DP * DP, p->nuc ? nullptr : s.PTg + (size_t)cat * B * DP * DP,
+                        p->nuc ? s.Prow + (size_t)cat * B * 16 : nullptr, s.stream);
+    } else {
     const double *dq = q;
     const bool q_from_templates = q_on_device && q == s.qbuf && p->coeffs_pending && !q_is_prob;
     if (q_on_device && q == s.qbuf && !q_is_prob) {
@@ -773,6 +825,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       s.coeff_busy[s.coeff_slot] = true;
     }
     tr.lap("launch_expm");
+    }
   }
   // kernel-duration stamps: every evaluation by default; HYPHY_HIP_TIMING_EVERY=n keeps one in n
   static const int timing_every = getenv("HYPHY_HIP_TIMING_EVERY") ? std::max(1, atoi(getenv("HYPHY_HIP_TIMING_EVERY"))) : 1;
@@ -1400,7 +1453,7 @@ static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
 static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                        const int64_t *q_nodes, int64_t n_q, const double *q, bool q_on_device, int q_is_probability,
                        const double *root_freqs, double *d_logl_out, bool reduce, bool floor_log, bool batch = false,
-                       bool force_persist = false) {
+                       bool force_persist = false, const MixSpec *mix = nullptr) {
   if (!p) return fail("partition == NULL");
   if (cat < 0) cat = 0;
   if (cat >= p->C) return fail("rate class out of range");
@@ -1462,7 +1515,7 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   p->slots_batch_mode = batch ? 1 : 0;
   for (Shard &s : p->shards)
     if (enqueue_eval(p, s, (int)cat, batch ? (int)p->C : 1, changed, pi_changed, slots_changed, q_nodes, n_q, q,
-                     q_on_device, q_is_probability, root_freqs, d_logl_out, reduce, floor_log)) {
+                     q_on_device, q_is_probability, root_freqs, d_logl_out, reduce, floor_log, mix)) {
       // some shard may hold a stale schedule / slot table / frequency vector now: rebuild everything next time
       p->cached_valid = 0;
       p->cached_pi.clear();
@@ -1495,6 +1548,31 @@ int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   if (logl_out) *logl_out = combine(parts);
   if (site_lik_out || site_scaler_out)
     return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
+  return 0;
+}
+
+/* Branch-site mixtures on every branch (the reference's "explicit form" models: BUSTED / BS-REL whole-alignment
+ * evaluation): P_b = sum_m weights exp(Q_bm), formed on the device. */
+int hyphy_hip_evaluate_mixture(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                               const int64_t *q_nodes, int64_t n_q, const int64_t *n_components, const double *q_dense,
+                               const double *weights, const double *root_freqs, double *logl_out, double *site_lik_out,
+                               int64_t *site_scaler_out) {
+  if (!p) return fail("partition == NULL");
+  if (n_q > 0 && (!n_components || !weights || !q_dense)) return fail("mixture evaluation: null argument");
+  MixSpec mix{n_components, weights, 0};
+  for (int64_t k = 0; k < n_q; k++) {
+    if (n_components[k] < 1 || n_components[k] > 16) return fail("mixture evaluation: 1..16 components per branch");
+    mix.n_tot += n_components[k];
+  }
+  if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, q_dense, false, 0, root_freqs, nullptr, true, false, false, false,
+                  n_q > 0 ? &mix : nullptr))
+    return -1;
+  if (collect_status(p)) return -1;
+  std::vector<double> parts;
+  for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
+  record_timings(p);
+  if (logl_out) *logl_out = combine(parts);
+  if (site_lik_out || site_scaler_out) return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
   return 0;
 }
 

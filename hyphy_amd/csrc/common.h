@@ -218,6 +218,8 @@ struct BcArgs {
 void launch_transpose_frag(const double *src_image, double *dst_image, const double *row_scale, int NW, hipStream_t stream);
 void launch_bc_eval(const BcArgs &a, hipStream_t stream);
 void launch_expm(const ExpmArgs &a, hipStream_t stream);
+void launch_mix_images(const double *P, const int *off, const double *w, const int32_t *slots, int n, int D, double *Pfrag,
+                       double *PTg, double *Prow, hipStream_t stream);
 void launch_site_fit(const SiteFitArgs &a, hipStream_t stream);
 void launch_prune_mfma(const PruneArgs &a, hipStream_t stream);
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream);

@@ -509,7 +509,50 @@ __global__ __launch_bounds__(256) void build_q_kernel(const double *__restrict__
   for (int idx = threadIdx.x; idx < N; idx += 256) out[idx] = qs[idx];
 }
 
+// Branch-site mixtures (the reference's "explicit form" models, tree.cpp:3047-3090): P_b = sum_m w_bm exp(Q_bm).  The
+// exponentials arrive row-major from the expm kernel; this writes the mixed matrix of every branch in the layouts the
+// pruning kernels read (A-operand image + column-gather image, or row-major for the 4-state path).
+__global__ __launch_bounds__(256) void mix_images_kernel(const double *__restrict__ P, const int *__restrict__ off,
+                                                         const double *__restrict__ w, const int32_t *__restrict__ slots,
+                                                         int D, int NT, double *__restrict__ Pfrag, double *__restrict__ PTg,
+                                                         double *__restrict__ Prow) {
+  const int b = blockIdx.x, m0 = off[b], m1 = off[b + 1], slot = slots ? slots[b] : b;
+  const int DP = 16 * NT, NKK = DP / 4, DD = D * D;
+  auto mixed = [&](int rr, int cc) -> double {
+    if (rr >= D || cc >= D) return 0.0;  // padded states carry exact zeros
+    double v = 0.;
+    for (int m = m0; m < m1; m++) v += w[m] * P[(size_t)m * DD + rr * D + cc];
+    return v;
+  };
+  if (Pfrag) {  // wave wb, k-step kk, lane l  <-  P[16 wb + (l & 15)][4 kk + (l >> 4)]
+    double *out = Pfrag + (size_t)slot * DP * DP;
+    for (int idx = threadIdx.x; idx < DP * DP; idx += blockDim.x) {
+      const int wb = idx / (NKK * 64), rem = idx - wb * (NKK * 64);
+      const int kk2 = rem >> 7, l = (rem >> 1) & 63, kb = rem & 1, kk = 2 * kk2 + kb;
+      out[idx] = mixed(16 * wb + (l & 15), 4 * kk + (l >> 4));
+    }
+  }
+  if (PTg) {  // [code][wb][gg][r]  <-  P[16 wb + 4 r + gg][code]
+    double *out = PTg + (size_t)slot * DP * DP;
+    for (int idx = threadIdx.x; idx < DP * DP; idx += blockDim.x) {
+      const int code = idx / (NT * 16), rem = idx - code * (NT * 16);
+      const int wb = rem >> 4, gg = (rem >> 2) & 3, r = rem & 3;
+      out[idx] = mixed(16 * wb + 4 * r + gg, code);
+    }
+  }
+  if (Prow) {
+    double *out = Prow + (size_t)slot * DD;
+    for (int idx = threadIdx.x; idx < DD; idx += blockDim.x) out[idx] = mixed(idx / D, idx % D);
+  }
+}
+
 }  // namespace
+
+void launch_mix_images(const double *P, const int *off, const double *w, const int32_t *slots, int n, int D, double *Pfrag,
+                       double *PTg, double *Prow, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(mix_images_kernel, dim3(n), dim3(256), 0, stream, P, off, w, slots, D, (D + 15) / 16, Pfrag, PTg, Prow);
+}
 
 void expm_read_profile(long long out[8]) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_expm_prof), 8 * sizeof(long long)); }
 

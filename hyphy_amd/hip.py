@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("HYPHY_HIP_LIB") or os.path.join(HERE, "lib", "libhyph
 
 EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
-    "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
+    "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
@@ -56,6 +56,8 @@ def load():
     lib.hyphy_hip_destroy.argtypes = [vp]
     lib.hyphy_hip_evaluate.restype = C.c_int
     lib.hyphy_hip_evaluate.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp, dp, dp, lp]
+    lib.hyphy_hip_evaluate_mixture.restype = C.c_int
+    lib.hyphy_hip_evaluate_mixture.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, lp, dp, dp, dp, dp, dp, lp]
     lib.hyphy_hip_evaluate_async.restype = C.c_int
     lib.hyphy_hip_evaluate_async.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp]
     lib.hyphy_hip_collect.restype = C.c_int
@@ -195,6 +197,23 @@ class HipPartition:
         sc = np.zeros(self.S, dtype=np.int64) if per_site else None
         _check(self._lib.hyphy_hip_evaluate(self._h, cat, _l(un), len(un), _l(qn), len(qn), _d(q),
                                             int(q_is_probability), _d(rf), C.byref(out), _d(sl), _l(sc)))
+        return (out.value, sl, sc) if per_site else out.value
+
+    def evaluate_mixture(self, update_nodes, q_nodes, q_components, weights, root_freqs, cat: int = -1, per_site: bool = False):
+        """Branch-site mixture on every listed branch: ``q_components`` [n_q, M, D, D] rate matrices, ``weights`` [n_q, M];
+        the device forms ``P_k = sum_m w_km exp(Q_km)`` (explicit-form models: BUSTED / BS-REL)."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        q = np.ascontiguousarray(q_components, dtype=np.float64)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        assert q.ndim == 4 and w.shape == q.shape[:2] and q.shape[0] == len(qn)
+        cnt = np.full(len(qn), q.shape[1], dtype=np.int64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        out = C.c_double(0.0)
+        sl = np.zeros(self.S) if per_site else None
+        sc = np.zeros(self.S, dtype=np.int64) if per_site else None
+        _check(self._lib.hyphy_hip_evaluate_mixture(self._h, cat, _l(un), len(un), _l(qn), len(qn), _l(cnt), _d(q), _d(w),
+                                                    _d(rf), C.byref(out), _d(sl), _l(sc)))
         return (out.value, sl, sc) if per_site else out.value
 
     def evaluate_async(self, update_nodes, q_nodes, q_dense, root_freqs, cat: int = -1, q_is_probability: bool = False):

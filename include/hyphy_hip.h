@@ -104,6 +104,20 @@ int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
                        int64_t *site_scaler_out);
 
 /*
+ * hyphy_hip_evaluate for models in the reference's "explicit form" (BUSTED, BS-REL, RELAX — the model is a
+ * formula of matrix exponentials, `Model M = ("Exp(Q1)*w1+Exp(Q2)*w2...", freqs, EXPLICIT_FORM_MATRIX_EXPONENTIAL)`,
+ * res/TemplateBatchFiles/libv3/models/codon/BS_REL.bf:34-60): the host's ExponentiateMatrices queues the Exp() arguments
+ * of every branch (variablecontainer.cpp:208-233), exponentiates each and recombines them through the formula
+ * (tree.cpp:3047-3090).  Here branch q_nodes[k] comes with n_components[k] numeric rate matrices (consecutive in
+ * q_dense) and their mixture weights; the device exponentiates all of them in one launch and forms
+ * P_k = sum_m weights[.] exp(Q[.]) directly in the layouts the pruning kernels read.
+ */
+int hyphy_hip_evaluate_mixture(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                               const int64_t *q_nodes, int64_t n_q, const int64_t *n_components /* [n_q] */,
+                               const double *q_dense /* [sum n_components][D*D] */, const double *weights /* [sum n_components] */,
+                               const double *root_freqs, double *logl_out, double *site_lik_out, int64_t *site_scaler_out);
+
+/*
  * The same evaluation split in two, so that the partitions of one likelihood function overlap (different devices, or
  * different streams of one device): enqueue every partition, then collect.  The reference's partition loop in
  * _LikelihoodFunction::Compute (src/core/likefunc.cpp:2524-2589) calls ComputeBlock(partID) serially and its MPI

@@ -43,6 +43,15 @@ struct _HyHipPart {
     long verify = -1;
   } call;
   long n_template_evals = 0, n_skipped = 0;
+  // mixture mode (explicit-form models: P_b = sum_m w_m Exp(Q_bm), weights built from GLOBAL variables only): per rate
+  // class 0 not analysed, 2 analysed — waiting for the verification against the host's own matrix, 1 enabled, -1 disabled
+  std::vector<int> mix_state;
+  long mix_M = 0, mix_probe = -1;
+  std::vector<_Formula *> mix_wf;                 // the M weight expressions (the model formula with Exp(.) -> 0 / 1)
+  std::vector<double> mix_probe_q;                // [M][D*D] rate matrices of the verification branch
+  std::vector<std::vector<double>> mix_q;         // per class: [B][M][D*D]
+  std::vector<std::vector<double>> mix_w;         // per class: [M] weights of the matrices stashed last
+  long n_mixture_evals = 0;
 };
 static std::map<const void *, std::vector<_HyHipPart>> _hyhip_lfs;
 static std::map<const void *, std::pair<const void *, long>> _hyhip_tree_owner;  // _TheTree* -> (lf, partition index)
@@ -52,7 +61,7 @@ long _hyhip_calls = 0L, _hyhip_cached_calls = 0L, _hyhip_deferred = 0L;
 // on the host when it returns); HYPHY_HIP_DEVICE_EXPM=0 keeps mode A, =always forces it (LFCompute benchmarks only:
 // ancestral reconstruction and simulation read the host matrices between evaluations).
 static int _hyhip_defer_depth = 0;
-extern bool (*_hyhip_defer_expm_hook)(_TheTree *, long, _List &, _List &, _SimpleList &);  // tree.cpp copy
+extern bool (*_hyhip_defer_expm_hook)(_TheTree *, long, _List &, _List &, _SimpleList &, _SimpleList &, bool);  // tree.cpp copy
 extern bool (*_hyhip_skip_recompute_hook)(_TheTree *, long, _CalcNode *, unsigned long, unsigned long);  // tree.cpp copy
 static int _hyhip_async_phase = 0;  // > 0: ComputeBlock enqueues the device evaluation and returns (pre-pass of Compute)
 static int _hyphy_hip_expm_mode(void) {
@@ -77,6 +86,9 @@ static void _hyphy_hip_teardown(const void *lf) {
   auto it = _hyhip_lfs.find(lf);
   if (it == _hyhip_lfs.end()) return;
   for (auto &hp : it->second) {
+    if (hp.part && getenv("HYPHY_HIP_VERBOSE") && hp.n_mixture_evals)
+      fprintf(stderr, "[hyphy_hip] mixture mode: %ld evaluations exponentiated and mixed their %ld-component branch-site mixtures on the device\n",
+              hp.n_mixture_evals, hp.mix_M);
     if (hp.part && getenv("HYPHY_HIP_VERBOSE") && hp.n_template_evals)
       fprintf(stderr, "[hyphy_hip] template mode: %ld evaluations took their rate matrices as coefficients (K = %ld), %ld RecomputeMatrix calls skipped\n",
               hp.n_template_evals, hp.tmpl_K, hp.n_skipped);
@@ -88,7 +100,8 @@ static void _hyphy_hip_teardown(const void *lf) {
   if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %ld ComputeBlock evaluations ran on the device so far (+ %ld through the branch cache); %ld matrix exponentials moved to the device\n", _hyhip_calls, _hyhip_cached_calls, _hyhip_deferred);
 }
 
-static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue, _SimpleList &parallel);
+static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue, _SimpleList &parallel,
+                                     _SimpleList &isExplicitForm, bool hasExpForm);
 static bool _hyphy_hip_skip_handler(_TheTree *t, long catID, _CalcNode *node, unsigned long nodeID, unsigned long n_nodes);
 
 static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_parts, _TheTree *cT,
@@ -160,6 +173,13 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   hp.tmpl_uploaded.assign(n_cat, 0);
   hp.tmpl_device_cat = -1;
   hp.call = _HyHipPart::Call();
+  hp.mix_state.assign(n_cat, getenv("HYPHY_HIP_MIXTURES") && !strcmp(getenv("HYPHY_HIP_MIXTURES"), "0") ? -1 : 0);
+  hp.mix_M = 0;
+  hp.mix_probe = -1;
+  for (_Formula *f : hp.mix_wf) delete f;
+  hp.mix_wf.clear();
+  hp.mix_q.assign(n_cat, std::vector<double>());
+  hp.mix_w.assign(n_cat, std::vector<double>());
   _hyhip_tree_owner[cT] = std::make_pair(lf, (long)i);
   if (_hyphy_hip_expm_mode() > 0) {
     _hyhip_defer_expm_hook = _hyphy_hip_defer_handler;
@@ -344,9 +364,151 @@ static bool _hyphy_hip_skip_handler(_TheTree *t, long catID, _CalcNode *node, un
   return true;
 }
 
+// ---- mixture mode (mode B, explicit-form models) -----------------------------------------------------------------------
+// The model is a formula of matrix exponentials (BUSTED, BS-REL, RELAX: "Exp(Q1)*w1+Exp(Q2)*w2...").  The host queues the
+// Exp() arguments of every branch, exponentiates them and evaluates the formula (tree.cpp:3011-3090).  When the formula is a
+// weighted SUM of the exponentials with weights that involve global variables only, the adapter takes the queue instead:
+// the weights are the model formula with Exp(.) replaced by 0 / 1 (parsed once by the host's own parser, evaluated per
+// call), and hyphy_hip_evaluate_mixture exponentiates and mixes on the device.  Accepted only after ONE branch's matrix
+// computed by the host's own formula agrees with sum_m w_m exp(Q_m) to 1e-12 (first evaluation).
+static bool _hyhip_build_weight_formulas(_HyHipPart &hp, _Formula *f, long M) {
+  if (!f) return false;
+  for (unsigned long i = 0; i < f->theFormula.lLength; i++) {  // everything the formula names directly must be global
+    _Operation *op = (_Operation *)f->theFormula(i);
+    long v = op->theData;
+    if (v < -1) v = -v - 2;
+    if (v >= 0) {
+      _Variable *var = LocateVar(v);
+      if (!var) return false;
+      if (var->ObjectClass() != MATRIX && !var->IsGlobal()) return false;  // a branch parameter among the weights
+    }
+  }
+  _String *fs = (_String *)f->toStr(kFormulaStringConversionNormal);
+  std::string text(fs->get_str());
+  DeleteObject(fs);
+  std::vector<std::pair<size_t, size_t>> spans;  // [begin, end) of every Exp(...) term
+  for (size_t pos = text.find("Exp("); pos != std::string::npos; pos = text.find("Exp(", pos)) {
+    if (pos > 0 && (isalnum((unsigned char)text[pos - 1]) || text[pos - 1] == '_' || text[pos - 1] == '.')) {
+      pos += 4;
+      continue;
+    }
+    size_t q = pos + 4;
+    int depth = 1;
+    while (q < text.size() && depth > 0) {
+      if (text[q] == '(') depth++;
+      else if (text[q] == ')') depth--;
+      q++;
+    }
+    if (depth != 0) return false;
+    spans.push_back(std::make_pair(pos, q));
+    pos = q;
+  }
+  if ((long)spans.size() != M) return false;
+  for (_Formula *old_f : hp.mix_wf) delete old_f;
+  hp.mix_wf.clear();
+  for (long m0 = 0; m0 < M; m0++) {
+    std::string w;
+    size_t at = 0;
+    for (long m = 0; m < M; m++) {
+      w += text.substr(at, spans[m].first - at);
+      w += m == m0 ? "(1)" : "(0)";
+      at = spans[m].second;
+    }
+    w += text.substr(at);
+    _String ws(w.c_str());
+    _Formula *wf = new _Formula(ws, nil);
+    if (wf->IsEmpty()) {
+      delete wf;
+      return false;
+    }
+    hp.mix_wf.push_back(wf);
+  }
+  return true;
+}
+static bool _hyhip_mixture_weights(_HyHipPart &hp, std::vector<double> &w) {
+  w.resize(hp.mix_wf.size());
+  for (size_t m = 0; m < hp.mix_wf.size(); m++) {
+    HBLObjectRef r = hp.mix_wf[m]->Compute();
+    if (!r || r->ObjectClass() != NUMBER) return false;
+    w[m] = r->Value();
+    if (!(w[m] == w[m])) return false;
+  }
+  return true;
+}
+static bool _hyhip_defer_mixture(_HyHipPart &hp, _TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue,
+                                 _SimpleList &parallel, _SimpleList &isExplicitForm) {
+  const long D = t->GetCodeBase(), DD = D * D, cat = catID < 0 ? 0 : catID;
+  if (cat >= (long)hp.mix_state.size() || hp.mix_state[cat] < 0 || hp.mix_state[cat] == 2) return false;
+  const long M = isExplicitForm.list_data[parallel.get(0)];
+  if (M < 1 || M > 16 || parallel.lLength % M || (hp.mix_M && hp.mix_M != M)) return false;
+  for (unsigned long g = 0; g < parallel.lLength; g += M) {  // groups of M consecutive queue entries, one node each
+    const void *nd = nodesToDo(parallel.get(g));
+    if (hp.code_of.find(nd) == hp.code_of.end()) return false;
+    for (long m = 0; m < M; m++) {
+      const long mid = parallel.get(g + m);
+      _Matrix *mx = (_Matrix *)matrixQueue(mid);
+      if (nodesToDo(mid) != nd || isExplicitForm.list_data[mid] != M || !mx || !mx->is_numeric() || mx->GetHDim() != D ||
+          mx->GetVDim() != D || !mx->theData)
+        return false;
+    }
+  }
+  if (hp.mix_state[cat] == 0) {
+    // first sight: build the weight expressions, remember one branch for the verification, let the host do this call
+    _CalcNode *first = (_CalcNode *)nodesToDo(parallel.get(0));
+    hp.mix_state[cat] = -1;
+    if (hp.mix_wf.empty() || hp.mix_M != M) {
+      if (!_hyhip_build_weight_formulas(hp, first->GetExplicitFormModel(first->map_global_to_local_category(catID)), M)) return false;
+      hp.mix_M = M;
+    }
+    hp.mix_probe = hp.code_of.at(first);
+    hp.mix_probe_q.assign((size_t)M * DD, 0.);
+    for (long m = 0; m < M; m++) _hyhip_dense_copy((_Matrix *)matrixQueue(parallel.get(m)), DD, hp.mix_probe_q.data() + (size_t)m * DD);
+    hp.mix_state[cat] = 2;
+    return false;
+  }
+  // enabled: take the whole queue
+  if (!_hyhip_mixture_weights(hp, hp.mix_w[cat])) return false;
+  if (hp.mix_q[cat].empty()) hp.mix_q[cat].assign(hp.code_of.size() * (size_t)M * DD, 0.);
+  hp.cat_arg[cat] = catID;
+  for (unsigned long g = 0; g < parallel.lLength; g += M) {
+    const long code = hp.code_of.at(nodesToDo(parallel.get(g)));
+    for (long m = 0; m < M; m++)
+      _hyhip_dense_copy((_Matrix *)matrixQueue(parallel.get(g + m)), DD, hp.mix_q[cat].data() + ((size_t)code * M + m) * DD);
+    hp.q_pending[cat][code] = 3;
+    if (!hp.host_stale[cat][code]) hp.n_stale++;
+    hp.host_stale[cat][code] = 3;
+  }
+  _hyhip_deferred += parallel.lLength;
+  return true;
+}
+// first evaluation after the analysis: does sum_m w_m exp(Q_m) reproduce the matrix the host's formula produced?
+static void _hyhip_verify_mixture(_HyHipPart &hp, _TheTree *t, long catID) {
+  const long D = t->GetCodeBase(), DD = D * D, cat = catID < 0 ? 0 : catID, M = hp.mix_M;
+  hp.mix_state[cat] = -1;
+  _Matrix *P = ((_CalcNode *)t->GetNodeFromFlatIndex(hp.mix_probe))->GetCompExp(catID);
+  std::vector<double> w, E((size_t)M * DD), host(DD);
+  if (!P || !P->theData || !_hyhip_mixture_weights(hp, w) || hyphy_hip_expm_batch(D, M, hp.mix_probe_q.data(), E.data()) != 0) return;
+  _hyhip_dense_copy(P, DD, host.data());
+  double err = 0.;
+  for (long e = 0; e < DD; e++) {
+    double v = 0.;
+    for (long m = 0; m < M; m++) v += w[m] * E[(size_t)m * DD + e];
+    err = fmax(err, fabs(v - host[e]));
+  }
+  hp.mix_state[cat] = err < 1e-12 ? 1 : -1;
+  if (getenv("HYPHY_HIP_VERBOSE"))
+    fprintf(stderr, "[hyphy_hip] explicit-form model, class %ld: %ld components, |host matrix - sum w exp(Q)| = %.2e -> %s\n", cat, M, err,
+            hp.mix_state[cat] == 1 ? "mixture mode (device exponentials + mixing)" : "host exponentials");
+}
+
 // ---- mode B: the host's ExponentiateMatrices hands its queue over instead of exponentiating (tree.cpp copy) ----
-static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue, _SimpleList &parallel) {
+static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue, _SimpleList &parallel,
+                                     _SimpleList &isExplicitForm, bool hasExpForm) {
   if (_hyhip_defer_depth <= 0) return false;
+  if (hasExpForm) {
+    _HyHipPart *mp = _hyhip_part_of_tree(t);
+    return mp ? _hyhip_defer_mixture(*mp, t, catID, nodesToDo, matrixQueue, parallel, isExplicitForm) : false;
+  }
   auto own = _hyhip_tree_owner.find(t);
   if (own == _hyhip_tree_owner.end()) return false;
   auto it = _hyhip_lfs.find(own->second.first);
@@ -484,7 +646,11 @@ static void _hyphy_hip_flush_part(_HyHipPart &hp, _TheTree *t) {
   const long D = t->GetCodeBase(), DD = D * D;
   for (size_t cat = 0; cat < hp.host_stale.size(); cat++)
     for (size_t code = 0; code < hp.host_stale[cat].size(); code++)
-      if (hp.host_stale[cat][code]) {
+      if (hp.host_stale[cat][code] == 3) {  // explicit-form mixture: the host's own formula (exponentials + recombination)
+        ((_CalcNode *)t->GetNodeFromFlatIndex(code))->RecomputeMatrix(hp.cat_arg[cat], t->categoryCount);
+        hp.host_stale[cat][code] = 0;
+        hp.q_pending[cat][code] = 0;
+      } else if (hp.host_stale[cat][code]) {
         _Matrix q(D, D, false, true);
         if (hp.host_stale[cat][code] == 2) _hyhip_template_dense(hp, (long)cat, (long)code, D, hp.qstash[cat].data() + code * DD);
         memcpy(q.theData, hp.qstash[cat].data() + code * DD, sizeof(double) * DD);
@@ -507,14 +673,44 @@ static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catI
   const bool first = !hp.cat_seen[cat];
   if (first) n_q = B;  // first evaluation of a rate class: hand over every transition matrix
   hp.qnodes.resize(n_q);
-  long n_pending = 0, n_template = 0;
+  if (cat < (long)hp.mix_state.size() && hp.mix_state[cat] == 2) _hyhip_verify_mixture(hp, t, catID);
+  long n_pending = 0, n_template = 0, n_mixture = 0;
   for (long k = 0; k < n_q; k++) {
     hp.qnodes[k] = first ? k : hp.code_of.at(matrices(k));
     n_pending += hp.q_pending[cat][hp.qnodes[k]] != 0;
     n_template += hp.q_pending[cat][hp.qnodes[k]] == 2;
+    n_mixture += hp.q_pending[cat][hp.qnodes[k]] == 3;
   }
   double ll = 0.;
   int rc = 0;
+  if (n_mixture > 0 && (n_mixture < n_q || go_async)) {  // mixed with other kinds (rare): the host's own matrices for everything
+    _hyphy_hip_flush_part(hp, t);
+    n_pending = n_template = n_mixture = 0;
+  }
+  if (n_q > 0 && n_mixture == n_q) {
+    const long M = hp.mix_M;
+    hp.pbuf.resize((size_t)n_q * M * DD + (size_t)n_q * M);
+    double *wq = hp.pbuf.data() + (size_t)n_q * M * DD;
+    std::vector<int64_t> cnt(n_q, M);
+    for (long k = 0; k < n_q; k++) {
+      memcpy(hp.pbuf.data() + (size_t)k * M * DD, hp.mix_q[cat].data() + (size_t)hp.qnodes[k] * M * DD, sizeof(double) * M * DD);
+      for (long m = 0; m < M; m++) wq[(size_t)k * M + m] = hp.mix_w[cat][m];
+    }
+    rc = hyphy_hip_evaluate_mixture(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(), n_q,
+                                    cnt.data(), hp.pbuf.data(), wq, t->GetProbs(), &ll, siteRes, (int64_t *)scc);
+    if (rc < 0) {
+      HandleApplicationError(_String("hyphy_hip_evaluate_mixture: ") & hyphy_hip_last_error());
+      return rc;
+    }
+    if (rc == 0) {
+      for (long k = 0; k < n_q; k++) hp.q_pending[cat][hp.qnodes[k]] = 0;
+      hp.cat_seen[cat] = 1;
+      hp.n_mixture_evals++;
+      _hyhip_calls++;
+      *result = ll;
+    }
+    return rc;
+  }
   if (n_q > 0 && n_template == n_q && !go_async) {
     // template mode: K coefficients per branch instead of D*D matrix entries; the device builds and exponentiates
     const long K = hp.tmpl_K;
@@ -642,6 +838,14 @@ static int _hyphy_hip_cached(const void *lf, long index, _TheTree *t, long catID
                              long *scc, hyFloat *result) {
   _HyHipPart &hp = _hyhip_lfs[lf][index];
   const long cat = catID < 0 ? 0 : catID, DD = t->GetCodeBase() * t->GetCodeBase();
+  if (hp.q_pending[cat][node] == 3) {  // (an explicit-form mixture: the host's own matrix for this one branch)
+    ((_CalcNode *)t->GetNodeFromFlatIndex(node))->RecomputeMatrix(hp.cat_arg[cat], t->categoryCount);
+    hp.q_pending[cat][node] = 0;
+    if (hp.host_stale[cat][node]) {
+      hp.host_stale[cat][node] = 0;
+      hp.n_stale--;
+    }
+  }
   if (hp.q_pending[cat][node] == 2) {  // (a template row: make it the dense rate matrix)
     _hyhip_template_dense(hp, cat, node, t->GetCodeBase(), hp.qstash[cat].data() + (size_t)node * DD);
     hp.q_pending[cat][node] = 1;
@@ -796,7 +1000,7 @@ OPTIMIZE = r'''
 TREE_HOOK_DEF = r'''
 #ifdef HYPHY_HIP
 // set by the likelihood-function adapter (likefunc.cpp copy); returns true when it took the queued rate matrices
-bool (*_hyhip_defer_expm_hook)(_TheTree *, long, _List &, _List &, _SimpleList &) = nullptr;
+bool (*_hyhip_defer_expm_hook)(_TheTree *, long, _List &, _List &, _SimpleList &, _SimpleList &, bool) = nullptr;
 // template mode: asked for every node of ExponentiateMatrices' first loop; true = the adapter derives this node's rate
 // matrix from the probes of this call, do not run RecomputeMatrix for it
 bool (*_hyhip_skip_recompute_hook)(_TheTree *, long, _CalcNode *, unsigned long, unsigned long) = nullptr;
@@ -812,9 +1016,13 @@ TREE_SKIP_NEW = r'''#ifdef HYPHY_HIP
                                   &isExplicitForm)) {'''
 TREE_HOOK_CALL = r'''
 #ifdef HYPHY_HIP
-  if (_hyhip_defer_expm_hook && !hasExpForm && serial.lLength == 0UL && parallel.lLength &&
-      _hyhip_defer_expm_hook(this, catID, nodesToDo, matrixQueue, parallel)) {
-    parallel.Clear();  // the device exponentiates these; nothing left for the OpenMP loop below
+  if (_hyhip_defer_expm_hook && serial.lLength == 0UL && parallel.lLength &&
+      _hyhip_defer_expm_hook(this, catID, nodesToDo, matrixQueue, parallel, isExplicitForm, hasExpForm)) {
+    parallel.Clear();  // the device exponentiates these; nothing left for the OpenMP loop below ...
+    if (computedExponentials) {  // ... nor (explicit-form models) for the recombination pass behind it
+      DeleteObject(computedExponentials);
+      computedExponentials = nil;
+    }
   }
 #endif
 '''

@@ -58,6 +58,30 @@ def codon_model_block(template, codon_freqs, rate_expr: str = "t", omega: str = 
     return "\n".join(lines)
 
 
+def codon_mixture_model_block(template, codon_freqs, omegas: Sequence[str], weights: Sequence[str], rate_expr: str = "t") -> str:
+    """Branch-site mixture in the reference's "explicit form" (syntax precedents:
+    ``tests/hbltests/RegressionTesting/expModelCrash.bf:1159``, ``res/TemplateBatchFiles/BranchSiteREL.bf:276``): one rate
+    matrix per omega class, ``Model = ("Exp(Q1)*w1+Exp(Q2)*w2...", freqs, EXPLICIT_FORM_MATRIX_EXPONENTIAL)`` — the
+    transition matrix of every branch is the weighted sum of the classes' exponentials (``tree.cpp:3047-3090``)."""
+    lines = []
+    for m, om in enumerate(omegas, start=1):
+        lines.append(f"MGQ{m} = {{61,61}};")
+        for (i, j, name, ns, pf) in template:
+            parts = []
+            if name != "AG":
+                parts.append(name)
+            if ns:
+                parts.append(om)
+            parts.append(rate_expr)
+            parts.append(_fmt(pf))
+            lines.append(f"MGQ{m}[{i}][{j}] := {'*'.join(parts)};")
+    fr = ",\n".join("{" + _fmt(v) + "}" for v in codon_freqs)
+    lines.append("vectorOfFrequencies = {\n" + fr + "};")
+    expr = "+".join(f"Exp(MGQ{m})*({w})" for m, w in enumerate(weights, start=1))
+    lines.append(f'Model MGM = ("{expr}", vectorOfFrequencies, EXPLICIT_FORM_MATRIX_EXPONENTIAL);')
+    return "\n".join(lines)
+
+
 def nuc_model_block(freqs, rate_expr: str = "t") -> str:
     from hyphy_amd.models import REV_NAMES
     lines = ["NQ = {4,4};"]
@@ -78,7 +102,8 @@ def build_script(*, fasta: str, newick: str, unit: int, model_block: str, model_
                  globals_: Dict[str, float], branch_t: Dict[str, float],
                  out_path: str, sweep: Optional[Dict] = None, threads: int = 0,
                  category: Optional[Dict] = None, per_site: bool = True, optimize: bool = False,
-                 constraints: Optional[Dict[str, str]] = None, extra_partitions: Optional[List[Dict]] = None) -> str:
+                 constraints: Optional[Dict[str, str]] = None, extra_partitions: Optional[List[Dict]] = None,
+                 upper_bounds: Optional[Dict[str, float]] = None) -> str:
     """One self-contained batch file.  ``sweep`` = {"param": "R", "start": .3, "step": .001,
     "n": N} runs the SURVEY A.8 timing loop and reports wall-clock seconds via Time(1)."""
     L: List[str] = ["VERBOSITY_LEVEL = -1;", "PRINT_DIGITS = 17;"]
@@ -87,6 +112,8 @@ def build_script(*, fasta: str, newick: str, unit: int, model_block: str, model_
             L.append(f"global {k} := {constraints[k]};")   # (tied parameter, e.g. CG := AT)
         else:
             L.append(f"global {k} = {_fmt(v)};")
+        if upper_bounds and k in upper_bounds:
+            L.append(f"{k} :< {_fmt(upper_bounds[k])};")   # (e.g. mixture weights live in [0, 1])
     if category:
         w = ",".join(_fmt(x) for x in category["weights"])
         v = ",".join(_fmt(x) for x in category["values"])
@@ -203,7 +230,7 @@ def parse_output(path: str) -> Dict:
 
 def evaluate(*, names, seqs, newick, unit, model_block, model_name, globals_, branch_t,
              sweep=None, threads=0, category=None, per_site=True, workdir=None, timeout=3600.0,
-             binary=None, extra_env=None, optimize=False, constraints=None, extra_partitions=None) -> Dict:
+             binary=None, extra_env=None, optimize=False, constraints=None, extra_partitions=None, upper_bounds=None) -> Dict:
     """Write fasta + script into a scratch dir, run the reference, parse the results."""
     own = workdir is None
     tmp = tempfile.mkdtemp(prefix="hyref_") if own else workdir
@@ -215,7 +242,7 @@ def evaluate(*, names, seqs, newick, unit, model_block, model_name, globals_, br
         fk = os.path.join(tmp, f"aln{k}.fasta")
         write_fasta(fk, part["names"], part["seqs"])
         xparts.append(dict(fasta=fk, newick=part["newick"], branch_t=part["branch_t"]))
-    txt = build_script(fasta=fasta, newick=newick, unit=unit, model_block=model_block, extra_partitions=xparts,
+    txt = build_script(fasta=fasta, newick=newick, unit=unit, model_block=model_block, extra_partitions=xparts, upper_bounds=upper_bounds,
                        model_name=model_name, globals_=globals_, branch_t=branch_t,
                        out_path=outp, sweep=sweep, threads=threads, category=category,
                        per_site=per_site, optimize=optimize, constraints=constraints)

@@ -17,6 +17,7 @@ Cases (SURVEY §8c "Fixtures to commit"):
   nuc_ambig     GTR with ambiguities
   nuc_deep      300-taxon ladder, rescaling in the 4-state path
   expm_*        P = Exp(Q) through _Matrix::Exponentiate for 4/20/61-state Q at several scales
+  codon_mix2/3  branch-site mixtures in the reference's explicit form (sum_m w_m Exp(Q_m) on every branch): BUSTED / BS-REL shape
   ref_smallcodon  the reference's own known-answer test SimpleOptimizations/SmallCodon.bf (data + expected log L)
   ref_fluHA       real data of SimpleOptimizations/IntermediateNuc.bf (HKY85, 349 influenza sequences: the 4-state path)
 """
@@ -94,6 +95,34 @@ def nuc_case(name, n_taxa, n_sites, seed, *, ladder=False, missing=0.0, rev=None
               root_freqs=NUC_FREQS, logl=res["logl"], site_logl=res["site_logl"])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
     print(f"{name}: logL = {res['logl']!r}  S = {pd.S}  n_ambig = {len(pd.ambig)}")
+
+
+def mixture_case(name="codon_mix2", n_taxa=12, n_codons=60, seed=41, omegas=(0.1, 2.5), weights=(0.7, 0.3)):
+    """Branch-site mixture in the reference's explicit form (BUSTED / BS-REL shape): every branch's transition matrix is
+    sum_m w_m Exp(Q_m), Q_m = MG94xREV with omega_m (`hbl.codon_mixture_model_block`)."""
+    syn = data.evolve(n_taxa, n_codons, 3, seed=seed)
+    flat = syn.flat
+    bt = branch_lengths(flat, seed + 7, 0.02, 0.3)
+    tmpl = models.mg94rev_template(POS_FREQS)
+    pi = models.f3x4_codon_freqs(POS_FREQS)
+    M = len(omegas)
+    g = dict(REV)
+    for m, om in enumerate(omegas, start=1):
+        g[f"R{m}"] = om
+    for m, w in enumerate(weights[:-1], start=1):
+        g[f"W{m}"] = w
+    wexpr = [f"W{m}" for m in range(1, M)] + ["(1" + "".join(f"-W{m}" for m in range(1, M)) + ")"]
+    block = hbl.codon_mixture_model_block(tmpl, pi, [f"R{m}" for m in range(1, M + 1)], wexpr)
+    res = hbl.evaluate(names=flat.leaf_names, seqs=syn.seqs, newick=tree.to_newick(syn.tree), unit=3, model_block=block,
+                       model_name="MGM", globals_=g, branch_t=bt)
+    pd = data.compress(syn.seqs, 3)
+    fx = dict(kind="codon_mixture", D=61, L=flat.L, flat_parents=flat.flat_parents, leaf_codes=pd.leaf_codes,
+              ambig=pd.ambig, pattern_freq=pd.pattern_freq, site_to_pattern=pd.site_to_pattern,
+              t=np.array([bt[n] for n in flat.branch_names()]), omegas=np.array(omegas), weights=np.array(weights),
+              rev=np.array([REV[k] for k in ("AC", "AT", "CG", "CT", "GT")]), pos_freqs=POS_FREQS,
+              root_freqs=pi, logl=res["logl"], site_logl=res["site_logl"])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(f"{name}: logL = {res['logl']!r}  S = {pd.S}")
 
 
 def expm_cases():
@@ -356,6 +385,11 @@ def fullsize_cases():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "mixture":
+        os.makedirs(OUT, exist_ok=True)
+        mixture_case()
+        mixture_case("codon_mix3", 20, 80, seed=43, omegas=(0.05, 0.8, 6.0), weights=(0.6, 0.3, 0.1))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
         if not hbl.have_reference():
             raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
@@ -377,6 +411,8 @@ def main():
     nuc_case("nuc_deep", 300, 40, seed=23, ladder=True, tlo=0.1, thi=0.5, p_change=0.25)
     expm_cases()
     marginal_support_case()
+    mixture_case()
+    mixture_case("codon_mix3", 20, 80, seed=43, omegas=(0.05, 0.8, 6.0), weights=(0.6, 0.3, 0.1))
     reference_test_case()
     reference_test_case_nuc()
 

@@ -860,3 +860,38 @@ def test_meme_driver_on_the_device():
     assert (res.beta_minus <= res.alpha + 1e-12).all()
     assert (res.logl_alt >= res.logl_null - 1e-7).all()
     assert ((res.p_value >= 0) & (res.p_value <= 1)).all()
+
+
+@pytest.mark.parametrize("name", ["codon_mix2", "codon_mix3"])
+def test_explicit_form_mixture_on_the_device_matches_reference(name):
+    """hyphy_hip_evaluate_mixture: every branch's transition matrix is sum_m w_m exp(Q_bm), exponentiated and mixed on
+    the device (the reference's explicit-form models, tree.cpp:3047-3090) — log L and per-site log L of the reference's
+    own explicit-form likelihood function, then a partial update (one branch's components change)."""
+    from hyphy_amd import models, tree
+    from oracle import oracle
+    fx = common.load(name)
+    rev = dict(zip(common.REV_KEYS, (float(x) for x in fx["rev"])))
+    t = np.asarray(fx["t"], dtype=np.float64)
+    nodes = common.all_nodes(fx)
+    Qc = np.stack([models.mg94rev_Q_batch(t, float(om), rev, fx["pos_freqs"]) for om in fx["omegas"]], axis=1)   # [B, M, D, D]
+    W = np.tile(np.asarray(fx["weights"], dtype=np.float64), (len(nodes), 1))
+    with _mk(fx) as part:
+        ll, lik, sc = part.evaluate_mixture(nodes, nodes, Qc, W, fx["root_freqs"], per_site=True)
+        ref = float(fx["logl"])
+        assert abs(ll - ref) <= RTOL * abs(ref), (ll, ref)
+        site = (np.log(lik) - sc * 64 * np.log(2.0))[fx["site_to_pattern"]]
+        assert np.max(np.abs(site - fx["site_logl"]) / np.abs(fx["site_logl"])) < RTOL
+        # partial update: branch 3 gets other components and weights; oracle with explicitly mixed matrices
+        L = int(fx["L"])
+        flat = tree.flat_from_parents(fx["flat_parents"], L)
+        node = 3
+        Q2 = Qc[node] * np.array([0.5, 2.0, 1.5][:Qc.shape[1]])[:, None, None]
+        w2 = np.asarray(fx["weights"], dtype=np.float64)[::-1].copy()
+        upd = flat.path_update_nodes(node)
+        got = part.evaluate_mixture(upd, np.array([node]), Q2[None], w2[None], fx["root_freqs"])
+        P = np.einsum("bm,bmij->bij", W, np.stack([oracle.expm(Qc[:, m], True) for m in range(Qc.shape[1])], axis=1))
+        P[node] = np.einsum("m,mij->ij", w2, oracle.expm(Q2, True))
+        op = oracle.OraclePartition(int(fx["D"]), fx["flat_parents"], L, fx["leaf_codes"], fx["ambig"], fx["pattern_freq"])
+        op.set_P(nodes, P)
+        want = op.compute_block(nodes, fx["root_freqs"])
+        assert abs(got - want) <= RTOL * abs(want), (got, want)

@@ -284,3 +284,40 @@ def test_hbl_two_partitions_on_the_device():
     gpu = hbl.evaluate(extra_partitions=xp, optimize=True, per_site=False, binary=HIP_BIN, extra_env=ENV, **a)
     assert _device_calls(gpu["stdout"]) > 50
     assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3
+
+
+def _mixture_case(n_taxa=12, n_codons=60, seed=41):
+    from hyphy_amd import data, models, tree
+    from oracle import hbl, make_golden as mg
+    syn = data.evolve(n_taxa, n_codons, 3, seed=seed)
+    bt = mg.branch_lengths(syn.flat, seed + 7, 0.02, 0.3)
+    block = hbl.codon_mixture_model_block(models.mg94rev_template(mg.POS_FREQS), models.f3x4_codon_freqs(mg.POS_FREQS),
+                                          ["R1", "R2"], ["W1", "(1-W1)"])
+    return dict(names=syn.flat.leaf_names, seqs=syn.seqs, newick=tree.to_newick(syn.tree), unit=3, model_block=block,
+                model_name="MGM", globals_=dict(R1=0.1, R2=2.5, W1=0.7, **mg.REV), branch_t=bt, upper_bounds=dict(W1=1.0))
+
+
+def test_hbl_explicit_form_mixture_through_device():
+    """BUSTED / BS-REL shaped model in the reference's explicit form (`Model = ("Exp(Q1)*W1+Exp(Q2)*(1-W1)", freqs,
+    EXPLICIT_FORM_MATRIX_EXPONENTIAL)`): LFCompute value and per-site values against the reference's golden, then a
+    complete Optimize in which the adapter takes the queued Exp() arguments (mode B, mixture mode): exponentials and
+    mixing on the device, the weights from the model formula itself; same optimum as the unmodified binary."""
+    _need_binaries()
+    from oracle import hbl
+    fx = common.load("codon_mix2")
+    case = _mixture_case()
+    res = hbl.evaluate(binary=HIP_BIN, extra_env=ENV, **case)
+    assert _device_calls(res["stdout"]) > 0
+    ref = float(fx["logl"])
+    assert abs(res["logl"] - ref) <= 1e-10 * abs(ref)
+    assert np.max(np.abs(res["site_logl"] - fx["site_logl"]) / np.abs(fx["site_logl"])) < 1e-10
+    cpu = hbl.evaluate(optimize=True, per_site=False, **case)
+    gpu = hbl.evaluate(optimize=True, per_site=False, binary=HIP_BIN, extra_env=ENV, **case)
+    m = re.findall(r"mixture mode: (\d+) evaluations exponentiated and mixed their (\d+)-component", gpu["stdout"])
+    assert m and int(m[-1][0]) > 10 and int(m[-1][1]) == 2, gpu["stdout"][-1200:]
+    assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3
+    # a sweep of the mixture weight with mode B forced: every point against the unmodified binary
+    sweep = dict(param="W1", start=0.3, step=0.02, n=20, record=20)
+    cpu = hbl.evaluate(sweep=sweep, per_site=False, **case)
+    gpu = hbl.evaluate(sweep=sweep, per_site=False, binary=HIP_BIN, extra_env=dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), **case)
+    assert np.max(np.abs(gpu["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10
