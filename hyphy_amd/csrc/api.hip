@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <set>
 
+#include <dlfcn.h>
+
 #include "../../include/hyphy_hip.h"
 #include "common.h"
 
@@ -23,6 +25,51 @@ int fail(const std::string &msg) {
   g_last_error = msg;
   return -1;
 }
+
+// ---- RCCL, loaded on first use (librccl.so is part of ROCm; a host that never all-reduces does not need it) -------------
+struct Rccl {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+  int (*CommDestroy)(void *comm) = nullptr;
+  int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t stream) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+struct RcclUniqueId {
+  char internal[128];  // NCCL_UNIQUE_ID_BYTES
+};
+typedef int (*rccl_init_rank_fn)(void **comm, int nranks, RcclUniqueId id, int rank);
+Rccl g_rccl;
+rccl_init_rank_fn g_rccl_init_rank = nullptr;
+constexpr int kNcclDouble = 8, kNcclSum = 0;
+
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(std::string("RCCL not available: ") + (dlerror() ? dlerror() : "librccl.so"));
+  g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+  g_rccl_init_rank = (rccl_init_rank_fn)dlsym(h, "ncclCommInitRank");
+  g_rccl.CommInitAll = (int (*)(void **, int, const int *))dlsym(h, "ncclCommInitAll");
+  g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+  g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+  g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+  g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+  g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl_init_rank || !g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllReduce ||
+      !g_rccl.GroupStart || !g_rccl.GroupEnd)
+    return fail("RCCL: missing symbols in librccl.so");
+  g_rccl.lib = h;
+  return 0;
+}
+#define RCCLCHK(expr)                                                                                         \
+  do {                                                                                                        \
+    int r_ = (expr);                                                                                          \
+    if (r_ != 0) return fail(std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "RCCL error")); \
+  } while (0)
 
 struct Trace {
   bool on;
@@ -81,6 +128,8 @@ struct Shard {
   double *bc_q = nullptr;
   int4 *prog = nullptr;       // program table (forest scheduling): (offset, entries, parent program, child programs)
   int4 *h_prog = nullptr;
+  double *ar_buf = nullptr;   // device scalar: this shard's partial log-L, all-reduced in place over RCCL
+  void *comm = nullptr;       // ncclComm_t of this shard (hyphy_hip_comm_init_rank / single-process group)
   double *mix_q = nullptr, *mix_p = nullptr, *mix_w = nullptr;  // branch-site mixtures: component rate matrices, their exponentials, weights
   int *mix_off = nullptr;
   size_t mix_cap = 0, mix_nq_cap = 0;
@@ -207,7 +256,7 @@ void free_shard(Shard &s) {
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
                  s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.codes_tile,
-                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.mix_q, s.mix_p, s.mix_w, s.mix_off, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
+                 s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.mix_q, s.mix_p, s.mix_w, s.mix_off, s.ar_buf, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops};
   for (void *d : dev)
     if (d) hipFree(d);
@@ -220,6 +269,7 @@ void free_shard(Shard &s) {
     if (e) hipEventDestroy(e);
   for (auto &e : s.coeff_ev)
     if (e) hipEventDestroy(e);
+  if (s.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s.comm);
   if (s.own_stream) hipStreamDestroy(s.own_stream);
   s = Shard();
 }
@@ -1546,6 +1596,28 @@ int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
   record_timings(p);
   if (logl_out) *logl_out = combine(parts);
+  if (logl_out && p->shards.size() > 1 && p->shards[0].comm && getenv("HYPHY_HIP_COMBINE") && !strcmp(getenv("HYPHY_HIP_COMBINE"), "rccl")) {
+    // the same sum as ONE group all-reduce over xGMI (every shard ends up with the total; shard 0's copy is returned)
+    for (Shard &s : p->shards) {
+      HIPCHK(hipSetDevice(s.device));
+      HIPCHK(hipMemcpyAsync(s.ar_buf, &s.h_out[0], sizeof(double), hipMemcpyHostToDevice, s.stream));
+    }
+    RCCLCHK(g_rccl.GroupStart());
+    for (Shard &s : p->shards) {
+      HIPCHK(hipSetDevice(s.device));
+      RCCLCHK(g_rccl.AllReduce(s.ar_buf, s.ar_buf, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
+    }
+    RCCLCHK(g_rccl.GroupEnd());
+    Shard &s0 = p->shards[0];
+    HIPCHK(hipSetDevice(s0.device));
+    double tot = 0.;
+    HIPCHK(hipMemcpyAsync(&tot, s0.ar_buf, sizeof(double), hipMemcpyDeviceToHost, s0.stream));
+    for (Shard &s : p->shards) {
+      HIPCHK(hipSetDevice(s.device));
+      HIPCHK(hipStreamSynchronize(s.stream));
+    }
+    *logl_out = tot;
+  }
   if (site_lik_out || site_scaler_out)
     return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
   return 0;
@@ -1573,6 +1645,95 @@ int hyphy_hip_evaluate_mixture(hyphy_hip_partition *p, int64_t cat, const int64_
   record_timings(p);
   if (logl_out) *logl_out = combine(parts);
   if (site_lik_out || site_scaler_out) return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
+  return 0;
+}
+
+/* ---- the all-reduce of the partition log-likelihood, over RCCL / xGMI, where a C++ host can reach it -------------------
+ * One process per GPU (HYPHYMPI-style hosts, `torchrun`-style launchers): rank 0 makes a 128-byte id
+ * (hyphy_hip_comm_unique_id), every rank receives it by whatever channel the host has (MPI_Bcast, a file) and calls
+ * hyphy_hip_comm_init_rank on its partition (which holds ITS shard of the patterns); hyphy_hip_evaluate_allreduce is then
+ * hyphy_hip_evaluate + ONE ncclAllReduce of one double per evaluation, enqueued on the partition's stream between the
+ * reduction kernel and the read-back: every rank returns the log-likelihood of the whole alignment. */
+int hyphy_hip_comm_unique_id(void *out128) {
+  if (!out128) return fail("null id buffer");
+  if (rccl_load()) return -1;
+  RCCLCHK(g_rccl.GetUniqueId(out128));
+  return 0;
+}
+
+int hyphy_hip_comm_init_rank(hyphy_hip_partition *p, const void *unique_id, int rank, int n_ranks) {
+  if (!p || !unique_id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail("comm_init_rank: bad arguments");
+  if (p->shards.size() != 1) return fail("comm_init_rank: one device per rank (device_count = 1)");
+  if (rccl_load()) return -1;
+  Shard &s = p->shards[0];
+  HIPCHK(hipSetDevice(s.device));
+  if (s.comm) {
+    g_rccl.CommDestroy(s.comm);
+    s.comm = nullptr;
+  }
+  RcclUniqueId id;
+  memcpy(id.internal, unique_id, sizeof id.internal);
+  RCCLCHK(g_rccl_init_rank(&s.comm, n_ranks, id, rank));
+  if (!s.ar_buf) HIPCHK(hipMalloc((void **)&s.ar_buf, 2 * sizeof(double)));
+  return 0;
+}
+
+/* In-place sum of one device double over the partition's communicator, on the partition's stream (asynchronous). */
+int hyphy_hip_allreduce_device(hyphy_hip_partition *p, double *d_value) {
+  if (!p || !d_value) return fail("allreduce: null argument");
+  if (p->shards.size() != 1 || !p->shards[0].comm) return fail("allreduce: hyphy_hip_comm_init_rank first");
+  Shard &s = p->shards[0];
+  HIPCHK(hipSetDevice(s.device));
+  RCCLCHK(g_rccl.AllReduce(d_value, d_value, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
+  return 0;
+}
+
+int hyphy_hip_evaluate_allreduce(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                                 const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
+                                 const double *root_freqs, double *logl_out) {
+  if (!p) return fail("partition == NULL");
+  if (p->shards.size() != 1 || !p->shards[0].comm) return fail("evaluate_allreduce: hyphy_hip_comm_init_rank first");
+  Shard &s = p->shards[0];
+  // partial log-L of this rank's patterns into a device scalar, summed over the ranks in-stream, one double back
+  if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, q_dense, false, q_is_probability, root_freqs, s.ar_buf, true, false))
+    return -1;
+  RCCLCHK(g_rccl.AllReduce(s.ar_buf, s.ar_buf, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
+  double host[2] = {0., 0.};
+  HIPCHK(hipMemcpyAsync(host, s.ar_buf, sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  HIPCHK(hipStreamSynchronize(s.stream));
+  s.seq_wait = 0.;
+  int32_t st = 0;
+  HIPCHK(hipMemcpy(&st, s.status, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (st) {
+    hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream);
+    return fail("Failed to compute a valid transition matrix; this is usually caused by ill-conditioned rate matrices "
+                "(e.g. very large rate values)");
+  }
+  if (logl_out) *logl_out = host[0];
+  return 0;
+}
+
+/* Single-process hosts with device_count > 1 (HyPhy proper): by default the shard partials come back over PCIe and are
+ * summed on the host with the reference's Neumaier combine; HYPHY_HIP_COMBINE=rccl (or this call) makes one RCCL group
+ * all-reduce of it instead — SURVEY 5 asks for both to be measurable. */
+int hyphy_hip_comm_init_all(hyphy_hip_partition *p) {
+  if (!p) return fail("partition == NULL");
+  if (rccl_load()) return -1;
+  const int n = (int)p->shards.size();
+  std::vector<int> devs(n);
+  std::vector<void *> comms(n, nullptr);
+  for (int k = 0; k < n; k++) devs[k] = p->shards[k].device;
+  for (int k = 0; k < n; k++)
+    for (int j = 0; j < k; j++)
+      if (devs[k] == devs[j]) return fail("comm_init_all: RCCL needs one distinct device per shard");
+  RCCLCHK(g_rccl.CommInitAll(comms.data(), n, devs.data()));
+  for (int k = 0; k < n; k++) {
+    Shard &s = p->shards[k];
+    HIPCHK(hipSetDevice(s.device));
+    if (s.comm) g_rccl.CommDestroy(s.comm);
+    s.comm = comms[k];
+    if (!s.ar_buf) HIPCHK(hipMalloc((void **)&s.ar_buf, 2 * sizeof(double)));
+  }
   return 0;
 }
 

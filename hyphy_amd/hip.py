@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("HYPHY_HIP_LIB") or os.path.join(HERE, "lib", "libhyph
 
 EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
-    "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
+    "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_comm_unique_id", "hyphy_hip_comm_init_rank", "hyphy_hip_comm_init_all", "hyphy_hip_allreduce_device", "hyphy_hip_evaluate_allreduce", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
@@ -56,6 +56,16 @@ def load():
     lib.hyphy_hip_destroy.argtypes = [vp]
     lib.hyphy_hip_evaluate.restype = C.c_int
     lib.hyphy_hip_evaluate.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp, dp, dp, lp]
+    lib.hyphy_hip_comm_unique_id.restype = C.c_int
+    lib.hyphy_hip_comm_unique_id.argtypes = [vp]
+    lib.hyphy_hip_comm_init_rank.restype = C.c_int
+    lib.hyphy_hip_comm_init_rank.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.hyphy_hip_comm_init_all.restype = C.c_int
+    lib.hyphy_hip_comm_init_all.argtypes = [vp]
+    lib.hyphy_hip_allreduce_device.restype = C.c_int
+    lib.hyphy_hip_allreduce_device.argtypes = [vp, vp]
+    lib.hyphy_hip_evaluate_allreduce.restype = C.c_int
+    lib.hyphy_hip_evaluate_allreduce.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp, dp]
     lib.hyphy_hip_evaluate_mixture.restype = C.c_int
     lib.hyphy_hip_evaluate_mixture.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, lp, dp, dp, dp, dp, dp, lp]
     lib.hyphy_hip_evaluate_async.restype = C.c_int
@@ -198,6 +208,31 @@ class HipPartition:
         _check(self._lib.hyphy_hip_evaluate(self._h, cat, _l(un), len(un), _l(qn), len(qn), _d(q),
                                             int(q_is_probability), _d(rf), C.byref(out), _d(sl), _l(sc)))
         return (out.value, sl, sc) if per_site else out.value
+
+    # -- RCCL (one process per GPU: the C-ABI's own all-reduce of the partition log-likelihood) ---------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(load().hyphy_hip_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def comm_init_rank(self, unique_id: bytes, rank: int, n_ranks: int):
+        buf = C.create_string_buffer(unique_id, 128)
+        _check(self._lib.hyphy_hip_comm_init_rank(self._h, C.cast(buf, C.c_void_p), rank, n_ranks))
+
+    def comm_init_all(self):
+        _check(self._lib.hyphy_hip_comm_init_all(self._h))
+
+    def evaluate_allreduce(self, update_nodes, q_nodes, q_dense, root_freqs, cat: int = -1, q_is_probability: bool = False):
+        """``evaluate`` on this rank's pattern shard + one RCCL all-reduce of the partial log-L: the whole alignment's value."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        q = np.ascontiguousarray(q_dense, dtype=np.float64) if len(qn) else None
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        out = C.c_double(0.0)
+        _check(self._lib.hyphy_hip_evaluate_allreduce(self._h, cat, _l(un), len(un), _l(qn), len(qn), _d(q), int(q_is_probability),
+                                                      _d(rf), C.byref(out)))
+        return out.value
 
     def evaluate_mixture(self, update_nodes, q_nodes, q_components, weights, root_freqs, cat: int = -1, per_site: bool = False):
         """Branch-site mixture on every listed branch: ``q_components`` [n_q, M, D, D] rate matrices, ``weights`` [n_q, M];

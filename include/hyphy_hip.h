@@ -132,6 +132,27 @@ int hyphy_hip_evaluate_async(hyphy_hip_partition *p, int64_t cat, const int64_t 
 int hyphy_hip_collect(hyphy_hip_partition *p, double *logl_out, double *site_lik_out, int64_t *site_scaler_out);
 
 /*
+ * The all-reduce of the partition log-likelihood over RCCL / xGMI, reachable from a C++ host (north_star: "a single RCCL
+ * allreduce of the partition log-likelihood over xGMI per evaluation").  librccl.so is loaded on first use.
+ *   one process per GPU:   rank 0: hyphy_hip_comm_unique_id(id) -> the host broadcasts the 128 bytes (MPI_Bcast in a
+ *                          HYPHYMPI build, a file ...) -> every rank: hyphy_hip_comm_init_rank(p, id, rank, n) on the
+ *                          partition that holds ITS pattern shard -> hyphy_hip_evaluate_allreduce(...) returns the
+ *                          log-likelihood of the whole alignment on every rank (evaluate + one ncclAllReduce of one
+ *                          double, in the partition's stream).  hyphy_hip_allreduce_device is the bare in-stream sum
+ *                          for callers of hyphy_hip_evaluate_device.
+ *   one process, N GPUs:   hyphy_hip_create(device_count = N) + hyphy_hip_comm_init_all(p): with HYPHY_HIP_COMBINE=rccl
+ *                          hyphy_hip_evaluate sums the shard partials by ONE group all-reduce instead of on the host
+ *                          (default: host-side Neumaier combine, likefunc.cpp:11046-11093).
+ */
+int hyphy_hip_comm_unique_id(void *out128);
+int hyphy_hip_comm_init_rank(hyphy_hip_partition *p, const void *unique_id, int rank, int n_ranks);
+int hyphy_hip_comm_init_all(hyphy_hip_partition *p);
+int hyphy_hip_allreduce_device(hyphy_hip_partition *p, double *d_value);
+int hyphy_hip_evaluate_allreduce(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                                 const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
+                                 const double *root_freqs, double *logl_out);
+
+/*
  * Same evaluation with device-resident inputs/outputs, enqueued asynchronously on the
  * partition's stream (device_count must be 1): d_q is a DEVICE pointer [n_q*D*D];
  * d_logl_out a DEVICE pointer to one double that receives this shard's partial

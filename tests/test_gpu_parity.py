@@ -895,3 +895,27 @@ def test_explicit_form_mixture_on_the_device_matches_reference(name):
         op.set_P(nodes, P)
         want = op.compute_block(nodes, fx["root_freqs"])
         assert abs(got - want) <= RTOL * abs(want), (got, want)
+
+
+def test_rccl_allreduce_entry_points_single_rank():
+    """The C-ABI's own all-reduce (hyphy_hip_comm_* / hyphy_hip_evaluate_allreduce, librccl loaded on first use): with a
+    communicator of ONE rank — all this box offers, RCCL refuses two ranks on one device — the all-reduced value is the
+    partition's own log-likelihood; the N-rank path differs only in the communicator (driver's multi-GPU runs)."""
+    fx = common.load("codon_wide")
+    Q = common.fixture_Q(fx)
+    nodes = common.all_nodes(fx)
+    hip = _hip()
+    with _mk(fx) as part:
+        ref = part.evaluate(nodes, nodes, Q, fx["root_freqs"])
+        part.comm_init_rank(hip.HipPartition.comm_unique_id(), 0, 1)
+        got = part.evaluate_allreduce(nodes, nodes, Q, fx["root_freqs"])
+        assert got == ref or abs(got - ref) <= 1e-13 * abs(ref)
+        assert abs(got - float(fx["logl"])) <= RTOL * abs(float(fx["logl"]))
+        # partial update through the same entry point
+        from hyphy_amd import tree
+        flat = tree.flat_from_parents(fx["flat_parents"], int(fx["L"]))
+        Q2 = Q[5:6] * 2.0
+        upd = flat.path_update_nodes(5)
+        a = part.evaluate_allreduce(upd, np.array([5]), Q2, fx["root_freqs"])
+        b = part.evaluate(upd, np.array([5]), Q2, fx["root_freqs"])
+        assert abs(a - b) <= 1e-13 * abs(b)
