@@ -989,6 +989,23 @@ LOOPCALL_NEW = r'''#ifdef HYPHY_HIP
 #endif
         if (blockMatrix) {'''
 
+# ---- block 4b: BenchmarkThreads (likefunc.cpp:219-420) ---------------------------------------------------------------
+# Optimize starts by timing Compute() at 1, 2, 3 ... threads (3-5 trials each, up to the machine's CPU count) to pick the
+# OpenMP width of the pruning loop.  With every partition on the device that loop never runs: skip the timing runs
+# (dozens of likelihood evaluations) and give the host-side leftovers (formula engine, mode-A exponentials) a fixed width.
+BENCHMARK = r'''
+#ifdef HYPHY_HIP
+  if (_hyphy_hip_enabled()) {
+    bool all_on_device = lf->CountObjects(kLFCountPartitions) > 0;
+    for (long i_ = 0; i_ < lf->CountObjects(kLFCountPartitions) && all_on_device; i_++) all_on_device = _hyphy_hip_active(lf, i_);
+    if (all_on_device) {
+      lf->SetThreadCount(MIN(16L, (long)hy_global::system_CPU_count));
+      return logL;
+    }
+  }
+#endif
+'''
+
 # ---- block 5: Optimize, first statement ----------------------------------------------------------------------------
 OPTIMIZE = r'''
 #ifdef HYPHY_HIP

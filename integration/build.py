@@ -51,6 +51,7 @@ def main():
     # no sticky scalers.
     lf = splice(lf, "      hyFloat sum = 0.;\n\n      if (doCachedComp >= 3) {", AB.COMPUTE, before=True)
     lf = splice(lf, "_Matrix *_LikelihoodFunction::Optimize(_AssociativeList const *options) {\n", AB.OPTIMIZE)
+    lf = splice(lf, "  if (lf->GetThreadCount() != 0)\n    return logL;\n", AB.BENCHMARK)
     # Compute(): all device partitions are enqueued before the first is collected (pre-pass + the loop's own call)
     lf = splice(lf, "    for (unsigned long partID = 0; partID < theTrees.lLength; partID++) {\n      if (blockDependancies.list_data[partID]) {\n        // has category variables",
                 AB.PREPASS, before=True)
