@@ -326,8 +326,6 @@ def main():
     omega0 = 0.3
 
     n_classes = wl.get("classes", 1)
-    if n_classes > 1 and N > 1:
-        raise SystemExit("the rate-class workload is single-GPU in this version")
     part = hip.HipPartition(D, flat.flat_parents, L, codes, None, freq, C_cat=n_classes,
                             device_first=(local if N > 1 else 0))
     part.set_q_templates(T)
@@ -349,7 +347,12 @@ def main():
         omega = omega0 + 0.001 * k
         coeffs[:, 1] = np.repeat(class_omega * omega, B) * coeffs[:, 0]
         if n_classes > 1:
-            return cat_step()      # build_q (3 x 125 matrices) + expm + batched pruning + mixing + reduction
+            v = cat_step()         # build_q (3 x 125 matrices) + expm + batched pruning + mixing + reduction
+            if N > 1:              # (classes are mixed per site on the rank that owns the site; the partial log-Ls add up)
+                d_logl[0] = v
+                hdist.allreduce_logl(d_logl[:1])
+                v = float(d_logl[0].item())
+            return v
         if N == 1 and sync:
             return sync_step()     # build_q + evaluate_built: log-L returned by the C-ABI call itself
         enqueue()      # device-side Q for every branch, then expm + pruning + reduction (C-ABI calls)

@@ -87,6 +87,7 @@ struct PruneArgs {
   // walked serially) and a TRUNK of join nodes above them.  A wave starts at a source, computes the edge product
   // towards the parent and arrives at it; the LAST arriver of a node multiplies the deposited products of its
   // siblings in, finalises the node and goes on upwards, everybody else deposits its product and retires.
+  int wave_variant;          // 0: production instantiation of prune_wave_kernel; > 0: experimental ones (HYPHY_HIP_WAVE_VARIANT)
   int chain;                 // 1: grid = (tiles, classes, sources), programs sorted by distance to the root
   const int4 *jn;            // [I] per internal node: (parent internal index or -1, arrivals needed | sum of internal child
                              //     indices << 8, offset of the node's trunk entries in ops, number of entries)

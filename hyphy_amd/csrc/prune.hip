@@ -508,8 +508,13 @@ __device__ __forceinline__ double row_sum4(double x) {
     }                                                                                                                    \
   }
 
-template <int NW, int NP, bool CLDS, bool TRACE = false>
-__global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *__restrict__ ops, const int4 *__restrict__ prog,
+// LB: the node finalised last lives in the wave's LDS tile (`stage`) instead of 32 registers (frees registers; the next
+//     product reads its B operand from LDS like a parked node's).  OCC: waves per SIMD the instantiation is compiled for.
+// PRE: a sibling's deposit is streamed into registers under the wave's own product (32 registers).
+// APF: the first A-operand chunk of the NEXT edge product is requested during the last k-step of the current one (the
+//      schedule names it), so that an edge does not start with an exposed L2 round trip.
+template <int NW, int NP, bool CLDS, bool TRACE = false, bool LB = false, int OCC = HYPHY_OCC3, bool PRE = true, bool APF = false>
+__global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restrict__ ops, const int4 *__restrict__ prog,
                                                                              const int4 *__restrict__ jn, PruneArgs a) {
   [[maybe_unused]] long long tr_t[3] = {0, 0, 0};
   [[maybe_unused]] int tr_levels = 0;
@@ -574,14 +579,21 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
   // registers and then waits for them with vmcnt(0) — eight exposed L2 round trips per edge).
   // `pre` != nullptr (wave-uniform): one 16-byte agent-scope load of a sibling's deposit rides along with every step.
   int polled = 0;  // (lane 0) arrival counter sampled near the end of an edge product, see the trunk loop
-  auto edge_product = [&](int branch, auto bsrc, const double *pre, const int *poll = nullptr) {
+  [[maybe_unused]] f64x2 Apre[NW];   // APF: first A chunk of branch `apre_branch`, requested under the previous product
+  [[maybe_unused]] int apre_branch = -1;
+  auto edge_product = [&](int branch, auto bsrc, const double *pre, const int *poll = nullptr, int next_branch = -1) {
     const double *pf = a.Pfrag + (size_t)branch * NW * TILE;  // uniform
     f64x4 D[NW];
 #pragma unroll
     for (int w = 0; w < NW; w++) D[w] = zeros;
     f64x2 Ac[NW], An[NW], bc, bn;
+    if (APF && apre_branch == branch) {
 #pragma unroll
-    for (int w = 0; w < NW; w++) Ac[w] = ld16(pf, (unsigned)((w * TILE + lane * 2) * 8));
+      for (int w = 0; w < NW; w++) Ac[w] = Apre[w];
+    } else {
+#pragma unroll
+      for (int w = 0; w < NW; w++) Ac[w] = ld16(pf, (unsigned)((w * TILE + lane * 2) * 8));
+    }
     bc = bsrc(0);
 #pragma unroll
     for (int k2 = 0; k2 < NKK / 2; k2++) {
@@ -591,6 +603,11 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
         bn = bsrc(k2 + 1);
       }
       if (pre) dreg[k2] = ld16_agent(pre, (unsigned)(k2 * 64 + lane) * 16u);
+      if (APF && k2 == NKK / 2 - 1 && next_branch >= 0) {
+        const double *pn = a.Pfrag + (size_t)next_branch * NW * TILE;  // uniform
+#pragma unroll
+        for (int w = 0; w < NW; w++) Apre[w] = ld16(pn, (unsigned)((w * TILE + lane * 2) * 8));
+      }
       if (poll && k2 == NKK / 2 - 2 && lane == 0) polled = __hip_atomic_load(poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -604,6 +621,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
     }
 #pragma unroll
     for (int w = 0; w < NW; w++) acc[w] *= D[w];
+    if (APF) apre_branch = next_branch;
   };
   auto leaf_gather = [&](int lf, int c) {
     const double *bl = a.PTg + (size_t)lf * DP * DP;  // uniform; [code][w][g][r]
@@ -617,11 +635,19 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
 
   // Interpreter of one run of schedule entries.  `own`: (trunk nodes of a chain schedule) internal index of the child
   // whose edge product this wave holds in `acc` already; `have_pre`: the deposit of the first OTHER child is in dreg.
-  auto run_ops = [&](const int4 *__restrict__ pops, int n_ops, int own, bool have_pre, int pre_cnt) {
+  auto run_ops = [&](const int4 *__restrict__ pops, int n_ops, int own, bool have_pre, int pre_cnt, int last_next = -1) {
   int4 op = pops[0];
   for (int oi = 0; oi < n_ops; oi++) {
     const int4 nxt = pops[oi + 1];
     const int kind = op.x & 3;
+    // APF: the edge after this one, when the schedule's next entry is an internal edge (or, behind the run's last entry,
+    // the caller's hint: the first trunk edge above a source)
+    int nb = -1;
+    if (APF) {
+      const int nk = nxt.x & 3;
+      if (oi + 1 < n_ops) nb = (nk == OPK_INTERNAL || nk == OPK_INTERNAL_GLOBAL) ? nxt.z : -1;
+      else nb = last_next;
+    }
     if (kind == OPK_LEAF) {
       const int nl = (op.x >> 8) & 0x7f;
       for (int i = 0; i < nl; i++) {
@@ -641,17 +667,18 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
       }
     } else if (kind == OPK_INTERNAL) {
       const int slot = (op.x >> 24) & 0xff;
-      if (slot < 2) {  // the node finalised by the previous entry: operand straight from registers
+      if (slot < 2) {  // the node finalised by the previous entry: operand straight from registers (LB: from its LDS tile)
         edge_product(op.z, [&](int k2) -> f64x2 {
-          return (f64x2){bch[k2 >> 1][(k2 & 1) * 2], bch[k2 >> 1][(k2 & 1) * 2 + 1]};
-        }, nullptr);
+          if constexpr (LB) return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2);
+          else return (f64x2){bch[k2 >> 1][(k2 & 1) * 2], bch[k2 >> 1][(k2 & 1) * 2 + 1]};
+        }, nullptr, nullptr, nb);
         cnt += bcnt;
       } else {
         const double *src = park + (slot - 2) * TILE;
         const int ccnt = park_cnt[slot - 2][sl];
         edge_product(op.z, [&](int k2) -> f64x2 {
           return *reinterpret_cast<const f64x2 *>(src + (k2 * 64 + lane) * 2);
-        }, nullptr);
+        }, nullptr, nullptr, nb);
         cnt += ccnt;
       }
     } else if (kind == OPK_DEP) {
@@ -695,7 +722,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
           *reinterpret_cast<f64x2 *>(stage + (k2 * 64 + lane) * 2) = ld16(src, (unsigned)(k2 * 64 + lane) * 16u);
       }
       edge_product(op.z, [&](int k2) -> f64x2 { return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2); },
-                   nullptr);
+                   nullptr, nullptr, nb);
       cnt += ccnt;
     }
 
@@ -721,6 +748,13 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
       for (int w = 0; w < NW; w++) {
         bch[w] = acc[w] * sc;
         acc[w] = ones;
+      }
+      if constexpr (LB) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          *reinterpret_cast<f64x2 *>(stage + ((2 * w) * 64 + lane) * 2) = (f64x2){bch[w][0], bch[w][1]};
+          *reinterpret_cast<f64x2 *>(stage + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){bch[w][2], bch[w][3]};
+        }
       }
       if (op.x & OPF_PUBLISH) {  // fragment root: another workgroup may consume it in this launch
 #pragma unroll
@@ -758,7 +792,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
  int4 prg;
  for (;;) {  // chained fragments: run program `cur`, then possibly its parent program
   prg = prog[cur];  // (scalar load: uniform control flow, schedule entries in SGPRs)
-  run_ops(ops + prg.x, prg.y, -1, false, 0);
+  run_ops(ops + prg.x, prg.y, -1, false, 0, (a.chain && jn[prg.w].x >= 0) ? a.L + prg.w : -1);
   if (a.chain || prg.z < 0) break;  // a chain source / the root program (or a stand-alone one)
   // arrival at the parent program: the wave that completes the parent's last child fragment (for this
   // tile) continues with the parent; every other wave retires.  Payload stores were write-through.
@@ -802,7 +836,7 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
         asm volatile("" ::: "memory");
         if (seen == need - 1) {
           last = true;
-          if (need == 2) {  // the one sibling: its deposit streams in under this wave's own product
+          if (PRE && need == 2) {  // the one sibling: its deposit streams in under this wave's own product
             const int sib = (jp.y >> 8) - c;
             pre = a.deposits + ((size_t)sib * a.ntiles + tile0) * TILE;
             pre_cnt = __hip_atomic_load(a.hand_cnt + ((size_t)sib * a.ntiles + tile0) * 32 + sl, __ATOMIC_RELAXED,
@@ -811,8 +845,9 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
         }
       }
       edge_product(a.L + c, [&](int k2) -> f64x2 {
-        return (f64x2){bch[k2 >> 1][(k2 & 1) * 2], bch[k2 >> 1][(k2 & 1) * 2 + 1]};
-      }, pre, last ? nullptr : ctr);
+        if constexpr (LB) return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2);
+        else return (f64x2){bch[k2 >> 1][(k2 & 1) * 2], bch[k2 >> 1][(k2 & 1) * 2 + 1]};
+      }, pre, last ? nullptr : ctr, jp.x >= 0 ? a.L + p : -1);
       cnt = bcnt;
       if (!last) {
         // (the counter was sampled two k-steps before the end of the product: its round trip is covered)
@@ -859,7 +894,12 @@ __global__ __launch_bounds__(64, HYPHY_OCC3) void prune_wave_kernel(const int4 *
     // root: L_s = sum_k root[s][k] pi[k]; bch holds the (scaled) root conditionals, bcnt its exponent
     double s = 0.;
 #pragma unroll
-    for (int kk = 0; kk < NKK; kk++) s = fma(bch[kk >> 2][kk & 3], a.pi[4 * kk + g], s);
+    for (int kk = 0; kk < NKK; kk++) {
+      double rv;
+      if constexpr (LB) rv = stage[frag_index(kk, lane)];
+      else rv = bch[kk >> 2][kk & 3];
+      s = fma(rv, a.pi[4 * kk + g], s);
+    }
     s = row_sum4(s);
     double wsum = 0.;
     long long wcnt = 0;
@@ -1346,6 +1386,28 @@ void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
     const size_t lds1 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
     if (a.timeline && NW == 4 && CLDS) {  // tracing build (HYPHY_HIP_TIMELINE)
       hipLaunchKernelGGL((prune_wave_kernel<4, 1, true, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      return;
+    }
+    if (NW == 4 && CLDS && a.wave_variant == 1) {  // experimental: finalised node in LDS, 2 waves per SIMD
+      if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 2, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      else hipLaunchKernelGGL((prune_wave_kernel<4, 1, true, false, true, 2, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      return;
+    }
+    if (NW == 4 && CLDS && a.wave_variant == 2 && a.n_slots <= 2) {  // experimental: ... 3 waves per SIMD, no register prefetch
+      hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 3, false>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      return;
+    }
+    if (NW == 4 && CLDS && a.wave_variant == 3 && a.n_slots <= 2) {  // experimental: ... 3 waves per SIMD, with the prefetch
+      hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 3, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      return;
+    }
+    if (NW == 4 && CLDS && a.wave_variant == 4) {  // experimental: finalised node in LDS + A-operand prefetch across edges
+      if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 2, true, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      else hipLaunchKernelGGL((prune_wave_kernel<4, 1, true, false, true, 2, true, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      return;
+    }
+    if (NW == 4 && CLDS && a.wave_variant == 5 && a.n_slots <= 2) {  // experimental: 3 waves per SIMD + A-operand prefetch
+      hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 3, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
       return;
     }
     if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<NW, 0, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);

@@ -23,6 +23,7 @@ for case in range(n_cases):
     slots, persist = str(int(rng.choice([2, 3]))), str(rng.choice(["lazy", "always"]))
     chain_m = str(int(rng.choice([0, 1, 2, 3, 5])))   # wave-per-tile kernel: chain schedule with sources of <= m nodes (0: level-peeled fragments)
     kernel, frag, slots, persist, chain_m = (os.environ.get("STRESS_" + k, v) for k, v in (("KERNEL", kernel), ("FRAGMENT", frag), ("SLOTS", slots), ("CACHE", persist), ("CHAIN_M", chain_m)))
+    os.environ["HYPHY_HIP_WAVE_VARIANT"] = os.environ.get("STRESS_WAVE_VARIANT", str(int(rng.choice([0, 0, 1, 2]))))  # instantiation of the wave kernel
     if int(chain_m) > 0:
         os.environ["HYPHY_HIP_CHAIN_M"] = str(chain_m)
     else:

@@ -41,6 +41,7 @@ for case in range(n_cases):
     tiles = os.environ.get("STRESS_TILES", str(int(rng.choice([1, 1, 2, 3, 4]))))  # patterns tiles per workgroup (workgroup kernel)
     shards = os.environ.get("STRESS_SHARDS", str(int(rng.choice([0, 0, 2, 3]))))  # pattern shards (here: all on one device)
     chain_m = os.environ.get("STRESS_CHAIN_M", str(int(rng.choice([0, 1, 2, 4]))))  # wave kernel: chain schedule (0: level-peeled fragments)
+    os.environ["HYPHY_HIP_WAVE_VARIANT"] = os.environ.get("STRESS_WAVE_VARIANT", str(int(rng.choice([0, 0, 1, 2]))))  # instantiation of the wave kernel
     if int(chain_m) > 0:
         os.environ["HYPHY_HIP_CHAIN_M"] = chain_m
     else:

@@ -79,3 +79,45 @@ def test_shard_ranges_are_a_partition():
             assert cover == list(range(n))
             sizes = [hdist.shard_range(n, r, world)[1] - hdist.shard_range(n, r, world)[0] for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_categories(rank, world, port, out_q):
+    """Rate classes under site sharding (bench.py --gpus N --workload busted3_64x10k): every rank mixes the classes of ITS
+    patterns (weighted-sum mode is per site, likefunc2.cpp:820-853), the mixed partial log-likelihoods add up."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    fx = common.load("codon_cat3")
+    C = len(fx["cat_weights"])
+    codes, freq, _ = hdist.shard_patterns(fx["leaf_codes"], fx["pattern_freq"], rank, world)
+    part = oracle.OraclePartition(int(fx["D"]), fx["flat_parents"], int(fx["L"]), codes, fx["ambig"], freq, C)
+    nodes = common.all_nodes(fx)
+    liks, scs = [], []
+    for c in range(C):
+        part.set_P(nodes, oracle.expm(common.fixture_Q(fx, float(fx["cat_values"][c])), True), cat=c)
+        lik, sc = part.site_block(nodes, fx["root_freqs"], cat=c)
+        liks.append(lik)
+        scs.append(sc)
+    ll, _, _ = oracle.mix_categories(fx["cat_weights"], np.array(liks), np.array(scs), freq)
+    partial = torch.tensor([float(ll)], dtype=torch.float64)
+    hdist.allreduce_logl(partial)
+    if rank == 0:
+        out_q.put(float(partial[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_site_sharding_with_rate_classes():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_categories, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    total = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = float(common.load("codon_cat3")["logl"])
+    assert abs(total - ref) <= 1e-11 * abs(ref)
