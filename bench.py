@@ -279,6 +279,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="mg94_64x10k", choices=sorted(WORKLOADS))
+    ap.add_argument("--preheat-s", type=float, default=0.3,
+                    help="seconds of untimed steps BEFORE the --warmup steps: the chip ramps its clocks over the first ~50 steps "
+                         "after an idle period (per-step 191 -> 167 us), longer than a 5-step warm-up; reported as preheat_s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="do not re-run under rocprofv3 for the HBM traffic of the dominant kernel")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -363,6 +366,19 @@ def main():
         return None
 
     ll0 = step(0)
+    # device preheat (clock ramp): the same number of steps on every rank (a step contains a collective when N > 1)
+    t_pre = time.perf_counter()
+    for _ in range(3):
+        step(1)
+    per = (time.perf_counter() - t_pre) / 3.0
+    n_pre = int(min(20000, max(0.0, args.preheat_s) / max(per, 1e-6)))
+    if N > 1:
+        cnt = torch.tensor([n_pre], dtype=torch.int64, device="cuda")
+        dist.broadcast(cnt, src=0)
+        n_pre = int(cnt.item())
+    for _ in range(n_pre):
+        step(1)
+    n_pre += 3
     for k in range(args.warmup):
         step(k + 1)
     t_exp = t_prune = t_red = 0.0
@@ -372,12 +388,18 @@ def main():
     t0 = time.perf_counter()
     last = None
     timed_values = [0.0] * args.steps
+    step_marks = [0.0] * args.steps if os.environ.get("HYPHY_BENCH_STEP_TIMES") else None   # (diagnostic: per-step wall clock)
     for k in range(args.steps):
         last = timed_values[k] = step(k + 1)
+        if step_marks is not None:
+            step_marks[k] = time.perf_counter()
     if N > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if step_marks is not None and rank == 0:
+        marks = np.diff(np.array([t0] + step_marks)) * 1e6
+        sys.stderr.write("[bench] per-step us: " + " ".join(f"{x:.0f}" for x in marks) + "\n")
     # kernel durations of the timed steps: HIP event pairs recorded by the library on ITS stream around the
     # pruning launches of every evaluation, read back only now (querying inside the loop perturbs it)
     pt = part.prune_timings(min(max(1, args.steps // TIMING_EVERY), 1024))
@@ -506,7 +528,7 @@ def main():
                       else f"full-tree log-L evals/sec ({args.workload})",
             "value": args.steps / dt, "unit": "evals/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "preheat_s": args.preheat_s, "preheat_steps": n_pre,
             "config": {"workload": args.workload, "states": D, "taxa": L, "codons" if D > 4 else "sites": wl["sites"],
                        "unique_patterns": int(S_all), "branches": int(B), "rate_classes": n_classes,
                        "parallelism": f"site-shard x{N}" if N > 1 else "single GPU",

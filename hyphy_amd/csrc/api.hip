@@ -1476,6 +1476,7 @@ static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   double best_ms = 1e30;
   int best = 0;
   char buf[64];
+  std::vector<std::pair<double, int>> ranked;  // (time, chain cut) of the first stage
   p->tune_report.clear();
   for (int c : cand) {
     p->chain_m_forced = c == -2 ? 0 : c;
@@ -1497,6 +1498,7 @@ static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
     ms = std::min(ms, ms2);
     snprintf(buf, sizeof buf, "%s%s%d:%.1fus", p->tune_report.empty() ? "" : " ", c == -2 ? "wg-kernel" : (c < 0 ? "levels" : "m"), c < 0 ? 0 : c, 1e3 * ms);
     p->tune_report += buf;
+    if (c > 0) ranked.push_back(std::make_pair((double)ms, c));
     if (ms < best_ms) {
       best_ms = ms;
       best = c;
@@ -1507,13 +1509,9 @@ static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   int best_wv = 0;
   p->wave_variant = 0;
   if (best > 0 && p->NW == 4 && !getenv("HYPHY_HIP_WAVE_VARIANT") && !getenv("HYPHY_HIP_SLOTS")) {
-    std::vector<int> ms;
-    for (size_t k = 0; k < cand.size(); k++)
-      if (cand[k] == best) {
-        if (k > 0 && cand[k - 1] > 0) ms.push_back(cand[k - 1]);
-        ms.push_back(best);
-        if (k + 1 < cand.size() && cand[k + 1] > 0) ms.push_back(cand[k + 1]);
-      }
+    std::vector<int> ms;  // the three fastest cuts of the first stage
+    std::sort(ranked.begin(), ranked.end());
+    for (size_t k = 0; k < ranked.size() && k < 3; k++) ms.push_back(ranked[k].second);
     for (int m : ms) {
       p->chain_m_forced = m;
       p->variant = 1;

@@ -854,7 +854,17 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
         const int seen = __builtin_amdgcn_readfirstlane(polled);
         asm volatile("" ::: "memory");
         if (seen != need - 1) {
-          // deposit the product (write-through), drain, count the arrival
+          // deposit the product (write-through), drain, count the arrival.
+          // Memory-ordering contract of every hand-off between waves of this launch (deposits here, fragment roots above):
+          //   producer  16-byte sc1 (write-through) payload stores -> asm "s_waitcnt vmcnt(0)" (an asm statement with a memory
+          //             clobber: the hardware drain AND a compiler barrier, invisible to the waitcnt-elision pass) -> relaxed
+          //             agent-scope RMW on the arrival counter;
+          //   consumer  the RMW / relaxed load that proves every producer has arrived -> compiler barrier -> sc1 loads (they
+          //             bypass the reader's L1, so no agent-scope acquire — no L1 invalidate — is needed).
+          // This is the "sc1 payload -> asm vmcnt(0) -> flag, sc1 loads on the reading side" form of MI355X_MICROARCH.md
+          // ("Valid forms"), valid under any workgroup -> XCD placement; a release/acquire pair on the counter would add a
+          // buffer_wbl2 and a buffer_inv (1.7 us each) to every join for accesses that never touch L1 / dirty L2 lines.
+          // tests/test_gpu_parity.py::test_chain_joins_within_and_across_xcds drives it with joins forced across / inside XCDs.
           double *out = a.deposits + ((size_t)c * a.ntiles + tile0) * TILE;  // uniform
           bool skip_store = false;
           if constexpr (TRACE) skip_store = (a.ablate & 256) != 0;

@@ -919,3 +919,45 @@ def test_rccl_allreduce_entry_points_single_rank():
         a = part.evaluate_allreduce(upd, np.array([5]), Q2, fx["root_freqs"])
         b = part.evaluate(upd, np.array([5]), Q2, fx["root_freqs"])
         assert abs(a - b) <= 1e-13 * abs(b)
+
+
+@pytest.mark.parametrize("n_tiles", [41, 48, 7])
+def test_chain_joins_within_and_across_xcds(n_tiles, monkeypatch):
+    """Chain schedules hand edge products between waves of ONE launch through global memory (write-through stores, drained,
+    then an agent-scope arrival; the last arriver reads with L1-bypassing loads).  Workgroup b runs on XCD b mod 8 and
+    the grid is (tiles, classes, sources): sibling chains of a tile sit n_tiles x (source distance) workgroups apart —
+    with an odd tile count every join crosses XCDs, with a multiple of 8 every join stays inside one.  Smallest sources
+    (m = 1: the most joins), poisoned allocations, 24 evaluations with changing parameters each against the oracle."""
+    from hyphy_amd import data, models, tree
+    from oracle import oracle
+    monkeypatch.setenv("HYPHY_HIP_KERNEL", "1")
+    monkeypatch.setenv("HYPHY_HIP_CHAIN_M", "1")
+    monkeypatch.setenv("HYPHY_HIP_POISON", "1")
+    rng = np.random.default_rng(100 + n_tiles)
+    root = tree.random_tree(48, rng, trifurcating_root=True)
+    flat = tree.flatten(root)
+    S = n_tiles * 16 - 3
+    states = rng.integers(0, 61, size=(flat.L, S))
+    base = rng.integers(0, 61, size=S)
+    states = np.where(rng.random((flat.L, S)) < 0.25, states, base[None, :])
+    pd = data.from_states(states, 61, compress_patterns=False)
+    pf = np.array([[0.3, 0.2, 0.25, 0.25], [0.2, 0.3, 0.3, 0.2], [0.25, 0.25, 0.2, 0.3]])
+    rev = dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4)
+    pi = models.f3x4_codon_freqs(pf)
+    B = flat.n_branches
+    nodes = np.arange(B, dtype=np.int64)
+    tb = rng.uniform(0.01, 0.4, B)
+    op = oracle.OraclePartition(61, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq)
+    hip = _hip()
+    with hip.HipPartition(61, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq) as part:
+        assert part.S == S
+        for k in range(24):
+            Q = models.mg94rev_Q_batch(tb * (1.0 + 0.05 * k), 0.2 + 0.1 * k, rev, pf)
+            got = part.evaluate(nodes, nodes, Q, pi)
+            if k % 4 == 0 or k >= 20:   # (the oracle takes ~0.1 s per evaluation here)
+                op.set_P(nodes, oracle.expm(Q, True))
+                want = op.compute_block(nodes, pi)
+                assert abs(got - want) <= RTOL * abs(want), (n_tiles, k, got, want)
+            else:
+                again = part.evaluate(nodes, nodes, Q, pi)   # same inputs, different arrival orders: same bits or rounding
+                assert abs(got - again) <= 1e-13 * abs(got), (n_tiles, k, got, again)
