@@ -496,6 +496,13 @@ __device__ __forceinline__ double row_sum4(double x) {
 // end] in 100 MHz ticks, trunk levels walked (+100 per prefetched join, +1000 per join won after depositing), how it
 // ended (0 deposited and retired, 1 reached the root, 2 retired at a fragment hand-off), HW_ID and XCC_ID; it also honours
 // HYPHY_HIP_ABLATE bits 256 / 512 (no deposit stores / no deposit reads: results invalid).
+// HYPHY_ABL (compile-time bitmask, diagnostic builds only, results invalid): 1 = with HYPHY_HIP_ABLATE=4096 every edge reads
+// branch 0's matrix image (A operand always cache-hot), 2 = one A chunk per edge instead of eight (no operand stream),
+// 4 = no leaf gathers, 8 = no rescaling test at a node's finalisation, 16 = no gather for the first leaf behind an edge
+// product (what a perfect prefetch under that product could hide).
+#ifndef HYPHY_ABL
+#define HYPHY_ABL 0
+#endif
 #define HYPHY_TRACE_STAMP(k) \
   if constexpr (TRACE) tr_t[k] = wall_clock64();
 #define HYPHY_TRACE_FINISH(how)                                                                                          \
@@ -578,11 +585,13 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
   // step k2 are issued (sched_barrier: left alone, the scheduler sinks the loads below the MFMAs to save
   // registers and then waits for them with vmcnt(0) — eight exposed L2 round trips per edge).
   // `pre` != nullptr (wave-uniform): one 16-byte agent-scope load of a sibling's deposit rides along with every step.
+  [[maybe_unused]] bool abl_after_edge = false;  // (HYPHY_ABL & 16: the first leaf behind an edge product is free)
+  [[maybe_unused]] const int abl_mask = (a.ablate & 4096) ? 0 : -1;  // (HYPHY_ABL == 1 builds only)
   int polled = 0;  // (lane 0) arrival counter sampled near the end of an edge product, see the trunk loop
   [[maybe_unused]] f64x2 Apre[NW];   // APF: first A chunk of branch `apre_branch`, requested under the previous product
   [[maybe_unused]] int apre_branch = -1;
   auto edge_product = [&](int branch, auto bsrc, const double *pre, const int *poll = nullptr, int next_branch = -1) {
-    const double *pf = a.Pfrag + (size_t)branch * NW * TILE;  // uniform
+    const double *pf = a.Pfrag + (size_t)((HYPHY_ABL & 1) ? (branch & abl_mask) : branch) * NW * TILE;  // uniform
     f64x4 D[NW];
 #pragma unroll
     for (int w = 0; w < NW; w++) D[w] = zeros;
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
     for (int k2 = 0; k2 < NKK / 2; k2++) {
       if (k2 + 1 < NKK / 2) {
 #pragma unroll
-        for (int w = 0; w < NW; w++) An[w] = ld16(pf, (unsigned)((w * TILE + ((k2 + 1) * 64 + lane) * 2) * 8));
+        for (int w = 0; w < NW; w++) An[w] = (HYPHY_ABL & 2) ? Ac[w] : ld16(pf, (unsigned)((w * TILE + ((k2 + 1) * 64 + lane) * 2) * 8));
         bn = bsrc(k2 + 1);
       }
       if (pre) dreg[k2] = ld16_agent(pre, (unsigned)(k2 * 64 + lane) * 16u);
@@ -621,6 +630,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
     }
 #pragma unroll
     for (int w = 0; w < NW; w++) acc[w] *= D[w];
+    if (HYPHY_ABL & 16) abl_after_edge = true;
     if (APF) apre_branch = next_branch;
   };
   auto leaf_gather = [&](int lf, int c) {
@@ -654,7 +664,8 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
         const int lf = (op.z >> (16 * i)) & 0xffff;
         const int c = leaf_code(lf);
         if (!(op.x & OPF_AMBIG) || !__any(c < 0)) {
-          leaf_gather(lf, c < 0 ? 0 : c);
+          if (!(HYPHY_ABL & 4) && !((HYPHY_ABL & 16) && i == 0 && abl_after_edge)) leaf_gather(lf, c < 0 ? 0 : c);
+          abl_after_edge = false;
         } else {  // ambiguity codes in this tile: full product with the resolution vector
           const double *av = a.ambig + (size_t)(c < 0 ? -c - 1 : 0) * DP;
           edge_product(lf, [&](int k2) -> f64x2 {
@@ -738,7 +749,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
       double s = 0.;
 #pragma unroll
       for (int w = 0; w < NW; w++) s += (acc[w][0] + acc[w][1]) + (acc[w][2] + acc[w][3]);
-      const double tot = row_sum4(s);
+      const double tot = (HYPHY_ABL & 8) ? 1.0 : row_sum4(s);
       double sc = 1.0;
       int m = 0;
       if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) m = rescale_decision(tot, sc);  // rare
