@@ -212,6 +212,7 @@ struct hyphy_hip_partition {
   std::vector<double> cached_weights;        // category weights currently on the device
   std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
   int root_slot = 0;
+  std::vector<int64_t> perm;                 // internal pattern j = caller's pattern perm[j] (empty: identity); see sort_patterns()
   int64_t pin_node = -1;                     // node code whose states are pinned for the evaluations that follow (-1: none)
   std::vector<int64_t> bc_node;              // per rate class: branch whose outside vector is resident (-1: none)
   std::vector<int> bc_use_pi;                // ... hangs off the root (frequencies applied at evaluation)
@@ -1110,18 +1111,62 @@ double combine(const std::vector<double> &parts) {
   return sum + corr;
 }
 
+inline int64_t caller_pattern(const hyphy_hip_partition *p, int64_t j) { return p->perm.empty() ? j : p->perm[j]; }
+
+// Pattern order on the device.  A leaf edge is a per-site column gather from the leaf branch's matrix (prune.hip: leaf_gather),
+// and the texture-address path coalesces the lanes of a quad that read the same cache lines: 16 sites with 16 different
+// states cost 4 000 cycles per gather under load, sites that share their state in runs of >= 4 cost 1 070
+// (tools/ubench/glds_probe.hip).  Patterns are therefore kept sorted — by their most frequent state first (conserved sites
+// of the same codon become neighbours), then lexicographically by leaf — which takes the distinct states per (leaf, tile)
+// from 14.2 to 3.9 on the headline alignment.  The order is internal: every per-pattern input and output of the C-ABI is
+// translated through `perm` (gather_sites, download_partials, set_pinned_states, site fits).
+void sort_patterns(hyphy_hip_partition *p, const int64_t *leaf_codes, int64_t L, int64_t S) {
+  if (S < 32) return;
+  std::vector<int64_t> major(S, 0);
+  {
+    std::vector<int> cnt;
+    for (int64_t k = 0; k < S; k++) {
+      cnt.assign((size_t)p->D, 0);
+      int best = 0;
+      for (int64_t l = 0; l < L; l++) {
+        const int64_t c = leaf_codes[l * S + k];
+        if (c >= 0 && c < p->D && ++cnt[(size_t)c] > cnt[(size_t)best]) best = (int)c;
+      }
+      major[k] = best;
+    }
+  }
+  p->perm.resize(S);
+  for (int64_t k = 0; k < S; k++) p->perm[k] = k;
+  std::sort(p->perm.begin(), p->perm.end(), [&](int64_t a, int64_t b) {
+    if (major[a] != major[b]) return major[a] < major[b];
+    for (int64_t l = 0; l < L; l++) {
+      const int64_t ca = leaf_codes[l * S + a], cb = leaf_codes[l * S + b];
+      if (ca != cb) return ca < cb;
+    }
+    return a < b;
+  });
+}
+
 int gather_sites(hyphy_hip_partition *p, int cat, double *site_lik_out, int64_t *site_scaler_out, bool mixed) {
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
     const double *lik = mixed ? s.mixed_lik : s.site_lik + (size_t)cat * s.S_pad;
     const int32_t *cn = mixed ? s.mixed_cnt : s.site_cnt + (size_t)cat * s.S_pad;
-    if (site_lik_out)
-      HIPCHK(hipMemcpyAsync(site_lik_out + s.s0, lik, s.S * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    if (site_lik_out) {
+      if (p->perm.empty()) {
+        HIPCHK(hipMemcpyAsync(site_lik_out + s.s0, lik, s.S * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+      } else {  // the device keeps its patterns sorted: scatter back into the caller's order
+        std::vector<double> tmp(s.S);
+        HIPCHK(hipMemcpyAsync(tmp.data(), lik, s.S * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(hipStreamSynchronize(s.stream));
+        for (int64_t k = 0; k < s.S; k++) site_lik_out[p->perm[s.s0 + k]] = tmp[k];
+      }
+    }
     if (site_scaler_out) {
       std::vector<int32_t> tmp(s.S);
       HIPCHK(hipMemcpyAsync(tmp.data(), cn, s.S * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
       HIPCHK(hipStreamSynchronize(s.stream));
-      for (int64_t k = 0; k < s.S; k++) site_scaler_out[s.s0 + k] = tmp[k];
+      for (int64_t k = 0; k < s.S; k++) site_scaler_out[caller_pattern(p, s.s0 + k)] = tmp[k];
     }
     HIPCHK(hipStreamSynchronize(s.stream));
   }
@@ -1236,6 +1281,9 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
   const int64_t B = p->B;
   int tiles_override = 0;
   if (const char *e = getenv("HYPHY_HIP_TILES")) tiles_override = atoi(e);
+  if (!p->nuc && !(getenv("HYPHY_HIP_SORT_PATTERNS") && atoi(getenv("HYPHY_HIP_SORT_PATTERNS")) == 0))
+    sort_patterns(p, leaf_codes, L, S);
+  auto src_pattern = [&](int64_t j) -> int64_t { return p->perm.empty() ? j : p->perm[j]; };
 
   int64_t base = S / nshards, rem = S % nshards, s0 = 0;
   for (int k = 0; k < nshards; k++) {
@@ -1384,9 +1432,9 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     // leaf table: int64 pattern-indexed -> packed int16 [L][S_pad]; padding patterns use state 0, weight 0
     std::vector<int16_t> codes((size_t)L * s.S_pad, 0);
     for (int64_t l = 0; l < L; l++)
-      for (int64_t k = 0; k < s.S; k++) codes[(size_t)l * s.S_pad + k] = (int16_t)leaf_codes[l * S + s.s0 + k];
+      for (int64_t k = 0; k < s.S; k++) codes[(size_t)l * s.S_pad + k] = (int16_t)leaf_codes[l * S + src_pattern(s.s0 + k)];
     std::vector<double> fr(s.S_pad, 0.0);
-    for (int64_t k = 0; k < s.S; k++) fr[k] = (double)pattern_freq[s.s0 + k];
+    for (int64_t k = 0; k < s.S; k++) fr[k] = (double)pattern_freq[src_pattern(s.s0 + k)];
     std::vector<double> amb((size_t)std::max<int64_t>(1, n_ambig) * DP, 0.0);
     const int astride = p->nuc ? 4 : DP;
     for (int64_t a = 0; a < n_ambig; a++)
@@ -1960,16 +2008,27 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
         for (int64_t n = 0; n < I; n++)
           for (int64_t k = 0; k < s.S; k++)
             for (int j = 0; j < 4; j++)
-              inode_cache[(n * S + s.s0 + k) * 4 + j] = tmp[((size_t)n * 4 + j) * s.S_pad + k];
+              inode_cache[(n * S + caller_pattern(p, s.s0 + k)) * 4 + j] = tmp[((size_t)n * 4 + j) * s.S_pad + k];
       } else {
         double *dtmp = nullptr;
         HIPCHK(hipMalloc((void **)&dtmp, (size_t)I * s.S * D * sizeof(double)));
         launch_unpack_partials_mfma(s.partials + (size_t)cat * s.partial_stride, (int)I, s.ntiles, p->NW, (int)D,
                                     (int)s.S, dtmp, s.stream);
-        hipError_t e = hipMemcpy2DAsync(inode_cache + s.s0 * D, (size_t)S * D * sizeof(double), dtmp,
-                                        (size_t)s.S * D * sizeof(double), (size_t)s.S * D * sizeof(double), (size_t)I,
-                                        hipMemcpyDeviceToHost, s.stream);
-        hipStreamSynchronize(s.stream);
+        hipError_t e;
+        if (p->perm.empty()) {
+          e = hipMemcpy2DAsync(inode_cache + s.s0 * D, (size_t)S * D * sizeof(double), dtmp,
+                               (size_t)s.S * D * sizeof(double), (size_t)s.S * D * sizeof(double), (size_t)I,
+                               hipMemcpyDeviceToHost, s.stream);
+          hipStreamSynchronize(s.stream);
+        } else {  // sorted patterns: through a host copy, one node at a time, back into the caller's pattern order
+          std::vector<double> tmp((size_t)s.S * D);
+          e = hipStreamSynchronize(s.stream);  // (the unpack kernel runs on the shard's stream)
+          for (int64_t n = 0; n < I && e == hipSuccess; n++) {
+            e = hipMemcpy(tmp.data(), dtmp + (size_t)n * s.S * D, tmp.size() * sizeof(double), hipMemcpyDeviceToHost);
+            for (int64_t k = 0; k < s.S; k++)
+              memcpy(inode_cache + ((size_t)n * S + p->perm[s.s0 + k]) * D, tmp.data() + (size_t)k * D, (size_t)D * sizeof(double));
+          }
+        }
         hipFree(dtmp);
         if (e != hipSuccess) return fail(std::string("download_partials: ") + hipGetErrorString(e));
       }
@@ -1980,7 +2039,7 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
                        hipMemcpyDeviceToHost));
       for (int64_t n = 0; n < I; n++)
         for (int64_t k = 0; k < s.S; k++) {
-          scaler_counts[n * S + s.s0 + k] = tmp[(size_t)n * s.S_pad + k];
+          scaler_counts[n * S + caller_pattern(p, s.s0 + k)] = tmp[(size_t)n * s.S_pad + k];
         }
     }
   }
@@ -2004,7 +2063,7 @@ int hyphy_hip_set_pinned_states(hyphy_hip_partition *p, int64_t node, const int6
     HIPCHK(hipSetDevice(s.device));
     std::vector<int16_t> h(s.S_pad, 0);
     for (int64_t k = 0; k < s.S; k++) {
-      const int64_t st = states[s.s0 + k];
+      const int64_t st = states[caller_pattern(p, s.s0 + k)];
       if (st < 0 || st >= p->D) return fail("set_pinned_states: state out of range");
       h[k] = (int16_t)st;
     }
@@ -2499,13 +2558,17 @@ static int site_fits_common(hyphy_hip_partition *p, int64_t n_sets, int64_t n_gr
     // site multipliers of this shard's pattern range, padded with zeros (padding sites: exp(0) = I, weightless)
     std::vector<double> sm((size_t)n_sets * s.S_pad * GK, 0.0);
     for (int64_t st = 0; st < n_sets; st++)
-      memcpy(sm.data() + (size_t)st * s.S_pad * GK, site_mult + ((size_t)st * S + s.s0) * GK, (size_t)s.S * GK * sizeof(double));
+      for (int64_t k = 0; k < s.S; k++)  // (per pattern: the device order is the sorted one)
+        memcpy(sm.data() + ((size_t)st * s.S_pad + k) * GK, site_mult + ((size_t)st * S + caller_pattern(p, s.s0 + k)) * GK,
+               (size_t)GK * sizeof(double));
     HIPCHK(hipMemcpyAsync(s.fit_smult, sm.data(), sm.size() * sizeof(double), hipMemcpyHostToDevice, s.stream));
     std::vector<double> wm;
     if (n_mix > 1) {  // mixture weights, same padding (they share the multipliers' allocation: need >= n_sets * n_mix)
       wm.assign((size_t)n_sets * s.S_pad * n_mix, 0.0);
       for (int64_t st = 0; st < n_sets; st++)
-        memcpy(wm.data() + (size_t)st * s.S_pad * n_mix, site_weights + ((size_t)st * S + s.s0) * n_mix, (size_t)s.S * n_mix * sizeof(double));
+        for (int64_t k = 0; k < s.S; k++)
+          memcpy(wm.data() + ((size_t)st * s.S_pad + k) * n_mix, site_weights + ((size_t)st * S + caller_pattern(p, s.s0 + k)) * n_mix,
+                 (size_t)n_mix * sizeof(double));
       HIPCHK(hipMemcpyAsync(s.fit_smix, wm.data(), wm.size() * sizeof(double), hipMemcpyHostToDevice, s.stream));
     }
     HIPCHK(hipMemcpyAsync(s.fit_bcoef, branch_coeffs, (size_t)B * K * sizeof(double), hipMemcpyHostToDevice, s.stream));
@@ -2552,7 +2615,7 @@ static int site_fits_common(hyphy_hip_partition *p, int64_t n_sets, int64_t n_gr
     HIPCHK(hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream));
     if (st) return fail("site fits: a site likelihood is not a number");
     for (int64_t k = 0; k < n_sets; k++)
-      memcpy(site_logl_out + (size_t)k * S + s.s0, out.data() + (size_t)k * s.S_pad, (size_t)s.S * sizeof(double));
+      for (int64_t j = 0; j < s.S; j++) site_logl_out[(size_t)k * S + caller_pattern(p, s.s0 + j)] = out[(size_t)k * s.S_pad + j];
   }
   return 0;
 }

@@ -53,12 +53,14 @@ __global__ __launch_bounds__(64) void probe(const double *table, const int *code
   if (lane == 0 && blockIdx.x == 0) cycles[0] = c1 - c0, cycles[1] = t1 - t0;
 }
 
-int main() {
+int main(int argc, char **argv) {
+  const int runlen = argc > 1 ? atoi(argv[1]) : 1;  // consecutive sites sharing a code (sorted patterns: ~4)
   const int NL = 64;
   std::vector<double> tab((size_t)NL * 4096);
   for (size_t i = 0; i < tab.size(); i++) tab[i] = 1.0 + (double)(i % 977) / 977.0 * 0.001;
   std::vector<int> codes(1024);
-  for (int i = 0; i < 1024; i++) codes[i] = (i * 37 + 11) % 61;
+  for (int i = 0; i < 1024; i++) codes[i] = ((i / runlen) * 37 + 11) % 61;
+  printf("run length %d\n", runlen);
   double *dt, *dout;
   int *dc;
   long long *dcy;
