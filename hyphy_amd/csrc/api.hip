@@ -416,7 +416,7 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
 // launches, fragment roots are handed up through the persisted copy in HBM.  With one workgroup per
 // 16-pattern tile walking the whole tree, 10k codons give only 624 workgroups for 768 resident
 // slots (and 78 per GPU when sharded 8 ways): cutting the tree multiplies the workgroup count.
-void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, bool full) {
+void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, bool full) {
   const int L = (int)p->L, I = (int)p->I;
   std::vector<char> touched(I, 0);
   if (full) {
@@ -659,6 +659,32 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
     p->levels.clear();
     p->levels.push_back(l0);  // one launch: grid.z = the leaf fragments; the rest is reached by chaining
   }
+}
+
+// Rescaling tests only where they are needed (wave-per-tile kernel, full passes).  A rescale multiplies by an exact power
+// of 2^64, so WHERE a node is tested does not change any mantissa — only underflow has to be excluded.  A node whose
+// internal children were all tested (their per-pattern sums are >= 2^-64 after the test) and that has at most four children
+// cannot fall below 2^-256 times the spread of a conditional vector, hundreds of binary orders above the denormals: its
+// own test is skipped (OPF_NOSCALE) and its parent tests again.  The root is always tested.  Saves the cross-lane sum,
+// the ballot and their latency in front of the next product at every other level (HYPHY_HIP_SCALE_THIN=0: test everywhere).
+void thin_rescale_tests(hyphy_hip_partition *p) {
+  static const bool on = !(getenv("HYPHY_HIP_SCALE_THIN") && atoi(getenv("HYPHY_HIP_SCALE_THIN")) == 0);
+  if (!on) return;
+  const int L = (int)p->L, I = (int)p->I;
+  std::vector<char> tested(I, 1);
+  for (int n = 0; n < I; n++) {  // children before parents
+    bool kids_tested = true;
+    for (int c : p->children[n])
+      if (c >= L && !tested[c - L]) kids_tested = false;
+    tested[n] = (n == I - 1 || !kids_tested || p->children[n].size() > 4 || n == p->pin_node - L) ? 1 : 0;
+  }
+  for (int4 &op : p->ops_host)
+    if ((op.x & OPF_LAST) && op.y >= 0 && op.y < I && !tested[op.y]) op.x |= OPF_NOSCALE;
+}
+
+void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, bool full) {
+  build_schedule_impl(p, update_nodes, n_update, full);
+  if (full && !p->nuc && p->variant == 1 && !p->shards.empty() && p->shards[0].T == 1) thin_rescale_tests(p);
 }
 
 int upload_small(Shard &s, const double *src, size_t n, double *dst) {

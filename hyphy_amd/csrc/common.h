@@ -57,7 +57,7 @@ __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1)
 // A parent's first entry needs no flag: the running product is reset when a parent is finalised.
 enum : int { OPK_LEAF = 0, OPK_INTERNAL = 1, OPK_INTERNAL_GLOBAL = 2, OPK_DEP = 3 };
 enum : int { OPF_HANDOFF = 4, OPF_LAST = 8, OPF_PARITY = 16, OPF_GSYNC = 32, OPF_AMBIG = 64, OPF_INREGS = 128,
-             OPF_NOPERSIST = 128, OPF_PUBLISH = 0x8000, OPF_NOPERSIST_NUC = 4 /* (nucleotide kernel: bit 7 is OPF_INREGS there) */ };
+             OPF_NOPERSIST = 128, OPF_NOSCALE = 0x4000 /* (wave-per-tile kernel, OPF_LAST entries: no rescaling test at this node) */, OPF_PUBLISH = 0x8000, OPF_NOPERSIST_NUC = 4 /* (nucleotide kernel: bit 7 is OPF_INREGS there) */ };
 #ifndef HYPHY_SLOTS1
 #define HYPHY_SLOTS1 5
 #endif

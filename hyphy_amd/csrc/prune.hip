@@ -659,7 +659,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
       else nb = last_next;
     }
     if (kind == OPK_LEAF) {
-      const int nl = (op.x >> 8) & 0x7f;
+      const int nl = (op.x >> 8) & 0x3f;
       for (int i = 0; i < nl; i++) {
         const int lf = (op.z >> (16 * i)) & 0xffff;
         const int c = leaf_code(lf);
@@ -746,14 +746,16 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
 #pragma unroll
           for (int r = 0; r < 4; r++) acc[w][r] = (16 * w + 4 * r + g == ps) ? acc[w][r] : 0.;
       }
-      double s = 0.;
-#pragma unroll
-      for (int w = 0; w < NW; w++) s += (acc[w][0] + acc[w][1]) + (acc[w][2] + acc[w][3]);
-      const double tot = (HYPHY_ABL & 8) ? 1.0 : row_sum4(s);
       double sc = 1.0;
-      int m = 0;
-      if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) m = rescale_decision(tot, sc);  // rare
-      cnt += m;
+      if (!(op.x & OPF_NOSCALE)) {  // (the host thins the tests out where underflow is impossible: api.hip thin_rescale_tests)
+        double s = 0.;
+#pragma unroll
+        for (int w = 0; w < NW; w++) s += (acc[w][0] + acc[w][1]) + (acc[w][2] + acc[w][3]);
+        const double tot = (HYPHY_ABL & 8) ? 1.0 : row_sum4(s);
+        int m = 0;
+        if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) m = rescale_decision(tot, sc);  // rare
+        cnt += m;
+      }
       double *out = a.partials + ((size_t)op.y * a.ntiles + tile0) * TILE;  // uniform
 #pragma unroll
       for (int w = 0; w < NW; w++) {
