@@ -1581,6 +1581,7 @@ static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   // second stage: the instantiation compiled for 3 waves per SIMD (finalised node in LDS, no parking slot, no register
   // prefetch of deposits) around the best cut — it wins where waves are plentiful (128 taxa x 100k codons: +7 %)
   int best_wv = 0;
+  const double stage1_ms = best_ms;
   p->wave_variant = 0;
   if (best > 0 && p->NW == 4 && !getenv("HYPHY_HIP_WAVE_VARIANT") && !getenv("HYPHY_HIP_SLOTS")) {
     std::vector<int> ms;  // the three fastest cuts of the first stage
@@ -1607,7 +1608,8 @@ static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
       ms1 = std::min(ms1, ms2);
       snprintf(buf, sizeof buf, " occ3/m%d:%.1fus", m, 1e3 * ms1);
       p->tune_report += buf;
-      if (ms1 < best_ms) {
+      // (2 % margin over the first stage: at equal tuner times the production pass of the 2-waves build is the faster one)
+      if (ms1 < 0.98 * stage1_ms && ms1 < best_ms) {
         best_ms = ms1;
         best = m;
         best_wv = 2;
