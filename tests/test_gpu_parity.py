@@ -961,3 +961,47 @@ def test_chain_joins_within_and_across_xcds(n_tiles, monkeypatch):
             else:
                 again = part.evaluate(nodes, nodes, Q, pi)   # same inputs, different arrival orders: same bits or rounding
                 assert abs(got - again) <= 1e-13 * abs(got), (n_tiles, k, got, again)
+
+
+def test_sorted_patterns_are_invisible_to_the_caller(monkeypatch):
+    """The library keeps its patterns sorted on the device (api.hip: sort_patterns); every per-pattern input and output of the
+    C-ABI is in the CALLER's order.  Same data through a sorting and a non-sorting partition: per-site likelihoods and
+    exponents, downloaded node conditionals, a pinned-states evaluation and forced pattern shards must agree entry by entry."""
+    from hyphy_amd import data, models, tree
+    rng = np.random.default_rng(77)
+    root = tree.random_tree(24, rng, trifurcating_root=True)
+    flat = tree.flatten(root)
+    S = 333
+    base = rng.integers(0, 61, size=S)
+    states = np.where(rng.random((flat.L, S)) < 0.2, rng.integers(0, 61, size=(flat.L, S)), base[None, :])
+    pd = data.from_states(states, 61, compress_patterns=False)
+    pf = np.array([[0.3, 0.2, 0.25, 0.25], [0.2, 0.3, 0.3, 0.2], [0.25, 0.25, 0.2, 0.3]])
+    pi = models.f3x4_codon_freqs(pf)
+    B = flat.n_branches
+    nodes = np.arange(B, dtype=np.int64)
+    Q = models.mg94rev_Q_batch(rng.uniform(0.02, 0.3, B), 0.4, dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4), pf)
+    pinned = rng.integers(0, 61, size=S)
+    hip = _hip()
+    out = {}
+    for label, env in (("sorted", {"HYPHY_HIP_SORT_PATTERNS": "1"}), ("caller", {"HYPHY_HIP_SORT_PATTERNS": "0"}),
+                       ("sorted_sharded", {"HYPHY_HIP_SORT_PATTERNS": "1", "HYPHY_HIP_FORCE_SHARDS": "3"})):
+        for k in ("HYPHY_HIP_SORT_PATTERNS", "HYPHY_HIP_FORCE_SHARDS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with hip.HipPartition(61, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq) as part:
+            ll, lik, sc = part.evaluate(nodes, nodes, Q, pi, per_site=True)
+            cache, counts = part.download_partials()
+            part.set_pinned_states(flat.L + 3, pinned)
+            llp, likp, scp = part.evaluate(nodes, np.zeros(0, dtype=np.int64), np.zeros((0, 61, 61)), pi, per_site=True)
+            part.set_pinned_states(None)
+        out[label] = (ll, np.log(lik) - 64 * np.log(2.0) * sc, cache, counts, llp, np.log(np.maximum(likp, 1e-300)) - 64 * np.log(2.0) * scp)
+    ref = out["caller"]
+    for label in ("sorted", "sorted_sharded"):
+        got = out[label]
+        assert abs(got[0] - ref[0]) <= 1e-12 * abs(ref[0]), label
+        assert np.allclose(got[1], ref[1], rtol=1e-12, atol=0), label          # per-site log-likelihoods, caller order
+        assert np.allclose(got[2], ref[2], rtol=1e-10, atol=1e-300), label      # node conditionals [I][S][D]
+        assert np.array_equal(got[3], ref[3]), label                            # exponents [I][S]
+        assert abs(got[4] - ref[4]) <= 1e-12 * abs(ref[4]), label
+        assert np.allclose(got[5], ref[5], rtol=1e-12, atol=0), label
