@@ -344,6 +344,7 @@ def main():
         cat_step = part.prepare_built_categories_step(nodes, nodes, class_w, pi, coeffs)
     else:
         enqueue = part.prepare_device_step(nodes, nodes, pi, d_logl.data_ptr(), coeffs)
+        fetch = part.prepare_fetch(d_logl.data_ptr())   # log-L behind the all-reduce -> host (host-mapped record, no D2H copy)
         sync_step = part.prepare_built_step(nodes, nodes, pi, coeffs)   # N == 1: synchronous C-ABI entry point
 
     def step(k, sync=True):
@@ -356,13 +357,15 @@ def main():
                 hdist.allreduce_logl(d_logl[:1])
                 v = float(d_logl[0].item())
             return v
-        if N == 1 and sync:
+        if N == 1 and sync and not os.environ.get("HYPHY_BENCH_DEVICE_STEP"):
             return sync_step()     # build_q + evaluate_built: log-L returned by the C-ABI call itself
         enqueue()      # device-side Q for every branch, then expm + pruning + reduction (C-ABI calls)
         if N > 1:
             hdist.allreduce_logl(d_logl[:1])                   # one RCCL all-reduce per evaluation
         if sync:
-            return float(d_logl[0].item())                     # log-L back on the host (synchronises)
+            if os.environ.get("HYPHY_BENCH_READBACK") == "item":
+                return float(d_logl[0].item())                 # (torch's device-to-host copy + synchronisation)
+            return fetch()                                     # log-L back on the host (synchronises)
         return None
 
     ll0 = step(0)

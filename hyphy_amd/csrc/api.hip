@@ -1948,6 +1948,35 @@ int hyphy_hip_evaluate_device(hyphy_hip_partition *p, int64_t cat, const int64_t
                      true, false);
 }
 
+/* A device scalar (the all-reduced log-likelihood of a multi-rank evaluation: hyphy_hip_evaluate_device + the caller's
+ * collective on the same stream) back on the host the way the synchronous entry points do it: a one-thread kernel behind
+ * everything queued on the partition's stream posts [value, 0, expm status, sequence word] into the host-mapped result
+ * record and the host spins on the sequence word — no device-to-host copy command, no stream synchronisation. */
+__global__ void publish_scalar_kernel(const double *__restrict__ value, double *__restrict__ rec, const int *__restrict__ status,
+                                      double seq) {
+  rec[0] = value[0];
+  rec[1] = 0.;
+  rec[2] = status ? (double)*status : 0.;
+  if (seq != 0.) {
+    __threadfence_system();
+    reinterpret_cast<volatile double *>(rec)[3] = seq;
+  }
+}
+
+int hyphy_hip_fetch_device_scalar(hyphy_hip_partition *p, const double *d_value, double *value_out) {
+  if (!p || !d_value || !value_out) return fail("fetch_device_scalar: null argument");
+  if (p->shards.size() != 1) return fail("fetch_device_scalar needs a single-device partition");
+  Shard &s = p->shards[0];
+  HIPCHK(hipSetDevice(s.device));
+  double *rec = s.d_hout ? s.d_hout : s.out;
+  hipLaunchKernelGGL(publish_scalar_kernel, dim3(1), dim3(1), 0, s.stream, d_value, rec, (const int *)s.status,
+                     next_seq(s, rec == s.d_hout));
+  HIPCHK(hipGetLastError());
+  if (collect_status(p)) return -1;
+  *value_out = s.h_out[0];
+  return 0;
+}
+
 int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update,
                                   const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
                                   const double *weights, const double *root_freqs, double *logl_out,

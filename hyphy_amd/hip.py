@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("HYPHY_HIP_LIB") or os.path.join(HERE, "lib", "libhyph
 
 EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
-    "hyphy_hip_evaluate_device", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_comm_unique_id", "hyphy_hip_comm_init_rank", "hyphy_hip_comm_init_all", "hyphy_hip_allreduce_device", "hyphy_hip_evaluate_allreduce", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
+    "hyphy_hip_evaluate_device", "hyphy_hip_fetch_device_scalar", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_comm_unique_id", "hyphy_hip_comm_init_rank", "hyphy_hip_comm_init_all", "hyphy_hip_allreduce_device", "hyphy_hip_evaluate_allreduce", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
@@ -72,6 +72,8 @@ def load():
     lib.hyphy_hip_evaluate_async.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp]
     lib.hyphy_hip_collect.restype = C.c_int
     lib.hyphy_hip_collect.argtypes = [vp, dp, dp, lp]
+    lib.hyphy_hip_fetch_device_scalar.restype = C.c_int
+    lib.hyphy_hip_fetch_device_scalar.argtypes = [vp, vp, C.POINTER(C.c_double)]
     lib.hyphy_hip_evaluate_device.restype = C.c_int
     lib.hyphy_hip_evaluate_device.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, vp, C.c_int, dp, vp]
     lib.hyphy_hip_evaluate_categories.restype = C.c_int
@@ -300,6 +302,19 @@ class HipPartition:
             if rc:
                 _check(rc)
         return step
+
+    def prepare_fetch(self, d_ptr: int):
+        """Zero-argument callable: the double at device address ``d_ptr`` (written by work queued on this partition's
+        stream, e.g. an all-reduce behind ``evaluate_device``) through the host-mapped result record -> float."""
+        lib, h, src, out = self._lib, self._h, C.c_void_p(d_ptr), C.c_double(0.0)
+        ref = C.byref(out)
+
+        def fetch():
+            rc = lib.hyphy_hip_fetch_device_scalar(h, src, ref)
+            if rc:
+                _check(rc)
+            return out.value
+        return fetch
 
     def prepare_built_step(self, update_nodes, q_nodes, root_freqs, coeffs: np.ndarray, cat: int = -1):
         """Zero-argument callable: ``build_q(coeffs)`` + synchronous ``evaluate_built`` -> log-L (float).

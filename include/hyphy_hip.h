@@ -163,6 +163,12 @@ int hyphy_hip_evaluate_device(hyphy_hip_partition *p, int64_t cat, const int64_t
                               const int64_t *q_nodes, int64_t n_q, const double *d_q, int q_is_probability,
                               const double *root_freqs, double *d_logl_out);
 
+/* Reads one double that lives in device memory and is produced by work queued on the partition's stream — the log-likelihood
+ * summed over ranks by the caller's own collective (RCCL all-reduce behind hyphy_hip_evaluate_device, SURVEY 8e: the
+ * reference's MPI ranks) — through the host-mapped result record: a one-thread kernel posts it, the host spins on the record's
+ * sequence word.  Replaces a device-to-host copy + stream synchronisation per evaluation.  Single-device partitions. */
+int hyphy_hip_fetch_device_scalar(hyphy_hip_partition *p, const double *d_value, double *value_out);
+
 /*
  * Rate-category batch (config "BUSTED 3-rate-class"): evaluates ALL C classes in one
  * schedule (classes are an extra batch dimension on the device) and mixes them exactly as
