@@ -153,10 +153,25 @@ def test_device_q_templates_match_host_q(materialize, monkeypatch):
         step()
         part.synchronize()
         got2 = float(d_out[0].item())
+        # the same device scalar through the host-mapped result record (hyphy_hip_fetch_device_scalar: what a multi-rank
+        # host uses behind its all-reduce), with further work queued in front of it and interleaved synchronous calls
+        fetch = part.prepare_fetch(d_out.data_ptr())
+        co[:, 1] = tb * omega
+        step()
+        got3 = fetch()
+        co[:, 1] = tb * 0.5
+        stream = torch.cuda.Stream()
+        part.set_stream(stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            step()
+            d_out[0] += 1.0      # (the caller's own work between the evaluation and the read-back, same stream)
+            got4 = fetch() - 1.0
+        part.set_stream(-1)      # (HYPHY_HIP_OWN_STREAM)
     with _mk(fx) as part:
         ref2 = part.evaluate(nodes, nodes, models.mg94rev_Q_batch(tb, 0.5, bench.REV, bench.POS_FREQS), pi)
     assert abs(got - ref) <= RTOL * abs(ref)
     assert abs(got2 - ref2) <= RTOL * abs(ref2)
+    assert got3 == got and abs(got4 - got2) <= 1e-12 * abs(got2)
 
 
 def test_q_is_probability_path():
