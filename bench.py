@@ -349,7 +349,10 @@ def main():
 
     def step(k, sync=True):
         omega = omega0 + 0.001 * k
-        coeffs[:, 1] = np.repeat(class_omega * omega, B) * coeffs[:, 0]
+        if n_classes > 1:
+            coeffs[:, 1] = np.repeat(class_omega * omega, B) * coeffs[:, 0]
+        else:
+            np.multiply(tb, omega, out=coeffs[:, 1])   # nonSynRate = omega * synRate on every branch (one numpy call: < 1 us)
         if n_classes > 1:
             v = cat_step()         # build_q (3 x 125 matrices) + expm + batched pruning + mixing + reduction
             if N > 1:              # (classes are mixed per site on the rank that owns the site; the partial log-Ls add up)
