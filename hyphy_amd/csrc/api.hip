@@ -140,6 +140,8 @@ struct Shard {
   int32_t *hand_cnt = nullptr;  // [classes][I][tiles][32] 2^64-exponents of fragment roots (own 128-byte line each)
   double *pi = nullptr;       // [DP]
   double *out = nullptr;      // [2]
+  double *pi_ones = nullptr;  // [DP] 1 for real states, 0 for padding: root frequencies of a re-rooted schedule (pi sits in a twin image)
+  bool twins_dirty = true;    // the transposed twin images (expm.hip) may lag behind the matrices they mirror
   double *wg_sum = nullptr;   // per-workgroup partial sums of the pruning kernel
   long long *wg_cnt = nullptr;
   int *wg_flag = nullptr;
@@ -212,6 +214,15 @@ struct hyphy_hip_partition {
   std::vector<double> cached_weights;        // category weights currently on the device
   std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
   int root_slot = 0;
+  // Re-rooted schedules.  The likelihood does not depend on where the pruning recursion is rooted if the edges between the given
+  // root and the new one are traversed with the transposed matrices (and pi is folded in on the old root's edge) — no
+  // reversibility assumed, the same identity the branch cache uses.  A root in the middle of the tree shortens every tile's
+  // critical path (the tree's height), which is what small and medium shards are bound by.  rr_path = internal indices from the
+  // given root (front) to the node the computation is rooted at (back); empty: the given root is already the best one.
+  std::vector<int> rr_path;
+  int emit_skip_par = -1, emit_skip_child = -1;  // (transient, build_schedule -> emit_program)
+  bool rr_use = false;                       // ask build_schedule for the re-rooted form (tuner / HYPHY_HIP_REROOT)
+  bool rr_active = false;                    // the current schedule is a re-rooted one
   std::vector<int64_t> perm;                 // internal pattern j = caller's pattern perm[j] (empty: identity); see sort_patterns()
   int64_t pin_node = -1;                     // node code whose states are pinned for the evaluations that follow (-1: none)
   std::vector<int64_t> bc_node;              // per rate class: branch whose outside vector is resident (-1: none)
@@ -258,7 +269,7 @@ void free_shard(Shard &s) {
   if (s.stream) hipStreamSynchronize(s.stream);
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
-                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.codes_tile,
+                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.pi_ones, s.codes_tile,
                  s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.mix_q, s.mix_p, s.mix_w, s.mix_off, s.ar_buf, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops};
   for (void *d : dev)
@@ -307,7 +318,12 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
   int fin = 0, root_slot = 0;
   for (size_t ti = 0; ti < nodes.size(); ti++) {
     const int par = nodes[ti];
-    const std::vector<int> &ch = p->children[par];
+    std::vector<int> ch_filtered;
+    if (par == p->emit_skip_par) {  // (re-rooted schedules: the given root no longer has the first node of rr_path below it)
+      for (int c : p->children[par])
+        if (c != p->emit_skip_child) ch_filtered.push_back(c);
+    }
+    const std::vector<int> &ch = par == p->emit_skip_par ? ch_filtered : p->children[par];
     std::vector<int4> entries;
     std::vector<int> release_after;
     auto internal_entry = [&](int c) {
@@ -450,6 +466,7 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
     else if (wgs < target) max_frag = (int)std::max<long>(4, (long)I * wgs / target);
   }
   p->chain = false;
+  p->rr_active = false;
   p->jn_host.clear();
   // ---- chain schedules (wave-per-tile kernel, full passes) -------------------------------------------------
   // Bottom subtrees of at most `m` internal nodes become SOURCE programs (walked serially by one wave, exactly like a
@@ -464,20 +481,50 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
                            (p->chain_m_forced < 0 && !getenv("HYPHY_HIP_CHAIN_M"));
   if (full && !p->nuc && p->variant >= 1 && !p->shards.empty() && !want_levels) {
     const Shard &s0 = p->shards[0];
+    // Topology the schedule is built on: the given one, or (re-rooted schedules) the same unrooted tree hung from rr_path.back();
+    // the edges of rr_path are then reversed.  rpar = parent, order = children before parents, on_path = index along rr_path.
+    const bool lazy_full = !p->sched_persist;
+    const int rr_env = getenv("HYPHY_HIP_REROOT") ? atoi(getenv("HYPHY_HIP_REROOT")) : -1;  // (1: always, 0: never, unset: the tuner decides)
+    const bool rr = !p->rr_path.empty() && (rr_env == 1 || (rr_env != 0 && p->rr_use)) && lazy_full && p->pin_node < 0 &&
+                    p->batch_classes <= 1 && p->C == 1;
+    std::vector<int> rpar(I, -1), on_path(I, -1), order;
+    for (int n = 0; n < I - 1; n++) rpar[n] = (int)p->parents[L + n];
+    int root_idx = I - 1;
+    if (rr) {
+      const std::vector<int> &a = p->rr_path;
+      for (size_t i = 0; i + 1 < a.size(); i++) rpar[a[i]] = a[i + 1];
+      rpar[a.back()] = -1;
+      root_idx = a.back();
+      for (size_t i = 0; i < a.size(); i++) on_path[a[i]] = (int)i;
+    }
     std::vector<int> size(I, 1), height(I, 1), to_root(I, 0);
     std::vector<std::vector<int>> ich(I);
     for (int n = 0; n < I; n++)
-      for (int c : p->children[n])
-        if (c >= L) {
-          ich[n].push_back(c - L);
-          size[n] += size[c - L];
-          height[n] = std::max(height[n], height[c - L] + 1);
+      if (rpar[n] >= 0) ich[rpar[n]].push_back(n);
+    {
+      std::vector<std::pair<int, size_t>> stack(1, std::make_pair(root_idx, (size_t)0));
+      while (!stack.empty()) {
+        std::pair<int, size_t> &t = stack.back();
+        if (t.second < ich[t.first].size()) {
+          const int c = ich[t.first][t.second++];
+          stack.push_back(std::make_pair(c, (size_t)0));
+        } else {
+          order.push_back(t.first);
+          stack.pop_back();
         }
-    for (int n = I - 2; n >= 0; n--) to_root[n] = to_root[(int)p->parents[L + n]] + 1;
+      }
+    }
+    for (int n : order)
+      for (int c : ich[n]) {
+        size[n] += size[c];
+        height[n] = std::max(height[n], height[c] + 1);
+      }
+    for (size_t k = order.size(); k-- > 0;)
+      if (rpar[order[k]] >= 0) to_root[order[k]] = to_root[rpar[order[k]]] + 1;
     auto count_sources = [&](int m) {
       int k = 0;
       for (int n = 0; n < I; n++)
-        if (size[n] <= m && (n == I - 1 || size[(int)p->parents[L + n]] > m)) k++;
+        if (size[n] <= m && on_path[n] <= 0 && (rpar[n] < 0 || size[rpar[n]] > m || on_path[rpar[n]] > 0)) k++;
       return k;
     };
     const long wgs = std::max(1, s0.ntiles) * (long)std::max<int64_t>(1, p->batch_classes);
@@ -495,10 +542,10 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
       struct Src { int root, prio; };
       std::vector<Src> srcs;
       std::vector<char> in_source(I, 0);
-      for (int n = I - 1; n >= 0; n--) {
-        const int par = (int)p->parents[L + n];
+      for (size_t k = order.size(); k-- > 0;) {  // parents before children; the nodes of rr_path above the given root stay trunk nodes
+        const int n = order[k], par = rpar[n];
         if (par >= 0 && in_source[par]) in_source[n] = 1;
-        else if (size[n] <= m) {
+        else if (size[n] <= m && on_path[n] <= 0) {  // (on_path == 0: the given root — a source like any other if it is small)
           in_source[n] = 1;
           srcs.push_back({n, to_root[n] + height[n]});
         }
@@ -523,18 +570,24 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
         }
         std::sort(nodes.begin(), nodes.end());
         int off, n;
+        p->emit_skip_par = rr ? p->rr_path[0] : -1;
+        p->emit_skip_child = rr ? L + p->rr_path[1] : -1;
         const int rs = emit_program(p, nodes, &off, &n, false, true);
+        p->emit_skip_par = p->emit_skip_child = -1;
         hyphy_hip_partition::Prog pr{off, n};
-        pr.parent = sr.root == I - 1 ? -1 : 0;
+        pr.parent = sr.root == root_idx ? -1 : 0;
         pr.need = sr.root;  // (chain schedules: w = the source's root node)
         p->programs.push_back(pr);
-        if (sr.root == I - 1) p->root_slot = rs;
+        if (sr.root == root_idx) p->root_slot = rs;
       }
       const bool lazy = !p->sched_persist;
       for (int n = 0; n < I; n++) {
         int sum = 0;
         for (int c : ich[n]) sum += c;
-        int4 j = make_int4(n == I - 1 ? -1 : (int)p->parents[L + n], (int)ich[n].size() | (sum << 8), 0, 0);
+        // x: parent | image slot of the edge above n << 16: the node's own branch L + n, or — reversed edges of a re-rooted
+        // schedule — the transposed twin of the branch of the NEXT node on the path (expm.hip; slot behind the branch cache's)
+        const int slot = (rr && on_path[n] >= 0) ? (int)(p->B + (I + 2) + on_path[n]) : L + n;
+        int4 j = make_int4(rpar[n] < 0 ? -1 : (rpar[n] | (slot << 16)), (int)ich[n].size() | (sum << 8), 0, 0);
         if (!in_source[n]) {  // trunk node: its leaf groups, one OPK_DEP entry per internal child, finalisation flags
           j.z = (int)p->ops_host.size();
           std::vector<int> leaves;
@@ -557,6 +610,7 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
       p->ops_host.push_back(make_int4(OPK_LEAF | (0xff << 24), 0, 0, 0));  // (the interpreter reads one entry ahead)
       p->levels.push_back({0, (int)p->programs.size()});
       p->chain = true;
+      p->rr_active = rr;
       if (getenv("HYPHY_HIP_VERBOSE")) {
         fprintf(stderr, "[hyphy_hip] chain schedule: m = %d, %zu sources (root node / distance):", m, srcs.size());
         for (const Src &sr : srcs) fprintf(stderr, " %d/%d", sr.root, sr.prio);
@@ -678,6 +732,8 @@ void thin_rescale_tests(hyphy_hip_partition *p) {
       if (c >= L && !tested[c - L]) kids_tested = false;
     tested[n] = (n == I - 1 || !kids_tested || p->children[n].size() > 4 || n == p->pin_node - L) ? 1 : 0;
   }
+  if (p->rr_active)  // (re-rooted schedule: the nodes whose children differ from the given topology — and the new root — always test)
+    for (int n : p->rr_path) tested[n] = 1;
   for (int4 &op : p->ops_host)
     if ((op.x & OPF_LAST) && op.y >= 0 && op.y < I && !tested[op.y]) op.x |= OPF_NOSCALE;
 }
@@ -705,6 +761,19 @@ double next_seq(Shard &s, bool host_record) {
   s.seq_wait = s.seq_next;
   s.seq_next += 1.;
   return s.seq_wait;
+}
+
+// Twin images of re-rooted schedules (ExpmArgs::n_twin): slot of twin j relative to the class base, and the refresh by the
+// branch cache's transpose kernel for the cases the exponential kernel did not cover (a writer other than the fused path,
+// new root frequencies without a new matrix).
+inline int twin_slot0(const hyphy_hip_partition *p) { return (int)(p->B + (p->I + 2)); }
+void refresh_twins(hyphy_hip_partition *p, Shard &s) {
+  if (p->rr_path.empty() || p->nuc) return;
+  const size_t DD = (size_t)p->DP * p->DP;
+  for (size_t j = 0; j + 1 < p->rr_path.size(); j++)
+    launch_transpose_frag(s.Pfrag + (size_t)(p->L + p->rr_path[j + 1]) * DD, s.Pfrag + (size_t)(twin_slot0(p) + (int)j) * DD,
+                          j == 0 ? s.pi : nullptr, p->NW, s.stream);
+  s.twins_dirty = false;
 }
 
 // Everything in a PruneArgs that does not depend on the schedule being launched.
@@ -742,6 +811,7 @@ PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
   pa.site_cnt = s.site_cnt + (size_t)cat * s.S_pad;
   pa.freq = s.freq;
   pa.wg_sum = s.wg_sum;
+  if (p->rr_active && p->chain && !p->nuc) pa.pi = s.pi_ones;  // (re-rooted schedule: pi is folded into the old root's twin image)
   pa.wg_cnt = s.wg_cnt;
   pa.wg_flag = s.wg_flag;
   pa.n_cat = n_cat_batch;
@@ -808,6 +878,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     std::vector<double> pi(p->nuc ? 4 : DP, 0.0);
     for (int64_t k = 0; k < D; k++) pi[k] = root_freqs[k];
     if (upload_small(s, pi.data(), pi.size(), s.pi)) return -1;
+    if (!p->rr_path.empty()) s.twins_dirty = true;  // (pi sits in the twin of the old root's edge; an expm launch that covers every twin clears this again)
   }
   tr.lap("ops+pi");
   if (p->all_timings) HIPCHK(hipEventRecord(s.ev[0], s.stream));
@@ -864,6 +935,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       ea.Pfrag = nullptr;
       ea.PTg = nullptr;
       launch_expm(ea, s.stream);
+      s.twins_dirty = true;  // (the mixing kernel writes matrix images without their twins)
       launch_mix_images(s.mix_p, s.mix_off, s.mix_w, d_slots, (int)n_q, (int)D,
                         p->nuc ? nullptr : s.Pfrag + (size_t)cat * B * DP * DP, p->nuc ? nullptr : s.PTg + (size_t)cat * B * DP * DP,
                         p->nuc ? s.Prow + (size_t)cat * B * 16 : nullptr, s.stream);
@@ -904,6 +976,18 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       ea.Prow = nullptr;
       ea.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
       ea.PTg = s.PTg + (size_t)cat * B * DP * DP;
+    }
+    if (!p->rr_path.empty() && !p->nuc && n_cat_batch <= 1) {  // keep the transposed twins in step with the matrices they mirror
+      const size_t k = p->rr_path.size() - 1;
+      ea.n_twin = (int)k;
+      for (size_t j = 0; j < k; j++) ea.twin_src[j] = (int)(p->L + p->rr_path[j + 1]);
+      ea.twin_dst0 = twin_slot0(p);
+      ea.twin_pi = s.pi;
+      size_t covered = 0;
+      for (int64_t q = 0; q < n_q; q++)
+        for (size_t j = 0; j < k; j++)
+          if (q_nodes[q] == ea.twin_src[j]) covered++;
+      if (covered == k) s.twins_dirty = false;           // every twin rewritten by this launch (with the current pi)
     }
     tr.lap("slots+q");
     launch_expm(ea, s.stream);
@@ -949,6 +1033,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     n_wg = prune_nuc_grid(na);
     launch_prune_nuc(na, s.stream);
   } else {
+    if (p->rr_active && p->chain && s.twins_dirty) refresh_twins(p, s);
     PruneArgs pa = base_prune_args(p, s, cat, n_cat_batch);
     pa.ops = s.ops;
     pa.n_ops = n_ops;
@@ -1146,6 +1231,48 @@ inline int64_t caller_pattern(const hyphy_hip_partition *p, int64_t j) { return 
 // of the same codon become neighbours), then lexicographically by leaf — which takes the distinct states per (leaf, tile)
 // from 14.2 to 3.9 on the headline alignment.  The order is internal: every per-pattern input and output of the C-ABI is
 // translated through `perm` (gather_sites, download_partials, set_pinned_states, site fits).
+// The internal node that minimises the tree's height (edges to the farthest leaf) when the tree is hung from it, and the path
+// to it from the given root (rr_path, see hyphy_hip_partition).  Topology only; ties keep the given root.
+void reroot_path(hyphy_hip_partition *p) {
+  const int L = (int)p->L, I = (int)p->I, N = L + I;
+  p->rr_path.clear();
+  if (I < 4 || N > 3000) return;  // (quadratic search)
+  std::vector<std::vector<int>> adj(N);
+  for (int n = 0; n < N - 1; n++) {
+    const int par = L + (int)p->parents[n];
+    adj[n].push_back(par);
+    adj[par].push_back(n);
+  }
+  auto height_from = [&](int r) {
+    int best = 0;
+    std::vector<std::pair<int, int>> stack(1, std::make_pair(r, -1));
+    std::vector<int> depth(N, 0);
+    while (!stack.empty()) {
+      const std::pair<int, int> t = stack.back();
+      stack.pop_back();
+      best = std::max(best, depth[t.first]);
+      for (int m : adj[t.first])
+        if (m != t.second) {
+          depth[m] = depth[t.first] + 1;
+          stack.push_back(std::make_pair(m, t.first));
+        }
+    }
+    return best;
+  };
+  const int root = N - 1;
+  int best = root, best_h = height_from(root);
+  for (int n = L; n < N - 1; n++) {
+    const int h = height_from(n);
+    if (h < best_h) best_h = h, best = n;
+  }
+  if (best == root) return;
+  std::vector<int> up;  // best -> ... -> root
+  for (int n = best; n != root; n = L + (int)p->parents[n]) up.push_back(n - L);
+  up.push_back(I - 1);
+  if ((int)up.size() - 1 > kMaxTwin) return;
+  p->rr_path.assign(up.rbegin(), up.rend());
+}
+
 void sort_patterns(hyphy_hip_partition *p, const int64_t *leaf_codes, int64_t L, int64_t S) {
   if (S < 32) return;
   std::vector<int64_t> major(S, 0);
@@ -1309,6 +1436,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
   if (const char *e = getenv("HYPHY_HIP_TILES")) tiles_override = atoi(e);
   if (!p->nuc && !(getenv("HYPHY_HIP_SORT_PATTERNS") && atoi(getenv("HYPHY_HIP_SORT_PATTERNS")) == 0))
     sort_patterns(p, leaf_codes, L, S);
+  if (!p->nuc && C == 1) reroot_path(p);
   auto src_pattern = [&](int64_t j) -> int64_t { return p->perm.empty() ? j : p->perm[j]; };
 
   int64_t base = S / nshards, rem = S % nshards, s0 = 0;
@@ -1416,7 +1544,13 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     if (p->nuc) {
       A_(s.Prow, (size_t)C * B * 16 * sizeof(double));
     } else {
-      A_(s.Pfrag, ((size_t)C * B + (size_t)C * (I + 2)) * DP * DP * sizeof(double));  // (+ transposed path matrices of the branch cache)
+      A_(s.Pfrag, ((size_t)C * B + (size_t)C * (I + 2) + kMaxTwin) * DP * DP * sizeof(double));  // (+ transposed path matrices of the branch cache, + twins of re-rooted schedules)
+      A_(s.pi_ones, (size_t)DP * sizeof(double));
+      {
+        std::vector<double> ones(DP, 0.);
+        for (int64_t k = 0; k < D; k++) ones[k] = 1.;
+        hipMemcpy(s.pi_ones, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice);
+      }
       A_(s.PTg, (size_t)C * B * DP * DP * sizeof(double));
     }
     A_(s.qbuf, (size_t)C * B * D * D * sizeof(double));
@@ -1510,6 +1644,7 @@ static int upload_schedule(hyphy_hip_partition *p, Shard &s) {
 }
 
 static void launch_prune_current(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch) {
+  if (p->rr_active && p->chain && s.twins_dirty) refresh_twins(p, s);
   PruneArgs pa = base_prune_args(p, s, cat, n_cat_batch);
   int n_ops = 0;
   for (const auto &pr : p->programs) n_ops = std::max(n_ops, pr.n);
@@ -1616,11 +1751,50 @@ static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
       }
     }
   }
+  // third stage: the same tree hung from the node that minimises its height (re-rooted schedules, hyphy_hip_partition::rr_path):
+  // shorter critical path per tile, the same work — wins on small and medium shards of unbalanced trees
+  bool best_rr = false;
+  p->rr_use = false;
+  if (best > 0 && !p->rr_path.empty() && n_cat_batch <= 1 && !getenv("HYPHY_HIP_REROOT")) {
+    std::vector<int> ms;
+    std::sort(ranked.begin(), ranked.end());
+    for (size_t k = 0; k < ranked.size() && k < 3; k++) ms.push_back(ranked[k].second);
+    for (int m : ms) {
+      p->chain_m_forced = m;
+      p->variant = 1;
+      p->wave_variant = best_wv;
+      p->n_slots = best_wv == 2 ? 2 : p->n_slots_wave;
+      p->rr_use = true;
+      build_schedule(p, nullptr, 0, true);
+      p->rr_use = false;
+      if (p->ops_host.size() > ops_capacity(p) || !p->chain || !p->rr_active) continue;
+      if (upload_schedule(p, s)) return -1;
+      float ms1 = 0.f, ms2 = 0.f;
+      launch_prune_current(p, s, cat, n_cat_batch);
+      HIPCHK(hipEventRecord(s.ev[0], s.stream));
+      launch_prune_current(p, s, cat, n_cat_batch);
+      HIPCHK(hipEventRecord(s.ev[1], s.stream));
+      launch_prune_current(p, s, cat, n_cat_batch);
+      HIPCHK(hipEventRecord(s.ev[2], s.stream));
+      HIPCHK(hipStreamSynchronize(s.stream));
+      HIPCHK(hipGetLastError());
+      if (hipEventElapsedTime(&ms1, s.ev[0], s.ev[1]) != hipSuccess || hipEventElapsedTime(&ms2, s.ev[1], s.ev[2]) != hipSuccess) continue;
+      ms1 = std::min(ms1, ms2);
+      snprintf(buf, sizeof buf, " rr/m%d:%.1fus", m, 1e3 * ms1);
+      p->tune_report += buf;
+      if (ms1 < 0.98 * best_ms) {
+        best_ms = ms1;
+        best = m;
+        best_rr = true;
+      }
+    }
+  }
+  p->rr_use = best_rr;
   p->wave_variant = best_wv;
   p->chain_m_forced = best == -2 ? 0 : best;
   set_kernel(best == -2 ? 0 : 1);
   if (best_wv == 2) p->n_slots = 2;
-  snprintf(buf, sizeof buf, " -> %s%s%d", best_wv == 2 ? "occ3/" : "", best == -2 ? "wg-kernel" : (best < 0 ? "levels" : "m"), best < 0 ? 0 : best);
+  snprintf(buf, sizeof buf, " -> %s%s%s%d", best_rr ? "rr/" : "", best_wv == 2 ? "occ3/" : "", best == -2 ? "wg-kernel" : (best < 0 ? "levels" : "m"), best < 0 ? 0 : best);
   p->tune_report += buf;
   if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] schedule tuner (%d classes per launch): %s\n", n_cat_batch, p->tune_report.c_str());
   return 0;
@@ -2128,6 +2302,7 @@ int hyphy_hip_set_pinned_states(hyphy_hip_partition *p, int64_t node, const int6
     HIPCHK(hipMemcpy(s.pin, h.data(), h.size() * sizeof(int16_t), hipMemcpyHostToDevice));
   }
   p->pin_node = node;
+  if (p->rr_active) p->cached_valid = 0;  // (re-rooted schedules are built for evaluations without pinned states)
   std::fill(p->bc_node.begin(), p->bc_node.end(), -1);
   return 0;
 }
@@ -2294,6 +2469,7 @@ int hyphy_hip_branch_cache_evaluate(hyphy_hip_partition *p, int64_t cat, int64_t
     ea.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
     ea.PTg = s.PTg + (size_t)cat * B * DP * DP;
     launch_expm(ea, s.stream);
+    s.twins_dirty = true;  // (this branch's image was rewritten without its twin, if it has one)
     BcArgs ba;
     ba.NW = p->NW;
     ba.S_pad = s.S_pad;
@@ -2718,7 +2894,15 @@ int hyphy_hip_set_stream(hyphy_hip_partition *p, void *stream) {
 
 void *hyphy_hip_stream(hyphy_hip_partition *p) { return p && !p->shards.empty() ? (void *)p->shards[0].stream : nullptr; }
 
-const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p) { return p ? p->tune_report.c_str() : ""; }
+const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p) {
+  if (!p) return "";
+  static thread_local std::string out;
+  char buf[96];
+  snprintf(buf, sizeof buf, " [current: %s%s, %zu program(s)]", p->chain ? "chain" : "levels", p->rr_active ? ", re-rooted" : "",
+           p->programs.size());
+  out = p->tune_report + buf;
+  return out.c_str();
+}
 
 int hyphy_hip_set_timing_detail(hyphy_hip_partition *p, int on) {
   if (!p) return fail("partition == NULL");

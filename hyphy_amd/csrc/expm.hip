@@ -343,6 +343,20 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
       out[idx] = (rr < D && cc < D) ? Xs[rr * LD + cc] : 0.0;  // padded states carry exact zeros
     }
   }
+  if (a.Pfrag && a.n_twin > 0) {
+    for (int j = 0; j < a.n_twin; j++)
+      if (slot == a.twin_src[j]) {  // (uniform) transposed twin for re-rooted schedules, pi-scaled on the old root's edge
+        double *out = a.Pfrag + (size_t)(a.twin_dst0 + j) * DP * DP;
+        for (int idx = tid; idx < DP * DP; idx += NTHR) {
+          const int wb = idx / (NKK * 64), rem = idx - wb * (NKK * 64);
+          const int kk2 = rem >> 7, l = (rem >> 1) & 63, kb = rem & 1, kk = 2 * kk2 + kb;
+          const int rr = 16 * wb + (l & 15), cc = 4 * kk + (l >> 4);
+          double v = (rr < D && cc < D) ? Xs[cc * LD + rr] : 0.0;
+          if (j == 0) v *= a.twin_pi[cc];
+          out[idx] = v;
+        }
+      }
+  }
   if (a.PTg) {
     // [code][wb][gg][r]  <-  P[16 wb + 4 r + gg][code]
     double *out = a.PTg + (size_t)slot * DP * DP;

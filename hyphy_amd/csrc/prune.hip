@@ -805,7 +805,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
  int4 prg;
  for (;;) {  // chained fragments: run program `cur`, then possibly its parent program
   prg = prog[cur];  // (scalar load: uniform control flow, schedule entries in SGPRs)
-  run_ops(ops + prg.x, prg.y, -1, false, 0, (a.chain && jn[prg.w].x >= 0) ? a.L + prg.w : -1);
+  run_ops(ops + prg.x, prg.y, -1, false, 0, (a.chain && jn[prg.w].x >= 0) ? (jn[prg.w].x >> 16) : -1);
   if (a.chain || prg.z < 0) break;  // a chain source / the root program (or a stand-alone one)
   // arrival at the parent program: the wave that completes the parent's last child fragment (for this
   // tile) continues with the parent; every other wave retires.  Payload stores were write-through.
@@ -833,9 +833,9 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
     int c = prg.w;
     int early = -1;  // arrival counter of c's parent, sampled (lane 0) while c itself was still being finalised
     for (;;) {
-      const int4 jc = jn[c];
+      const int4 jc = jn[c];  // x = parent (internal index) | matrix-image slot of the edge c -> parent << 16; -1: c is the root
       if (jc.x < 0) break;  // c is the root: epilogue below
-      const int p = jc.x;
+      const int p = jc.x & 0xffff;
       const int4 jp = jn[p];
       const int need = jp.y & 0xff;
       int *ctr = a.frag_ctr + (size_t)p * a.ntiles + tile0;
@@ -857,10 +857,10 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
           }
         }
       }
-      edge_product(a.L + c, [&](int k2) -> f64x2 {
+      edge_product(jc.x >> 16, [&](int k2) -> f64x2 {
         if constexpr (LB) return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2);
         else return (f64x2){bch[k2 >> 1][(k2 & 1) * 2], bch[k2 >> 1][(k2 & 1) * 2 + 1]};
-      }, pre, last ? nullptr : ctr, jp.x >= 0 ? a.L + p : -1);
+      }, pre, last ? nullptr : ctr, jp.x >= 0 ? (jp.x >> 16) : -1);
       cnt = bcnt;
       if (!last) {
         // (the counter was sampled two k-steps before the end of the product: its round trip is covered)
@@ -905,8 +905,8 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
       if (need > 1 && lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
       // sample the NEXT level's arrival counter now: the round trip hides behind p's leaves, deposits and finalisation
       early = -1;
-      if (jp.x >= 0 && (jn[jp.x].y & 0xff) > 1 && lane == 0)
-        early = __hip_atomic_load(a.frag_ctr + (size_t)jp.x * a.ntiles + tile0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (jp.x >= 0 && (jn[jp.x & 0xffff].y & 0xff) > 1 && lane == 0)
+        early = __hip_atomic_load(a.frag_ctr + (size_t)(jp.x & 0xffff) * a.ntiles + tile0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       run_ops(ops + jp.z, jp.w, c, pre != nullptr, pre_cnt);
       if constexpr (TRACE) tr_levels += 1 + (pre ? 100 : 0);
       c = p;

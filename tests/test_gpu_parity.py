@@ -421,7 +421,9 @@ def test_lazy_persistence_is_transparent(kernel, monkeypatch):
         for n in range(op.I):
             x, y = cache[n], op.cache[0][n]
             assert np.allclose(x / x.sum(1, keepdims=True), y / y.sum(1, keepdims=True), rtol=1e-9, atol=1e-300), (policy, n)
-    assert results["lazy"][:4] == results["always"][:4]
+    # (not bit for bit: the steady-state passes of the lazy policy may run a re-rooted schedule, a different order of the same products)
+    for x, y in zip(results["lazy"][:4], results["always"][:4]):
+        assert abs(x - y) <= 1e-13 * abs(y)
 
 
 def test_lazy_persistence_nucleotide_path():
@@ -1020,3 +1022,72 @@ def test_sorted_patterns_are_invisible_to_the_caller(monkeypatch):
         assert np.array_equal(got[3], ref[3]), label                            # exponents [I][S]
         assert abs(got[4] - ref[4]) <= 1e-12 * abs(ref[4]), label
         assert np.allclose(got[5], ref[5], rtol=1e-12, atol=0), label
+
+
+@pytest.mark.parametrize("shape", ["caterpillar", "random"])
+def test_rerooted_schedules_match_oracle_without_reversibility(shape, monkeypatch):
+    """Re-rooted schedules (api.hip: rr_path) hang the computation from the node that minimises the tree's height and walk the
+    edges between the given root and that node with transposed matrices, pi folded in on the old root's edge.  Nothing about
+    that needs a reversible model: random NON-reversible rate matrices and root frequencies that are not their stationary
+    distribution, forced re-rooting, against the oracle — steady-state full passes (lazy persistence: the re-rooted form), new
+    root frequencies alone, one path branch alone, a pinned evaluation in between (falls back to the given root) and per-site
+    values."""
+    from hyphy_amd import data, tree
+    from oracle import oracle
+    monkeypatch.setenv("HYPHY_HIP_REROOT", "1")
+    monkeypatch.setenv("HYPHY_HIP_KERNEL", "1")
+    monkeypatch.setenv("HYPHY_HIP_CHAIN_M", "3")
+    monkeypatch.setenv("HYPHY_HIP_POISON", "1")
+    rng = np.random.default_rng(2024)
+    root = tree.caterpillar_tree(14) if shape == "caterpillar" else tree.random_tree(40, rng, trifurcating_root=True)
+    flat = tree.flatten(root)
+    S, D = 16 * 9 + 5, 61
+    base = rng.integers(0, D, size=S)
+    states = np.where(rng.random((flat.L, S)) < 0.3, rng.integers(0, D, size=(flat.L, S)), base[None, :])
+    pd = data.from_states(states, D, compress_patterns=False)
+    B = flat.n_branches
+    nodes = np.arange(B, dtype=np.int64)
+
+    def random_q(scale):
+        Q = rng.random((B, D, D)) * (rng.random((B, D, D)) < 0.15) * scale[:, None, None]
+        for b in range(B):
+            np.fill_diagonal(Q[b], 0.0)
+            np.fill_diagonal(Q[b], -Q[b].sum(axis=1))
+        return Q
+
+    Q = random_q(rng.uniform(0.05, 0.4, B))
+    pi = rng.random(D) + 0.1
+    pi /= pi.sum()
+    op = oracle.OraclePartition(D, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq)
+    op.set_P(nodes, oracle.expm(Q, True))
+    hip = _hip()
+    with hip.HipPartition(D, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq) as part:
+        def check(tag, q_nodes, q):
+            want = op.compute_block(nodes, pi)
+            got, lik, sc = part.evaluate(nodes, q_nodes, q, pi, per_site=True)
+            assert abs(got - want) <= RTOL * abs(want), (shape, tag, got, want, part.schedule_info())
+            return got
+        check("first", nodes, Q)                       # persisting pass, given root
+        for k in range(3):                             # steady state: lazy full passes -> re-rooted
+            Q = random_q(rng.uniform(0.05, 0.4, B))
+            op.set_P(nodes, oracle.expm(Q, True))
+            check(f"full{k}", nodes, Q)
+        assert "re-rooted" in part.schedule_info(), part.schedule_info()
+        pi = rng.random(D) + 0.1                       # new root frequencies, no new matrix
+        pi /= pi.sum()
+        check("pi only", np.zeros(0, dtype=np.int64), np.zeros((0, D, D)))
+        for b in (B - 1, B - 2, 0):                    # single branches (the last internal ones sit next to the given root)
+            qb = random_q(rng.uniform(0.05, 0.4, B))[b:b + 1]
+            Q[b] = qb[0]
+            op.set_P(np.array([b]), oracle.expm(qb, True))
+            check(f"branch {b}", np.array([b], dtype=np.int64), qb)
+        st = rng.integers(0, D, size=S)
+        part.set_pinned_states(flat.L + 1, st)
+        op.set_branch(flat.L + 1, st)
+        want = op.compute_block(nodes, pi)
+        got = part.evaluate(nodes, np.zeros(0, dtype=np.int64), np.zeros((0, D, D)), pi)
+        part.set_pinned_states(None)
+        op.set_branch(None)
+        if np.isfinite(want):
+            assert abs(got - want) <= RTOL * abs(want), (shape, "pinned", got, want)
+        check("after pin", np.zeros(0, dtype=np.int64), np.zeros((0, D, D)))
