@@ -174,7 +174,7 @@ struct SiteFitArgs {
   int32_t *status;
 };
 
-constexpr int kMaxTwin = 6;  // longest path (in edges) between the given root and the root a re-rooted schedule computes at
+constexpr int kMaxTwin = 32;  // longest path (in edges) between the given root and the root a re-rooted schedule computes at
 
 struct ExpmArgs {
   const double *Q;           // [n][D*D] row-major (rate matrices, or probabilities if is_prob)
@@ -195,7 +195,7 @@ struct ExpmArgs {
   // re-rooted schedules (api.hip: reroot_path): matrix j of twin_src (a slot number) also leaves the TRANSPOSED image
   // M[r][c] = P[c][r] (times twin_pi[c] for j == 0, the edge that leaves the old root) in slot twin_dst0 + j of Pfrag
   int n_twin = 0;
-  int twin_src[kMaxTwin] = {0, 0, 0, 0, 0, 0};
+  int twin_src[kMaxTwin] = {};
   int twin_dst0 = 0;
   const double *twin_pi = nullptr;
 };

@@ -1024,7 +1024,7 @@ def test_sorted_patterns_are_invisible_to_the_caller(monkeypatch):
         assert np.allclose(got[5], ref[5], rtol=1e-12, atol=0), label
 
 
-@pytest.mark.parametrize("shape", ["caterpillar", "random"])
+@pytest.mark.parametrize("shape", ["caterpillar", "long caterpillar", "random"])
 def test_rerooted_schedules_match_oracle_without_reversibility(shape, monkeypatch):
     """Re-rooted schedules (api.hip: rr_path) hang the computation from the node that minimises the tree's height and walk the
     edges between the given root and that node with transposed matrices, pi folded in on the old root's edge.  Nothing about
@@ -1039,7 +1039,8 @@ def test_rerooted_schedules_match_oracle_without_reversibility(shape, monkeypatc
     monkeypatch.setenv("HYPHY_HIP_CHAIN_M", "3")
     monkeypatch.setenv("HYPHY_HIP_POISON", "1")
     rng = np.random.default_rng(2024)
-    root = tree.caterpillar_tree(14) if shape == "caterpillar" else tree.random_tree(40, rng, trifurcating_root=True)
+    root = (tree.caterpillar_tree(14) if shape == "caterpillar" else tree.caterpillar_tree(44) if shape == "long caterpillar"
+            else tree.random_tree(40, rng, trifurcating_root=True))
     flat = tree.flatten(root)
     S, D = 16 * 9 + 5, 61
     base = rng.integers(0, D, size=S)
