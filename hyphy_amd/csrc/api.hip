@@ -2286,6 +2286,7 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
 int hyphy_hip_set_pinned_states(hyphy_hip_partition *p, int64_t node, const int64_t *states) {
   if (!p) return fail("partition == NULL");
   if (node < 0 || !states) {
+    if (p->pin_node >= 0 && p->rr_use) p->cached_valid = 0;  // (back to the re-rooted form of the steady-state passes)
     p->pin_node = -1;
     return 0;
   }
