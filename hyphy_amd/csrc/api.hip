@@ -220,6 +220,7 @@ struct hyphy_hip_partition {
   // critical path (the tree's height), which is what small and medium shards are bound by.  rr_path = internal indices from the
   // given root (front) to the node the computation is rooted at (back); empty: the given root is already the best one.
   std::vector<int> rr_path;
+  std::vector<std::vector<int>> rr_cands;    // the (at most two) height-minimising nodes' paths; rr_path is the one in use
   int emit_skip_par = -1, emit_skip_child = -1;  // (transient, build_schedule -> emit_program)
   bool rr_use = false;                       // ask build_schedule for the re-rooted form (tuner / HYPHY_HIP_REROOT)
   bool rr_active = false;                    // the current schedule is a re-rooted one
@@ -1236,41 +1237,54 @@ inline int64_t caller_pattern(const hyphy_hip_partition *p, int64_t j) { return 
 void reroot_path(hyphy_hip_partition *p) {
   const int L = (int)p->L, I = (int)p->I, N = L + I;
   p->rr_path.clear();
-  if (I < 4 || N > 3000) return;  // (quadratic search)
+  p->rr_cands.clear();
+  if (I < 4) return;
   std::vector<std::vector<int>> adj(N);
   for (int n = 0; n < N - 1; n++) {
     const int par = L + (int)p->parents[n];
     adj[n].push_back(par);
     adj[par].push_back(n);
   }
-  auto height_from = [&](int r) {
-    int best = 0;
-    std::vector<std::pair<int, int>> stack(1, std::make_pair(r, -1));
-    std::vector<int> depth(N, 0);
-    while (!stack.empty()) {
-      const std::pair<int, int> t = stack.back();
-      stack.pop_back();
-      best = std::max(best, depth[t.first]);
-      for (int m : adj[t.first])
-        if (m != t.second) {
-          depth[m] = depth[t.first] + 1;
-          stack.push_back(std::make_pair(m, t.first));
+  // distances (in edges) from `r` to every node, BFS parents in `from`; returns the farthest LEAF
+  auto sweep = [&](int r, std::vector<int> &dist, std::vector<int> &from) {
+    dist.assign(N, -1);
+    from.assign(N, -1);
+    std::vector<int> queue(1, r);
+    dist[r] = 0;
+    int far = -1;
+    for (size_t h = 0; h < queue.size(); h++) {
+      const int n = queue[h];
+      if (n < L && (far < 0 || dist[n] > dist[far])) far = n;
+      for (int m : adj[n])
+        if (dist[m] < 0) {
+          dist[m] = dist[n] + 1;
+          from[m] = n;
+          queue.push_back(m);
         }
     }
-    return best;
+    return far;
   };
+  // The nodes of least eccentricity over the leaves are the middle of a longest leaf-to-leaf path (two sweeps).
   const int root = N - 1;
-  int best = root, best_h = height_from(root);
-  for (int n = L; n < N - 1; n++) {
-    const int h = height_from(n);
-    if (h < best_h) best_h = h, best = n;
+  std::vector<int> d0, f0, du, fu;
+  const int u = sweep(root, d0, f0);
+  const int root_height = d0[u];
+  const int v = sweep(u, du, fu);
+  const int D = du[v];
+  if (root_height <= (D + 1) / 2) return;  // the given root is as good as any
+  std::vector<int> mids;
+  for (int n = v; n != u; n = fu[n])  // walk v -> u: the one or two middle nodes
+    if ((du[n] == D / 2 || du[n] == (D + 1) / 2) && n >= L && n != root) mids.push_back(n);
+  std::sort(mids.begin(), mids.end(), [&](int x, int y) { return d0[x] < d0[y]; });  // closest to the given root first
+  p->rr_cands.clear();
+  for (int best : mids) {
+    std::vector<int> up;  // best -> ... -> root
+    for (int n = best; n != root; n = L + (int)p->parents[n]) up.push_back(n - L);
+    up.push_back(I - 1);
+    if ((int)up.size() - 1 > kMaxTwin) continue;
+    p->rr_cands.push_back(std::vector<int>(up.rbegin(), up.rend()));
   }
-  if (best == root) return;
-  std::vector<int> up;  // best -> ... -> root
-  for (int n = best; n != root; n = L + (int)p->parents[n]) up.push_back(n - L);
-  up.push_back(I - 1);
-  if ((int)up.size() - 1 > kMaxTwin) return;
-  p->rr_path.assign(up.rbegin(), up.rend());
+  if (!p->rr_cands.empty()) p->rr_path = p->rr_cands[0];
 }
 
 void sort_patterns(hyphy_hip_partition *p, const int64_t *leaf_codes, int64_t L, int64_t S) {
@@ -1759,7 +1773,13 @@ static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
     std::vector<int> ms;
     std::sort(ranked.begin(), ranked.end());
     for (size_t k = 0; k < ranked.size() && k < 3; k++) ms.push_back(ranked[k].second);
+    size_t best_cand = 0;
+    for (size_t ci = 0; ci < p->rr_cands.size(); ci++)
     for (int m : ms) {
+      if (p->rr_path != p->rr_cands[ci]) {
+        p->rr_path = p->rr_cands[ci];
+        for (Shard &sh : p->shards) sh.twins_dirty = true;  // (other twins: refreshed by the transpose kernel before the launch)
+      }
       p->chain_m_forced = m;
       p->variant = 1;
       p->wave_variant = best_wv;
@@ -1780,13 +1800,18 @@ static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
       HIPCHK(hipGetLastError());
       if (hipEventElapsedTime(&ms1, s.ev[0], s.ev[1]) != hipSuccess || hipEventElapsedTime(&ms2, s.ev[1], s.ev[2]) != hipSuccess) continue;
       ms1 = std::min(ms1, ms2);
-      snprintf(buf, sizeof buf, " rr/m%d:%.1fus", m, 1e3 * ms1);
+      snprintf(buf, sizeof buf, " rr%zu/m%d:%.1fus", ci, m, 1e3 * ms1);
       p->tune_report += buf;
-      if (ms1 < 0.98 * best_ms) {
+      if (ms1 < (best_rr ? 1.0 : 0.98) * best_ms) {
         best_ms = ms1;
         best = m;
         best_rr = true;
+        best_cand = ci;
       }
+    }
+    if (p->rr_path != p->rr_cands[best_cand]) {
+      p->rr_path = p->rr_cands[best_cand];
+      for (Shard &sh : p->shards) sh.twins_dirty = true;
     }
   }
   p->rr_use = best_rr;
