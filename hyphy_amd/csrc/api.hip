@@ -1271,7 +1271,7 @@ void reroot_path(hyphy_hip_partition *p) {
   const int root_height = d0[u];
   const int v = sweep(u, du, fu);
   const int D = du[v];
-  if (root_height <= (D + 1) / 2) return;  // the given root is as good as any
+  (void)root_height;  // (a given root that is itself a centre node keeps the other centre node as a candidate: the tuner times both)
   std::vector<int> mids;
   for (int n = v; n != u; n = fu[n])  // walk v -> u: the one or two middle nodes
     if ((du[n] == D / 2 || du[n] == (D + 1) / 2) && n >= L && n != root) mids.push_back(n);
