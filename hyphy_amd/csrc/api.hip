@@ -1802,7 +1802,9 @@ static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
       ms1 = std::min(ms1, ms2);
       snprintf(buf, sizeof buf, " rr%zu/m%d:%.1fus", ci, m, 1e3 * ms1);
       p->tune_report += buf;
-      if (ms1 < (best_rr ? 1.0 : 0.98) * best_ms) {
+      // (5 % margin against the given root: the tuner's pass ranked a re-rooted form of the headline tree 4.5 % ahead that was
+      // 1 % behind in production)
+      if (ms1 < (best_rr ? 1.0 : 0.95) * best_ms) {
         best_ms = ms1;
         best = m;
         best_rr = true;
