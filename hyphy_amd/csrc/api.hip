@@ -2922,6 +2922,34 @@ int hyphy_hip_set_stream(hyphy_hip_partition *p, void *stream) {
 
 void *hyphy_hip_stream(hyphy_hip_partition *p) { return p && !p->shards.empty() ? (void *)p->shards[0].stream : nullptr; }
 
+/* Host-only planning helpers (no device needed): what hyphy_hip_create decides from the topology and the leaf table alone. */
+int64_t hyphy_hip_plan_reroot(int64_t L, int64_t I, const int64_t *flat_parents, int64_t candidate, int64_t *path_out, int64_t cap) {
+  if (L < 2 || I < 1 || !flat_parents) return -1;
+  hyphy_hip_partition tmp;
+  tmp.L = L;
+  tmp.I = I;
+  tmp.parents.assign(flat_parents, flat_parents + L + I);
+  for (int64_t n = 0; n < L + I - 1; n++)
+    if (flat_parents[n] < 0 || flat_parents[n] >= I) return -1;
+  reroot_path(&tmp);
+  if (candidate < 0 || candidate >= (int64_t)tmp.rr_cands.size()) return 0;
+  const std::vector<int> &path = tmp.rr_cands[(size_t)candidate];
+  for (size_t k = 0; k < path.size() && (int64_t)k < cap; k++)
+    if (path_out) path_out[k] = path[k];
+  return (int64_t)path.size();
+}
+
+int hyphy_hip_plan_pattern_order(int64_t D, int64_t L, int64_t S, const int64_t *leaf_codes, int64_t *order_out) {
+  if (D < 2 || L < 1 || S < 1 || !leaf_codes || !order_out) return -1;
+  hyphy_hip_partition tmp;
+  tmp.D = D;
+  tmp.L = L;
+  tmp.S = S;
+  sort_patterns(&tmp, leaf_codes, L, S);
+  for (int64_t k = 0; k < S; k++) order_out[k] = tmp.perm.empty() ? k : tmp.perm[k];
+  return 0;
+}
+
 const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p) {
   if (!p) return "";
   static thread_local std::string out;

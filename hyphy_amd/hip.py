@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("HYPHY_HIP_LIB") or os.path.join(HERE, "lib", "libhyph
 
 EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
-    "hyphy_hip_evaluate_device", "hyphy_hip_fetch_device_scalar", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_comm_unique_id", "hyphy_hip_comm_init_rank", "hyphy_hip_comm_init_all", "hyphy_hip_allreduce_device", "hyphy_hip_evaluate_allreduce", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
+    "hyphy_hip_evaluate_device", "hyphy_hip_fetch_device_scalar", "hyphy_hip_plan_reroot", "hyphy_hip_plan_pattern_order", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_comm_unique_id", "hyphy_hip_comm_init_rank", "hyphy_hip_comm_init_all", "hyphy_hip_allreduce_device", "hyphy_hip_evaluate_allreduce", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
@@ -72,6 +72,10 @@ def load():
     lib.hyphy_hip_evaluate_async.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp]
     lib.hyphy_hip_collect.restype = C.c_int
     lib.hyphy_hip_collect.argtypes = [vp, dp, dp, lp]
+    lib.hyphy_hip_plan_reroot.restype = C.c_int64
+    lib.hyphy_hip_plan_reroot.argtypes = [C.c_int64, C.c_int64, lp, C.c_int64, lp, C.c_int64]
+    lib.hyphy_hip_plan_pattern_order.restype = C.c_int
+    lib.hyphy_hip_plan_pattern_order.argtypes = [C.c_int64, C.c_int64, C.c_int64, lp, lp]
     lib.hyphy_hip_fetch_device_scalar.restype = C.c_int
     lib.hyphy_hip_fetch_device_scalar.argtypes = [vp, vp, C.POINTER(C.c_double)]
     lib.hyphy_hip_evaluate_device.restype = C.c_int
@@ -143,6 +147,25 @@ def _d(a):
 
 def _l(a):
     return a.ctypes.data_as(C.POINTER(C.c_int64)) if a is not None else None
+
+
+def plan_reroot(flat_parents, L: int, candidate: int = 0) -> np.ndarray:
+    """Host-only: internal indices from the given root to the ``candidate``-th height-minimising node (empty: none)."""
+    fp = np.ascontiguousarray(flat_parents, dtype=np.int64)
+    out = np.zeros(64, dtype=np.int64)
+    n = int(load().hyphy_hip_plan_reroot(int(L), len(fp) - int(L), _l(fp), int(candidate), _l(out), len(out)))
+    if n < 0:
+        raise HipError("plan_reroot: bad arguments")
+    return out[:n].copy()
+
+
+def plan_pattern_order(D: int, leaf_codes) -> np.ndarray:
+    """Host-only: the order in which the library stores the patterns on the device (caller's pattern indices)."""
+    lc = np.ascontiguousarray(leaf_codes, dtype=np.int64)
+    out = np.zeros(lc.shape[1], dtype=np.int64)
+    if load().hyphy_hip_plan_pattern_order(int(D), lc.shape[0], lc.shape[1], _l(lc), _l(out)):
+        raise HipError("plan_pattern_order: bad arguments")
+    return out
 
 
 def device_count() -> int:

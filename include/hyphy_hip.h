@@ -339,6 +339,15 @@ const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p);
 /* What the schedule tuner measured for this partition ("" before it ran): on the first steady-state full pass the
  * library times the (idempotent) pruning pass under each candidate cut of the tree — level-peeled fragments, or chains
  * with source subtrees of at most m internal nodes — and keeps the fastest.  HYPHY_HIP_TUNE=0 disables it. */
+/* Host-only planning helpers (no device is touched): decisions hyphy_hip_create takes from the topology / the leaf table alone,
+ * exposed for inspection and for tests that run without a GPU.
+ *   hyphy_hip_plan_reroot       the path (internal indices, given root first) to the `candidate`-th (0, 1) height-minimising
+ *                               node the steady-state passes may be rooted at (re-rooted schedules); returns the
+ *                               number of nodes on the path, 0 if there is no such candidate, < 0 on bad arguments.
+ *   hyphy_hip_plan_pattern_order  the device-side pattern order (order_out[j] = caller's pattern stored j-th). */
+int64_t hyphy_hip_plan_reroot(int64_t L, int64_t I, const int64_t *flat_parents, int64_t candidate, int64_t *path_out, int64_t cap);
+int hyphy_hip_plan_pattern_order(int64_t D, int64_t L, int64_t S, const int64_t *leaf_codes, int64_t *order_out);
+
 const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p);
 
 const char *hyphy_hip_last_error(void);
