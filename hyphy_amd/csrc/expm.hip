@@ -140,6 +140,7 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
   const int slot = a.slots ? a.slots[m] : m;
   const double *Q = a.Q + (size_t)m * D * D;
 
+  bool diag_pending = false;  // (uniform) fused construction: the diagonal of Q is still zero in LDS
   if (a.templates) {
     // fused device-side rate-matrix construction: Q = sum_k c_k T_k, then the diagonal by column-order
     // subtraction (the order of _Matrix::MultByFreqs, matrix.cpp:1664-1674).  Every load of a thread is
@@ -167,16 +168,7 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
       const int idx = tid + e * NTHR, r = idx / DP, c = idx - r * DP;
       Xs[r * LD + c] = v[e];
     }
-    __syncthreads();
-    if (tid < D) {
-      double d = 0.;
-#pragma unroll
-      for (int c = 0; c < DP; c++) {  // (unrolled: the LDS reads pipeline; the diagonal itself and padding hold 0)
-        const double x = Xs[tid * LD + c];
-        d -= (c != tid) ? x : 0.;
-      }
-      Xs[tid * LD + tid] = d;
-    }
+    diag_pending = true;  // (the diagonal = minus the row sum comes out of the norm pass below: one pass over the matrix, not two)
   } else {
     for (int idx = tid; idx < DP * DP; idx += NTHR) {
       const int r = idx / DP, c = idx - r * DP;
@@ -192,11 +184,13 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
     constexpr int PARTS = NTHR / DP >= 1 ? NTHR / DP : 1, SEG = DP / PARTS;
     {
       const int line = tid / PARTS, part = tid - line * PARTS;
-      double rs = 0., cs = 0.;
+      double rs = 0., cs = 0., rsum = 0.;
       if (line < DP) {
 #pragma unroll
         for (int k = 0; k < SEG; k++) {
-          rs += fabs(Xs[line * LD + part * SEG + k]);
+          const double x = Xs[line * LD + part * SEG + k];
+          rsum += x;
+          rs += fabs(x);
           cs += fabs(Xs[(part * SEG + k) * LD + line]);
         }
       }
@@ -204,8 +198,14 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
       for (int off = 1; off < PARTS; off <<= 1) {  // PARTS is a power of two <= 8: partners sit in the same wave
         rs += __shfl_xor(rs, off);
         cs += __shfl_xor(cs, off);
+        rsum += __shfl_xor(rsum, off);
       }
       if (line < DP && part == 0) {
+        if (diag_pending && line < D) {  // fused construction: Q_ii = -(row sum); it enters both absolute sums
+          Xs[line * LD + line] = -rsum;
+          rs += fabs(rsum);
+          cs += fabs(rsum);
+        }
         red[line] = rs;
         red[DP + line] = cs;
       }
