@@ -11,6 +11,7 @@
 // (matrix.cpp:5703-5721): on the GPU a dense 64^3 MFMA product is cheaper than CSR bookkeeping
 // (SURVEY §2.1 K10).  With ||Q/2^p|| <= 1/4 the truncation error is < 2.5e-18.
 #include "common.h"
+#include <type_traits>
 
 namespace hyhip {
 
@@ -152,16 +153,48 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
     double v[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; e++) v[e] = 0.;
-    for (int k = 0; k < K; k++) {
-      const double cf = ck[k];
-      const double *Tk = a.templates + (size_t)k * D * D;
+    // (specialised on K <= 4 so that the loads of ALL templates are in flight together: one memory round trip, not K)
+    auto accumulate = [&](auto kc) {
+      constexpr int KC = decltype(kc)::value;
+      double cf[KC], t[KC][EPT];
 #pragma unroll
-      for (int e = 0; e < EPT; e++) {
-        const int idx = tid + e * NTHR, r = idx / DP, c = idx - r * DP;
-        const bool in = r < D && c < D && r != c;
-        const double t = Tk[in ? r * D + c : 0];
-        v[e] += in ? cf * t : 0.;
+      for (int k = 0; k < KC; k++) cf[k] = ck[k];
+#pragma unroll
+      for (int k = 0; k < KC; k++) {
+        const double *Tk = a.templates + (size_t)k * D * D;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+          const int idx = tid + e * NTHR, r = idx / DP, c = idx - r * DP;
+          const bool in = r < D && c < D && r != c;
+          t[k][e] = Tk[in ? r * D + c : 0];
+        }
       }
+#pragma unroll
+      for (int k = 0; k < KC; k++)
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+          const int idx = tid + e * NTHR, r = idx / DP, c = idx - r * DP;
+          const bool in = r < D && c < D && r != c;
+          v[e] += in ? cf[k] * t[k][e] : 0.;
+        }
+    };
+    switch (K) {
+      case 1: accumulate(std::integral_constant<int, 1>()); break;
+      case 2: accumulate(std::integral_constant<int, 2>()); break;
+      case 3: accumulate(std::integral_constant<int, 3>()); break;
+      case 4: accumulate(std::integral_constant<int, 4>()); break;
+      default:
+        for (int k = 0; k < K; k++) {
+          const double cf = ck[k];
+          const double *Tk = a.templates + (size_t)k * D * D;
+#pragma unroll
+          for (int e = 0; e < EPT; e++) {
+            const int idx = tid + e * NTHR, r = idx / DP, c = idx - r * DP;
+            const bool in = r < D && c < D && r != c;
+            const double t = Tk[in ? r * D + c : 0];
+            v[e] += in ? cf * t : 0.;
+          }
+        }
     }
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
