@@ -35,7 +35,12 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         for r in csv.DictReader(open(f)):
             acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     # steady state: drop the first two dispatches of every kernel (persisting first pass, schedule tuner)
-    means = {k: {c: (sum(v[2:]) / len(v[2:]) if len(v) > 4 else sum(v) / len(v)) for c, v in dd.items()} for k, dd in acc.items()}
+    # steady state: the MEDIAN over the dispatches of every kernel (the first evaluations persist everything and the schedule
+    # tuner launches the pruning kernel under a dozen candidate cuts; means would mix those in)
+    def med(v):
+        w = sorted(v)
+        return w[len(w) // 2] if len(w) % 2 else 0.5 * (w[len(w) // 2 - 1] + w[len(w) // 2])
+    means = {k: {c: med(v) for c, v in dd.items()} for k, dd in acc.items()}
     means_all[wl] = means
     wj = os.path.join(src, f"wl_{wl}.json")
     if os.path.exists(wj):
