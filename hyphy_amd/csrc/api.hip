@@ -1,23 +1,12 @@
-// C-ABI of libhyphy_hip.so (include/hyphy_hip.h): partition state, post-order schedule
-// construction, pattern sharding over devices, kernel sequencing.  Host-side bookkeeping only —
-// all arithmetic of the hot path happens in expm.hip / prune.hip.
-#include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <time.h>
-
-#include <algorithm>
-#include <set>
-
-#include <dlfcn.h>
-
-#include "../../include/hyphy_hip.h"
-#include "common.h"
+// C-ABI of libhyphy_hip.so (include/hyphy_hip.h): partition state, pattern sharding over devices, evaluation entry
+// points, kernel sequencing.  The schedule compiler lives in schedule.hip, the run-time tuner in tuner.hip, RCCL in
+// comm.hip; shared host-side types in partition.h.  Host-side bookkeeping only — all arithmetic of the hot path happens
+// in expm.hip / prune.hip / sitefit.hip.
+#include "partition.h"
 
 using namespace hyhip;
 
-namespace {
+namespace hyhip {
 
 thread_local std::string g_last_error;
 
@@ -26,251 +15,16 @@ int fail(const std::string &msg) {
   return -1;
 }
 
-// ---- RCCL, loaded on first use (librccl.so is part of ROCm; a host that never all-reduces does not need it) -------------
-struct Rccl {
-  void *lib = nullptr;
-  int (*GetUniqueId)(void *) = nullptr;
-  int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
-  int (*CommDestroy)(void *comm) = nullptr;
-  int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t stream) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char *(*GetErrorString)(int) = nullptr;
-};
-struct RcclUniqueId {
-  char internal[128];  // NCCL_UNIQUE_ID_BYTES
-};
-typedef int (*rccl_init_rank_fn)(void **comm, int nranks, RcclUniqueId id, int rank);
-Rccl g_rccl;
-rccl_init_rank_fn g_rccl_init_rank = nullptr;
-constexpr int kNcclDouble = 8, kNcclSum = 0;
-
-int rccl_load() {
-  if (g_rccl.lib) return 0;
-  void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) return fail(std::string("RCCL not available: ") + (dlerror() ? dlerror() : "librccl.so"));
-  g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
-  g_rccl_init_rank = (rccl_init_rank_fn)dlsym(h, "ncclCommInitRank");
-  g_rccl.CommInitAll = (int (*)(void **, int, const int *))dlsym(h, "ncclCommInitAll");
-  g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
-  g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
-  g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
-  g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
-  g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-  if (!g_rccl.GetUniqueId || !g_rccl_init_rank || !g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllReduce ||
-      !g_rccl.GroupStart || !g_rccl.GroupEnd)
-    return fail("RCCL: missing symbols in librccl.so");
-  g_rccl.lib = h;
-  return 0;
-}
-#define RCCLCHK(expr)                                                                                         \
-  do {                                                                                                        \
-    int r_ = (expr);                                                                                          \
-    if (r_ != 0) return fail(std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "RCCL error")); \
-  } while (0)
-
-struct Trace {
-  bool on;
-  double t0;
-  const char *what;
-  static double now() {
-    timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
-  }
-  explicit Trace(const char *w) : on(getenv("HYPHY_HIP_TRACE") != nullptr), t0(0), what(w) {
-    if (on) t0 = now();
-  }
-  void lap(const char *stage) {
-    if (!on) return;
-    double t = now();
-    fprintf(stderr, "[hyphy_hip trace] %s/%s %.1f us\n", what, stage, t - t0);
-    t0 = t;
-  }
-};
-
-#define HIPCHK(expr)                                                                              \
-  do {                                                                                            \
-    hipError_t e_ = (expr);                                                                       \
-    if (e_ != hipSuccess) {                                                                       \
-      return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                             \
-    }                                                                                             \
-  } while (0)
-
-constexpr int kTimingRing = 1024;
-
-struct Shard {
-  int device = 0;
-  hipStream_t stream = nullptr;      // stream in use
-  hipStream_t own_stream = nullptr;  // stream created (and destroyed) by the library
-  int64_t s0 = 0, S = 0;  // pattern range [s0, s0+S) of the partition
-  int S_pad = 0, ntiles = 0, T = 1, cus = 256;
-  int16_t *codes = nullptr;
-  double *freq = nullptr;
-  double *ambig = nullptr;
-  double *partials = nullptr;  // [C] x per-class block
-  int32_t *counts = nullptr;   // [C][I][S_pad]
-  double *site_lik = nullptr;  // [C][S_pad]
-  int32_t *site_cnt = nullptr;
-  double *mixed_lik = nullptr;
-  int32_t *mixed_cnt = nullptr;
-  double *Pfrag = nullptr, *PTg = nullptr, *Prow = nullptr;  // [C][B]...
-  double *qbuf = nullptr;                                   // [C*B*D*D]
-  int32_t *slots = nullptr;                                 // [C*B]
-  int4 *ops = nullptr;
-  int16_t *codes_tile = nullptr;  // [tile][L][16] copy of the leaf table (wave-per-tile kernels)
-  int16_t *pin = nullptr;         // [S_pad] pinned states (hyphy_hip_set_pinned_states)
-  int4 *bc_ops = nullptr;         // branch cache: schedule of the re-rooted chain, its one-entry program table,
-  int4 *bc_prog = nullptr;        //   the slot word and the rate matrix of the cached branch
-  int32_t *bc_slot = nullptr;
-  double *bc_q = nullptr;
-  int4 *prog = nullptr;       // program table (forest scheduling): (offset, entries, parent program, child programs)
-  int4 *h_prog = nullptr;
-  double *ar_buf = nullptr;   // device scalar: this shard's partial log-L, all-reduced in place over RCCL
-  void *comm = nullptr;       // ncclComm_t of this shard (hyphy_hip_comm_init_rank / single-process group)
-  double *mix_q = nullptr, *mix_p = nullptr, *mix_w = nullptr;  // branch-site mixtures: component rate matrices, their exponentials, weights
-  int *mix_off = nullptr;
-  size_t mix_cap = 0, mix_nq_cap = 0;
-  int4 *jn = nullptr;         // chain schedules: per internal node (parent, arrivals needed | child sum << 8, trunk entries offset, count)
-  int4 *h_jn = nullptr;
-  double *deposits = nullptr; // chain schedules: [C][I][ntiles][TILE] edge products of non-last arrivers (allocated on first use)
-  int *frag_ctr = nullptr;    // [classes][programs][tiles] arrivals of child fragments (wave-per-tile kernel)
-  int32_t *hand_cnt = nullptr;  // [classes][I][tiles][32] 2^64-exponents of fragment roots (own 128-byte line each)
-  double *pi = nullptr;       // [DP]
-  double *out = nullptr;      // [2]
-  double *pi_ones = nullptr;  // [DP] 1 for real states, 0 for padding: root frequencies of a re-rooted schedule (pi sits in a twin image)
-  bool twins_dirty = true;    // the transposed twin images (expm.hip) may lag behind the matrices they mirror
-  double *wg_sum = nullptr;   // per-workgroup partial sums of the pruning kernel
-  long long *wg_cnt = nullptr;
-  int *wg_flag = nullptr;
-  int wg_cap = 0;
-  int32_t *status = nullptr;  // [1]
-  double *weights = nullptr;  // [C]
-  double *templates = nullptr;
-  double *coeffs = nullptr;
-  // pinned host staging
-  int4 *h_ops = nullptr;
-  double *h_out = nullptr;    // pinned, host-mapped: the reduction kernel writes [log-L, scaler sum, status] here
-  double *d_hout = nullptr;   // device-side address of h_out
-  int32_t *h_slots = nullptr;
-  double *h_coeffs = nullptr;  // pinned ring (4 x C*B*K) for build_q coefficients
-  double *d_hcoeffs = nullptr; // ... as the device sees it (host-mapped): the fused expm kernel reads it directly
-  const double *coeffs_cur = nullptr;  // coefficients of the pending fused build (device-visible pointer)
-  unsigned coeff_turn = 0;
-  // The fused expm kernel reads a ring slot over PCIe when it EXECUTES.  On the asynchronous path
-  // (hyphy_hip_evaluate_device) the host may run ahead of the device: an event recorded behind the consuming launch
-  // guards the slot, and hyphy_hip_build_q waits for it before rewriting the slot.
-  hipEvent_t coeff_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool coeff_busy[4] = {false, false, false, false};
-  int coeff_slot = -1;                 // ring slot of the staged coefficients
-  int64_t coeff_rows = 0;              // rows staged by the last hyphy_hip_build_q (0: nothing staged)
-  bool qbuf_built = false;             // ... and materialised in qbuf (HYPHY_HIP_MATERIALIZE_Q)
-  double *h_small = nullptr;  // pi / weights staging
-  size_t h_small_cap = 0;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  std::vector<hipEvent_t> ring;  // kTimingRing pairs (start, end) around the pruning launches
-  uint64_t ring_count = 0;       // evaluations stamped so far
-  uint64_t eval_count = 0;
-  size_t partial_stride = 0;  // doubles per class
-  // completion of the synchronous entry points: the reduction kernel writes a sequence number behind the result
-  // record in host-mapped memory and the host spins on it (hipStreamSynchronize costs several microseconds more)
-  double seq_next = 1., seq_wait = 0.;
-  // per-site batched fits (hyphy_hip_site_fits_evaluate), allocated on first use
-  double *fit_Timg = nullptr, *fit_bcoef = nullptr, *fit_smult = nullptr, *fit_smix = nullptr, *fit_out = nullptr,
-         *fit_scratch = nullptr, *fit_pi = nullptr;
-  int *fit_bgroup = nullptr;
-  int32_t *fit_scratch_cnt = nullptr;
-  int4 *fit_ops = nullptr;
-  size_t fit_sets_cap = 0, fit_scratch_sets = 0;
-  bool fit_static_current = false;  // template images + schedule on the device match the host copies
-};
-
-}  // namespace
-
-struct hyphy_hip_partition {
-  int64_t D = 0, S = 0, L = 0, I = 0, C = 1, B = 0;
-  int DP = 0, NW = 0;
-  bool nuc = false;
-  std::vector<int64_t> parents;              // [L+I]
-  std::vector<std::vector<int>> children;    // per internal node, ascending node codes
-  std::vector<Shard> shards;
-  std::vector<char> initialized;             // per class: a full evaluation has populated the caches
-  std::vector<char> leaf_has_ambig;          // per leaf: any ambiguity code in its row of the leaf table
-  std::vector<int4> ops_host;
-  std::vector<int64_t> cached_update;        // update list the device schedule was built for
-  bool cached_full = false;
-  int cached_valid = 0;
-  // Lazy persistence of the conditionals (cache_policy 1, default; HYPHY_HIP_CACHE=always turns it off): a full
-  // pass that follows a full pass (a sweep over a global parameter) keeps its nodes in registers / LDS only —
-  // nothing reads the persisted copies before the next full pass overwrites them — except the nodes some later
-  // schedule entry of the same pass re-reads.  `resident[c]`: the persisted copies of class c are current;
-  // a partial update, a branch-cache build or a download that finds them stale first re-runs a persisting pass.
-  int cache_policy = 1;
-  std::vector<char> resident, last_full;
-  bool cached_persist = true, sched_persist = true, sched_full = true;
-  std::vector<double> cached_pi;             // root frequencies currently on the device
-  std::vector<double> cached_weights;        // category weights currently on the device
-  std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
-  int root_slot = 0;
-  // Re-rooted schedules.  The likelihood does not depend on where the pruning recursion is rooted if the edges between the given
-  // root and the new one are traversed with the transposed matrices (and pi is folded in on the old root's edge) — no
-  // reversibility assumed, the same identity the branch cache uses.  A root in the middle of the tree shortens every tile's
-  // critical path (the tree's height), which is what small and medium shards are bound by.  rr_path = internal indices from the
-  // given root (front) to the node the computation is rooted at (back); empty: the given root is already the best one.
-  std::vector<int> rr_path;
-  std::vector<std::vector<int>> rr_cands;    // the (at most two) height-minimising nodes' paths; rr_path is the one in use
-  int emit_skip_par = -1, emit_skip_child = -1;  // (transient, build_schedule -> emit_program)
-  bool rr_use = false;                       // ask build_schedule for the re-rooted form (tuner / HYPHY_HIP_REROOT)
-  bool rr_active = false;                    // the current schedule is a re-rooted one
-  std::vector<int64_t> perm;                 // internal pattern j = caller's pattern perm[j] (empty: identity); see sort_patterns()
-  int64_t pin_node = -1;                     // node code whose states are pinned for the evaluations that follow (-1: none)
-  std::vector<int64_t> bc_node;              // per rate class: branch whose outside vector is resident (-1: none)
-  std::vector<int> bc_use_pi;                // ... hangs off the root (frequencies applied at evaluation)
-  int variant = 0;                           // pruning kernel variant (common.h PruneArgs::variant)
-  int n_slots = 0;                           // LDS slots the schedules are compiled for (0: lds_slots(T))
-  struct Prog { int off, n, parent = -1, need = 0; };
-  bool chain = false;                        // the current schedule is a chain schedule (common.h PruneArgs::chain)
-  bool kernel_forced = false;                // HYPHY_HIP_KERNEL / T > 1: the tuner must not switch kernels
-  int n_slots_wave = 3;                      // LDS slot budget of the wave-per-tile kernel's schedules
-  double *h_qstage = nullptr;                // pinned copy of the caller's matrices for hyphy_hip_evaluate_async
-  size_t h_qstage_cap = 0;
-  bool async_pending = false;                // an asynchronous evaluation has not been collected yet
-  int64_t async_cat = 0;
-  int wave_variant = 0;                      // instantiation of the wave-per-tile kernel (0: 2 waves per SIMD; 2: 3 waves per SIMD,
-                                             // finalised node in LDS, no parking slot) — chosen by the schedule tuner
-  int chain_m_forced = 0;                    // cut chosen by the schedule tuner: > 0 source size limit m, -1 level-peeled fragments, 0 heuristic
-  int64_t tuned_for = 0;                     // batch_classes the tuner ran for (0: not yet)
-  std::string tune_report;                   // what the tuner measured (hyphy_hip_schedule_info)
-  std::vector<int4> jn_host;                 // ... its per-node join table
-  struct Level { int first, count; };
-  std::vector<Prog> programs;                // (offset, padded entry count) into ops_host
-  std::vector<Level> levels;                 // launches: programs [first, first+count) run concurrently
-  int64_t batch_classes = 1;                 // rate classes batched into the pruning launch being scheduled
-  int slots_batch_mode = -1;                 // whether the slot table on the device was written for a class batch
-  bool all_timings = getenv("HYPHY_HIP_ALL_TIMINGS") != nullptr;  // also stamp expm / reduction (2 more event records)
-  bool coeffs_pending = false;               // build_q staged coefficients; the next evaluate_device(q_buffer) fuses
-                                             // the rate-matrix construction into the expm kernel
-  int64_t K = 0;                             // Q templates
-  std::vector<double> templates_host;        // [K][D][D] as passed to hyphy_hip_set_q_templates
-  std::vector<int4> fit_ops_host;            // per-site fits: full schedule compiled for kSiteFitParkSlots parking slots
-  int fit_n_ops = 0;
-  bool fit_spills = false;                   // ... some node goes through the scratch copy
-  double fit_kernel_ms = 0.;                 // duration of the last site-fit kernel (max over shards)
-  double timings[3] = {0, 0, 0};
-};
+const double kOwnQBuffer = 0.;
 
 namespace {
-
-size_t ops_capacity(const hyphy_hip_partition *p) { return (size_t)(p->L + p->I) + 4 * (size_t)p->I + 8; }
 
 void free_shard(Shard &s) {
   hipSetDevice(s.device);
   if (s.stream) hipStreamSynchronize(s.stream);
   void *dev[] = {s.codes, s.freq,  s.ambig,  s.partials, s.counts, s.site_lik, s.site_cnt, s.mixed_lik, s.mixed_cnt,
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
-                 s.weights, s.templates, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.pi_ones, s.codes_tile,
+                 s.weights, s.templates, s.templates_pad, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.pi_ones, s.codes_tile,
                  s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.mix_q, s.mix_p, s.mix_w, s.mix_off, s.ar_buf, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops};
   for (void *d : dev)
@@ -287,461 +41,6 @@ void free_shard(Shard &s) {
   if (s.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s.comm);
   if (s.own_stream) hipStreamDestroy(s.own_stream);
   s = Shard();
-}
-
-// Build the post-order schedule for the nodes the host marked dirty.  update_nodes comes from
-// DetermineNodesForUpdate (tree.cpp:3117-3331): dirty nodes, their ancestors and the direct
-// children of every touched internal node.  We recompute every internal node that is the parent
-// of a listed node (plus ancestors, defensively) from ALL its children; children whose
-// conditionals were not recomputed in this call are read back from the persisted device copy.
-// Append one *program* (the schedule of a connected set of touched internal nodes, ascending =
-// post-order) to p->ops_host.  Children that are internal nodes outside `nodes` are read from the
-// persisted copy in HBM (they were finalised by an earlier launch or are unchanged).  The program is
-// padded to an even entry count plus two trailing no-ops (the device loop is unrolled by two and
-// fetches entries two ahead).  Returns the LDS slot its last node was finalised into.
-int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *offset_out, int *n_out,
-                 bool handoff = false, bool is_root_program = true) {
-  const int L = (int)p->L, I = (int)p->I;
-  const int T = p->shards.empty() ? 1 : p->shards[0].T;
-  const int G = p->nuc ? 1 : (T <= 2 ? 2 : 1);  // leaves per leaf-group entry (prune.hip)
-  // A finished node whose parent is the next node of the program is read by that parent straight from
-  // the exchange slot it was finalised into (slots 0/1 alternate with the finalisation count, so the
-  // writer of the NEXT finalisation never touches it); otherwise it is parked in an LDS slot
-  // (2..lds_slots(T)-1) until its parent comes up or — when the slots run out — re-read from HBM.
-  std::vector<int> slot_of(I, -1);      // LDS slot holding internal node i (valid until consumed)
-  std::vector<char> recomputed(I, 0);   // finalised earlier in THIS program
-  const int n_slots = p->n_slots > 0 ? p->n_slots : lds_slots(T);
-  std::vector<char> slot_busy(n_slots, 0);
-  std::vector<int> last_entry(I, -1);   // index (in ops_host) of the OPF_LAST entry of a node finalised by this program
-  const bool lazy = !p->sched_persist;
-  const int np_flag = p->nuc ? OPF_NOPERSIST_NUC : OPF_NOPERSIST;
-  const int off = (int)p->ops_host.size();
-  int fin = 0, root_slot = 0;
-  for (size_t ti = 0; ti < nodes.size(); ti++) {
-    const int par = nodes[ti];
-    std::vector<int> ch_filtered;
-    if (par == p->emit_skip_par) {  // (re-rooted schedules: the given root no longer has the first node of rr_path below it)
-      for (int c : p->children[par])
-        if (c != p->emit_skip_child) ch_filtered.push_back(c);
-    }
-    const std::vector<int> &ch = par == p->emit_skip_par ? ch_filtered : p->children[par];
-    std::vector<int4> entries;
-    std::vector<int> release_after;
-    auto internal_entry = [&](int c) {
-      int4 op;
-      op.y = par;
-      op.z = c;
-      op.w = c - L;
-      // (4-state kernel: only parking slots are LDS; the node finalised last is still in registers)
-      const int sl = p->nuc ? (slot_of[c - L] >= 2 ? slot_of[c - L] : -1) : slot_of[c - L];
-      if (sl >= 0) {
-        op.x = OPK_INTERNAL | (sl << 24);
-        if (sl >= 2) release_after.push_back(sl);  // reusable only after this parent's barrier
-        slot_of[c - L] = -1;
-      } else {
-        op.x = OPK_INTERNAL_GLOBAL | (0xff << 24);
-        const bool inregs = p->nuc && ti > 0 && nodes[ti - 1] == c - L;  // (4-state kernel: child still in registers)
-        if (recomputed[c - L]) {
-          op.x |= OPF_GSYNC;
-          if (!inregs && last_entry[c - L] >= 0) p->ops_host[last_entry[c - L]].x &= ~np_flag;  // re-read below: must be stored
-        }
-        else if (handoff) op.x |= OPF_HANDOFF;  // root of a child fragment finished by another workgroup of this launch
-        if (inregs) op.x |= OPF_INREGS;
-      }
-      entries.push_back(op);
-    };
-    // order: [child finalised by the previous entry] -> leaves (grouped) -> other internal children
-    int first_internal = -1;
-    if (ti > 0)
-      for (int c : ch)
-        if (c >= L && c - L == nodes[ti - 1]) first_internal = c;
-    if (first_internal >= 0) internal_entry(first_internal);
-    std::vector<int> leaves;
-    for (int c : ch)
-      if (c < L) leaves.push_back(c);
-    // leaves in groups of G; a leaf that carries ambiguity codes (in this shard) forms a group of its own
-    // (its tiles may need a full matrix product instead of the column gather)
-    for (size_t k = 0; k < leaves.size();) {
-      int nl = 1;
-      const bool amb0 = p->leaf_has_ambig[leaves[k]];
-      if (!amb0 && G > 1 && k + 1 < leaves.size() && !p->leaf_has_ambig[leaves[k + 1]]) nl = 2;
-      const unsigned l0 = (unsigned)leaves[k], l1 = nl > 1 ? (unsigned)leaves[k + 1] : l0;
-      int4 op;
-      op.x = OPK_LEAF | (amb0 ? OPF_AMBIG : 0) | (nl << 8) | (0xff << 24);
-      op.y = par;
-      op.z = (int)(l0 | (l1 << 16));
-      op.w = 0;
-      entries.push_back(op);
-      k += nl;
-    }
-    for (int c : ch)
-      if (c >= L && c != first_internal) internal_entry(c);
-    // destination slot of the finished node
-    int dst = fin & 1;
-    const bool next_consumes = ti + 1 < nodes.size() && p->parents[L + par] == nodes[ti + 1];
-    {
-      if (!next_consumes && ti + 1 < nodes.size()) {
-        dst = -1;
-        for (int sidx = 2; sidx < n_slots; sidx++)
-          if (!slot_busy[sidx]) {
-            dst = sidx;
-            break;
-          }
-        if (dst >= 0) {
-          slot_busy[dst] = 1;
-          slot_of[par] = dst;
-        } else {
-          dst = fin & 1;  // no parking slot free: the consumer will re-read the persisted copy
-        }
-      } else {
-        slot_of[par] = dst;  // consumed by the very next parent from the exchange slot (or: last node)
-      }
-    }
-    entries.back().x |= OPF_LAST | ((fin & 1) ? OPF_PARITY : 0) | (dst << 16);
-    if (handoff && !is_root_program && ti + 1 == nodes.size()) entries.back().x |= OPF_PUBLISH;  // fragment root
-    // lazy persistence: skip the store of this node unless it is the root of a fragment (read by another
-    // program) — a later consumer through the persisted copy clears the flag again
-    if (lazy && (is_root_program || ti + 1 < nodes.size())) entries.back().x |= np_flag;
-    last_entry[par] = (int)p->ops_host.size() + (int)entries.size() - 1;
-    for (const int4 &e : entries) p->ops_host.push_back(e);
-    for (int sidx : release_after) slot_busy[sidx] = 0;
-    recomputed[par] = 1;
-    root_slot = dst;
-    fin++;
-  }
-  int4 nop;
-  nop.x = OPK_LEAF | (0xff << 24);
-  nop.y = 0;
-  nop.z = 0;
-  nop.w = 0;
-  if ((p->ops_host.size() - off) & 1) p->ops_host.push_back(nop);
-  *offset_out = off;
-  *n_out = (int)p->ops_host.size() - off;
-  p->ops_host.push_back(nop);
-  p->ops_host.push_back(nop);
-  return root_slot;
-}
-
-// Build the device schedule for the nodes the host marked dirty.  update_nodes comes from
-// DetermineNodesForUpdate (tree.cpp:3117-3331): dirty nodes, their ancestors and the direct
-// children of every touched internal node.  We recompute every internal node that is the parent
-// of a listed node (plus ancestors, defensively) from ALL its children; children whose
-// conditionals were not recomputed in this call are read back from the persisted device copy.
-//
-// Full evaluations are cut into LEVELS of independent subtree fragments ("forest scheduling"): the
-// fragments of one level run concurrently as separate workgroups (grid.z), levels are separate
-// launches, fragment roots are handed up through the persisted copy in HBM.  With one workgroup per
-// 16-pattern tile walking the whole tree, 10k codons give only 624 workgroups for 768 resident
-// slots (and 78 per GPU when sharded 8 ways): cutting the tree multiplies the workgroup count.
-void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, bool full) {
-  const int L = (int)p->L, I = (int)p->I;
-  std::vector<char> touched(I, 0);
-  if (full) {
-    std::fill(touched.begin(), touched.end(), 1);
-  } else {
-    for (int64_t k = 0; k < n_update; k++) {
-      int64_t n = update_nodes[k];
-      if (n < 0 || n >= L + I) continue;
-      int64_t par = p->parents[n];
-      while (par >= 0 && !touched[par]) {
-        touched[par] = 1;
-        par = p->parents[L + par];
-      }
-    }
-  }
-  p->ops_host.clear();
-  p->programs.clear();
-  p->levels.clear();
-  std::vector<int> touched_list;
-  for (int par = 0; par < I; par++)
-    if (touched[par]) touched_list.push_back(par);
-  if (touched_list.empty()) return;
-
-  // fragment size: aim at >= ~6 workgroups per CU over the whole launch sequence
-  int max_frag = I;
-  if (full && !p->nuc && !p->shards.empty()) {
-    const Shard &s0 = p->shards[0];
-    const long wgs = std::max(1, s0.ntiles / std::max(1, s0.T)) * (long)std::max<int64_t>(1, p->batch_classes);
-    const long target = 6L * s0.cus;
-    if (const char *e = getenv("HYPHY_HIP_FRAGMENT")) max_frag = std::max(1, atoi(e));
-    else if (wgs < target) max_frag = (int)std::max<long>(4, (long)I * wgs / target);
-  }
-  p->chain = false;
-  p->rr_active = false;
-  p->jn_host.clear();
-  // ---- chain schedules (wave-per-tile kernel, full passes) -------------------------------------------------
-  // Bottom subtrees of at most `m` internal nodes become SOURCE programs (walked serially by one wave, exactly like a
-  // fragment); every node above them is a TRUNK node, reached by chains: a wave that finishes node c computes the
-  // edge product towards the parent and arrives there, the last arriver finalises the parent and goes on (prune.hip).
-  // The critical path of a tile is then the height of the tree (not the size of its largest fragment), and the grid is
-  // dispatched source-major with the sources sorted by their distance to the root, so that every tile's critical path
-  // starts first and the short chains that join near the root fill the end of the launch (tools/flow_sim.py).
-  // (HYPHY_HIP_CUT=levels or an explicit HYPHY_HIP_FRAGMENT keep the level-peeled fragments; HYPHY_HIP_CHAIN_M sets m)
-  const bool want_levels = (getenv("HYPHY_HIP_CUT") && !strcmp(getenv("HYPHY_HIP_CUT"), "levels")) ||
-                           (getenv("HYPHY_HIP_FRAGMENT") && !getenv("HYPHY_HIP_CHAIN_M")) ||
-                           (p->chain_m_forced < 0 && !getenv("HYPHY_HIP_CHAIN_M"));
-  if (full && !p->nuc && p->variant >= 1 && !p->shards.empty() && !want_levels) {
-    const Shard &s0 = p->shards[0];
-    // Topology the schedule is built on: the given one, or (re-rooted schedules) the same unrooted tree hung from rr_path.back();
-    // the edges of rr_path are then reversed.  rpar = parent, order = children before parents, on_path = index along rr_path.
-    const bool lazy_full = !p->sched_persist;
-    const int rr_env = getenv("HYPHY_HIP_REROOT") ? atoi(getenv("HYPHY_HIP_REROOT")) : -1;  // (1: always, 0: never, unset: the tuner decides)
-    const bool rr = !p->rr_path.empty() && (rr_env == 1 || (rr_env != 0 && p->rr_use)) && lazy_full && p->pin_node < 0 &&
-                    p->batch_classes <= 1 && p->C == 1;
-    std::vector<int> rpar(I, -1), on_path(I, -1), order;
-    for (int n = 0; n < I - 1; n++) rpar[n] = (int)p->parents[L + n];
-    int root_idx = I - 1;
-    if (rr) {
-      const std::vector<int> &a = p->rr_path;
-      for (size_t i = 0; i + 1 < a.size(); i++) rpar[a[i]] = a[i + 1];
-      rpar[a.back()] = -1;
-      root_idx = a.back();
-      for (size_t i = 0; i < a.size(); i++) on_path[a[i]] = (int)i;
-    }
-    std::vector<int> size(I, 1), height(I, 1), to_root(I, 0);
-    std::vector<std::vector<int>> ich(I);
-    for (int n = 0; n < I; n++)
-      if (rpar[n] >= 0) ich[rpar[n]].push_back(n);
-    {
-      std::vector<std::pair<int, size_t>> stack(1, std::make_pair(root_idx, (size_t)0));
-      while (!stack.empty()) {
-        std::pair<int, size_t> &t = stack.back();
-        if (t.second < ich[t.first].size()) {
-          const int c = ich[t.first][t.second++];
-          stack.push_back(std::make_pair(c, (size_t)0));
-        } else {
-          order.push_back(t.first);
-          stack.pop_back();
-        }
-      }
-    }
-    for (int n : order)
-      for (int c : ich[n]) {
-        size[n] += size[c];
-        height[n] = std::max(height[n], height[c] + 1);
-      }
-    for (size_t k = order.size(); k-- > 0;)
-      if (rpar[order[k]] >= 0) to_root[order[k]] = to_root[rpar[order[k]]] + 1;
-    auto count_sources = [&](int m) {
-      int k = 0;
-      for (int n = 0; n < I; n++)
-        if (size[n] <= m && on_path[n] <= 0 && (rpar[n] < 0 || size[rpar[n]] > m || on_path[rpar[n]] > 0)) k++;
-      return k;
-    };
-    const long wgs = std::max(1, s0.ntiles) * (long)std::max<int64_t>(1, p->batch_classes);
-    const long target = 24L * s0.cus;  // >= 3 rounds of the 8 resident waves per CU
-    int m = 1;
-    if (const char *e = getenv("HYPHY_HIP_CHAIN_M")) m = std::max(1, atoi(e));
-    else if (p->chain_m_forced > 0) m = p->chain_m_forced;
-    else {
-      if (wgs >= target) m = I;  // enough tiles: one wave walks the whole tree
-      else
-        for (int t = 2; t <= 8; t++)
-          if ((long)count_sources(t) * wgs >= target) m = t;
-    }
-    if (m < I) {
-      struct Src { int root, prio; };
-      std::vector<Src> srcs;
-      std::vector<char> in_source(I, 0);
-      for (size_t k = order.size(); k-- > 0;) {  // parents before children; the nodes of rr_path above the given root stay trunk nodes
-        const int n = order[k], par = rpar[n];
-        if (par >= 0 && in_source[par]) in_source[n] = 1;
-        else if (size[n] <= m && on_path[n] <= 0) {  // (on_path == 0: the given root — a source like any other if it is small)
-          in_source[n] = 1;
-          srcs.push_back({n, to_root[n] + height[n]});
-        }
-      }
-      std::stable_sort(srcs.begin(), srcs.end(), [](const Src &x, const Src &y) { return x.prio > y.prio || (x.prio == y.prio && x.root < y.root); });
-      // Tiny sources next to the root would be dispatched last and, arriving last at their joins, carry the serial
-      // remainder of the trunk while the chip drains: dispatched FIRST they deposit and retire in a few microseconds,
-      // and the long chains that arrive later go on with the trunk (HYPHY_HIP_TINY_FIRST = largest source size moved up).
-      {
-        const int tiny = getenv("HYPHY_HIP_TINY_FIRST") ? atoi(getenv("HYPHY_HIP_TINY_FIRST")) : 0;
-        if (tiny > 0) std::stable_partition(srcs.begin(), srcs.end(), [&](const Src &x) { return size[x.root] <= tiny; });
-      }
-      p->jn_host.assign(I, make_int4(-1, 0, 0, 0));
-      for (const Src &sr : srcs) {
-        std::vector<int> nodes;  // the subtree below sr.root, ascending = post-order
-        std::vector<int> stack(1, sr.root);
-        while (!stack.empty()) {
-          const int n = stack.back();
-          stack.pop_back();
-          nodes.push_back(n);
-          for (int c : ich[n]) stack.push_back(c);
-        }
-        std::sort(nodes.begin(), nodes.end());
-        int off, n;
-        p->emit_skip_par = rr ? p->rr_path[0] : -1;
-        p->emit_skip_child = rr ? L + p->rr_path[1] : -1;
-        const int rs = emit_program(p, nodes, &off, &n, false, true);
-        p->emit_skip_par = p->emit_skip_child = -1;
-        hyphy_hip_partition::Prog pr{off, n};
-        pr.parent = sr.root == root_idx ? -1 : 0;
-        pr.need = sr.root;  // (chain schedules: w = the source's root node)
-        p->programs.push_back(pr);
-        if (sr.root == root_idx) p->root_slot = rs;
-      }
-      const bool lazy = !p->sched_persist;
-      for (int n = 0; n < I; n++) {
-        int sum = 0;
-        for (int c : ich[n]) sum += c;
-        // x: parent | image slot of the edge above n << 16: the node's own branch L + n, or — reversed edges of a re-rooted
-        // schedule — the transposed twin of the branch of the NEXT node on the path (expm.hip; slot behind the branch cache's)
-        const int slot = (rr && on_path[n] >= 0) ? (int)(p->B + (I + 2) + on_path[n]) : L + n;
-        int4 j = make_int4(rpar[n] < 0 ? -1 : (rpar[n] | (slot << 16)), (int)ich[n].size() | (sum << 8), 0, 0);
-        if (!in_source[n]) {  // trunk node: its leaf groups, one OPK_DEP entry per internal child, finalisation flags
-          j.z = (int)p->ops_host.size();
-          std::vector<int> leaves;
-          for (int c : p->children[n])
-            if (c < L) leaves.push_back(c);
-          for (size_t k = 0; k < leaves.size();) {
-            int nl = 1;
-            const bool amb0 = p->leaf_has_ambig[leaves[k]];
-            if (!amb0 && k + 1 < leaves.size() && !p->leaf_has_ambig[leaves[k + 1]]) nl = 2;
-            const unsigned l0 = (unsigned)leaves[k], l1 = nl > 1 ? (unsigned)leaves[k + 1] : l0;
-            p->ops_host.push_back(make_int4(OPK_LEAF | (amb0 ? OPF_AMBIG : 0) | (nl << 8) | (0xff << 24), n, (int)(l0 | (l1 << 16)), 0));
-            k += nl;
-          }
-          for (int c : ich[n]) p->ops_host.push_back(make_int4(OPK_DEP | (0xff << 24), n, L + c, c));
-          p->ops_host.back().x |= OPF_LAST | (lazy ? OPF_NOPERSIST : 0);
-          j.w = (int)p->ops_host.size() - j.z;
-        }
-        p->jn_host[n] = j;
-      }
-      p->ops_host.push_back(make_int4(OPK_LEAF | (0xff << 24), 0, 0, 0));  // (the interpreter reads one entry ahead)
-      p->levels.push_back({0, (int)p->programs.size()});
-      p->chain = true;
-      p->rr_active = rr;
-      if (getenv("HYPHY_HIP_VERBOSE")) {
-        fprintf(stderr, "[hyphy_hip] chain schedule: m = %d, %zu sources (root node / distance):", m, srcs.size());
-        for (const Src &sr : srcs) fprintf(stderr, " %d/%d", sr.root, sr.prio);
-        fprintf(stderr, "\n");
-      }
-      return;
-    }
-  }
-  if (max_frag >= I || !full) {  // one program (also: every partial update)
-    int off, n;
-    p->root_slot = emit_program(p, touched_list, &off, &n);
-    p->programs.push_back({off, n});
-    p->levels.push_back({0, 1});
-    return;
-  }
-  // peel levels: a level's fragments are the maximal subtrees (in what is left of the tree) with at
-  // most max_frag internal nodes; their roots become HBM-resident inputs of the next level.
-  // Wave-per-tile kernel: ONE launch; the fragments are chained on the device — the workgroup that
-  // completes the last child fragment of a program (per tile) goes on to run that program itself
-  // (arrival counters, prune.hip), so the levels below only define the cut, not launches.
-  const bool chained = p->variant >= 1;
-  std::vector<int> prog_of(I, -1);
-  std::vector<char> done(I, 0);
-  std::vector<int> size(I, 0);
-  for (;;) {
-    for (int n = 0; n < I; n++) {  // post-order: children before parents
-      if (done[n]) { size[n] = 0; continue; }
-      int sz = 1;
-      for (int c : p->children[n])
-        if (c >= L) sz += size[c - L];
-      size[n] = sz;
-    }
-    const int root = I - 1;
-    const int first_prog = (int)p->programs.size();
-    std::vector<std::vector<int>> frags;
-    if (size[root] <= max_frag) {
-      std::vector<int> rest;
-      for (int n = 0; n < I; n++)
-        if (!done[n]) rest.push_back(n);
-      frags.push_back(rest);
-    } else {
-      // fragment roots: size <= max_frag while the parent's is larger
-      std::vector<int> frag_root(I, -1);
-      for (int n = I - 1; n >= 0; n--) {  // parents before children
-        if (done[n]) continue;
-        const int par = (int)p->parents[L + n];
-        if (par >= 0 && !done[par] && frag_root[par] >= 0) frag_root[n] = frag_root[par];
-        else if (size[n] <= max_frag) frag_root[n] = n;
-      }
-      std::vector<int> index(I, -1);
-      for (int n = 0; n < I; n++) {
-        if (done[n] || frag_root[n] < 0) continue;
-        if (index[frag_root[n]] < 0) {
-          index[frag_root[n]] = (int)frags.size();
-          frags.push_back(std::vector<int>());
-        }
-        frags[index[frag_root[n]]].push_back(n);
-      }
-    }
-    // longest fragments first: the grid is dispatched in program order within a tile, and a tile's chained
-    // parent program can only start after its slowest child
-    if (chained)
-      std::stable_sort(frags.begin(), frags.end(),
-                       [](const std::vector<int> &x, const std::vector<int> &y) { return x.size() > y.size(); });
-    bool finished = false;
-    for (const std::vector<int> &f : frags) {
-      int off, n;
-      const int rs = emit_program(p, f, &off, &n, chained, f.back() == root);
-      p->programs.push_back({off, n});
-      for (int nd : f) prog_of[nd] = (int)p->programs.size() - 1;
-      for (int nd : f) done[nd] = 1;
-      if (f.back() == root) {
-        p->root_slot = rs;
-        finished = true;
-      }
-    }
-    p->levels.push_back({first_prog, (int)frags.size()});
-    if (getenv("HYPHY_HIP_VERBOSE")) {
-      fprintf(stderr, "[hyphy_hip] level %zu: %zu fragment(s), internal nodes:", p->levels.size() - 1, frags.size());
-      for (const std::vector<int> &f : frags) fprintf(stderr, " %zu", f.size());
-      fprintf(stderr, "\n");
-    }
-    if (finished) break;
-  }
-  if (chained) {
-    for (size_t k = 0; k < p->programs.size(); k++) {
-      // the fragment root is the parent (y) of the last OPF_LAST entry of the program
-      int froot = -1;
-      for (int e = 0; e < p->programs[k].n; e++) {
-        const int4 &op = p->ops_host[p->programs[k].off + e];
-        if (op.x & OPF_LAST) froot = op.y;
-      }
-      const int par_node = froot >= 0 ? (int)p->parents[L + froot] : -1;
-      if (par_node >= 0) {
-        p->programs[k].parent = prog_of[par_node];
-        p->programs[p->programs[k].parent].need++;
-      }
-    }
-    const auto l0 = p->levels[0];
-    p->levels.clear();
-    p->levels.push_back(l0);  // one launch: grid.z = the leaf fragments; the rest is reached by chaining
-  }
-}
-
-// Rescaling tests only where they are needed (wave-per-tile kernel, full passes).  A rescale multiplies by an exact power
-// of 2^64, so WHERE a node is tested does not change any mantissa — only underflow has to be excluded.  A node whose
-// internal children were all tested (their per-pattern sums are >= 2^-64 after the test) and that has at most four children
-// cannot fall below 2^-256 times the spread of a conditional vector, hundreds of binary orders above the denormals: its
-// own test is skipped (OPF_NOSCALE) and its parent tests again.  The root is always tested.  Saves the cross-lane sum,
-// the ballot and their latency in front of the next product at every other level (HYPHY_HIP_SCALE_THIN=0: test everywhere).
-void thin_rescale_tests(hyphy_hip_partition *p) {
-  static const bool on = !(getenv("HYPHY_HIP_SCALE_THIN") && atoi(getenv("HYPHY_HIP_SCALE_THIN")) == 0);
-  if (!on) return;
-  const int L = (int)p->L, I = (int)p->I;
-  std::vector<char> tested(I, 1);
-  for (int n = 0; n < I; n++) {  // children before parents
-    bool kids_tested = true;
-    for (int c : p->children[n])
-      if (c >= L && !tested[c - L]) kids_tested = false;
-    tested[n] = (n == I - 1 || !kids_tested || p->children[n].size() > 4 || n == p->pin_node - L) ? 1 : 0;
-  }
-  if (p->rr_active)  // (re-rooted schedule: the nodes whose children differ from the given topology — and the new root — always test)
-    for (int n : p->rr_path) tested[n] = 1;
-  for (int4 &op : p->ops_host)
-    if ((op.x & OPF_LAST) && op.y >= 0 && op.y < I && !tested[op.y]) op.x |= OPF_NOSCALE;
-}
-
-void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, bool full) {
-  build_schedule_impl(p, update_nodes, n_update, full);
-  if (full && !p->nuc && p->variant == 1 && !p->shards.empty() && p->shards[0].T == 1) thin_rescale_tests(p);
 }
 
 int upload_small(Shard &s, const double *src, size_t n, double *dst) {
@@ -764,10 +63,11 @@ double next_seq(Shard &s, bool host_record) {
   return s.seq_wait;
 }
 
+}  // namespace
+
 // Twin images of re-rooted schedules (ExpmArgs::n_twin): slot of twin j relative to the class base, and the refresh by the
 // branch cache's transpose kernel for the cases the exponential kernel did not cover (a writer other than the fused path,
 // new root frequencies without a new matrix).
-inline int twin_slot0(const hyphy_hip_partition *p) { return (int)(p->B + (p->I + 2)); }
 void refresh_twins(hyphy_hip_partition *p, Shard &s) {
   if (p->rr_path.empty() || p->nuc) return;
   const size_t DD = (size_t)p->DP * p->DP;
@@ -833,17 +133,8 @@ PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
   return pa;
 }
 
-// "use the shard's own Q buffer" (filled / staged by hyphy_hip_build_q on every shard)
-const double kOwnQBuffer = 0.;
+namespace {
 
-// branch-site mixture: matrix k of the evaluation is sum_m weights[off_k + m] exp(q[off_k + m]), count[k] components
-struct MixSpec {
-  const int64_t *count;
-  const double *weights;
-  int64_t n_tot;
-};
-
-// Enqueue everything for one rate class on one shard.  q may be a host or device pointer.
 int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, bool sched_changed, bool pi_changed,
                  bool slots_changed, const int64_t *q_nodes, int64_t n_q,
                  const double *q, bool q_on_device, int q_is_prob, const double *root_freqs, double *d_logl_out,
@@ -966,7 +257,9 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     ea.prof = getenv("HYPHY_HIP_EXPM_PROF") ? 1 : 0;
     if (q_from_templates) {  // fused build: coefficients were staged by hyphy_hip_build_q
       ea.templates = s.templates;
+      ea.templates_pad = s.templates_pad;
       ea.coeffs = s.coeffs_cur ? s.coeffs_cur : s.coeffs;
+      ea.coeffs_host = (s.coeffs_cur && s.d_hcoeffs) ? s.h_coeffs + (s.coeffs_cur - s.d_hcoeffs) : nullptr;
       ea.K = (int)p->K;
     }
     if (p->nuc) {
@@ -1150,6 +443,8 @@ int prepare_schedule(hyphy_hip_partition *p, int cat, const int64_t *update_node
   return 0;
 }
 
+}  // namespace
+
 // Wait for every shard and read its host-mapped result record [log-L, scaler sum, status].
 int collect_status(hyphy_hip_partition *p) {
   static const bool expm_prof = getenv("HYPHY_HIP_EXPM_PROF") != nullptr;
@@ -1223,96 +518,7 @@ double combine(const std::vector<double> &parts) {
   return sum + corr;
 }
 
-inline int64_t caller_pattern(const hyphy_hip_partition *p, int64_t j) { return p->perm.empty() ? j : p->perm[j]; }
-
-// Pattern order on the device.  A leaf edge is a per-site column gather from the leaf branch's matrix (prune.hip: leaf_gather),
-// and the texture-address path coalesces the lanes of a quad that read the same cache lines: 16 sites with 16 different
-// states cost 4 000 cycles per gather under load, sites that share their state in runs of >= 4 cost 1 070
-// (tools/ubench/glds_probe.hip).  Patterns are therefore kept sorted — by their most frequent state first (conserved sites
-// of the same codon become neighbours), then lexicographically by leaf — which takes the distinct states per (leaf, tile)
-// from 14.2 to 3.9 on the headline alignment.  The order is internal: every per-pattern input and output of the C-ABI is
-// translated through `perm` (gather_sites, download_partials, set_pinned_states, site fits).
-// The internal node that minimises the tree's height (edges to the farthest leaf) when the tree is hung from it, and the path
-// to it from the given root (rr_path, see hyphy_hip_partition).  Topology only; ties keep the given root.
-void reroot_path(hyphy_hip_partition *p) {
-  const int L = (int)p->L, I = (int)p->I, N = L + I;
-  p->rr_path.clear();
-  p->rr_cands.clear();
-  if (I < 4) return;
-  std::vector<std::vector<int>> adj(N);
-  for (int n = 0; n < N - 1; n++) {
-    const int par = L + (int)p->parents[n];
-    adj[n].push_back(par);
-    adj[par].push_back(n);
-  }
-  // distances (in edges) from `r` to every node, BFS parents in `from`; returns the farthest LEAF
-  auto sweep = [&](int r, std::vector<int> &dist, std::vector<int> &from) {
-    dist.assign(N, -1);
-    from.assign(N, -1);
-    std::vector<int> queue(1, r);
-    dist[r] = 0;
-    int far = -1;
-    for (size_t h = 0; h < queue.size(); h++) {
-      const int n = queue[h];
-      if (n < L && (far < 0 || dist[n] > dist[far])) far = n;
-      for (int m : adj[n])
-        if (dist[m] < 0) {
-          dist[m] = dist[n] + 1;
-          from[m] = n;
-          queue.push_back(m);
-        }
-    }
-    return far;
-  };
-  // The nodes of least eccentricity over the leaves are the middle of a longest leaf-to-leaf path (two sweeps).
-  const int root = N - 1;
-  std::vector<int> d0, f0, du, fu;
-  const int u = sweep(root, d0, f0);
-  const int root_height = d0[u];
-  const int v = sweep(u, du, fu);
-  const int D = du[v];
-  (void)root_height;  // (a given root that is itself a centre node keeps the other centre node as a candidate: the tuner times both)
-  std::vector<int> mids;
-  for (int n = v; n != u; n = fu[n])  // walk v -> u: the one or two middle nodes
-    if ((du[n] == D / 2 || du[n] == (D + 1) / 2) && n >= L && n != root) mids.push_back(n);
-  std::sort(mids.begin(), mids.end(), [&](int x, int y) { return d0[x] < d0[y]; });  // closest to the given root first
-  p->rr_cands.clear();
-  for (int best : mids) {
-    std::vector<int> up;  // best -> ... -> root
-    for (int n = best; n != root; n = L + (int)p->parents[n]) up.push_back(n - L);
-    up.push_back(I - 1);
-    if ((int)up.size() - 1 > kMaxTwin) continue;
-    p->rr_cands.push_back(std::vector<int>(up.rbegin(), up.rend()));
-  }
-  if (!p->rr_cands.empty()) p->rr_path = p->rr_cands[0];
-}
-
-void sort_patterns(hyphy_hip_partition *p, const int64_t *leaf_codes, int64_t L, int64_t S) {
-  if (S < 32) return;
-  std::vector<int64_t> major(S, 0);
-  {
-    std::vector<int> cnt;
-    for (int64_t k = 0; k < S; k++) {
-      cnt.assign((size_t)p->D, 0);
-      int best = 0;
-      for (int64_t l = 0; l < L; l++) {
-        const int64_t c = leaf_codes[l * S + k];
-        if (c >= 0 && c < p->D && ++cnt[(size_t)c] > cnt[(size_t)best]) best = (int)c;
-      }
-      major[k] = best;
-    }
-  }
-  p->perm.resize(S);
-  for (int64_t k = 0; k < S; k++) p->perm[k] = k;
-  std::sort(p->perm.begin(), p->perm.end(), [&](int64_t a, int64_t b) {
-    if (major[a] != major[b]) return major[a] < major[b];
-    for (int64_t l = 0; l < L; l++) {
-      const int64_t ca = leaf_codes[l * S + a], cb = leaf_codes[l * S + b];
-      if (ca != cb) return ca < cb;
-    }
-    return a < b;
-  });
-}
+namespace {
 
 int gather_sites(hyphy_hip_partition *p, int cat, double *site_lik_out, int64_t *site_scaler_out, bool mixed) {
   for (Shard &s : p->shards) {
@@ -1341,6 +547,8 @@ int gather_sites(hyphy_hip_partition *p, int cat, double *site_lik_out, int64_t 
 }
 
 }  // namespace
+
+}  // namespace hyhip
 
 extern "C" {
 
@@ -1631,206 +839,14 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
   return 0;
 }
 
-// Upload the current schedule to one shard and launch its pruning kernel(s) (no expm, no reduction): the body of an
-// evaluation's pruning step, shared with the schedule tuner.
-static int upload_schedule(hyphy_hip_partition *p, Shard &s) {
-  HIPCHK(hipSetDevice(s.device));
-  HIPCHK(hipStreamSynchronize(s.stream));
-  if (p->ops_host.empty()) return 0;
-  memcpy(s.h_ops, p->ops_host.data(), p->ops_host.size() * sizeof(int4));
-  HIPCHK(hipMemcpyAsync(s.ops, s.h_ops, p->ops_host.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
-  for (size_t k = 0; k < p->programs.size(); k++)
-    s.h_prog[k] = make_int4(p->programs[k].off, p->programs[k].n, p->programs[k].parent, p->programs[k].need);
-  HIPCHK(hipMemcpyAsync(s.prog, s.h_prog, p->programs.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
-  if (p->chain) {
-    memcpy(s.h_jn, p->jn_host.data(), p->jn_host.size() * sizeof(int4));
-    HIPCHK(hipMemcpyAsync(s.jn, s.h_jn, p->jn_host.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
-    if (!s.deposits) {
-      const size_t bytes = (size_t)p->C * s.partial_stride * sizeof(double);
-      HIPCHK(hipMalloc((void **)&s.deposits, bytes));
-      if (getenv("HYPHY_HIP_POISON")) {
-        HIPCHK(hipMemset(s.deposits, 0xff, bytes));
-        HIPCHK(hipDeviceSynchronize());
-      }
-    }
-  }
-  return 0;
-}
+}  // extern "C"
 
-static void launch_prune_current(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch) {
-  if (p->rr_active && p->chain && s.twins_dirty) refresh_twins(p, s);
-  PruneArgs pa = base_prune_args(p, s, cat, n_cat_batch);
-  int n_ops = 0;
-  for (const auto &pr : p->programs) n_ops = std::max(n_ops, pr.n);
-  pa.ops = s.ops;
-  pa.n_ops = n_ops;
-  pa.n_prog_total = p->chain ? (int)p->I : (int)p->programs.size();
-  pa.chain = p->chain ? 1 : 0;
-  pa.jn = s.jn;
-  pa.deposits = s.deposits;
-  if (const char *ab = getenv("HYPHY_HIP_ABLATE")) pa.ablate = atoi(ab);
-  for (size_t lv = 0; lv < p->levels.size(); lv++) {
-    pa.prog = s.prog + p->levels[lv].first;
-    pa.n_prog = p->levels[lv].count;
-    pa.do_root = (lv + 1 == p->levels.size()) ? 1 : 0;
-    launch_prune_mfma(pa, s.stream);
-  }
-}
+namespace hyhip {
 
-// Schedule tuner.  How a full pass is best cut (level-peeled fragments, or chains with sources of at most m nodes)
-// depends on the tree's shape, the shard size and the number of classes in the launch; the pruning pass is idempotent,
-// so on the first steady-state full pass (lazy persistence: nothing but the root is stored) the library simply runs
-// the pass under each candidate cut on the resident transition matrices, times it with an event pair and keeps the
-// fastest (a few milliseconds, once per partition and class-batch mode).  HYPHY_HIP_TUNE=0 or any explicit cut
-// (HYPHY_HIP_CHAIN_M / HYPHY_HIP_CUT / HYPHY_HIP_FRAGMENT) disables it.
-static int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
-  p->tuned_for = p->batch_classes;
-  const int I = (int)p->I;
-  Shard &s = p->shards[0];
-  std::vector<int> cand = {-1};
-  for (int m : {3, 5, 8, 12, 16, 24, 40, 64})
-    if (m < I) cand.push_back(m);
-  const int T0 = s.T;
-  if (!p->kernel_forced && T0 == 1 && s.ntiles < 2 * s.cus) cand.push_back(-2);  // the row-split workgroup kernel (small shards)
-  auto set_kernel = [&](int v) {
-    p->variant = v;
-    p->n_slots = v >= 1 ? p->n_slots_wave : lds_slots(T0);
-  };
-  double best_ms = 1e30;
-  int best = 0;
-  char buf[64];
-  std::vector<std::pair<double, int>> ranked;  // (time, chain cut) of the first stage
-  p->tune_report.clear();
-  for (int c : cand) {
-    p->chain_m_forced = c == -2 ? 0 : c;
-    set_kernel(c == -2 ? 0 : 1);
-    build_schedule(p, nullptr, 0, true);
-    if (p->ops_host.size() > ops_capacity(p)) continue;
-    if (c > 0 && !p->chain) continue;  // (m >= I: the same as no cut)
-    if (upload_schedule(p, s)) return -1;
-    float ms = 0.f, ms2 = 0.f;
-    launch_prune_current(p, s, cat, n_cat_batch);  // warm-up (instruction cache, schedule in L2)
-    HIPCHK(hipEventRecord(s.ev[0], s.stream));
-    launch_prune_current(p, s, cat, n_cat_batch);
-    HIPCHK(hipEventRecord(s.ev[1], s.stream));
-    launch_prune_current(p, s, cat, n_cat_batch);
-    HIPCHK(hipEventRecord(s.ev[2], s.stream));
-    HIPCHK(hipStreamSynchronize(s.stream));
-    HIPCHK(hipGetLastError());
-    if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) != hipSuccess || hipEventElapsedTime(&ms2, s.ev[1], s.ev[2]) != hipSuccess) continue;
-    ms = std::min(ms, ms2);
-    snprintf(buf, sizeof buf, "%s%s%d:%.1fus", p->tune_report.empty() ? "" : " ", c == -2 ? "wg-kernel" : (c < 0 ? "levels" : "m"), c < 0 ? 0 : c, 1e3 * ms);
-    p->tune_report += buf;
-    if (c > 0) ranked.push_back(std::make_pair((double)ms, c));
-    if (ms < best_ms) {
-      best_ms = ms;
-      best = c;
-    }
-  }
-  // second stage: the instantiation compiled for 3 waves per SIMD (finalised node in LDS, no parking slot, no register
-  // prefetch of deposits) around the best cut — it wins where waves are plentiful (128 taxa x 100k codons: +7 %)
-  int best_wv = 0;
-  const double stage1_ms = best_ms;
-  p->wave_variant = 0;
-  if (best > 0 && p->NW == 4 && !getenv("HYPHY_HIP_WAVE_VARIANT") && !getenv("HYPHY_HIP_SLOTS")) {
-    std::vector<int> ms;  // the three fastest cuts of the first stage
-    std::sort(ranked.begin(), ranked.end());
-    for (size_t k = 0; k < ranked.size() && k < 3; k++) ms.push_back(ranked[k].second);
-    for (int m : ms) {
-      p->chain_m_forced = m;
-      p->variant = 1;
-      p->n_slots = 2;
-      p->wave_variant = 2;
-      build_schedule(p, nullptr, 0, true);
-      if (p->ops_host.size() > ops_capacity(p) || !p->chain) continue;
-      if (upload_schedule(p, s)) return -1;
-      float ms1 = 0.f, ms2 = 0.f;
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[0], s.stream));
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[1], s.stream));
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[2], s.stream));
-      HIPCHK(hipStreamSynchronize(s.stream));
-      HIPCHK(hipGetLastError());
-      if (hipEventElapsedTime(&ms1, s.ev[0], s.ev[1]) != hipSuccess || hipEventElapsedTime(&ms2, s.ev[1], s.ev[2]) != hipSuccess) continue;
-      ms1 = std::min(ms1, ms2);
-      snprintf(buf, sizeof buf, " occ3/m%d:%.1fus", m, 1e3 * ms1);
-      p->tune_report += buf;
-      // (2 % margin over the first stage: at equal tuner times the production pass of the 2-waves build is the faster one)
-      if (ms1 < 0.98 * stage1_ms && ms1 < best_ms) {
-        best_ms = ms1;
-        best = m;
-        best_wv = 2;
-      }
-    }
-  }
-  // third stage: the same tree hung from the node that minimises its height (re-rooted schedules, hyphy_hip_partition::rr_path):
-  // shorter critical path per tile, the same work — wins on small and medium shards of unbalanced trees
-  bool best_rr = false;
-  p->rr_use = false;
-  if (best > 0 && !p->rr_path.empty() && n_cat_batch <= 1 && !getenv("HYPHY_HIP_REROOT")) {
-    std::vector<int> ms;
-    std::sort(ranked.begin(), ranked.end());
-    for (size_t k = 0; k < ranked.size() && k < 3; k++) ms.push_back(ranked[k].second);
-    size_t best_cand = 0;
-    for (size_t ci = 0; ci < p->rr_cands.size(); ci++)
-    for (int m : ms) {
-      if (p->rr_path != p->rr_cands[ci]) {
-        p->rr_path = p->rr_cands[ci];
-        for (Shard &sh : p->shards) sh.twins_dirty = true;  // (other twins: refreshed by the transpose kernel before the launch)
-      }
-      p->chain_m_forced = m;
-      p->variant = 1;
-      p->wave_variant = best_wv;
-      p->n_slots = best_wv == 2 ? 2 : p->n_slots_wave;
-      p->rr_use = true;
-      build_schedule(p, nullptr, 0, true);
-      p->rr_use = false;
-      if (p->ops_host.size() > ops_capacity(p) || !p->chain || !p->rr_active) continue;
-      if (upload_schedule(p, s)) return -1;
-      float ms1 = 0.f, ms2 = 0.f;
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[0], s.stream));
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[1], s.stream));
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[2], s.stream));
-      HIPCHK(hipStreamSynchronize(s.stream));
-      HIPCHK(hipGetLastError());
-      if (hipEventElapsedTime(&ms1, s.ev[0], s.ev[1]) != hipSuccess || hipEventElapsedTime(&ms2, s.ev[1], s.ev[2]) != hipSuccess) continue;
-      ms1 = std::min(ms1, ms2);
-      snprintf(buf, sizeof buf, " rr%zu/m%d:%.1fus", ci, m, 1e3 * ms1);
-      p->tune_report += buf;
-      // (5 % margin against the given root: the tuner's pass ranked a re-rooted form of the headline tree 4.5 % ahead that was
-      // 1 % behind in production)
-      if (ms1 < (best_rr ? 1.0 : 0.95) * best_ms) {
-        best_ms = ms1;
-        best = m;
-        best_rr = true;
-        best_cand = ci;
-      }
-    }
-    if (p->rr_path != p->rr_cands[best_cand]) {
-      p->rr_path = p->rr_cands[best_cand];
-      for (Shard &sh : p->shards) sh.twins_dirty = true;
-    }
-  }
-  p->rr_use = best_rr;
-  p->wave_variant = best_wv;
-  p->chain_m_forced = best == -2 ? 0 : best;
-  set_kernel(best == -2 ? 0 : 1);
-  if (best_wv == 2) p->n_slots = 2;
-  snprintf(buf, sizeof buf, " -> %s%s%s%d", best_rr ? "rr/" : "", best_wv == 2 ? "occ3/" : "", best == -2 ? "wg-kernel" : (best < 0 ? "levels" : "m"), best < 0 ? 0 : best);
-  p->tune_report += buf;
-  if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] schedule tuner (%d classes per launch): %s\n", n_cat_batch, p->tune_report.c_str());
-  return 0;
-}
-
-static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                        const int64_t *q_nodes, int64_t n_q, const double *q, bool q_on_device, int q_is_probability,
-                       const double *root_freqs, double *d_logl_out, bool reduce, bool floor_log, bool batch = false,
-                       bool force_persist = false, const MixSpec *mix = nullptr) {
+                       const double *root_freqs, double *d_logl_out, bool reduce, bool floor_log, bool batch,
+                       bool force_persist, const MixSpec *mix) {
   if (!p) return fail("partition == NULL");
   if (cat < 0) cat = 0;
   if (cat >= p->C) return fail("rate class out of range");
@@ -1912,6 +928,10 @@ static int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   return 0;  // (coefficients staged by hyphy_hip_build_q stay valid — and pending — until the next hyphy_hip_build_q)
 }
 
+}  // namespace hyhip
+
+extern "C" {
+
 int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                        const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
                        const double *root_freqs, double *logl_out, double *site_lik_out, int64_t *site_scaler_out) {
@@ -1972,95 +992,6 @@ int hyphy_hip_evaluate_mixture(hyphy_hip_partition *p, int64_t cat, const int64_
   record_timings(p);
   if (logl_out) *logl_out = combine(parts);
   if (site_lik_out || site_scaler_out) return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
-  return 0;
-}
-
-/* ---- the all-reduce of the partition log-likelihood, over RCCL / xGMI, where a C++ host can reach it -------------------
- * One process per GPU (HYPHYMPI-style hosts, `torchrun`-style launchers): rank 0 makes a 128-byte id
- * (hyphy_hip_comm_unique_id), every rank receives it by whatever channel the host has (MPI_Bcast, a file) and calls
- * hyphy_hip_comm_init_rank on its partition (which holds ITS shard of the patterns); hyphy_hip_evaluate_allreduce is then
- * hyphy_hip_evaluate + ONE ncclAllReduce of one double per evaluation, enqueued on the partition's stream between the
- * reduction kernel and the read-back: every rank returns the log-likelihood of the whole alignment. */
-int hyphy_hip_comm_unique_id(void *out128) {
-  if (!out128) return fail("null id buffer");
-  if (rccl_load()) return -1;
-  RCCLCHK(g_rccl.GetUniqueId(out128));
-  return 0;
-}
-
-int hyphy_hip_comm_init_rank(hyphy_hip_partition *p, const void *unique_id, int rank, int n_ranks) {
-  if (!p || !unique_id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail("comm_init_rank: bad arguments");
-  if (p->shards.size() != 1) return fail("comm_init_rank: one device per rank (device_count = 1)");
-  if (rccl_load()) return -1;
-  Shard &s = p->shards[0];
-  HIPCHK(hipSetDevice(s.device));
-  if (s.comm) {
-    g_rccl.CommDestroy(s.comm);
-    s.comm = nullptr;
-  }
-  RcclUniqueId id;
-  memcpy(id.internal, unique_id, sizeof id.internal);
-  RCCLCHK(g_rccl_init_rank(&s.comm, n_ranks, id, rank));
-  if (!s.ar_buf) HIPCHK(hipMalloc((void **)&s.ar_buf, 2 * sizeof(double)));
-  return 0;
-}
-
-/* In-place sum of one device double over the partition's communicator, on the partition's stream (asynchronous). */
-int hyphy_hip_allreduce_device(hyphy_hip_partition *p, double *d_value) {
-  if (!p || !d_value) return fail("allreduce: null argument");
-  if (p->shards.size() != 1 || !p->shards[0].comm) return fail("allreduce: hyphy_hip_comm_init_rank first");
-  Shard &s = p->shards[0];
-  HIPCHK(hipSetDevice(s.device));
-  RCCLCHK(g_rccl.AllReduce(d_value, d_value, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
-  return 0;
-}
-
-int hyphy_hip_evaluate_allreduce(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
-                                 const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
-                                 const double *root_freqs, double *logl_out) {
-  if (!p) return fail("partition == NULL");
-  if (p->shards.size() != 1 || !p->shards[0].comm) return fail("evaluate_allreduce: hyphy_hip_comm_init_rank first");
-  Shard &s = p->shards[0];
-  // partial log-L of this rank's patterns into a device scalar, summed over the ranks in-stream, one double back
-  if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, q_dense, false, q_is_probability, root_freqs, s.ar_buf, true, false))
-    return -1;
-  RCCLCHK(g_rccl.AllReduce(s.ar_buf, s.ar_buf, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
-  double host[2] = {0., 0.};
-  HIPCHK(hipMemcpyAsync(host, s.ar_buf, sizeof(double), hipMemcpyDeviceToHost, s.stream));
-  HIPCHK(hipStreamSynchronize(s.stream));
-  s.seq_wait = 0.;
-  int32_t st = 0;
-  HIPCHK(hipMemcpy(&st, s.status, sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (st) {
-    hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream);
-    return fail("Failed to compute a valid transition matrix; this is usually caused by ill-conditioned rate matrices "
-                "(e.g. very large rate values)");
-  }
-  if (logl_out) *logl_out = host[0];
-  return 0;
-}
-
-/* Single-process hosts with device_count > 1 (HyPhy proper): by default the shard partials come back over PCIe and are
- * summed on the host with the reference's Neumaier combine; HYPHY_HIP_COMBINE=rccl (or this call) makes one RCCL group
- * all-reduce of it instead — SURVEY 5 asks for both to be measurable. */
-int hyphy_hip_comm_init_all(hyphy_hip_partition *p) {
-  if (!p) return fail("partition == NULL");
-  if (rccl_load()) return -1;
-  const int n = (int)p->shards.size();
-  std::vector<int> devs(n);
-  std::vector<void *> comms(n, nullptr);
-  for (int k = 0; k < n; k++) devs[k] = p->shards[k].device;
-  for (int k = 0; k < n; k++)
-    for (int j = 0; j < k; j++)
-      if (devs[k] == devs[j]) return fail("comm_init_all: RCCL needs one distinct device per shard");
-  RCCLCHK(g_rccl.CommInitAll(comms.data(), n, devs.data()));
-  for (int k = 0; k < n; k++) {
-    Shard &s = p->shards[k];
-    HIPCHK(hipSetDevice(s.device));
-    if (s.comm) g_rccl.CommDestroy(s.comm);
-    s.comm = comms[k];
-    if (!s.ar_buf) HIPCHK(hipMalloc((void **)&s.ar_buf, 2 * sizeof(double)));
-  }
   return 0;
 }
 
@@ -2564,6 +1495,16 @@ int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_
   return 0;
 }
 
+// [K][64*64] copies of the templates for expm64_kernel: zero padding, zero diagonals (the kernel derives Q_ii itself)
+static std::vector<double> padded_templates(const double *templates, int64_t K, int64_t D) {
+  std::vector<double> pad((size_t)K * 64 * 64, 0.0);
+  for (int64_t k = 0; k < K; k++)
+    for (int64_t r = 0; r < D; r++)
+      for (int64_t c = 0; c < D; c++)
+        if (r != c) pad[((size_t)k * 64 + r) * 64 + c] = templates[((size_t)k * D + r) * D + c];
+  return pad;
+}
+
 int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *templates) {
   if (!p || K < 1 || !templates) return fail("invalid templates");
   const int64_t D = p->D;
@@ -2587,6 +1528,13 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
       if (!s.coeff_ev[k]) HIPCHK(hipEventCreateWithFlags(&s.coeff_ev[k], hipEventDisableTiming));
     }
     HIPCHK(hipMemcpy(s.templates, templates, (size_t)K * D * D * sizeof(double), hipMemcpyHostToDevice));
+    if (s.templates_pad) hipFree(s.templates_pad);
+    s.templates_pad = nullptr;
+    if (p->DP == 64) {
+      HIPCHK(hipMalloc((void **)&s.templates_pad, (size_t)K * 64 * 64 * sizeof(double)));
+      const std::vector<double> pad = padded_templates(templates, K, D);
+      HIPCHK(hipMemcpy(s.templates_pad, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
   }
   p->K = K;
   p->templates_host.assign(templates, templates + (size_t)K * D * D);
@@ -2610,6 +1558,11 @@ int hyphy_hip_update_q_templates(hyphy_hip_partition *p, int64_t K, const double
     //  wait on the stream keeps it simple: the previous evaluation has been collected by the time a host adapter gets here)
     HIPCHK(hipStreamSynchronize(s.stream));
     HIPCHK(hipMemcpyAsync(s.templates, p->templates_host.data(), n * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    if (s.templates_pad) {
+      const std::vector<double> pad = padded_templates(templates, K, D);
+      HIPCHK(hipMemcpyAsync(s.templates_pad, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice, s.stream));
+      HIPCHK(hipStreamSynchronize(s.stream));  // (pageable source that goes out of scope)
+    }
     s.fit_static_current = false;
   }
   return 0;
@@ -2921,44 +1874,6 @@ int hyphy_hip_set_stream(hyphy_hip_partition *p, void *stream) {
 }
 
 void *hyphy_hip_stream(hyphy_hip_partition *p) { return p && !p->shards.empty() ? (void *)p->shards[0].stream : nullptr; }
-
-/* Host-only planning helpers (no device needed): what hyphy_hip_create decides from the topology and the leaf table alone. */
-int64_t hyphy_hip_plan_reroot(int64_t L, int64_t I, const int64_t *flat_parents, int64_t candidate, int64_t *path_out, int64_t cap) {
-  if (L < 2 || I < 1 || !flat_parents) return -1;
-  hyphy_hip_partition tmp;
-  tmp.L = L;
-  tmp.I = I;
-  tmp.parents.assign(flat_parents, flat_parents + L + I);
-  for (int64_t n = 0; n < L + I - 1; n++)
-    if (flat_parents[n] < 0 || flat_parents[n] >= I) return -1;
-  reroot_path(&tmp);
-  if (candidate < 0 || candidate >= (int64_t)tmp.rr_cands.size()) return 0;
-  const std::vector<int> &path = tmp.rr_cands[(size_t)candidate];
-  for (size_t k = 0; k < path.size() && (int64_t)k < cap; k++)
-    if (path_out) path_out[k] = path[k];
-  return (int64_t)path.size();
-}
-
-int hyphy_hip_plan_pattern_order(int64_t D, int64_t L, int64_t S, const int64_t *leaf_codes, int64_t *order_out) {
-  if (D < 2 || L < 1 || S < 1 || !leaf_codes || !order_out) return -1;
-  hyphy_hip_partition tmp;
-  tmp.D = D;
-  tmp.L = L;
-  tmp.S = S;
-  sort_patterns(&tmp, leaf_codes, L, S);
-  for (int64_t k = 0; k < S; k++) order_out[k] = tmp.perm.empty() ? k : tmp.perm[k];
-  return 0;
-}
-
-const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p) {
-  if (!p) return "";
-  static thread_local std::string out;
-  char buf[96];
-  snprintf(buf, sizeof buf, " [current: %s%s, %zu program(s)]", p->chain ? "chain" : "levels", p->rr_active ? ", re-rooted" : "",
-           p->programs.size());
-  out = p->tune_report + buf;
-  return out.c_str();
-}
 
 int hyphy_hip_set_timing_detail(hyphy_hip_partition *p, int on) {
   if (!p) return fail("partition == NULL");

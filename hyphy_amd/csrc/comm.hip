@@ -1,0 +1,128 @@
+// RCCL over xGMI for libhyphy_hip.so: librccl is loaded on first use (a host that never all-reduces does not need it),
+// plus the C-ABI entry points that sum the partition log-likelihood over ranks / devices.
+#include <dlfcn.h>
+
+#include "partition.h"
+
+namespace hyhip {
+
+Rccl g_rccl;
+rccl_init_rank_fn g_rccl_init_rank = nullptr;
+
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(std::string("RCCL not available: ") + (dlerror() ? dlerror() : "librccl.so"));
+  g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+  g_rccl_init_rank = (rccl_init_rank_fn)dlsym(h, "ncclCommInitRank");
+  g_rccl.CommInitAll = (int (*)(void **, int, const int *))dlsym(h, "ncclCommInitAll");
+  g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+  g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+  g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+  g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+  g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl_init_rank || !g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllReduce ||
+      !g_rccl.GroupStart || !g_rccl.GroupEnd)
+    return fail("RCCL: missing symbols in librccl.so");
+  g_rccl.lib = h;
+  return 0;
+}
+
+}  // namespace hyhip
+
+using namespace hyhip;
+
+extern "C" {
+
+/* ---- the all-reduce of the partition log-likelihood, over RCCL / xGMI, where a C++ host can reach it -------------------
+ * One process per GPU (HYPHYMPI-style hosts, `torchrun`-style launchers): rank 0 makes a 128-byte id
+ * (hyphy_hip_comm_unique_id), every rank receives it by whatever channel the host has (MPI_Bcast, a file) and calls
+ * hyphy_hip_comm_init_rank on its partition (which holds ITS shard of the patterns); hyphy_hip_evaluate_allreduce is then
+ * hyphy_hip_evaluate + ONE ncclAllReduce of one double per evaluation, enqueued on the partition's stream between the
+ * reduction kernel and the read-back: every rank returns the log-likelihood of the whole alignment. */
+int hyphy_hip_comm_unique_id(void *out128) {
+  if (!out128) return fail("null id buffer");
+  if (rccl_load()) return -1;
+  RCCLCHK(g_rccl.GetUniqueId(out128));
+  return 0;
+}
+
+int hyphy_hip_comm_init_rank(hyphy_hip_partition *p, const void *unique_id, int rank, int n_ranks) {
+  if (!p || !unique_id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail("comm_init_rank: bad arguments");
+  if (p->shards.size() != 1) return fail("comm_init_rank: one device per rank (device_count = 1)");
+  if (rccl_load()) return -1;
+  Shard &s = p->shards[0];
+  HIPCHK(hipSetDevice(s.device));
+  if (s.comm) {
+    g_rccl.CommDestroy(s.comm);
+    s.comm = nullptr;
+  }
+  RcclUniqueId id;
+  memcpy(id.internal, unique_id, sizeof id.internal);
+  RCCLCHK(g_rccl_init_rank(&s.comm, n_ranks, id, rank));
+  if (!s.ar_buf) HIPCHK(hipMalloc((void **)&s.ar_buf, 2 * sizeof(double)));
+  return 0;
+}
+
+/* In-place sum of one device double over the partition's communicator, on the partition's stream (asynchronous). */
+int hyphy_hip_allreduce_device(hyphy_hip_partition *p, double *d_value) {
+  if (!p || !d_value) return fail("allreduce: null argument");
+  if (p->shards.size() != 1 || !p->shards[0].comm) return fail("allreduce: hyphy_hip_comm_init_rank first");
+  Shard &s = p->shards[0];
+  HIPCHK(hipSetDevice(s.device));
+  RCCLCHK(g_rccl.AllReduce(d_value, d_value, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
+  return 0;
+}
+
+int hyphy_hip_evaluate_allreduce(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                                 const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
+                                 const double *root_freqs, double *logl_out) {
+  if (!p) return fail("partition == NULL");
+  if (p->shards.size() != 1 || !p->shards[0].comm) return fail("evaluate_allreduce: hyphy_hip_comm_init_rank first");
+  Shard &s = p->shards[0];
+  // partial log-L of this rank's patterns into a device scalar, summed over the ranks in-stream, one double back
+  if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, q_dense, false, q_is_probability, root_freqs, s.ar_buf, true, false))
+    return -1;
+  RCCLCHK(g_rccl.AllReduce(s.ar_buf, s.ar_buf, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
+  double host[2] = {0., 0.};
+  HIPCHK(hipMemcpyAsync(host, s.ar_buf, sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  HIPCHK(hipStreamSynchronize(s.stream));
+  s.seq_wait = 0.;
+  int32_t st = 0;
+  HIPCHK(hipMemcpy(&st, s.status, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (st) {
+    hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream);
+    return fail("Failed to compute a valid transition matrix; this is usually caused by ill-conditioned rate matrices "
+                "(e.g. very large rate values)");
+  }
+  if (logl_out) *logl_out = host[0];
+  return 0;
+}
+
+/* Single-process hosts with device_count > 1 (HyPhy proper): by default the shard partials come back over PCIe and are
+ * summed on the host with the reference's Neumaier combine; HYPHY_HIP_COMBINE=rccl (or this call) makes one RCCL group
+ * all-reduce of it instead — SURVEY 5 asks for both to be measurable. */
+int hyphy_hip_comm_init_all(hyphy_hip_partition *p) {
+  if (!p) return fail("partition == NULL");
+  if (rccl_load()) return -1;
+  const int n = (int)p->shards.size();
+  std::vector<int> devs(n);
+  std::vector<void *> comms(n, nullptr);
+  for (int k = 0; k < n; k++) devs[k] = p->shards[k].device;
+  for (int k = 0; k < n; k++)
+    for (int j = 0; j < k; j++)
+      if (devs[k] == devs[j]) return fail("comm_init_all: RCCL needs one distinct device per shard");
+  RCCLCHK(g_rccl.CommInitAll(comms.data(), n, devs.data()));
+  for (int k = 0; k < n; k++) {
+    Shard &s = p->shards[k];
+    HIPCHK(hipSetDevice(s.device));
+    if (s.comm) g_rccl.CommDestroy(s.comm);
+    s.comm = comms[k];
+    if (!s.ar_buf) HIPCHK(hipMalloc((void **)&s.ar_buf, 2 * sizeof(double)));
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -198,6 +198,11 @@ struct ExpmArgs {
   int twin_src[kMaxTwin] = {};
   int twin_dst0 = 0;
   const double *twin_pi = nullptr;
+  // expm64_kernel (49..64 states): the templates zero-padded to [K][64*64] with zero diagonals (aligned loads, no masks);
+  // the host's view of `coeffs` when it is host-mapped memory (launch_expm may copy it into the kernel-argument block)
+  const double *templates_pad = nullptr;
+  const double *coeffs_host = nullptr;
+  int coef_inline = 0;       // (set by launch_expm) the coefficients are in the kernel's second argument
 };
 void expm_read_profile(long long out[8]);
 

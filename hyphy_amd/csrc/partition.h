@@ -1,0 +1,280 @@
+// Internal host-side definitions shared by the host translation units of libhyphy_hip.so:
+//   api.hip       the C-ABI (include/hyphy_hip.h): partition life cycle, evaluation entry points, kernel sequencing
+//   schedule.hip  the schedule compiler (post-order programs, chain / level-peeled cuts, re-rooting, pattern order)
+//   tuner.hip     the run-time schedule tuner and the launch of the current schedule
+//   comm.hip      RCCL (loaded on first use) and the all-reduce entry points
+// Host-side bookkeeping only — all arithmetic of the hot path happens in expm.hip / prune.hip / sitefit.hip.
+#pragma once
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <algorithm>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/hyphy_hip.h"
+#include "common.h"
+
+namespace hyhip {
+
+extern thread_local std::string g_last_error;
+int fail(const std::string &msg);
+
+// ---- RCCL, loaded on first use (librccl.so is part of ROCm; a host that never all-reduces does not need it) -------------
+struct Rccl {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+  int (*CommDestroy)(void *comm) = nullptr;
+  int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t stream) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+struct RcclUniqueId {
+  char internal[128];  // NCCL_UNIQUE_ID_BYTES
+};
+typedef int (*rccl_init_rank_fn)(void **comm, int nranks, RcclUniqueId id, int rank);
+extern Rccl g_rccl;
+extern rccl_init_rank_fn g_rccl_init_rank;
+constexpr int kNcclDouble = 8, kNcclSum = 0;
+int rccl_load();
+#define RCCLCHK(expr)                                                                                         \
+  do {                                                                                                        \
+    int r_ = (expr);                                                                                          \
+    if (r_ != 0) return fail(std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "RCCL error")); \
+  } while (0)
+
+struct Trace {
+  bool on;
+  double t0;
+  const char *what;
+  static double now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+  }
+  explicit Trace(const char *w) : on(getenv("HYPHY_HIP_TRACE") != nullptr), t0(0), what(w) {
+    if (on) t0 = now();
+  }
+  void lap(const char *stage) {
+    if (!on) return;
+    double t = now();
+    fprintf(stderr, "[hyphy_hip trace] %s/%s %.1f us\n", what, stage, t - t0);
+    t0 = t;
+  }
+};
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+    }                                                                                             \
+  } while (0)
+
+constexpr int kTimingRing = 1024;
+
+struct Shard {
+  int device = 0;
+  hipStream_t stream = nullptr;      // stream in use
+  hipStream_t own_stream = nullptr;  // stream created (and destroyed) by the library
+  int64_t s0 = 0, S = 0;  // pattern range [s0, s0+S) of the partition
+  int S_pad = 0, ntiles = 0, T = 1, cus = 256;
+  int16_t *codes = nullptr;
+  double *freq = nullptr;
+  double *ambig = nullptr;
+  double *partials = nullptr;  // [C] x per-class block
+  int32_t *counts = nullptr;   // [C][I][S_pad]
+  double *site_lik = nullptr;  // [C][S_pad]
+  int32_t *site_cnt = nullptr;
+  double *mixed_lik = nullptr;
+  int32_t *mixed_cnt = nullptr;
+  double *Pfrag = nullptr, *PTg = nullptr, *Prow = nullptr;  // [C][B]...
+  double *qbuf = nullptr;                                   // [C*B*D*D]
+  int32_t *slots = nullptr;                                 // [C*B]
+  int4 *ops = nullptr;
+  int16_t *codes_tile = nullptr;  // [tile][L][16] copy of the leaf table (wave-per-tile kernels)
+  int16_t *pin = nullptr;         // [S_pad] pinned states (hyphy_hip_set_pinned_states)
+  int4 *bc_ops = nullptr;         // branch cache: schedule of the re-rooted chain, its one-entry program table,
+  int4 *bc_prog = nullptr;        //   the slot word and the rate matrix of the cached branch
+  int32_t *bc_slot = nullptr;
+  double *bc_q = nullptr;
+  int4 *prog = nullptr;       // program table (forest scheduling): (offset, entries, parent program, child programs)
+  int4 *h_prog = nullptr;
+  double *ar_buf = nullptr;   // device scalar: this shard's partial log-L, all-reduced in place over RCCL
+  void *comm = nullptr;       // ncclComm_t of this shard (hyphy_hip_comm_init_rank / single-process group)
+  double *mix_q = nullptr, *mix_p = nullptr, *mix_w = nullptr;  // branch-site mixtures: component rate matrices, their exponentials, weights
+  int *mix_off = nullptr;
+  size_t mix_cap = 0, mix_nq_cap = 0;
+  int4 *jn = nullptr;         // chain schedules: per internal node (parent, arrivals needed | child sum << 8, trunk entries offset, count)
+  int4 *h_jn = nullptr;
+  double *deposits = nullptr; // chain schedules: [C][I][ntiles][TILE] edge products of non-last arrivers (allocated on first use)
+  int *frag_ctr = nullptr;    // [classes][programs][tiles] arrivals of child fragments (wave-per-tile kernel)
+  int32_t *hand_cnt = nullptr;  // [classes][I][tiles][32] 2^64-exponents of fragment roots (own 128-byte line each)
+  double *pi = nullptr;       // [DP]
+  double *out = nullptr;      // [2]
+  double *pi_ones = nullptr;  // [DP] 1 for real states, 0 for padding: root frequencies of a re-rooted schedule (pi sits in a twin image)
+  bool twins_dirty = true;    // the transposed twin images (expm.hip) may lag behind the matrices they mirror
+  double *wg_sum = nullptr;   // per-workgroup partial sums of the pruning kernel
+  long long *wg_cnt = nullptr;
+  int *wg_flag = nullptr;
+  int wg_cap = 0;
+  int32_t *status = nullptr;  // [1]
+  double *weights = nullptr;  // [C]
+  double *templates = nullptr;
+  double *templates_pad = nullptr;  // [K][64*64] zero-padded, zero diagonals (expm64_kernel; DP == 64 only)
+  double *coeffs = nullptr;
+  // pinned host staging
+  int4 *h_ops = nullptr;
+  double *h_out = nullptr;    // pinned, host-mapped: the reduction kernel writes [log-L, scaler sum, status] here
+  double *d_hout = nullptr;   // device-side address of h_out
+  int32_t *h_slots = nullptr;
+  double *h_coeffs = nullptr;  // pinned ring (4 x C*B*K) for build_q coefficients
+  double *d_hcoeffs = nullptr; // ... as the device sees it (host-mapped): the fused expm kernel reads it directly
+  const double *coeffs_cur = nullptr;  // coefficients of the pending fused build (device-visible pointer)
+  unsigned coeff_turn = 0;
+  // The fused expm kernel reads a ring slot over PCIe when it EXECUTES.  On the asynchronous path
+  // (hyphy_hip_evaluate_device) the host may run ahead of the device: an event recorded behind the consuming launch
+  // guards the slot, and hyphy_hip_build_q waits for it before rewriting the slot.
+  hipEvent_t coeff_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool coeff_busy[4] = {false, false, false, false};
+  int coeff_slot = -1;                 // ring slot of the staged coefficients
+  int64_t coeff_rows = 0;              // rows staged by the last hyphy_hip_build_q (0: nothing staged)
+  bool qbuf_built = false;             // ... and materialised in qbuf (HYPHY_HIP_MATERIALIZE_Q)
+  double *h_small = nullptr;  // pi / weights staging
+  size_t h_small_cap = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ring;  // kTimingRing pairs (start, end) around the pruning launches
+  uint64_t ring_count = 0;       // evaluations stamped so far
+  uint64_t eval_count = 0;
+  size_t partial_stride = 0;  // doubles per class
+  // completion of the synchronous entry points: the reduction kernel writes a sequence number behind the result
+  // record in host-mapped memory and the host spins on it (hipStreamSynchronize costs several microseconds more)
+  double seq_next = 1., seq_wait = 0.;
+  // per-site batched fits (hyphy_hip_site_fits_evaluate), allocated on first use
+  double *fit_Timg = nullptr, *fit_bcoef = nullptr, *fit_smult = nullptr, *fit_smix = nullptr, *fit_out = nullptr,
+         *fit_scratch = nullptr, *fit_pi = nullptr;
+  int *fit_bgroup = nullptr;
+  int32_t *fit_scratch_cnt = nullptr;
+  int4 *fit_ops = nullptr;
+  size_t fit_sets_cap = 0, fit_scratch_sets = 0;
+  bool fit_static_current = false;  // template images + schedule on the device match the host copies
+};
+
+}  // namespace hyhip
+
+struct hyphy_hip_partition {
+  int64_t D = 0, S = 0, L = 0, I = 0, C = 1, B = 0;
+  int DP = 0, NW = 0;
+  bool nuc = false;
+  std::vector<int64_t> parents;              // [L+I]
+  std::vector<std::vector<int>> children;    // per internal node, ascending node codes
+  std::vector<hyhip::Shard> shards;
+  std::vector<char> initialized;             // per class: a full evaluation has populated the caches
+  std::vector<char> leaf_has_ambig;          // per leaf: any ambiguity code in its row of the leaf table
+  std::vector<int4> ops_host;
+  std::vector<int64_t> cached_update;        // update list the device schedule was built for
+  bool cached_full = false;
+  int cached_valid = 0;
+  // Lazy persistence of the conditionals (cache_policy 1, default; HYPHY_HIP_CACHE=always turns it off): a full
+  // pass that follows a full pass (a sweep over a global parameter) keeps its nodes in registers / LDS only —
+  // nothing reads the persisted copies before the next full pass overwrites them — except the nodes some later
+  // schedule entry of the same pass re-reads.  `resident[c]`: the persisted copies of class c are current;
+  // a partial update, a branch-cache build or a download that finds them stale first re-runs a persisting pass.
+  int cache_policy = 1;
+  std::vector<char> resident, last_full;
+  bool cached_persist = true, sched_persist = true, sched_full = true;
+  std::vector<double> cached_pi;             // root frequencies currently on the device
+  std::vector<double> cached_weights;        // category weights currently on the device
+  std::vector<std::vector<int64_t>> cached_slots;  // per class: q_nodes list currently on the device
+  int root_slot = 0;
+  // Re-rooted schedules.  The likelihood does not depend on where the pruning recursion is rooted if the edges between the given
+  // root and the new one are traversed with the transposed matrices (and pi is folded in on the old root's edge) — no
+  // reversibility assumed, the same identity the branch cache uses.  A root in the middle of the tree shortens every tile's
+  // critical path (the tree's height), which is what small and medium shards are bound by.  rr_path = internal indices from the
+  // given root (front) to the node the computation is rooted at (back); empty: the given root is already the best one.
+  std::vector<int> rr_path;
+  std::vector<std::vector<int>> rr_cands;    // the (at most two) height-minimising nodes' paths; rr_path is the one in use
+  int emit_skip_par = -1, emit_skip_child = -1;  // (transient, build_schedule -> emit_program)
+  bool rr_use = false;                       // ask build_schedule for the re-rooted form (tuner / HYPHY_HIP_REROOT)
+  bool rr_active = false;                    // the current schedule is a re-rooted one
+  std::vector<int64_t> perm;                 // internal pattern j = caller's pattern perm[j] (empty: identity); see sort_patterns()
+  int64_t pin_node = -1;                     // node code whose states are pinned for the evaluations that follow (-1: none)
+  std::vector<int64_t> bc_node;              // per rate class: branch whose outside vector is resident (-1: none)
+  std::vector<int> bc_use_pi;                // ... hangs off the root (frequencies applied at evaluation)
+  int variant = 0;                           // pruning kernel variant (common.h PruneArgs::variant)
+  int n_slots = 0;                           // LDS slots the schedules are compiled for (0: lds_slots(T))
+  struct Prog { int off, n, parent = -1, need = 0; };
+  bool chain = false;                        // the current schedule is a chain schedule (common.h PruneArgs::chain)
+  bool kernel_forced = false;                // HYPHY_HIP_KERNEL / T > 1: the tuner must not switch kernels
+  int n_slots_wave = 3;                      // LDS slot budget of the wave-per-tile kernel's schedules
+  double *h_qstage = nullptr;                // pinned copy of the caller's matrices for hyphy_hip_evaluate_async
+  size_t h_qstage_cap = 0;
+  bool async_pending = false;                // an asynchronous evaluation has not been collected yet
+  int64_t async_cat = 0;
+  int wave_variant = 0;                      // instantiation of the wave-per-tile kernel (0: 2 waves per SIMD; 2: 3 waves per SIMD,
+                                             // finalised node in LDS, no parking slot) — chosen by the schedule tuner
+  int chain_m_forced = 0;                    // cut chosen by the schedule tuner: > 0 source size limit m, -1 level-peeled fragments, 0 heuristic
+  int64_t tuned_for = 0;                     // batch_classes the tuner ran for (0: not yet)
+  std::string tune_report;                   // what the tuner measured (hyphy_hip_schedule_info)
+  std::vector<int4> jn_host;                 // ... its per-node join table
+  struct Level { int first, count; };
+  std::vector<Prog> programs;                // (offset, padded entry count) into ops_host
+  std::vector<Level> levels;                 // launches: programs [first, first+count) run concurrently
+  int64_t batch_classes = 1;                 // rate classes batched into the pruning launch being scheduled
+  int slots_batch_mode = -1;                 // whether the slot table on the device was written for a class batch
+  bool all_timings = getenv("HYPHY_HIP_ALL_TIMINGS") != nullptr;  // also stamp expm / reduction (2 more event records)
+  bool coeffs_pending = false;               // build_q staged coefficients; the next evaluate_device(q_buffer) fuses
+                                             // the rate-matrix construction into the expm kernel
+  int64_t K = 0;                             // Q templates
+  std::vector<double> templates_host;        // [K][D][D] as passed to hyphy_hip_set_q_templates
+  std::vector<int4> fit_ops_host;            // per-site fits: full schedule compiled for kSiteFitParkSlots parking slots
+  int fit_n_ops = 0;
+  bool fit_spills = false;                   // ... some node goes through the scratch copy
+  double fit_kernel_ms = 0.;                 // duration of the last site-fit kernel (max over shards)
+  double timings[3] = {0, 0, 0};
+};
+
+namespace hyhip {
+
+inline size_t ops_capacity(const hyphy_hip_partition *p) { return (size_t)(p->L + p->I) + 4 * (size_t)p->I + 8; }
+inline int64_t caller_pattern(const hyphy_hip_partition *p, int64_t j) { return p->perm.empty() ? j : p->perm[j]; }
+inline int twin_slot0(const hyphy_hip_partition *p) { return (int)(p->B + (p->I + 2)); }
+
+// "use the shard's own Q buffer" (filled / staged by hyphy_hip_build_q on every shard): compared by address
+extern const double kOwnQBuffer;
+
+// branch-site mixture: matrix k of the evaluation is sum_m weights[off_k + m] exp(q[off_k + m]), count[k] components
+struct MixSpec {
+  const int64_t *count;
+  const double *weights;
+  int64_t n_tot;
+};
+
+// schedule.hip
+int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *offset_out, int *n_out, bool handoff = false,
+                 bool is_root_program = true);
+void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, bool full);
+void reroot_path(hyphy_hip_partition *p);
+void sort_patterns(hyphy_hip_partition *p, const int64_t *leaf_codes, int64_t L, int64_t S);
+// tuner.hip
+int upload_schedule(hyphy_hip_partition *p, Shard &s);
+void launch_prune_current(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch);
+int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch);
+// api.hip
+void refresh_twins(hyphy_hip_partition *p, Shard &s);
+PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch);
+int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update, const int64_t *q_nodes,
+                int64_t n_q, const double *q, bool q_on_device, int q_is_probability, const double *root_freqs,
+                double *d_logl_out, bool reduce, bool floor_log, bool batch = false, bool force_persist = false,
+                const MixSpec *mix = nullptr);
+int collect_status(hyphy_hip_partition *p);
+void record_timings(hyphy_hip_partition *p);
+double combine(const std::vector<double> &parts);
+
+}  // namespace hyhip
