@@ -14,8 +14,14 @@ Workloads:  mg94_64x10k (default; BASELINE.json metric: 61-state MG94 codon, 64 
 
 Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
                    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
-Patterns are sharded contiguously over the ranks (one process per GPU, device-resident partial
-log-L, torch.distributed all_reduce == RCCL over xGMI).  Total work is fixed -> "strong".
+Patterns are sharded contiguously over the ranks (one process per GPU).  The collective is the library's own
+(`--collective cabi`, default): rank 0 makes an RCCL unique id through the C-ABI, the 128 bytes travel over the
+torch.distributed store, every rank calls hyphy_hip_comm_init_rank, and a step is hyphy_hip_build_q +
+hyphy_hip_evaluate_built_allreduce — local evaluation, ONE ncclAllReduce of one double on the partition's stream, the sum
+back through the host-mapped record.  (`--collective torch`: torch.distributed.all_reduce on the same stream instead;
+torch.distributed is otherwise only used for the barriers around the timed region and to gather the ranks' timings.)
+Total work is fixed -> "strong".  `--single-process --gpus N [--combine host|rccl]` is the other form (one host thread
+drives N devices, HyPhy proper): shard partials combined on the host (Neumaier) or by one RCCL group all-reduce.
 """
 import argparse
 import json
@@ -50,6 +56,19 @@ WORKLOADS = {
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (== vector) peak, AMD datasheet; see DESIGN.md §roofline
 HBM_PEAK_GBS = 8000.0
+HBM_ACHIEVABLE_GBS = 6300.0    # what a streaming kernel reaches (MI355X_MICROARCH.md)
+
+
+def measured_instruction_peak():
+    """Chip-wide rate v_mfma_f64_16x16x4_f64 sustains from one operand pair (tools/ubench_mfma_f64 under PMC): the best
+    'mfma only' line of the committed run, or None when the file is not there."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r01_ubench_mfma_f64.txt")
+    try:
+        vals = [float(m.group(1)) for m in (re.search(r"^mfma only.*MFMA\s+([0-9.]+) TF", ln) for ln in open(path)) if m]
+        return (max(vals), "profiles/r01_ubench_mfma_f64.txt") if vals else (None, None)
+    except OSError:
+        return None, None
 
 
 # The library brackets the pruning launches of an evaluation with a HIP event pair on its stream (two barrier
@@ -84,7 +103,34 @@ def alg_work(D, S, L, I):
     return flops, bytes_
 
 
-def cpu_baseline(wl, syn, omega0, t_branch, n_threads, steps, budget_s=32.0):
+def cpu_thread_sweep(wl, syn, omega0, t_branch, candidates, seconds_each=3.0):
+    """Short differenced runs of the reference binary at each thread count (same script as cpu_baseline): evals/s per count.
+    The unmodified reference has a sweet spot (its OpenMP blocks: 16 of 128 cores won the r01 sweep); the count that the
+    long run uses is chosen HERE, on this box, not taken from a profile of another one."""
+    from oracle import hbl
+    from hyphy_amd import tree as htree
+    tmpl = models.mg94rev_template(POS_FREQS)
+    pi = models.f3x4_codon_freqs(POS_FREQS)
+    g = dict(R=omega0, **REV)
+    bt = {n: t_branch for n in syn.flat.branch_names()}
+    scale = (syn.flat.L / 64.0) * (syn.states.shape[1] / 10000.0)
+    out = {}
+    for thr in candidates:
+        rate0 = 7.0 * min(thr, 8)              # rough expectation, only sizes the run
+        n_long = int(max(8, min(2000, seconds_each * rate0 / scale)))
+        n_short = max(2, n_long // 8)
+        secs = {}
+        for n in (n_short, n_long):
+            t0 = time.perf_counter()
+            hbl.evaluate(names=syn.flat.leaf_names, seqs=syn.seqs, newick=htree.to_newick(syn.tree), unit=3,
+                         model_block=hbl.codon_model_block(tmpl, pi), model_name="MGM", globals_=g, branch_t=bt,
+                         sweep=dict(param="R", start=omega0, step=0.001, n=n, record=0), threads=thr, per_site=False, timeout=600.0)
+            secs[n] = time.perf_counter() - t0
+        out[thr] = (n_long - n_short) / max(secs[n_long] - secs[n_short], 1e-3)
+    return out
+
+
+def cpu_baseline(wl, syn, omega0, t_branch, n_threads, steps, budget_s=20.0):
     """Reference CPU path timed on this host: the real hyphy binary (oracle/_ref).  Bounded sample of the same
     workload: the LFCompute sweep of SURVEY A.8 at ONE thread and at `n_threads` (the best count of the sweep in
     profiles/), each timed as the difference of two runs of different length (wall clock of the whole process:
@@ -102,7 +148,7 @@ def cpu_baseline(wl, syn, omega0, t_branch, n_threads, steps, budget_s=32.0):
     scale = (syn.flat.L / 64.0) * (syn.states.shape[1] / 10000.0)   # cost of one evaluation relative to the headline workload
     out = {}
     ref = {}
-    for thr, rate0 in ((1, 10.0), (n_threads, 75.0)):
+    for thr, rate0 in ((1, 8.0), (n_threads, 75.0)):
         if thr in out:
             continue
         n_long = int(max(12, min(20000, budget_s * rate0 / scale)))
@@ -127,7 +173,7 @@ def cpu_baseline(wl, syn, omega0, t_branch, n_threads, steps, budget_s=32.0):
     cb = dict(value=best["value"], unit="evals/s", cores=n_threads, kind="reference",
               sample=f"{best['evals']} LFCompute calls with R swept in {best['seconds']:.1f} s (difference of two runs of "
                      f"the same script with different loop lengths, process wall clock) on the same alignment/tree, reference "
-                     f"hyphy 2.5.100 built by oracle/Makefile.ref, NUMBER_THREADS={n_threads} (best of the thread sweep in profiles/)",
+                     f"hyphy 2.5.100 built by oracle/Makefile.ref, NUMBER_THREADS={n_threads} (best of this run's thread sweep: cpu_baseline.thread_sweep)",
               seconds=best["seconds"],
               one_thread=dict(value=out[1]["value"], unit="evals/s", cores=1, evals=out[1]["evals"], seconds=out[1]["seconds"]))
     return cb, ref
@@ -291,6 +337,16 @@ def main():
     ap.add_argument("--site-fits", type=int, default=0, metavar="SETS",
                     help="also time per-site batched fits (SURVEY 8f-4): every pattern under its own (alpha, beta), "
                          "SETS candidate parameter vectors per pattern and launch")
+    ap.add_argument("--collective", choices=["auto", "cabi", "torch"], default="auto",
+                    help="N > 1: who sums the ranks' partial log-likelihoods.  cabi (auto for N > 1): the library's own in-stream "
+                         "ncclAllReduce (hyphy_hip_evaluate_built_allreduce); torch: torch.distributed.all_reduce on the same stream.  "
+                         "With --gpus 1, cabi runs the same entry point on a one-rank communicator (its overhead on one GPU)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N from ONE process (hyphy_hip_create with device_count = N; not under torch.distributed.run)")
+    ap.add_argument("--combine", choices=["host", "rccl"], default="host",
+                    help="--single-process: shard partials summed on the host (Neumaier) or by one RCCL group all-reduce")
+    ap.add_argument("--cold-s", type=float, default=0.25,
+                    help="idle seconds before the un-preheated measurement that is reported as value_cold (0: skip it)")
     ap.add_argument("--fel", action="store_true",
                     help="with --site-fits: also run the whole FEL-style analysis (alternative + null fit of every "
                          "pattern, hyphy_amd/fel.py) and report its wall time")
@@ -301,15 +357,26 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     N = args.gpus
     dist = None
-    if N > 1:
+    single = bool(args.single_process)
+    multi = N > 1 and not single           # one process per GPU
+    if single:
+        if world != 1:
+            raise SystemExit("--single-process is one process driving N devices: do not launch it with torch.distributed.run")
+        os.environ["HYPHY_HIP_COMBINE"] = args.combine
+    elif N > 1:
         if world != N:
             raise SystemExit(f"--gpus {N} needs WORLD_SIZE={N} (launch with torch.distributed.run)")
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")   # == RCCL on ROCm
+        dist.init_process_group("nccl")   # == RCCL on ROCm (barriers, timing gather, the id broadcast)
     import torch
-    torch.cuda.set_device(local if N > 1 else 0)
+    torch.cuda.set_device(local if multi else 0)
+    collective = args.collective
+    if collective == "auto":
+        collective = "cabi" if multi else "none"
+    if single or (N == 1 and collective == "torch"):
+        collective = "none"
 
     wl = WORKLOADS[args.workload]
     syn = data.evolve(wl["taxa"], wl["sites"], wl["unit"], seed=wl["seed"], p_change=wl.get("p_change", 0.04))
@@ -320,7 +387,7 @@ def main():
     flat = syn.flat
     S_all, L, I, B = pd_all.S, flat.L, flat.I, flat.n_branches
     # contiguous pattern shard of this rank (the reference's OpenMP site blocks, likefunc.cpp:10995-11044)
-    codes, freq, (lo, hi) = hdist.shard_patterns(pd_all.leaf_codes, pd_all.pattern_freq, rank, N)
+    codes, freq, (lo, hi) = hdist.shard_patterns(pd_all.leaf_codes, pd_all.pattern_freq, rank, N if multi else 1)
 
     T, pi = templates_for(wl["unit"])
     t_branch = 0.05
@@ -330,12 +397,23 @@ def main():
 
     n_classes = wl.get("classes", 1)
     part = hip.HipPartition(D, flat.flat_parents, L, codes, None, freq, C_cat=n_classes,
-                            device_first=(local if N > 1 else 0))
+                            device_first=(local if multi else 0), device_count=(N if single else 1))
     part.set_q_templates(T)
+    if single and args.combine == "rccl":
+        part.comm_init_all()
     stream = torch.cuda.Stream()             # everything (kernels, RCCL, the .item() copy) in ONE stream
     torch.cuda.set_stream(stream)
-    part.set_stream(stream.cuda_stream)
+    if not single:
+        part.set_stream(stream.cuda_stream)
     d_logl = torch.zeros(2, dtype=torch.float64, device="cuda")
+    if collective == "cabi":
+        # the library's own communicator: rank 0 makes the id, the 128 bytes travel through torch.distributed's store
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(hip.HipPartition.comm_unique_id()), dtype=torch.uint8))
+        if multi:
+            dist.broadcast(uid, src=0)
+        part.comm_init_rank(bytes(uid.cpu().numpy().tobytes()), rank, N if multi else 1)
     coeffs = np.empty((B * n_classes, 2))
     coeffs[:, 0] = np.tile(tb, n_classes)
     class_omega = np.array([0.1, 1.0, 5.0][:n_classes]) / 0.3 if n_classes > 1 else np.array([1.0])
@@ -346,6 +424,7 @@ def main():
         enqueue = part.prepare_device_step(nodes, nodes, pi, d_logl.data_ptr(), coeffs)
         fetch = part.prepare_fetch(d_logl.data_ptr())   # log-L behind the all-reduce -> host (host-mapped record, no D2H copy)
         sync_step = part.prepare_built_step(nodes, nodes, pi, coeffs)   # N == 1: synchronous C-ABI entry point
+        ar_step = part.prepare_built_allreduce_step(nodes, nodes, pi, coeffs) if collective == "cabi" else None
 
     def step(k, sync=True):
         omega = omega0 + 0.001 * k
@@ -355,16 +434,18 @@ def main():
             np.multiply(tb, omega, out=coeffs[:, 1])   # nonSynRate = omega * synRate on every branch (one numpy call: < 1 us)
         if n_classes > 1:
             v = cat_step()         # build_q (3 x 125 matrices) + expm + batched pruning + mixing + reduction
-            if N > 1:              # (classes are mixed per site on the rank that owns the site; the partial log-Ls add up)
+            if multi:              # (classes are mixed per site on the rank that owns the site; the partial log-Ls add up)
                 d_logl[0] = v
                 hdist.allreduce_logl(d_logl[:1])
                 v = float(d_logl[0].item())
             return v
-        if N == 1 and sync and not os.environ.get("HYPHY_BENCH_DEVICE_STEP"):
-            return sync_step()     # build_q + evaluate_built: log-L returned by the C-ABI call itself
+        if sync and ar_step is not None:
+            return ar_step()       # build_q + evaluate_built_allreduce: local pass, in-stream ncclAllReduce, value on every rank
+        if (not multi) and sync and not os.environ.get("HYPHY_BENCH_DEVICE_STEP"):
+            return sync_step()     # build_q + evaluate_built: log-L returned by the C-ABI call itself (all shards if --single-process)
         enqueue()      # device-side Q for every branch, then expm + pruning + reduction (C-ABI calls)
-        if N > 1:
-            hdist.allreduce_logl(d_logl[:1])                   # one RCCL all-reduce per evaluation
+        if multi:
+            hdist.allreduce_logl(d_logl[:1])                   # one RCCL all-reduce per evaluation (torch.distributed)
         if sync:
             if os.environ.get("HYPHY_BENCH_READBACK") == "item":
                 return float(d_logl[0].item())                 # (torch's device-to-host copy + synchronisation)
@@ -377,8 +458,29 @@ def main():
     for _ in range(3):
         step(1)
     per = (time.perf_counter() - t_pre) / 3.0
+    # value_cold: the driver's exact protocol (W warm-up steps, K timed steps) on a chip that has just idled — no preheat
+    value_cold = None
+    if args.cold_s > 0:
+        time.sleep(args.cold_s)
+        for k in range(args.warmup):
+            step(k + 1)
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k + 1)
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dtc = time.perf_counter() - tc0
+        if multi:
+            tcm = torch.tensor([dtc], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tcm, op=dist.ReduceOp.MAX)
+            dtc = float(tcm.item())
+        value_cold = args.steps / dtc
     n_pre = int(min(20000, max(0.0, args.preheat_s) / max(per, 1e-6)))
-    if N > 1:
+    if multi:
         cnt = torch.tensor([n_pre], dtype=torch.int64, device="cuda")
         dist.broadcast(cnt, src=0)
         n_pre = int(cnt.item())
@@ -388,7 +490,7 @@ def main():
     for k in range(args.warmup):
         step(k + 1)
     t_exp = t_prune = t_red = 0.0
-    if N > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -399,7 +501,7 @@ def main():
         last = timed_values[k] = step(k + 1)
         if step_marks is not None:
             step_marks[k] = time.perf_counter()
-    if N > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -415,21 +517,33 @@ def main():
         # expm (incl. the fused rate-matrix build) and reduction kernels: event-timed on a few extra steps AFTER the
         # timed region (two more event records per step would perturb it)
         part.set_all_timings(True)
-        te, tr_ = [], []
+        te, tr_, ta = [], [], []
         for k in range(8):
             step(args.steps + 1 + k)
             tm = part.last_timings()
             te.append(tm[0])
             tr_.append(tm[2])
+            ta.append(part.last_allreduce_ms())
         part.set_all_timings(False)
         t_exp, t_red = float(np.median(te)), float(np.median(tr_))
-    if N > 1:
+        t_ar = float(np.median(ta)) if collective == "cabi" else None
+    else:
+        t_ar = None
+    per_rank = None
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # every rank's own numbers (the line is printed by rank 0): shard size, kernel / expm / reduction / all-reduce ms
+        mine = torch.tensor([float(hi - lo), t_prune / max(1, args.steps), t_exp or 0.0, t_red or 0.0, t_ar or 0.0],
+                            dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(N)]
+        dist.all_gather(allr, mine)
+        per_rank = [dict(rank=r, patterns=int(v[0].item()), kernel_ms=float(v[1].item()), expm_ms=float(v[2].item()),
+                         reduce_ms=float(v[3].item()), allreduce_ms=float(v[4].item())) for r, v in enumerate(allr)]
 
     branch_cache = None
-    if args.branch_cache and n_classes == 1 and N == 1 and D > 4:
+    if args.branch_cache and n_classes == 1 and N == 1 and D > 4 and collective == "none":
         # one-branch line search (the optimiser's inner loop): all parameters fixed, ONE branch
         # length varies; each evaluation = 1 expm + 1 [D x D] x [D x S] contraction + reduction
         node = L + I // 2                                  # an internal branch in the middle of the tree
@@ -483,18 +597,31 @@ def main():
             roof = dict(bound="mfma", achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=ach / FP64_MFMA_PEAK_TFLOPS, traffic=None)
         else:
+            # 4 states.  SURVEY 8d's algorithmic bytes assume every internal conditional vector goes through HBM once each
+            # way; the kernel keeps them on chip (registers / LDS parking, lazy persistence), so that model is not what the
+            # memory system sees.  `achieved` / `frac` stay the contract's algorithmic figure only while it is meaningful
+            # (<= the peak); the numbers to hold the kernel against are `traffic_rate_gbs` (counter bytes / time, vs the
+            # ~6.3 TB/s a streaming kernel reaches) and `valu_tflops` (algorithmic flops / time, vs the 78.6 TFLOP/s FP64
+            # vector peak): the kernel is bound by instruction issue, between the two roofs.
             ach = bytes_ / (prune_ms * 1e-3) / 1e9
-            roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
-            roof["note"] = ("algorithmic bytes follow SURVEY 8d (every internal conditional vector written and read once); the "
-                            "kernel keeps conditionals on chip and, in a sweep of full passes, persists none (lazy persistence), "
-                            "so its real HBM traffic is below the algorithmic figure and frac can exceed 1")
+            roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS if ach <= HBM_PEAK_GBS else None),
+                        traffic=None)
+            roof["achievable_gbs"] = HBM_ACHIEVABLE_GBS
+            roof["valu_tflops"] = flops / (prune_ms * 1e-3) / 1e12
+            roof["valu_frac"] = roof["valu_tflops"] / FP64_MFMA_PEAK_TFLOPS
+            if roof["frac"] is None:
+                roof["note"] = ("algorithmic bytes / time exceeds the HBM peak: the modelled traffic (every conditional vector through "
+                                "HBM) does not exist — see traffic_rate_gbs (PMC) and valu_tflops")
         roof["kernel"] = part.prune_kernel_name()
         if bound == "mfma":
             # measured ceiling of the instruction the kernel issues (tools/ubench_mfma_f64 under PMC,
             # profiles/r01_ubench_mfma_f64.txt): v_mfma_f64_16x16x4_f64 sustains ~49 TFLOP/s chip-wide at 2.39 GHz
             # (one per ~100 cycles per SIMD); `peak` stays the datasheet figure
             roof["instruction"] = "v_mfma_f64_16x16x4_f64"
-            roof["instruction_peak_measured"] = 49.2   # microbenchmark, one operand pair; site_fit_kernel sustains 48.7 in a real kernel
+            ipk, ipk_src = measured_instruction_peak()
+            if ipk is not None:
+                roof["instruction_peak_measured"] = ipk   # TFLOP/s, one operand pair; site_fit_kernel sustains 48.7 in a real kernel
+                roof["instruction_peak_source"] = ipk_src
         # forest scheduling: the pruning pass of ONE evaluation is `launches_per_step` launches of the same
         # kernel (levels of subtree fragments).  achieved = (algorithmic work of the pass / launches) / (mean
         # launch duration) = work of the pass / time of the pass; rocprofv3's per-launch average x launches
@@ -506,6 +633,8 @@ def main():
         roof["timed_steps_sampled"] = f"1 in {TIMING_EVERY}"
         roof["expm_ms"] = t_exp       # median of 8 event-timed steps after the timed region; None: not measured
         roof["reduce_ms"] = t_red
+        if t_ar is not None:
+            roof["allreduce_ms"] = t_ar   # the in-stream ncclAllReduce of one double (same 8 steps)
         roof["alg_flops_per_step"] = flops
         roof["alg_bytes_per_step"] = bytes_
         # HBM traffic per launch: measured now (two rocprofv3 counter passes of this same script), else the value of the
@@ -529,29 +658,45 @@ def main():
             # counter bytes per launch / launch duration: what the memory system really moved (for the 4-state kernel this,
             # not the algorithmic figure, is the number to hold against the ~6.3 TB/s achievable HBM rate)
             roof["traffic_rate_gbs"] = roof["traffic"] / (roof["kernel_ms_per_launch"] * 1e-3) / 1e9
+            if bound == "hbm":
+                roof["traffic_frac_of_achievable"] = roof["traffic_rate_gbs"] / HBM_ACHIEVABLE_GBS
         out = {
             "metric": "full-tree log-L evals/sec, 61-state MG94 codon, 64 taxa x 10k codons" if args.workload == "mg94_64x10k"
                       else f"full-tree log-L evals/sec ({args.workload})",
             "value": args.steps / dt, "unit": "evals/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic", "preheat_s": args.preheat_s, "preheat_steps": n_pre,
+            "value_cold": value_cold,   # the same K steps behind the same W warm-up steps on an idle chip (no preheat); None: skipped
             "config": {"workload": args.workload, "states": D, "taxa": L, "codons" if D > 4 else "sites": wl["sites"],
                        "unique_patterns": int(S_all), "branches": int(B), "rate_classes": n_classes,
-                       "parallelism": f"site-shard x{N}" if N > 1 else "single GPU",
+                       "parallelism": (f"site-shard x{N}, one process per GPU" if multi else
+                                       f"site-shard x{N}, one process, shard partials combined by {args.combine}" if single and N > 1 else "single GPU"),
+                       "collective": ({"cabi": "hyphy_hip_evaluate_built_allreduce (in-stream ncclAllReduce of one double, C-ABI communicator)",
+                                       "torch": "torch.distributed.all_reduce on the partition's stream", "none": None}[collective]),
+                       "patterns_rank0": int(S_rank),
                        "step": "device Q build + expm of all branches + full pruning pass + reduction" +
-                               (" + RCCL all-reduce" if N > 1 else "") + ", log-L returned to host every step"},
+                               (" + RCCL all-reduce" if (multi or collective == "cabi") else "") + ", log-L returned to host every step"},
             "logl_first": ll0, "logl_last": last,
             "roofline": roof,
+            **({"per_rank": per_rank} if per_rank else {}),
             **({"branch_cache": branch_cache} if branch_cache else {}),
             **({"site_fits": site_fits} if site_fits else {}),
         }
         if pipelined:
             out["value_pipelined_no_host_sync"] = pipelined
         if not args.no_cpu_baseline and N == 1 and n_classes == 1:
-            nthr = args.cpu_threads or min(os.cpu_count() or 1, 16)   # 16 = best of the 1..128 sweep (profiles/)
-            cb = ref = None
+            cb = ref = sweep = None
             try:
-                cb, ref = cpu_baseline(wl, syn, omega0, t_branch, nthr, args.steps)
+                from oracle import hbl
+                nthr = args.cpu_threads
+                if not nthr and hbl.have_reference() and wl["unit"] == 3:
+                    ncpu = os.cpu_count() or 1
+                    cands = sorted({c for c in (8, 16, 32, 64) if 1 < c <= ncpu}) or [ncpu]   # (all 256 hardware threads: 4 evals/s)
+                    sweep = cpu_thread_sweep(wl, syn, omega0, t_branch, cands) if cands else {}
+                    nthr = max(sweep, key=sweep.get) if sweep else 1
+                cb, ref = cpu_baseline(wl, syn, omega0, t_branch, nthr or 1, args.steps)
+                if cb is not None and sweep:
+                    cb["thread_sweep"] = {str(k): v for k, v in sweep.items()}   # evals/s of short runs at each count (this box)
             except Exception as e:  # reference binary missing / failed: fall back to the C restatement
                 sys.stderr.write(f"[bench] reference baseline unavailable: {e}\n")
             if cb is None:
@@ -578,7 +723,7 @@ def main():
             out["parity"] = par
         print(json.dumps(out))
     part.close()
-    if N > 1:
+    if multi:
         dist.destroy_process_group()
 
 

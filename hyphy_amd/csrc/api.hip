@@ -34,6 +34,8 @@ void free_shard(Shard &s) {
     if (h) hipHostFree(h);
   for (auto &e : s.ev)
     if (e) hipEventDestroy(e);
+  for (auto &e : s.ev_ar)
+    if (e) hipEventDestroy(e);
   for (auto &e : s.ring)
     if (e) hipEventDestroy(e);
   for (auto &e : s.coeff_ev)
@@ -230,7 +232,8 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       s.twins_dirty = true;  // (the mixing kernel writes matrix images without their twins)
       launch_mix_images(s.mix_p, s.mix_off, s.mix_w, d_slots, (int)n_q, (int)D,
                         p->nuc ? nullptr : s.Pfrag + (size_t)cat * B * DP * DP, p->nuc ? nullptr : s.PTg + (size_t)cat * B * DP * DP,
-                        p->nuc ? s.Prow + (size_t)cat * B * 16 : nullptr, s.stream);
+                        p->nuc ? s.Prow + (size_t)cat * B * 16 : nullptr, s.stream,
+                        p->nuc ? s.Prow + ((size_t)p->C * B + (size_t)cat * B) * 16 : nullptr);
     } else {
     const double *dq = q;
     const bool q_from_templates = q_on_device && q == s.qbuf && p->coeffs_pending && !q_is_prob;
@@ -264,6 +267,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     }
     if (p->nuc) {
       ea.Prow = s.Prow + (size_t)cat * B * 16;
+      ea.PTrow = s.Prow + ((size_t)p->C * B + (size_t)cat * B) * 16;  // (transposed copies behind the row-major ones)
       ea.Pfrag = nullptr;
       ea.PTg = nullptr;
     } else {
@@ -284,8 +288,8 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       if (covered == k) s.twins_dirty = false;           // every twin rewritten by this launch (with the current pi)
     }
     tr.lap("slots+q");
-    launch_expm(ea, s.stream);
-    if (q_from_templates && d_logl_out && s.coeff_slot >= 0) {  // asynchronous caller: guard the ring slot until the kernel has run
+    const bool coeffs_consumed = launch_expm(ea, s.stream);
+    if (q_from_templates && d_logl_out && s.coeff_slot >= 0 && !coeffs_consumed) {  // asynchronous caller: guard the ring slot until the kernel has run
       HIPCHK(hipEventRecord(s.coeff_ev[s.coeff_slot], s.stream));
       s.coeff_busy[s.coeff_slot] = true;
     }
@@ -308,8 +312,10 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     na.ops = s.ops + (p->programs.empty() ? 0 : p->programs[0].off);
     na.n_ops = n_ops;
     na.S_pad = s.S_pad;
+    na.L = (int)p->L;
     na.root_inode = (int)p->I - 1;
     na.P = s.Prow + (size_t)cat * B * 16;
+    na.PT = s.Prow + ((size_t)p->C * B + (size_t)cat * B) * 16;
     na.codes = s.codes;
     na.pin = s.pin;
     na.pin_leaf = (p->pin_node >= 0 && p->pin_node < p->L) ? (int)p->pin_node : -1;
@@ -338,7 +344,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     pa.ablate = 0;
     if (const char *ab = getenv("HYPHY_HIP_ABLATE")) pa.ablate = atoi(ab);
     const char *tl_path = getenv("HYPHY_HIP_TIMELINE");
-    const bool tl_wave = p->variant >= 1;  // wave-per-tile kernel: one record of 8 words per wave of the grid
+    const bool tl_wave = p->variant == 1;  // wave-per-tile kernel: one record of 8 words per wave of the grid
     const size_t tl_waves = (size_t)s.ntiles * std::max(1, n_cat_batch) * std::max<size_t>(1, p->programs.size());
     const size_t tl_n = tl_wave ? tl_waves * 8 : (size_t)kTraceWG * p->NW * std::max(1, n_ops) * 4;
     if (tl_path && n_ops > 0 && s.T == 1) {
@@ -559,7 +565,7 @@ int hyphy_hip_prune_launches(hyphy_hip_partition *p) { return p ? (int)std::max<
 const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p) {
   if (!p) return "";
   if (p->nuc) return "prune_nuc_kernel";
-  return p->variant == 1 ? "prune_wave_kernel" : "prune_mfma_kernel";
+  return p->variant == 1 ? "prune_wave_kernel" : "prune_mfma_kernel";  // (variant 2: the same kernel on a chain schedule)
 }
 
 int64_t hyphy_hip_prune_timings(hyphy_hip_partition *p, double *out_ms, int64_t n) {
@@ -691,6 +697,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     s.T = T;
     s.cus = cus;
     if (p->nuc) p->n_slots = 2 + kNucParkSlots;  // (prune_nuc_kernel parks pending nodes in LDS)
+    if (p->nuc) p->nuc_leaf_pairs = prune_nuc_takes_leaf_pairs((int)L);
     if (!p->nuc) {
       // Kernel choice (measured, tools/sweep_small_shards.sh): the wave-per-tile kernel (no cross-wave
       // exchange, child -> parent through registers) wins once every SIMD holds ~2 waves of it — 160 vs 183 us
@@ -703,7 +710,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       p->variant = tiles >= (int64_t)cus / 4 ? 1 : 0;
       p->kernel_forced = false;
       if (const char *e = getenv("HYPHY_HIP_KERNEL")) {  // (diagnostic override)
-        p->variant = atoi(e) ? 1 : 0;
+        p->variant = std::max(0, std::min(2, atoi(e)));  // 0: workgroup per tile, 1: wave per tile, 2: workgroup per tile on chain schedules
         p->kernel_forced = true;
       }
       if (T != 1) {
@@ -712,10 +719,10 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       }
       p->n_slots_wave = 3;  // two "exchange" ids (register hand-over) + one wave-private LDS parking slot
       if (const char *e = getenv("HYPHY_HIP_SLOTS")) p->n_slots_wave = atoi(e) == 2 ? 2 : 3;
-      p->n_slots = p->variant >= 1 ? p->n_slots_wave : lds_slots(T);
+      p->n_slots = p->variant == 1 ? p->n_slots_wave : lds_slots(T);
     }
     if (p->nuc) {
-      s.S_pad = (int)((s.S + 255) / 256 * 256);
+      s.S_pad = (int)((s.S + 511) / 512 * 512);  // (prune_nuc2_kernel: 256 threads x 2 patterns per workgroup)
       s.ntiles = 0;
       s.partial_stride = (size_t)I * 4 * s.S_pad;
     } else {
@@ -764,7 +771,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     A_(s.mixed_lik, (size_t)s.S_pad * sizeof(double));
     A_(s.mixed_cnt, (size_t)s.S_pad * sizeof(int32_t));
     if (p->nuc) {
-      A_(s.Prow, (size_t)C * B * 16 * sizeof(double));
+      A_(s.Prow, (size_t)2 * C * B * 16 * sizeof(double));  // row-major, then transposed (prune_nuc2_kernel)
     } else {
       A_(s.Pfrag, ((size_t)C * B + (size_t)C * (I + 2) + kMaxTwin) * DP * DP * sizeof(double));  // (+ transposed path matrices of the branch cache, + twins of re-rooted schedules)
       A_(s.pi_ones, (size_t)DP * sizeof(double));
@@ -890,7 +897,7 @@ int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes
   {
     const bool tune_on = p->tuned_for != p->batch_classes && !(getenv("HYPHY_HIP_TUNE") && atoi(getenv("HYPHY_HIP_TUNE")) == 0) && !getenv("HYPHY_HIP_CHAIN_M") &&
                                 !getenv("HYPHY_HIP_CUT") && !getenv("HYPHY_HIP_FRAGMENT");
-    if (tune_on && !p->nuc && (p->variant >= 1 || (p->tuned_for != 0 && !p->kernel_forced)) && p->sched_full && !p->sched_persist &&
+    if (tune_on && !p->nuc && (p->variant >= 1 || (!p->kernel_forced && p->shards[0].ntiles >= 32)) && p->shards[0].T == 1 && p->sched_full && !p->sched_persist &&
         p->tuned_for != p->batch_classes && p->initialized[cat]) {
       if (tune_schedule(p, (int)cat, batch ? (int)p->C : 1)) return -1;
       build_schedule(p, update_nodes, n_update, true);  // the chosen cut
@@ -928,6 +935,29 @@ int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes
   return 0;  // (coefficients staged by hyphy_hip_build_q stay valid — and pending — until the next hyphy_hip_build_q)
 }
 
+// value of a device scalar behind everything queued on the (single) shard's stream -> host, through the host-mapped record
+__global__ void publish_scalar_kernel(const double *__restrict__ value, double *__restrict__ rec, const int *__restrict__ status,
+                                      double seq) {
+  rec[0] = value[0];
+  rec[1] = 0.;
+  rec[2] = status ? (double)*status : 0.;
+  if (seq != 0.) {
+    __threadfence_system();
+    reinterpret_cast<volatile double *>(rec)[3] = seq;
+  }
+}
+int publish_and_collect(hyphy_hip_partition *p, const double *d_value, double *value_out) {
+  Shard &s = p->shards[0];
+  HIPCHK(hipSetDevice(s.device));
+  double *rec = s.d_hout ? s.d_hout : s.out;
+  hipLaunchKernelGGL(publish_scalar_kernel, dim3(1), dim3(1), 0, s.stream, d_value, rec, (const int *)s.status,
+                     next_seq(s, rec == s.d_hout));
+  HIPCHK(hipGetLastError());
+  if (collect_status(p)) return -1;
+  *value_out = s.h_out[0];
+  return 0;
+}
+
 }  // namespace hyhip
 
 extern "C" {
@@ -942,29 +972,7 @@ int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *updat
   if (collect_status(p)) return -1;
   for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
   record_timings(p);
-  if (logl_out) *logl_out = combine(parts);
-  if (logl_out && p->shards.size() > 1 && p->shards[0].comm && getenv("HYPHY_HIP_COMBINE") && !strcmp(getenv("HYPHY_HIP_COMBINE"), "rccl")) {
-    // the same sum as ONE group all-reduce over xGMI (every shard ends up with the total; shard 0's copy is returned)
-    for (Shard &s : p->shards) {
-      HIPCHK(hipSetDevice(s.device));
-      HIPCHK(hipMemcpyAsync(s.ar_buf, &s.h_out[0], sizeof(double), hipMemcpyHostToDevice, s.stream));
-    }
-    RCCLCHK(g_rccl.GroupStart());
-    for (Shard &s : p->shards) {
-      HIPCHK(hipSetDevice(s.device));
-      RCCLCHK(g_rccl.AllReduce(s.ar_buf, s.ar_buf, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
-    }
-    RCCLCHK(g_rccl.GroupEnd());
-    Shard &s0 = p->shards[0];
-    HIPCHK(hipSetDevice(s0.device));
-    double tot = 0.;
-    HIPCHK(hipMemcpyAsync(&tot, s0.ar_buf, sizeof(double), hipMemcpyDeviceToHost, s0.stream));
-    for (Shard &s : p->shards) {
-      HIPCHK(hipSetDevice(s.device));
-      HIPCHK(hipStreamSynchronize(s.stream));
-    }
-    *logl_out = tot;
-  }
+  if (combine_shards(p, logl_out)) return -1;
   if (site_lik_out || site_scaler_out)
     return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
   return 0;
@@ -1058,15 +1066,7 @@ int hyphy_hip_evaluate_built(hyphy_hip_partition *p, int64_t cat, const int64_t 
   Trace tr("evaluate_built");
   if (collect_status(p)) return -1;
   tr.lap("wait");
-  if (logl_out) {
-    if (p->shards.size() == 1) *logl_out = p->shards[0].h_out[0];
-    else {
-      std::vector<double> parts;
-      for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
-      *logl_out = combine(parts);
-    }
-  }
-  return 0;
+  return combine_shards(p, logl_out);
 }
 
 int hyphy_hip_evaluate_device(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
@@ -1084,29 +1084,11 @@ int hyphy_hip_evaluate_device(hyphy_hip_partition *p, int64_t cat, const int64_t
  * collective on the same stream) back on the host the way the synchronous entry points do it: a one-thread kernel behind
  * everything queued on the partition's stream posts [value, 0, expm status, sequence word] into the host-mapped result
  * record and the host spins on the sequence word — no device-to-host copy command, no stream synchronisation. */
-__global__ void publish_scalar_kernel(const double *__restrict__ value, double *__restrict__ rec, const int *__restrict__ status,
-                                      double seq) {
-  rec[0] = value[0];
-  rec[1] = 0.;
-  rec[2] = status ? (double)*status : 0.;
-  if (seq != 0.) {
-    __threadfence_system();
-    reinterpret_cast<volatile double *>(rec)[3] = seq;
-  }
-}
 
 int hyphy_hip_fetch_device_scalar(hyphy_hip_partition *p, const double *d_value, double *value_out) {
   if (!p || !d_value || !value_out) return fail("fetch_device_scalar: null argument");
   if (p->shards.size() != 1) return fail("fetch_device_scalar needs a single-device partition");
-  Shard &s = p->shards[0];
-  HIPCHK(hipSetDevice(s.device));
-  double *rec = s.d_hout ? s.d_hout : s.out;
-  hipLaunchKernelGGL(publish_scalar_kernel, dim3(1), dim3(1), 0, s.stream, d_value, rec, (const int *)s.status,
-                     next_seq(s, rec == s.d_hout));
-  HIPCHK(hipGetLastError());
-  if (collect_status(p)) return -1;
-  *value_out = s.h_out[0];
-  return 0;
+  return publish_and_collect(p, d_value, value_out);
 }
 
 int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update,

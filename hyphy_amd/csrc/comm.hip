@@ -30,6 +30,42 @@ int rccl_load() {
   return 0;
 }
 
+// Sum of the shard partials of a single-process, multi-device partition (every shard's record has been collected):
+// the reference's Neumaier combine on the host (likefunc.cpp:11046-11093), or — HYPHY_HIP_COMBINE=rccl behind
+// hyphy_hip_comm_init_all — ONE group all-reduce over xGMI (every shard ends up with the total; shard 0's copy is returned).
+int combine_shards(hyphy_hip_partition *p, double *logl_out) {
+  if (!logl_out) return 0;
+  if (p->shards.size() == 1) {
+    *logl_out = p->shards[0].h_out[0];
+    return 0;
+  }
+  std::vector<double> parts;
+  for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
+  *logl_out = combine(parts);
+  const char *mode = getenv("HYPHY_HIP_COMBINE");
+  if (!(mode && !strcmp(mode, "rccl") && p->shards[0].comm)) return 0;
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipMemcpyAsync(s.ar_buf, &s.h_out[0], sizeof(double), hipMemcpyHostToDevice, s.stream));
+  }
+  RCCLCHK(g_rccl.GroupStart());
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    RCCLCHK(g_rccl.AllReduce(s.ar_buf, s.ar_buf, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
+  }
+  RCCLCHK(g_rccl.GroupEnd());
+  Shard &s0 = p->shards[0];
+  HIPCHK(hipSetDevice(s0.device));
+  double tot = 0.;
+  HIPCHK(hipMemcpyAsync(&tot, s0.ar_buf, sizeof(double), hipMemcpyDeviceToHost, s0.stream));
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipStreamSynchronize(s.stream));
+  }
+  *logl_out = tot;
+  return 0;
+}
+
 }  // namespace hyhip
 
 using namespace hyhip;
@@ -76,6 +112,40 @@ int hyphy_hip_allreduce_device(hyphy_hip_partition *p, double *d_value) {
   return 0;
 }
 
+// The collective + read-back behind a local evaluation that left this rank's partial in s.ar_buf.  A rank whose local
+// evaluation FAILED (validation, a HIP error) still joins the collective — with NaN — so that the other ranks are not left
+// waiting in it; every rank then sees NaN and the failing one returns its own error.
+static int allreduce_and_fetch(hyphy_hip_partition *p, int local_rc, double *logl_out) {
+  Shard &s = p->shards[0];
+  const std::string local_error = g_last_error;
+  if (hipSetDevice(s.device) != hipSuccess) return fail("hipSetDevice failed");
+  if (local_rc) {
+    static const double kNaN = NAN;
+    if (hipMemcpyAsync(s.ar_buf, &kNaN, sizeof(double), hipMemcpyHostToDevice, s.stream) != hipSuccess) return -1;
+  }
+  const bool stamp = p->all_timings;
+  if (stamp) {
+    for (auto &e : s.ev_ar)
+      if (!e) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventRecord(s.ev_ar[0], s.stream));
+  }
+  RCCLCHK(g_rccl.AllReduce(s.ar_buf, s.ar_buf, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
+  if (stamp) HIPCHK(hipEventRecord(s.ev_ar[1], s.stream));
+  double v = 0.;
+  const int rc = publish_and_collect(p, s.ar_buf, &v);  // (host-mapped record: no copy command, no stream synchronisation)
+  if (stamp) {
+    float ms = 0.f;
+    if (hipEventSynchronize(s.ev_ar[1]) == hipSuccess && hipEventElapsedTime(&ms, s.ev_ar[0], s.ev_ar[1]) == hipSuccess) p->allreduce_ms = ms;
+  }
+  if (local_rc) {
+    g_last_error = local_error;
+    return -1;
+  }
+  if (rc) return -1;
+  if (logl_out) *logl_out = v;
+  return 0;
+}
+
 int hyphy_hip_evaluate_allreduce(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                                  const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
                                  const double *root_freqs, double *logl_out) {
@@ -83,23 +153,24 @@ int hyphy_hip_evaluate_allreduce(hyphy_hip_partition *p, int64_t cat, const int6
   if (p->shards.size() != 1 || !p->shards[0].comm) return fail("evaluate_allreduce: hyphy_hip_comm_init_rank first");
   Shard &s = p->shards[0];
   // partial log-L of this rank's patterns into a device scalar, summed over the ranks in-stream, one double back
-  if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, q_dense, false, q_is_probability, root_freqs, s.ar_buf, true, false))
-    return -1;
-  RCCLCHK(g_rccl.AllReduce(s.ar_buf, s.ar_buf, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
-  double host[2] = {0., 0.};
-  HIPCHK(hipMemcpyAsync(host, s.ar_buf, sizeof(double), hipMemcpyDeviceToHost, s.stream));
-  HIPCHK(hipStreamSynchronize(s.stream));
-  s.seq_wait = 0.;
-  int32_t st = 0;
-  HIPCHK(hipMemcpy(&st, s.status, sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (st) {
-    hipMemsetAsync(s.status, 0, sizeof(int32_t), s.stream);
-    return fail("Failed to compute a valid transition matrix; this is usually caused by ill-conditioned rate matrices "
-                "(e.g. very large rate values)");
-  }
-  if (logl_out) *logl_out = host[0];
-  return 0;
+  const int rc = eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, q_dense, false, q_is_probability, root_freqs, s.ar_buf, true, false);
+  return allreduce_and_fetch(p, rc, logl_out);
 }
+
+/* The same behind hyphy_hip_build_q (template models: coefficients, not matrices, cross PCIe): the step a site-sharded
+ * likelihood function takes per evaluation — local rate-matrix construction + exponentials + pruning + reduction, ONE
+ * ncclAllReduce of one double on the partition's stream, the reduced value back through the host-mapped record. */
+int hyphy_hip_evaluate_built_allreduce(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                                       const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out) {
+  if (!p) return fail("partition == NULL");
+  if (!p->K) return fail("evaluate_built_allreduce: templates not set");
+  if (p->shards.size() != 1 || !p->shards[0].comm) return fail("evaluate_built_allreduce: hyphy_hip_comm_init_rank first");
+  Shard &s = p->shards[0];
+  const int rc = eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, &kOwnQBuffer, true, 0, root_freqs, s.ar_buf, true, false);
+  return allreduce_and_fetch(p, rc, logl_out);
+}
+
+double hyphy_hip_last_allreduce_ms(const hyphy_hip_partition *p) { return p ? p->allreduce_ms : 0.; }
 
 /* Single-process hosts with device_count > 1 (HyPhy proper): by default the shard partials come back over PCIe and are
  * summed on the host with the reference's Neumaier combine; HYPHY_HIP_COMBINE=rccl (or this call) makes one RCCL group

@@ -129,8 +129,10 @@ struct NucArgs {
   const int4 *ops;
   int n_ops;
   int S_pad;
+  int L;                     // leaves (prune_nuc2_kernel keeps their transposed matrices in LDS)
   int root_inode;
   const double *P;           // [B][16] row-major 4x4
+  const double *PT;          // [B][16] the same matrices transposed ([state j][row i]); nullptr: prune_nuc_kernel only
   const int16_t *codes;      // [L][S_pad]
   int pin_inode, pin_leaf;   // pinned node (see PruneArgs)
   const int16_t *pin;
@@ -183,6 +185,7 @@ struct ExpmArgs {
   int D;
   int is_prob;
   double *Prow;              // optional [.][D*D] row-major output (slot-indexed)
+  double *PTrow = nullptr;   // optional (4 states): the transposed matrices [.][16], read by prune_nuc2_kernel
   double *Pfrag;             // optional [.][NW][NKK*64]
   double *PTg;               // optional [.][DP][NW][16]  column-gather image (leaf edges): [code][wb][g][r] = P[16wb + 4r + g][code]
   int32_t *status;           // [1] set to nonzero if any matrix failed (NaN / ill-conditioned)
@@ -231,9 +234,9 @@ struct BcArgs {
 // launchers (defined in the .hip files)
 void launch_transpose_frag(const double *src_image, double *dst_image, const double *row_scale, int NW, hipStream_t stream);
 void launch_bc_eval(const BcArgs &a, hipStream_t stream);
-void launch_expm(const ExpmArgs &a, hipStream_t stream);
+bool launch_expm(const ExpmArgs &a, hipStream_t stream);  // true: fused-construction coefficients were copied at launch
 void launch_mix_images(const double *P, const int *off, const double *w, const int32_t *slots, int n, int D, double *Pfrag,
-                       double *PTg, double *Prow, hipStream_t stream);
+                       double *PTg, double *Prow, hipStream_t stream, double *PTrow = nullptr);
 void launch_site_fit(const SiteFitArgs &a, hipStream_t stream);
 void launch_prune_mfma(const PruneArgs &a, hipStream_t stream);
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream);
@@ -243,6 +246,7 @@ void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *
                       double *out_cnt, const int *status, hipStream_t stream, double seq = 0.);
 int prune_mfma_grid(const PruneArgs &a);
 int prune_nuc_grid(const NucArgs &a);
+bool prune_nuc_takes_leaf_pairs(int L);  // the kernel launch_prune_nuc picks for L leaves reads leaf groups of two
 void launch_mix_categories(const double *site_lik /*[C][S_pad]*/, const int32_t *site_cnt, const double *weights_dev,
                            int C, int S_pad, double *mixed_lik, int32_t *mixed_cnt, hipStream_t stream);
 void launch_build_q(const double *templates, const double *coeffs, int n, int K, int D, double *Q, hipStream_t stream);

@@ -1053,6 +1053,10 @@ __global__ void expm_nuc_kernel(ExpmArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; k++) a.Prow[(size_t)slot * 16 + k] = R[k];
   }
+  if (a.PTrow) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) a.PTrow[(size_t)slot * 16 + k] = R[4 * (k & 3) + (k >> 2)];
+  }
 }
 
 // Q_b = sum_k coeff[b][k] T_k off-diagonal, diagonal = -(row sum)   
@@ -1086,7 +1090,7 @@ __global__ __launch_bounds__(256) void build_q_kernel(const double *__restrict__
 __global__ __launch_bounds__(256) void mix_images_kernel(const double *__restrict__ P, const int *__restrict__ off,
                                                          const double *__restrict__ w, const int32_t *__restrict__ slots,
                                                          int D, int NT, double *__restrict__ Pfrag, double *__restrict__ PTg,
-                                                         double *__restrict__ Prow) {
+                                                         double *__restrict__ Prow, double *__restrict__ PTrow) {
   const int b = blockIdx.x, m0 = off[b], m1 = off[b + 1], slot = slots ? slots[b] : b;
   const int DP = 16 * NT, NKK = DP / 4, DD = D * D;
   auto mixed = [&](int rr, int cc) -> double {
@@ -1115,23 +1119,29 @@ __global__ __launch_bounds__(256) void mix_images_kernel(const double *__restric
     double *out = Prow + (size_t)slot * DD;
     for (int idx = threadIdx.x; idx < DD; idx += blockDim.x) out[idx] = mixed(idx / D, idx % D);
   }
+  if (PTrow) {
+    double *out = PTrow + (size_t)slot * DD;
+    for (int idx = threadIdx.x; idx < DD; idx += blockDim.x) out[idx] = mixed(idx % D, idx / D);
+  }
 }
 
 }  // namespace
 
 void launch_mix_images(const double *P, const int *off, const double *w, const int32_t *slots, int n, int D, double *Pfrag,
-                       double *PTg, double *Prow, hipStream_t stream) {
+                       double *PTg, double *Prow, hipStream_t stream, double *PTrow) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(mix_images_kernel, dim3(n), dim3(256), 0, stream, P, off, w, slots, D, (D + 15) / 16, Pfrag, PTg, Prow);
+  hipLaunchKernelGGL(mix_images_kernel, dim3(n), dim3(256), 0, stream, P, off, w, slots, D, (D + 15) / 16, Pfrag, PTg, Prow, PTrow);
 }
 
 void expm_read_profile(long long out[8]) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_expm_prof), 8 * sizeof(long long)); }
 
-void launch_expm(const ExpmArgs &a, hipStream_t stream) {
-  if (a.n <= 0) return;
+// returns true when the coefficients of a fused construction travelled in the kernel-argument block (the caller's staging
+// buffer is free again on return), false when the kernel will read them from `coeffs` when it executes
+bool launch_expm(const ExpmArgs &a, hipStream_t stream) {
+  if (a.n <= 0) return false;
   if (a.D == 4 && !a.Pfrag && !a.PTg) {
     hipLaunchKernelGGL(expm_nuc_kernel, dim3((a.n + 63) / 64), dim3(64), 0, stream, a);
-    return;
+    return false;
   }
   // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of the function: the single-process
   // multi-device path (hyphy_hip_create with device_count > 1) launches on every device of the node
@@ -1201,9 +1211,10 @@ void launch_expm(const ExpmArgs &a, hipStream_t stream) {
         case 2: hipLaunchKernelGGL((expm64_kernel<2>), dim3(2 * b.n), dim3(512), lds64, stream, b, ci); break;
         default: hipLaunchKernelGGL((expm64_kernel<1>), dim3(b.n), dim3(512), lds64, stream, b, ci); break;
       }
-      break;
+      return b.coef_inline != 0;
     }
   }
+  return false;
 }
 
 void launch_build_q(const double *templates, const double *coeffs, int n, int K, int D, double *Q, hipStream_t stream) {

@@ -149,6 +149,7 @@ struct Shard {
   double *h_small = nullptr;  // pi / weights staging
   size_t h_small_cap = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_ar[2] = {nullptr, nullptr};  // around the all-reduce of hyphy_hip_evaluate*_allreduce (timing detail on)
   std::vector<hipEvent_t> ring;  // kTimingRing pairs (start, end) around the pruning launches
   uint64_t ring_count = 0;       // evaluations stamped so far
   uint64_t eval_count = 0;
@@ -172,6 +173,7 @@ struct hyphy_hip_partition {
   int64_t D = 0, S = 0, L = 0, I = 0, C = 1, B = 0;
   int DP = 0, NW = 0;
   bool nuc = false;
+  bool nuc_leaf_pairs = false;               // 4 states: leaf entries carry up to two leaves (prune_nuc2_kernel; prune_nuc_kernel takes one)
   std::vector<int64_t> parents;              // [L+I]
   std::vector<std::vector<int>> children;    // per internal node, ascending node codes
   std::vector<hyhip::Shard> shards;
@@ -238,6 +240,7 @@ struct hyphy_hip_partition {
   bool fit_spills = false;                   // ... some node goes through the scratch copy
   double fit_kernel_ms = 0.;                 // duration of the last site-fit kernel (max over shards)
   double timings[3] = {0, 0, 0};
+  double allreduce_ms = 0.;                  // duration of the last in-stream all-reduce (timing detail on; else 0)
 };
 
 namespace hyhip {
@@ -274,7 +277,10 @@ int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes
                 double *d_logl_out, bool reduce, bool floor_log, bool batch = false, bool force_persist = false,
                 const MixSpec *mix = nullptr);
 int collect_status(hyphy_hip_partition *p);
+int publish_and_collect(hyphy_hip_partition *p, const double *d_value, double *value_out);  // (single-shard partitions)
 void record_timings(hyphy_hip_partition *p);
 double combine(const std::vector<double> &parts);
+// comm.hip
+int combine_shards(hyphy_hip_partition *p, double *logl_out);
 
 }  // namespace hyhip

@@ -15,6 +15,8 @@
 //    with ambiguity codes take the MFMA path with their resolution vector as the B operand.
 //  * Rescaling is stateless per evaluation: integer exponents per (node, pattern) are carried up
 //    the tree; observable contract of SURVEY A.5 (l_s, c_s with L_s = l_s 2^(-64 c_s)).
+#include <stdlib.h>
+
 #include "common.h"
 
 #ifndef HYPHY_OCC
@@ -161,14 +163,28 @@ __device__ __forceinline__ void root_epilogue(const PruneArgs &a, const double *
 //
 // CLDS: leaf codes of the workgroup's tiles are staged in LDS (the common case); the !CLDS variant
 // (thousands of taxa) reads them from global memory.
-template <int NW, int T, bool CLDS, bool TRACE, int ABL = 0>
+// CHAIN (r03, T = 1): chain schedules for the row-split workgroup (api: "team" kernel, PruneArgs::variant 2).  grid.z indexes
+// the SOURCE programs of a chain schedule (schedule.hip); behind its source the workgroup walks the trunk exactly like the
+// wave-per-tile kernel does — edge product towards the parent, arrival at the parent's counter, the last arriver multiplies
+// the deposited products of its siblings in and goes on — but every product is split over the NW waves (16 MFMAs each
+// instead of 64 from one wave), the waves agree on every arrival through one LDS word, and each wave deposits / fetches only
+// its own 16 rows.  A tile's critical path is then (height of the tree) x (a quarter of the wave kernel's edge latency):
+// what small shards — a rank's share of an alignment at 4 or 8 GPUs — are bound by.
+template <int NW, int T, bool CLDS, bool TRACE, int ABL = 0, bool CHAIN = false>
 __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_kernel(const int4 *__restrict__ ops,
                                                                                PruneArgs a) {
+  static_assert(!CHAIN || T == 1, "chain schedules: one tile per workgroup");
   // forest scheduling: grid.z = subtree fragment of this level, each with its own program
   const int4 prg = a.prog[blockIdx.z];
+  const int4 *const ops0 = ops;
   ops += prg.x;
   {  // rate-class batching: one grid row per class, same schedule, class-strided buffers
     const size_t cat = blockIdx.y;
+    if (CHAIN) {
+      a.frag_ctr += cat * (size_t)a.n_prog_total * a.ntiles;
+      a.hand_cnt += cat * (size_t)(a.root_inode + 1) * a.ntiles * 32;
+      a.deposits += cat * a.cs_partials;
+    }
     a.Pfrag += cat * a.cs_P;
     a.PTg += cat * a.cs_P;
     a.partials += cat * a.cs_partials;
@@ -262,6 +278,69 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
     acc[t] = (f64x4){1., 1., 1., 1.};
     cnt[t] = 0;
   }
+
+  // Finalise the parent: publish this wave's 16 rows and its partial site sums, ONE barrier, decide the rescale, persist.
+  // `opx` = flag word of the parent's last entry, `mid` = what to do between the LDS part and the persist stores.
+  auto finalise = [&](int opx, int parent, long long *tl, bool trace, auto mid) {
+      // Finalise the parent: publish this wave's 16 rows and its partial site sums, ONE barrier,
+      // decide the rescale, persist.  The exchange slot and psum buffer alternate between successive
+      // finalisations (parity chosen by the host), so a wave that runs ahead writes into the other
+      // buffer and cannot get two nodes ahead (it has to pass the next node's barrier first).
+      const int par2 = (opx >> 4) & 1;
+      const int slot = (opx >> 16) & 0xff;
+      
+      if (parent == a.pin_inode) {  // pinned internal node: only the pinned state survives (tree_evaluator.cpp:589-594)
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+          const int ps = (int)a.pin[(tile0 + t) * 16 + sl];
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[t][r] = (16 * w + 4 * r + g == ps) ? acc[t][r] : 0.;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        psum[par2][t][w * 64 + lane] = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+        double *dst = xbuf + (slot * T + t) * TILE;
+        if (!(ablate & 32)) {  // kk = 4w + r  ->  frag_index(kk, lane): two 16-byte stores
+          *reinterpret_cast<f64x2 *>(dst + ((2 * w) * 64 + lane) * 2) = (f64x2){acc[t][0], acc[t][1]};
+          *reinterpret_cast<f64x2 *>(dst + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){acc[t][2], acc[t][3]};
+        }
+      }
+      if (!(ablate & 2)) lds_barrier();
+      if (trace && lane == 0) tl[2] = clock64();
+      double sc[T];
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        // site total over all NW*4 row groups, fixed order (identical in every wave)
+        double tot = 0.;
+#pragma unroll
+        for (int q = 0; q < NW * 4; q++) tot += psum[par2][t][q * 16 + sl];
+        sc[t] = 1.0;
+        int m = 0;
+        if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) m = rescale_decision(tot, sc[t]);  // rare
+        cnt[t] += m;
+        slot_scale[slot][w][t][sl] = sc[t];  // (the 4 row-group lanes of a site store the same value)
+        slot_cnt[slot][w][t][sl] = cnt[t];
+      }
+      // ARRIVE before the persist stores are issued: the vector-memory counter is in-order and counts
+      // stores; this way the stores have the whole following entry to complete.
+      mid();
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        // persist this wave's rows (== its own accumulator, times the exact power-of-two scale) and
+        // the exponent: fire and forget
+        double *out = a.partials + ((size_t)parent * a.ntiles + tile0 + t) * TILE + (size_t)w * 256;  // uniform
+        const f64x4 q = acc[t] * sc[t];
+        if (!(ablate & 4) && !(opx & OPF_NOPERSIST)) {  // (lazy persistence: the host knows nobody re-reads this node)
+          st16(out, (unsigned)lane * 16u, (f64x2){q[0], q[1]});
+          st16(out, (unsigned)(64 + lane) * 16u, (f64x2){q[2], q[3]});
+          if (w == 0 && g == 0) a.counts[(size_t)parent * S_pad + (tile0 + t) * 16 + sl] = cnt[t];
+        }
+        acc[t] = (f64x4){1., 1., 1., 1.};  // the next entry starts a new parent
+        cnt[t] = 0;
+      }
+      if (trace && lane == 0) tl[3] = clock64();
+  };
 
   // one schedule entry: multiply one child edge (or leaf group) into the parent's running product and,
   // after the parent's last child, finalise it.  `nxt` = payload of the following entry (in flight).
@@ -380,64 +459,7 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
       if (lane == 0) tl[1] = clock64();
     }
     if (op.x & OPF_LAST) {
-      // Finalise the parent: publish this wave's 16 rows and its partial site sums, ONE barrier,
-      // decide the rescale, persist.  The exchange slot and psum buffer alternate between successive
-      // finalisations (parity chosen by the host), so a wave that runs ahead writes into the other
-      // buffer and cannot get two nodes ahead (it has to pass the next node's barrier first).
-      const int par2 = (op.x >> 4) & 1;
-      const int slot = (op.x >> 16) & 0xff;
-      const int parent = op.y;
-      if (parent == a.pin_inode) {  // pinned internal node: only the pinned state survives (tree_evaluator.cpp:589-594)
-#pragma unroll
-        for (int t = 0; t < T; t++) {
-          const int ps = (int)a.pin[(tile0 + t) * 16 + sl];
-#pragma unroll
-          for (int r = 0; r < 4; r++) acc[t][r] = (16 * w + 4 * r + g == ps) ? acc[t][r] : 0.;
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < T; t++) {
-        psum[par2][t][w * 64 + lane] = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
-        double *dst = xbuf + (slot * T + t) * TILE;
-        if (!(ablate & 32)) {  // kk = 4w + r  ->  frag_index(kk, lane): two 16-byte stores
-          *reinterpret_cast<f64x2 *>(dst + ((2 * w) * 64 + lane) * 2) = (f64x2){acc[t][0], acc[t][1]};
-          *reinterpret_cast<f64x2 *>(dst + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){acc[t][2], acc[t][3]};
-        }
-      }
-      if (!(ablate & 2)) lds_barrier();
-      if (trace && lane == 0) tl[2] = clock64();
-      double sc[T];
-#pragma unroll
-      for (int t = 0; t < T; t++) {
-        // site total over all NW*4 row groups, fixed order (identical in every wave)
-        double tot = 0.;
-#pragma unroll
-        for (int q = 0; q < NW * 4; q++) tot += psum[par2][t][q * 16 + sl];
-        sc[t] = 1.0;
-        int m = 0;
-        if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) m = rescale_decision(tot, sc[t]);  // rare
-        cnt[t] += m;
-        slot_scale[slot][w][t][sl] = sc[t];  // (the 4 row-group lanes of a site store the same value)
-        slot_cnt[slot][w][t][sl] = cnt[t];
-      }
-      // ARRIVE before the persist stores are issued: the vector-memory counter is in-order and counts
-      // stores; this way the stores have the whole following entry to complete.
-      arrive(nxt);
-#pragma unroll
-      for (int t = 0; t < T; t++) {
-        // persist this wave's rows (== its own accumulator, times the exact power-of-two scale) and
-        // the exponent: fire and forget
-        double *out = a.partials + ((size_t)parent * a.ntiles + tile0 + t) * TILE + (size_t)w * 256;  // uniform
-        const f64x4 q = acc[t] * sc[t];
-        if (!(ablate & 4) && !(op.x & OPF_NOPERSIST)) {  // (lazy persistence: the host knows nobody re-reads this node)
-          st16(out, (unsigned)lane * 16u, (f64x2){q[0], q[1]});
-          st16(out, (unsigned)(64 + lane) * 16u, (f64x2){q[2], q[3]});
-          if (w == 0 && g == 0) a.counts[(size_t)parent * S_pad + (tile0 + t) * 16 + sl] = cnt[t];
-        }
-        acc[t] = (f64x4){1., 1., 1., 1.};  // the next entry starts a new parent
-        cnt[t] = 0;
-      }
-      if (trace && lane == 0) tl[3] = clock64();
+      finalise(op.x, op.y, tl, trace, [&]() { arrive(nxt); });
     } else {
       arrive(nxt);
     }
@@ -467,6 +489,162 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
     opB = opD;
   }
 
+  if constexpr (CHAIN) {
+    // ---- the trunk (see the wave-per-tile kernel for the protocol and its memory-ordering contract) ----
+    __shared__ int s_word[2];  // arrival counter values, read / updated by thread 0 and agreed on through LDS
+    int cur = prg.z & 0xff;    // exchange slot the source's root was finalised into
+    int c = prg.w;             // internal index of the node whose conditionals are in slot `cur`
+    const int tile = tile0;
+    const int4 *__restrict__ jn = a.jn;
+    // this wave's rows of the A-operand image of one branch: 8 x 16 bytes per lane, requested a whole level ahead
+    auto load_image = [&](int branch, Payload &pa) {
+      const double *bfr = a.Pfrag + ((size_t)branch * NW + w) * TILE;  // uniform
+#pragma unroll
+      for (int k = 0; k < NKK / 2 && k < 8; k++) pa.v[k] = ld16(bfr, (unsigned)(k * 64 + lane) * 16u);
+    };
+    // One trunk entry's operands, requested one entry ahead of their use.  Straight-line on purpose (always four 16-byte
+    // loads and one 4-byte load, addresses chosen with uniform selects): a leaf group's two column gathers, or this
+    // wave's rows of a deposited product (+ its exponents).  L1-bypassing loads throughout — deposits come from other CUs.
+    struct Item {
+      f64x2 v[4];
+      int cnt;
+    };
+    auto issue = [&](const int4 &op, Item &it) {
+      const bool is_leaf = (op.x & 3) == OPK_LEAF;
+      const int nl = (op.x >> 8) & 0x7f;
+      const int leaf0 = is_leaf ? (op.z & 0xffff) : 0, leaf1 = (is_leaf && nl > 1) ? ((op.z >> 16) & 0xffff) : leaf0;
+      const int c0 = leaf_code(leaf0, 0), c1 = leaf_code(leaf1, 0);
+      const int child = is_leaf ? 0 : op.w;
+      const double *dep = a.deposits + ((size_t)child * a.ntiles + tile) * TILE + (size_t)w * 256;             // uniform
+      const double *b0 = is_leaf ? a.PTg + ((size_t)leaf0 * DP * NW + w) * 16 : dep;                         // uniform
+      const double *b1 = is_leaf ? a.PTg + ((size_t)leaf1 * DP * NW + w) * 16 : dep;                         // uniform
+      const unsigned g0 = (unsigned)((c0 < 0 ? 0 : c0) * NW * 16 + g * 4) * 8u, g1 = (unsigned)((c1 < 0 ? 0 : c1) * NW * 16 + g * 4) * 8u;
+      const unsigned o0 = is_leaf ? g0 : (unsigned)lane * 16u, o0b = is_leaf ? g0 + 16u : (unsigned)(64 + lane) * 16u;
+      const unsigned o1 = is_leaf ? g1 : (unsigned)lane * 16u, o1b = is_leaf ? g1 + 16u : (unsigned)(64 + lane) * 16u;
+      it.v[0] = ld16_agent(b0, o0);
+      it.v[1] = ld16_agent(b0, o0b);
+      it.v[2] = ld16_agent(b1, o1);
+      it.v[3] = ld16_agent(b1, o1b);
+      it.cnt = __hip_atomic_load(a.hand_cnt + ((size_t)child * a.ntiles + tile) * 32 + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    Payload pimg;
+    // `s_early[k & 1]`: arrival counter of level k's parent, sampled by thread 0 a whole level ahead (while the node below is
+    // finalised: the round trip is covered) and agreed on through LDS.  If every sibling had arrived by then, this workgroup
+    // WILL be the last arriver: it skips its own deposit and has the siblings' deposits in flight under its own product.
+    __shared__ int s_early[2];
+    int lvl = 0;
+    {
+      const int4 j0 = jn[c];
+      if (j0.x >= 0) {
+        load_image(j0.x >> 16, pimg);
+        const int par0 = j0.x & 0xffff;
+        if ((jn[par0].y & 0xff) > 1 && threadIdx.x == 0)
+          s_early[0] = __hip_atomic_load(a.frag_ctr + (size_t)par0 * a.ntiles + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      lds_barrier();
+    }
+    for (;; lvl++) {
+      const int4 jc = jn[c];  // x = parent | matrix-image slot of the edge c -> parent << 16; -1: c is the root
+      if (jc.x < 0) break;
+      const int par = jc.x & 0xffff;
+      const int4 jp = jn[par];
+      const int need = jp.y & 0xff;
+      int *ctr = a.frag_ctr + (size_t)par * a.ntiles + tile;
+      const bool pred = need <= 1 || s_early[lvl & 1] == need - 1;  // (uniform over the workgroup)
+      asm volatile("" ::: "memory");
+      const int4 *tops = ops0 + jp.z;  // (followed by a no-op entry: one entry ahead is always readable)
+      int4 op = tops[0];
+      Item itA, itB;
+      if (pred && jp.w > 0) issue(op, itA);
+      // this wave's 16 rows of the edge product P_branch x (conditionals of c)
+      f64x4 prod;
+      int pcnt;
+      {
+        const double csc = slot_scale[cur][w][0][sl];
+        pcnt = slot_cnt[cur][w][0][sl];
+        f64x4 d0 = (f64x4){0., 0., 0., 0.}, d1 = d0;
+#pragma unroll
+        for (int k2 = 0; k2 < NKK / 2; k2++) {
+          const f64x2 bv = *reinterpret_cast<const f64x2 *>(xbuf + cur * TILE + (k2 * 64 + lane) * 2);
+          d0 = mfma(pimg.v[k2 % 8][0], bv[0], d0);
+          d1 = mfma(pimg.v[k2 % 8][1], bv[1], d1);
+        }
+        prod = (d0 + d1) * csc;
+      }
+      if (jp.x >= 0) load_image(jp.x >> 16, pimg);  // the edge above `par`: in flight while this level joins and finalises
+      if (!pred) {
+        // deposit this workgroup's product (each wave its rows), drain, count the arrival
+        double *out = a.deposits + ((size_t)c * a.ntiles + tile) * TILE + (size_t)w * 256;  // uniform
+        st16_agent(out, (unsigned)lane * 16u, (f64x2){prod[0], prod[1]});
+        st16_agent(out, (unsigned)(64 + lane) * 16u, (f64x2){prod[2], prod[3]});
+        if (w == 0 && g == 0)
+          __hip_atomic_store(a.hand_cnt + ((size_t)c * a.ntiles + tile) * 32 + sl, pcnt, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();  // every wave's payload has left for L2
+        if (threadIdx.x == 0) s_word[1] = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_barrier();
+        if (s_word[1] + 1 < need) return;  // somebody else will finish `par`
+        asm volatile("" ::: "memory");
+        if (jp.w > 0) issue(op, itA);
+      }
+      if (threadIdx.x == 0) {
+        if (need > 1) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        if (jp.x >= 0 && (jn[jp.x & 0xffff].y & 0xff) > 1)  // the NEXT level's arrivals, sampled now
+          s_early[(lvl + 1) & 1] = __hip_atomic_load(a.frag_ctr + (size_t)(jp.x & 0xffff) * a.ntiles + tile, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // `par`: own product, leaf columns, the deposited products of the other children
+      acc[0] = prod;
+      cnt[0] = pcnt;
+      int lastx = 0;
+      auto consume = [&](const int4 &o, const Item &it) {
+        lastx = o.x;
+        if ((o.x & 3) == OPK_LEAF) {
+          const int nl = (o.x >> 8) & 0x7f;
+          bool slow = false;
+          if (o.x & OPF_AMBIG) {
+            const int leaf0 = o.z & 0xffff;
+            slow = __any(leaf_code(leaf0, 0) < 0) != 0;  // (a leaf with ambiguity codes forms a group of its own)
+          }
+          if (!slow) {
+            if (nl > 0) acc[0] *= (f64x4){it.v[0][0], it.v[0][1], it.v[1][0], it.v[1][1]};
+            if (nl > 1) acc[0] *= (f64x4){it.v[2][0], it.v[2][1], it.v[3][0], it.v[3][1]};
+          } else {  // ambiguity codes in this tile: product with the resolution vectors
+            const int leaf = o.z & 0xffff;
+            const int cd = leaf_code(leaf, 0);
+            const double *Af = a.Pfrag + ((size_t)leaf * NW + w) * TILE;
+            const double *av = a.ambig + (size_t)(cd < 0 ? -cd - 1 : 0) * DP;
+            f64x4 d = (f64x4){0., 0., 0., 0.};
+#pragma unroll 2
+            for (int kk = 0; kk < NKK; kk++) {
+              const double bv = (cd >= 0) ? ((4 * kk + g == cd) ? 1.0 : 0.0) : av[4 * kk + g];
+              d = mfma(Af[frag_index(kk, lane)], bv, d);
+            }
+            acc[0] *= d;
+          }
+        } else if (o.w != c) {  // OPK_DEP: deposited by the workgroup that computed it (its arrival was counted)
+          acc[0] *= (f64x4){it.v[0][0], it.v[0][1], it.v[1][0], it.v[1][1]};
+          cnt[0] += it.cnt;
+        }
+      };
+      for (int oi = 0; oi < jp.w; oi += 2) {  // unrolled by two: ping-pong operand registers, no copies
+        const int4 opn = tops[oi + 1];
+        if (oi + 1 < jp.w) issue(opn, itB);
+        consume(op, itA);
+        if (oi + 1 < jp.w) {
+          op = tops[oi + 2];
+          if (oi + 2 < jp.w) issue(op, itA);
+          consume(opn, itB);
+        }
+      }
+      cur ^= 1;
+      finalise((lastx & (OPF_NOPERSIST | OPF_LAST)) | (cur ? OPF_PARITY : 0) | (cur << 16), par, nullptr, false, []() {});
+      c = par;
+    }
+    root_epilogue<NW, T>(a, xbuf + (size_t)cur * T * TILE, &slot_scale[cur][w][0][0], &slot_cnt[cur][w][0][0], tile0, w, lane);
+    return;
+  }
   if (a.do_root)
     root_epilogue<NW, T>(a, xbuf + (size_t)a.root_slot * T * TILE, &slot_scale[a.root_slot][w][0][0],
                          &slot_cnt[a.root_slot][w][0][0], tile0, w, lane);
@@ -1225,6 +1403,272 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// 4-state kernel, r03 (`prune_nuc2_kernel<NP, PIN>`).  r02's kernel above was bound by neither memory (0.5 TB/s) nor
+// arithmetic: ~40 scalar + vector instructions per schedule entry and pattern, most of them moving the matrix between
+// SGPR sets and selecting a leaf's column with compare/select chains.  What changed:
+//  * a leaf edge is a LOOKUP: the transposed leaf matrices sit in LDS ([leaf][state][row], 128 bytes per leaf, filled once per
+//    workgroup) and a thread fetches the four entries of its pattern's column with two 16-byte reads — the four possible
+//    columns of a leaf cover all 32 banks exactly once, so any mix of states in a wave is conflict-free;
+//  * an internal edge uses the row-stochastic form of the reference's 4-state path (_handle4x4_pruning_case_direct,
+//    tree_evaluator.cpp:2253-2273): (P v)_i = (c0 P_i0 + c1 P_i1) + (v_3 + c2 P_i2), c_j = v_j - v_3 — 12 multiply-adds and
+//    3 subtractions, the matrix arriving through scalar loads one entry ahead (loop unrolled by two: no register moves);
+//  * NP patterns per thread share every scalar instruction, branch and wait of an entry and give the vector unit NP
+//    independent chains;
+//  * the rescaling test costs one wave ballot per finalisation unless some pattern really is out of range;
+//  * block reduction by wave shuffles + one LDS round instead of an 8-barrier tree.
+// Same schedule format, same exponent bookkeeping, same outputs as prune_nuc_kernel (which stays for trees whose leaf
+// matrices do not fit LDS).
+// ---------------------------------------------------------------------------------------------
+template <int NP, bool PIN>
+__global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict__ ops, const double *__restrict__ PTm,
+                                                         NucArgs a) {
+  constexpr int WGP = 256 * NP;  // patterns per workgroup
+  extern __shared__ __align__(16) double nlds[];
+  double *PT = nlds;                                                   // [L][4 states][4 rows]
+  double *park = nlds + (size_t)a.L * 16;                              // [slot][NP][4][256]
+  int *park_cnt = reinterpret_cast<int *>(park + kNucParkSlots * NP * 4 * 256);  // [slot][NP][256]
+  const int tid = threadIdx.x;
+  const size_t S_pad = a.S_pad;
+  const int s0 = blockIdx.x * WGP + tid;  // pattern q of this thread: s0 + 256 q
+  for (int idx = tid; idx < a.L * 16; idx += 256) PT[idx] = PTm[idx];  // (leaves are branches 0 .. L-1)
+  __syncthreads();
+  double acc[NP][4], b[NP][4];
+  int cnt[NP], bcnt[NP];
+#pragma unroll
+  for (int q = 0; q < NP; q++) {
+    cnt[q] = bcnt[q] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[q][j] = 1., b[q][j] = 0.;
+  }
+  // a leaf entry carries one or two leaves (api: leaf groups; a leaf with ambiguity codes forms a group of its own)
+  auto codes_of = [&](const int4 &o, int (&code)[2][NP]) {
+    const int nl = (o.x & 3) == OPK_LEAF ? ((o.x >> 8) & 0x7f) : 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int lf = (o.z >> (16 * i)) & 0xffff;
+#pragma unroll
+      for (int q = 0; q < NP; q++) {
+        code[i][q] = 0;
+        if (i < nl) {
+          if (PIN && lf == a.pin_leaf) code[i][q] = (int)a.pin[s0 + 256 * q];  // (pinned leaf: its states replace the data)
+          else code[i][q] = (int)a.codes[(size_t)lf * S_pad + s0 + 256 * q];
+        }
+      }
+    }
+  };
+  // columns 0..2 of an internal child's matrix = the first 12 doubles of its TRANSPOSED copy (PTm: [branch][state j][row i]);
+  // uniform address: three 32-byte scalar loads.  Leaf entries need no matrix here (LDS lookup).
+  auto load_P = [&](const int4 &o, double (&P)[12]) {
+    if ((o.x & 3) == OPK_LEAF) return;
+    const double *src = PTm + (size_t)o.z * 16;
+#pragma unroll
+    for (int e = 0; e < 12; e++) P[e] = src[e];
+  };
+  // one schedule entry: `code` = this thread's leaf codes (leaf entries), P = columns 0..2 of the child's transition matrix
+  auto entry = [&](const int4 &op, const double (&P)[12], const int (&code)[2][NP]) {
+    const int kind = op.x & 3, parent = op.y;
+    if (kind == OPK_LEAF) {
+      const int nl = (op.x >> 8) & 0x7f;
+      if (nl == 0) return;  // padding entry
+      const int lf = op.z & 0xffff;
+      bool any_ambig = false;
+#pragma unroll
+      for (int q = 0; q < NP; q++) any_ambig = any_ambig || code[0][q] < 0;
+      if (!__any(any_ambig)) {
+        const int lf1 = (op.z >> 16) & 0xffff;
+        f64x2 c01[2][NP], c23[2][NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) {  // (all lookups of the group in flight together)
+          const f64x2 *col = reinterpret_cast<const f64x2 *>(PT + lf * 16 + code[0][q] * 4);
+          c01[0][q] = col[0], c23[0][q] = col[1];
+          const f64x2 *col1 = reinterpret_cast<const f64x2 *>(PT + lf1 * 16 + (nl > 1 ? code[1][q] : 0) * 4);
+          c01[1][q] = col1[0], c23[1][q] = col1[1];
+        }
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+          acc[q][0] *= c01[0][q][0];
+          acc[q][1] *= c01[0][q][1];
+          acc[q][2] *= c23[0][q][0];
+          acc[q][3] *= c23[0][q][1];
+        }
+        if (nl > 1) {
+#pragma unroll
+          for (int q = 0; q < NP; q++) {
+            acc[q][0] *= c01[1][q][0];
+            acc[q][1] *= c01[1][q][1];
+            acc[q][2] *= c23[1][q][0];
+            acc[q][3] *= c23[1][q][1];
+          }
+        }
+      } else {  // (a leaf with ambiguity codes: always a group of one)
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+          double cv[4];
+          if (code[0][q] >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) cv[j] = (j == code[0][q]) ? 1. : 0.;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) cv[j] = a.ambig[(size_t)(-code[0][q] - 1) * 4 + j];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {  // (rare path: the leaf's full matrix from its LDS copy, [state j][row i])
+            double m = PT[lf * 16 + i] * cv[0];
+            m = fma(PT[lf * 16 + 4 + i], cv[1], m);
+            m = fma(PT[lf * 16 + 8 + i], cv[2], m);
+            m = fma(PT[lf * 16 + 12 + i], cv[3], m);
+            acc[q][i] *= m;
+          }
+        }
+      }
+    } else {
+      if (kind == OPK_INTERNAL) {  // parked by this thread in LDS (its parent was not the next entry)
+        const int ps = ((op.x >> 24) & 0xff) - 2;
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) b[q][j] = park[((ps * NP + q) * 4 + j) * 256 + tid];
+          bcnt[q] = park_cnt[(ps * NP + q) * 256 + tid];
+        }
+      } else if (!(op.x & OPF_INREGS)) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+          const size_t base = (size_t)op.w * 4 * S_pad + s0 + 256 * q;
+#pragma unroll
+          for (int j = 0; j < 4; j++) b[q][j] = a.partials[base + j * S_pad];
+          bcnt[q] = a.counts[(size_t)op.w * S_pad + s0 + 256 * q];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NP; q++) {
+        cnt[q] += bcnt[q];
+        const double c0 = b[q][0] - b[q][3], c1 = b[q][1] - b[q][3], c2 = b[q][2] - b[q][3], c3 = b[q][3];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const double t0 = fma(c1, P[4 + i], c0 * P[i]);
+          const double t1 = fma(c2, P[8 + i], c3);
+          acc[q][i] *= t0 + t1;
+        }
+      }
+    }
+    if (op.x & OPF_LAST) {
+      bool odd = false;
+      double tot[NP];
+#pragma unroll
+      for (int q = 0; q < NP; q++) {
+        if (PIN && parent == a.pin_inode) {  // pinned internal node: only the pinned state survives
+          const int ps = (int)a.pin[s0 + 256 * q];
+#pragma unroll
+          for (int i = 0; i < 4; i++) acc[q][i] = (i == ps) ? acc[q][i] : 0.;
+        }
+        tot[q] = (acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]);
+        odd = odd || !(tot[q] >= kScalerThreshold && tot[q] <= kScalerUp);
+      }
+      if (__any(odd)) {  // rare: some pattern of the wave needs (or cannot have) a rescale
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+          double sc;
+          const int m = rescale_decision(tot[q], sc);
+          if (m != 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[q][j] *= sc;
+            cnt[q] += m;
+          }
+        }
+      }
+      const int dslot = (op.x >> 16) & 0xff;
+#pragma unroll
+      for (int q = 0; q < NP; q++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[q][j] = acc[q][j];
+        bcnt[q] = cnt[q];
+        if (dslot >= 2) {  // pending node: its parent comes later in the schedule
+#pragma unroll
+          for (int j = 0; j < 4; j++) park[(((dslot - 2) * NP + q) * 4 + j) * 256 + tid] = b[q][j];
+          park_cnt[((dslot - 2) * NP + q) * 256 + tid] = cnt[q];
+        }
+        if (!(op.x & OPF_NOPERSIST_NUC)) {  // (lazy persistence: the host knows nobody re-reads this node)
+          const size_t base = (size_t)parent * 4 * S_pad + s0 + 256 * q;
+#pragma unroll
+          for (int j = 0; j < 4; j++) a.partials[base + j * S_pad] = b[q][j];
+          a.counts[(size_t)parent * S_pad + s0 + 256 * q] = cnt[q];
+        }
+        acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 1.;  // the next entry starts a new parent
+        cnt[q] = 0;
+      }
+    }
+  };
+  // Software pipeline, unrolled by two: matrix and leaf codes of entry i + 1 are requested before entry i is processed.
+  // Programs are padded to an even entry count and followed by two no-op entries.
+  // (schedule words two entries ahead: their scalar load has returned by the time they address the matrix / code loads)
+  int4 opA = ops[0], opB = ops[1];
+  double PA[12], PB[12];
+#pragma unroll
+  for (int e = 0; e < 12; e++) PA[e] = PB[e] = 0.;
+  int cA[2][NP], cB[2][NP];
+  load_P(opA, PA);
+  codes_of(opA, cA);
+  for (int oi = 0; oi < a.n_ops; oi += 2) {
+    const int4 opC = ops[oi + 2];
+    load_P(opB, PB);
+    codes_of(opB, cB);
+    entry(opA, PA, cA);
+    const int4 opD = ops[oi + 3];
+    load_P(opC, PA);
+    codes_of(opC, cA);
+    entry(opB, PB, cB);
+    opA = opC;
+    opB = opD;
+  }
+  // root: L_s = sum_k root[s][k] pi[k]; this workgroup's share of sum_s f_s log L_s and of the integer scaler sum
+  double term = 0.;
+  long long tc = 0;
+  int fl = 0;
+  if (a.n_ops > 0) {
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+      const int s = s0 + 256 * q;
+      double Lk = b[q][0] * a.pi[0];
+      Lk = fma(b[q][1], a.pi[1], Lk);
+      Lk = fma(b[q][2], a.pi[2], Lk);
+      Lk = fma(b[q][3], a.pi[3], Lk);
+      a.site_lik[s] = Lk;
+      a.site_cnt[s] = bcnt[q];
+      const double f = a.freq[s];
+      if (f != 0.) {
+        if (Lk != Lk || isinf(Lk)) fl |= 2;
+        else if (Lk <= 0.) fl |= 1;
+        else {
+          term += log(Lk) * f;
+          tc += (long long)bcnt[q] * (long long)f;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {  // fixed-order butterfly inside the wave, then the four waves in order
+    term += __shfl_xor(term, off);
+    tc += __shfl_xor(tc, off);
+    fl |= __shfl_xor(fl, off);
+  }
+  __syncthreads();  // (the parking area is dead: its first bytes carry the four waves' partial sums)
+  double *rs = park;
+  long long *rc = reinterpret_cast<long long *>(park + 4);
+  int *rf = reinterpret_cast<int *>(park + 8);
+  if ((tid & 63) == 0) {
+    rs[tid >> 6] = term;
+    rc[tid >> 6] = tc;
+    rf[tid >> 6] = fl;
+  }
+  __syncthreads();
+  if (tid == 0 && a.n_ops > 0) {
+    a.wg_sum[blockIdx.x] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    a.wg_cnt[blockIdx.x] = (rc[0] + rc[1]) + (rc[2] + rc[3]);
+    a.wg_flag[blockIdx.x] = rf[0] | rf[1] | rf[2] | rf[3];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // logL = sum_s f_s log L_s  -  64 ln2 * sum_s f_s c_s      (tree_evaluator.cpp:4114-4128 Kahan sum,
 // likefunc.cpp:11123 scaler correction).  One workgroup; per-thread Kahan accumulation over a
 // fixed stride, then a fixed-order tree: deterministic run to run.  The scaler part is summed in
@@ -1437,6 +1881,10 @@ void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
     else hipLaunchKernelGGL((prune_wave_kernel<NW, 1, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
     return;
   }
+  if (a.variant == 2 && a.chain && a.T == 1) {  // row-split workgroups on a chain schedule: grid = (tiles, classes, sources)
+    hipLaunchKernelGGL((prune_mfma_kernel<NW, 1, CLDS, false, 0, true>), grid, block, lds, stream, a.ops, a);
+    return;
+  }
   if (a.timeline) {  // tracing build of the kernel (HYPHY_HIP_TIMELINE), T = 1 only
     hipLaunchKernelGGL((prune_mfma_kernel<NW, 1, CLDS, true>), grid, block, lds, stream, a.ops, a);
     return;
@@ -1494,10 +1942,52 @@ void launch_prune_mfma(const PruneArgs &a, hipStream_t stream) {
   }
 }
 
+// prune_nuc2_kernel: NP patterns per thread while the leaf matrices (128 bytes each) and the parking slots fit LDS
+static int nuc_forced() {
+  static const int forced = getenv("HYPHY_HIP_NUC") ? atoi(getenv("HYPHY_HIP_NUC")) : -1;  // 0: r02 kernel, 1 / 2: patterns per thread
+  return forced;
+}
+bool prune_nuc_takes_leaf_pairs(int L) { return nuc_forced() != 0 && L <= 256; }
+static int nuc2_np(const NucArgs &a) {
+  const int forced = nuc_forced();
+  if (!prune_nuc_takes_leaf_pairs(a.L) || !a.PT) return 0;
+  if (forced == 1 || a.S_pad % 512 != 0) return 1;
+  if (forced == 2) return 2;
+  return a.S_pad >= 512 * 4 * 256 ? 2 : 1;  // two patterns per thread once that still leaves >= 4 workgroups per CU
+}
+static size_t nuc2_lds(const NucArgs &a, int np) {
+  return (size_t)a.L * 16 * sizeof(double) + (size_t)kNucParkSlots * np * 256 * (4 * sizeof(double) + sizeof(int));
+}
+
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream) {
   if (a.n_ops <= 0) return;
-  if (a.pin_leaf >= 0 || a.pin_inode >= 0) hipLaunchKernelGGL(prune_nuc_kernel<true>, dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a.ops, a.P, a);
-  else hipLaunchKernelGGL(prune_nuc_kernel<false>, dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a.ops, a.P, a);
+  const bool pin = a.pin_leaf >= 0 || a.pin_inode >= 0;
+  const int np = nuc2_np(a);
+  if (np == 0) {
+    if (pin) hipLaunchKernelGGL(prune_nuc_kernel<true>, dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a.ops, a.P, a);
+    else hipLaunchKernelGGL(prune_nuc_kernel<false>, dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a.ops, a.P, a);
+    return;
+  }
+  static bool attr_done[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_done[dev]) {  // (2 patterns per thread: 74 KiB of parking + up to 32 KiB of leaf matrices)
+    const int cap = 112 * 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    attr_done[dev] = true;
+  }
+  const dim3 grid(a.S_pad / (256 * np)), block(256);
+  const size_t lds = nuc2_lds(a, np);
+  if (np == 2) {
+    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<2, true>), grid, block, lds, stream, a.ops, a.PT, a);
+    else hipLaunchKernelGGL((prune_nuc2_kernel<2, false>), grid, block, lds, stream, a.ops, a.PT, a);
+  } else {
+    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true>), grid, block, lds, stream, a.ops, a.PT, a);
+    else hipLaunchKernelGGL((prune_nuc2_kernel<1, false>), grid, block, lds, stream, a.ops, a.PT, a);
+  }
 }
 
 void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,
@@ -1526,7 +2016,10 @@ void launch_bc_eval(const BcArgs &a, hipStream_t stream) {
     default: hipLaunchKernelGGL(bc_eval_kernel<4>, grid, block, 0, stream, a); break;
   }
 }
-int prune_nuc_grid(const NucArgs &a) { return (a.S_pad + 255) / 256; }
+int prune_nuc_grid(const NucArgs &a) {
+  const int np = nuc2_np(a);
+  return np ? a.S_pad / (256 * np) : (a.S_pad + 255) / 256;
+}
 
 void launch_mix_categories(const double *site_lik, const int32_t *site_cnt, const double *weights_dev, int C,
                            int S_pad, double *mixed_lik, int32_t *mixed_cnt, hipStream_t stream) {

@@ -21,7 +21,7 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
                  bool is_root_program) {
   const int L = (int)p->L, I = (int)p->I;
   const int T = p->shards.empty() ? 1 : p->shards[0].T;
-  const int G = p->nuc ? 1 : (T <= 2 ? 2 : 1);  // leaves per leaf-group entry (prune.hip)
+  const int G = p->nuc ? (p->nuc_leaf_pairs ? 2 : 1) : (T <= 2 ? 2 : 1);  // leaves per leaf-group entry (prune.hip)
   // A finished node whose parent is the next node of the program is read by that parent straight from
   // the exchange slot it was finalised into (slots 0/1 alternate with the finalisation count, so the
   // writer of the NEXT finalisation never touches it); otherwise it is parked in an LDS slot
@@ -259,6 +259,16 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
         for (int t = 2; t <= 8; t++)
           if ((long)count_sources(t) * wgs >= target) m = t;
     }
+    // What the join table can describe (the kernels decode jn[n].x = parent | image slot << 16 with "negative = root", and
+    // jn[n].y = arrivals needed | child sum << 8): parents below 2^16, image slots — the twins of a re-rooted schedule sit
+    // behind the branch cache's, at B + I + 2 + k — below 2^15, at most 255 internal children per node.  A tree beyond that
+    // (upwards of ~10 000 taxa, or a star of > 255 subtrees) is walked by the cuts that need no join table.
+    {
+      bool ok = I <= 65535 && (long)p->B + I + 2 + kMaxTwin < 32768;
+      for (int n = 0; n < I && ok; n++)
+        if (ich[n].size() > 255) ok = false;
+      if (!ok) m = I;
+    }
     if (m < I) {
       struct Src { int root, prio; };
       std::vector<Src> srcs;
@@ -297,6 +307,7 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
         p->emit_skip_par = p->emit_skip_child = -1;
         hyphy_hip_partition::Prog pr{off, n};
         pr.parent = sr.root == root_idx ? -1 : 0;
+        if (p->variant == 2) pr.parent = rs;  // (row-split workgroups: the exchange slot the source's root ends up in)
         pr.need = sr.root;  // (chain schedules: w = the source's root node)
         p->programs.push_back(pr);
         if (sr.root == root_idx) p->root_slot = rs;
@@ -304,7 +315,7 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
       const bool lazy = !p->sched_persist;
       for (int n = 0; n < I; n++) {
         int sum = 0;
-        for (int c : ich[n]) sum += c;
+        if (ich[n].size() == 2) sum = ich[n][0] + ich[n][1];  // (read by a wave that finds its ONE sibling already arrived)
         // x: parent | image slot of the edge above n << 16: the node's own branch L + n, or — reversed edges of a re-rooted
         // schedule — the transposed twin of the branch of the NEXT node on the path (expm.hip; slot behind the branch cache's)
         const int slot = (rr && on_path[n] >= 0) ? (int)(p->B + (I + 2) + on_path[n]) : L + n;
@@ -352,7 +363,7 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
   // Wave-per-tile kernel: ONE launch; the fragments are chained on the device — the workgroup that
   // completes the last child fragment of a program (per tile) goes on to run that program itself
   // (arrival counters, prune.hip), so the levels below only define the cut, not launches.
-  const bool chained = p->variant >= 1;
+  const bool chained = p->variant == 1;
   std::vector<int> prog_of(I, -1);
   std::vector<char> done(I, 0);
   std::vector<int> size(I, 0);
@@ -586,6 +597,70 @@ int hyphy_hip_plan_pattern_order(int64_t D, int64_t L, int64_t S, const int64_t 
   tmp.S = S;
   sort_patterns(&tmp, leaf_codes, L, S);
   for (int64_t k = 0; k < S; k++) order_out[k] = tmp.perm.empty() ? k : tmp.perm[k];
+  return 0;
+}
+
+int hyphy_hip_plan_schedule(int64_t L, int64_t I, const int64_t *flat_parents, int64_t kernel, int64_t chain_m, int64_t ntiles,
+                            int64_t reroot, int64_t *info_out) {
+  if (L < 2 || I < 1 || !flat_parents || !info_out || kernel < 0 || kernel > 2 || ntiles < 1) return -1;
+  hyphy_hip_partition tmp;
+  tmp.D = 61; tmp.L = L; tmp.I = I; tmp.C = 1; tmp.B = L + I - 1; tmp.NW = 4; tmp.DP = 64;
+  tmp.parents.assign(flat_parents, flat_parents + L + I);
+  tmp.children.assign(I, std::vector<int>());
+  for (int64_t n = 0; n < L + I - 1; n++) {
+    const int64_t par = flat_parents[n];
+    if (par < 0 || par >= I || (n >= L && par <= n - L)) return -1;
+    tmp.children[par].push_back((int)n);
+  }
+  tmp.leaf_has_ambig.assign(L, 0);
+  tmp.shards.resize(1);
+  tmp.shards[0].T = 1;
+  tmp.shards[0].ntiles = (int)ntiles;
+  tmp.shards[0].S_pad = (int)ntiles * 16;
+  tmp.shards[0].cus = 256;
+  tmp.variant = (int)kernel;
+  tmp.n_slots = kernel == 1 ? tmp.n_slots_wave : lds_slots(1);
+  tmp.chain_m_forced = (int)chain_m;
+  tmp.sched_persist = false;  // a steady-state (lazy) full pass
+  if (reroot) {
+    reroot_path(&tmp);
+    tmp.rr_use = true;
+  }
+  build_schedule(&tmp, nullptr, 0, true);
+  int64_t max_slot = 0, max_need = 0, bad = 0, trunk = 0;
+  if (tmp.chain) {
+    // decode every record exactly as prune.hip does and hold it against the topology the schedule was built on
+    std::vector<int> rpar(I, -1);
+    for (int64_t n = 0; n + 1 < I; n++) rpar[n] = (int)flat_parents[L + n];
+    if (tmp.rr_active) {
+      for (size_t i = 0; i + 1 < tmp.rr_path.size(); i++) rpar[tmp.rr_path[i]] = tmp.rr_path[i + 1];
+      rpar[tmp.rr_path.back()] = -1;
+    }
+    std::vector<int> kids(I, 0);
+    for (int64_t n = 0; n < I; n++)
+      if (rpar[n] >= 0) kids[rpar[n]]++;
+    for (int64_t n = 0; n < I; n++) {
+      const int4 j = tmp.jn_host[n];
+      if (rpar[n] < 0) {
+        if (j.x >= 0) bad++;
+      } else {
+        if (j.x < 0 || (j.x & 0xffff) != rpar[n]) bad++;
+        max_slot = std::max<int64_t>(max_slot, j.x >> 16);
+      }
+      if ((j.y & 0xff) != kids[n]) bad++;
+      max_need = std::max<int64_t>(max_need, j.y & 0xff);
+      if (j.w > 0) trunk++;
+    }
+  }
+  info_out[0] = tmp.chain ? 1 : 0;
+  info_out[1] = (int64_t)tmp.programs.size();
+  info_out[2] = (int64_t)tmp.ops_host.size();
+  info_out[3] = max_slot;
+  info_out[4] = max_need;
+  info_out[5] = bad;
+  info_out[6] = tmp.rr_active ? 1 : 0;
+  info_out[7] = trunk;
+  tmp.shards.clear();
   return 0;
 }
 

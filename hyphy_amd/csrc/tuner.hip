@@ -60,142 +60,126 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   p->tuned_for = p->batch_classes;
   const int I = (int)p->I;
   Shard &s = p->shards[0];
-  std::vector<int> cand = {-1};
-  for (int m : {3, 5, 8, 12, 16, 24, 40, 64})
-    if (m < I) cand.push_back(m);
   const int T0 = s.T;
-  if (!p->kernel_forced && T0 == 1 && s.ntiles < 2 * s.cus) cand.push_back(-2);  // the row-split workgroup kernel (small shards)
-  auto set_kernel = [&](int v) {
-    p->variant = v;
-    p->n_slots = v >= 1 ? p->n_slots_wave : lds_slots(T0);
+  // a candidate: kernel (0 row-split workgroups / 1 wave per tile / 2 row-split workgroups on a chain schedule), cut
+  // (m > 0: chain schedule with sources of at most m nodes, -1: level-peeled fragments, 0: the kernel's own heuristic),
+  // instantiation of the wave kernel (0 / 2: three waves per SIMD), re-rooting candidate (-1: the given root)
+  struct Cand { int kernel, m, wv, rr; };
+  auto label = [](const Cand &c) {
+    char b[48];
+    snprintf(b, sizeof b, "%s%s%s%d", c.rr >= 0 ? (c.rr ? "rr1/" : "rr0/") : "", c.wv == 2 ? "occ3/" : "",
+             c.kernel == 0 ? "wg-kernel" : (c.kernel == 2 ? "team/m" : (c.m < 0 ? "levels" : "m")), c.m < 0 ? 0 : c.m);
+    return std::string(b);
   };
-  double best_ms = 1e30;
-  int best = 0;
-  char buf[64];
-  std::vector<std::pair<double, int>> ranked;  // (time, chain cut) of the first stage
-  p->tune_report.clear();
-  for (int c : cand) {
-    p->chain_m_forced = c == -2 ? 0 : c;
-    set_kernel(c == -2 ? 0 : 1);
+  auto apply = [&](const Cand &c) -> bool {  // build the candidate's schedule; false: not applicable
+    p->variant = c.kernel;
+    p->wave_variant = c.kernel == 1 ? c.wv : 0;
+    p->n_slots = c.kernel == 1 ? (c.wv == 2 ? 2 : p->n_slots_wave) : lds_slots(T0);
+    p->chain_m_forced = c.m;
+    if (c.rr >= 0 && p->rr_path != p->rr_cands[(size_t)c.rr]) {
+      p->rr_path = p->rr_cands[(size_t)c.rr];
+      for (Shard &sh : p->shards) sh.twins_dirty = true;  // (other twins: refreshed by the transpose kernel before the launch)
+    }
+    p->rr_use = c.rr >= 0;
     build_schedule(p, nullptr, 0, true);
-    if (p->ops_host.size() > ops_capacity(p)) continue;
-    if (c > 0 && !p->chain) continue;  // (m >= I: the same as no cut)
-    if (upload_schedule(p, s)) return -1;
+    if (p->ops_host.size() > ops_capacity(p)) return false;
+    if (c.m > 0 && !p->chain) return false;  // (m >= I, or a tree the join table cannot describe: the same as no cut)
+    if (c.rr >= 0 && !p->rr_active) return false;
+    return true;
+  };
+  int err = 0;
+  auto time_it = [&](const Cand &c) -> double {  // fastest of two passes behind a warm-up pass, ms; < 0: not measured
+    if (!apply(c)) return -1.;
+    if (upload_schedule(p, s)) {
+      err = -1;
+      return -1.;
+    }
     float ms = 0.f, ms2 = 0.f;
     launch_prune_current(p, s, cat, n_cat_batch);  // warm-up (instruction cache, schedule in L2)
-    HIPCHK(hipEventRecord(s.ev[0], s.stream));
+    if (hipEventRecord(s.ev[0], s.stream) != hipSuccess) return -1.;
     launch_prune_current(p, s, cat, n_cat_batch);
-    HIPCHK(hipEventRecord(s.ev[1], s.stream));
+    if (hipEventRecord(s.ev[1], s.stream) != hipSuccess) return -1.;
     launch_prune_current(p, s, cat, n_cat_batch);
-    HIPCHK(hipEventRecord(s.ev[2], s.stream));
-    HIPCHK(hipStreamSynchronize(s.stream));
-    HIPCHK(hipGetLastError());
-    if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) != hipSuccess || hipEventElapsedTime(&ms2, s.ev[1], s.ev[2]) != hipSuccess) continue;
-    ms = std::min(ms, ms2);
-    snprintf(buf, sizeof buf, "%s%s%d:%.1fus", p->tune_report.empty() ? "" : " ", c == -2 ? "wg-kernel" : (c < 0 ? "levels" : "m"), c < 0 ? 0 : c, 1e3 * ms);
-    p->tune_report += buf;
-    if (c > 0) ranked.push_back(std::make_pair((double)ms, c));
-    if (ms < best_ms) {
-      best_ms = ms;
+    if (hipEventRecord(s.ev[2], s.stream) != hipSuccess) return -1.;
+    if (hipStreamSynchronize(s.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+      err = fail("schedule tuner: a candidate launch failed");
+      return -1.;
+    }
+    if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) != hipSuccess || hipEventElapsedTime(&ms2, s.ev[1], s.ev[2]) != hipSuccess) return -1.;
+    const double t = std::min(ms, ms2);
+    p->tune_report += (p->tune_report.empty() ? "" : " ") + label(c) + ":";
+    char b[32];
+    snprintf(b, sizeof b, "%.1fus", 1e3 * t);
+    p->tune_report += b;
+    return t;
+  };
+  p->tune_report.clear();
+  Cand best{1, -1, 0, -1};
+  double best_ms = 1e30;
+  // ---- first stage: the cut, per kernel ----
+  std::vector<Cand> stage1;
+  const int forced = p->kernel_forced ? p->variant : -1;  // HYPHY_HIP_KERNEL / T > 1: only that kernel's cuts compete
+  if (forced < 0 || forced == 1) {
+    stage1.push_back({1, -1, 0, -1});
+    for (int m : {3, 5, 8, 12, 16, 24, 40, 64})
+      if (m < I) stage1.push_back({1, m, 0, -1});
+  }
+  const bool small = T0 == 1 && s.ntiles < 2 * s.cus;   // below two tiles per CU
+  const bool medium = T0 == 1 && s.ntiles < 4 * s.cus;
+  if ((forced < 0 && small) || forced == 0) stage1.push_back({0, 0, 0, -1});  // one workgroup walks the whole tree of its tile
+  static const bool team_on = !(getenv("HYPHY_HIP_TEAM") && atoi(getenv("HYPHY_HIP_TEAM")) == 0);
+  if (((forced < 0 && medium && team_on) || forced == 2) && T0 == 1)
+    for (int m : {3, 5, 8, 12, 16, 24})
+      if (m < I) stage1.push_back({2, m, 0, -1});
+  std::vector<std::pair<double, int>> ranked[3];  // per kernel: (time, cut) of the chain schedules
+  for (const Cand &c : stage1) {
+    const double t = time_it(c);
+    if (err) return -1;
+    if (t < 0.) continue;
+    if (c.m > 0) ranked[c.kernel].push_back(std::make_pair(t, c.m));
+    if (t < best_ms) {
+      best_ms = t;
       best = c;
     }
   }
-  // second stage: the instantiation compiled for 3 waves per SIMD (finalised node in LDS, no parking slot, no register
-  // prefetch of deposits) around the best cut — it wins where waves are plentiful (128 taxa x 100k codons: +7 %)
-  int best_wv = 0;
+  for (auto &r : ranked) std::sort(r.begin(), r.end());
+  // ---- second stage: the wave kernel's instantiation compiled for 3 waves per SIMD (finalised node in LDS, no parking
+  // slot, no register prefetch of deposits) on its three fastest cuts — it wins where waves are plentiful ----
   const double stage1_ms = best_ms;
-  p->wave_variant = 0;
-  if (best > 0 && p->NW == 4 && !getenv("HYPHY_HIP_WAVE_VARIANT") && !getenv("HYPHY_HIP_SLOTS")) {
-    std::vector<int> ms;  // the three fastest cuts of the first stage
-    std::sort(ranked.begin(), ranked.end());
-    for (size_t k = 0; k < ranked.size() && k < 3; k++) ms.push_back(ranked[k].second);
-    for (int m : ms) {
-      p->chain_m_forced = m;
-      p->variant = 1;
-      p->n_slots = 2;
-      p->wave_variant = 2;
-      build_schedule(p, nullptr, 0, true);
-      if (p->ops_host.size() > ops_capacity(p) || !p->chain) continue;
-      if (upload_schedule(p, s)) return -1;
-      float ms1 = 0.f, ms2 = 0.f;
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[0], s.stream));
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[1], s.stream));
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[2], s.stream));
-      HIPCHK(hipStreamSynchronize(s.stream));
-      HIPCHK(hipGetLastError());
-      if (hipEventElapsedTime(&ms1, s.ev[0], s.ev[1]) != hipSuccess || hipEventElapsedTime(&ms2, s.ev[1], s.ev[2]) != hipSuccess) continue;
-      ms1 = std::min(ms1, ms2);
-      snprintf(buf, sizeof buf, " occ3/m%d:%.1fus", m, 1e3 * ms1);
-      p->tune_report += buf;
+  int wave_wv = 0;  // instantiation the wave kernel's candidates of the third stage use
+  if (best.kernel == 1 && best.m > 0 && p->NW == 4 && !getenv("HYPHY_HIP_WAVE_VARIANT") && !getenv("HYPHY_HIP_SLOTS"))
+    for (size_t k = 0; k < ranked[1].size() && k < 3; k++) {
+      const Cand c{1, ranked[1][k].second, 2, -1};
+      const double t = time_it(c);
+      if (err) return -1;
       // (2 % margin over the first stage: at equal tuner times the production pass of the 2-waves build is the faster one)
-      if (ms1 < 0.98 * stage1_ms && ms1 < best_ms) {
-        best_ms = ms1;
-        best = m;
-        best_wv = 2;
+      if (t >= 0. && t < 0.98 * stage1_ms && t < best_ms) {
+        best_ms = t;
+        best = c;
+        wave_wv = 2;
       }
     }
-  }
-  // third stage: the same tree hung from the node that minimises its height (re-rooted schedules, hyphy_hip_partition::rr_path):
-  // shorter critical path per tile, the same work — wins on small and medium shards of unbalanced trees
-  bool best_rr = false;
-  p->rr_use = false;
-  if (best > 0 && !p->rr_path.empty() && n_cat_batch <= 1 && !getenv("HYPHY_HIP_REROOT")) {
-    std::vector<int> ms;
-    std::sort(ranked.begin(), ranked.end());
-    for (size_t k = 0; k < ranked.size() && k < 3; k++) ms.push_back(ranked[k].second);
-    size_t best_cand = 0;
+  // ---- third stage: the same tree hung from the node that minimises its height (re-rooted schedules): shorter critical
+  // path per tile, the same work — wins on small and medium shards of unbalanced trees ----
+  if (best.m > 0 && !p->rr_path.empty() && n_cat_batch <= 1 && !getenv("HYPHY_HIP_REROOT")) {
+    const int kn = best.kernel;
+    bool rr_won = false;
     for (size_t ci = 0; ci < p->rr_cands.size(); ci++)
-    for (int m : ms) {
-      if (p->rr_path != p->rr_cands[ci]) {
-        p->rr_path = p->rr_cands[ci];
-        for (Shard &sh : p->shards) sh.twins_dirty = true;  // (other twins: refreshed by the transpose kernel before the launch)
+      for (size_t k = 0; k < ranked[kn].size() && k < 3; k++) {
+        const Cand c{kn, ranked[kn][k].second, kn == 1 ? wave_wv : 0, (int)ci};
+        const double t = time_it(c);
+        if (err) return -1;
+        // (5 % margin against the given root: the tuner's pass ranked a re-rooted form of the headline tree 4.5 % ahead that
+        // was 1 % behind in production)
+        if (t >= 0. && t < (rr_won ? 1.0 : 0.95) * best_ms) {
+          best_ms = t;
+          best = c;
+          rr_won = true;
+        }
       }
-      p->chain_m_forced = m;
-      p->variant = 1;
-      p->wave_variant = best_wv;
-      p->n_slots = best_wv == 2 ? 2 : p->n_slots_wave;
-      p->rr_use = true;
-      build_schedule(p, nullptr, 0, true);
-      p->rr_use = false;
-      if (p->ops_host.size() > ops_capacity(p) || !p->chain || !p->rr_active) continue;
-      if (upload_schedule(p, s)) return -1;
-      float ms1 = 0.f, ms2 = 0.f;
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[0], s.stream));
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[1], s.stream));
-      launch_prune_current(p, s, cat, n_cat_batch);
-      HIPCHK(hipEventRecord(s.ev[2], s.stream));
-      HIPCHK(hipStreamSynchronize(s.stream));
-      HIPCHK(hipGetLastError());
-      if (hipEventElapsedTime(&ms1, s.ev[0], s.ev[1]) != hipSuccess || hipEventElapsedTime(&ms2, s.ev[1], s.ev[2]) != hipSuccess) continue;
-      ms1 = std::min(ms1, ms2);
-      snprintf(buf, sizeof buf, " rr%zu/m%d:%.1fus", ci, m, 1e3 * ms1);
-      p->tune_report += buf;
-      // (5 % margin against the given root: the tuner's pass ranked a re-rooted form of the headline tree 4.5 % ahead that was
-      // 1 % behind in production)
-      if (ms1 < (best_rr ? 1.0 : 0.95) * best_ms) {
-        best_ms = ms1;
-        best = m;
-        best_rr = true;
-        best_cand = ci;
-      }
-    }
-    if (p->rr_path != p->rr_cands[best_cand]) {
-      p->rr_path = p->rr_cands[best_cand];
-      for (Shard &sh : p->shards) sh.twins_dirty = true;
-    }
   }
-  p->rr_use = best_rr;
-  p->wave_variant = best_wv;
-  p->chain_m_forced = best == -2 ? 0 : best;
-  set_kernel(best == -2 ? 0 : 1);
-  if (best_wv == 2) p->n_slots = 2;
-  snprintf(buf, sizeof buf, " -> %s%s%s%d", best_rr ? "rr/" : "", best_wv == 2 ? "occ3/" : "", best == -2 ? "wg-kernel" : (best < 0 ? "levels" : "m"), best < 0 ? 0 : best);
-  p->tune_report += buf;
+  apply(best);  // (leaves kernel, slot budget, instantiation, cut and re-rooting path set; the caller rebuilds the schedule)
+  p->tune_report += " -> " + label(best);
   if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] schedule tuner (%d classes per launch): %s\n", n_cat_batch, p->tune_report.c_str());
   return 0;
 }

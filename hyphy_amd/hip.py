@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("HYPHY_HIP_LIB") or os.path.join(HERE, "lib", "libhyph
 
 EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
-    "hyphy_hip_evaluate_device", "hyphy_hip_fetch_device_scalar", "hyphy_hip_plan_reroot", "hyphy_hip_plan_pattern_order", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_comm_unique_id", "hyphy_hip_comm_init_rank", "hyphy_hip_comm_init_all", "hyphy_hip_allreduce_device", "hyphy_hip_evaluate_allreduce", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
+    "hyphy_hip_evaluate_device", "hyphy_hip_fetch_device_scalar", "hyphy_hip_plan_reroot", "hyphy_hip_plan_pattern_order", "hyphy_hip_plan_schedule", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_comm_unique_id", "hyphy_hip_comm_init_rank", "hyphy_hip_comm_init_all", "hyphy_hip_allreduce_device", "hyphy_hip_evaluate_allreduce", "hyphy_hip_evaluate_built_allreduce", "hyphy_hip_last_allreduce_ms", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
@@ -76,6 +76,8 @@ def load():
     lib.hyphy_hip_plan_reroot.argtypes = [C.c_int64, C.c_int64, lp, C.c_int64, lp, C.c_int64]
     lib.hyphy_hip_plan_pattern_order.restype = C.c_int
     lib.hyphy_hip_plan_pattern_order.argtypes = [C.c_int64, C.c_int64, C.c_int64, lp, lp]
+    lib.hyphy_hip_plan_schedule.restype = C.c_int
+    lib.hyphy_hip_plan_schedule.argtypes = [C.c_int64, C.c_int64, lp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, lp]
     lib.hyphy_hip_fetch_device_scalar.restype = C.c_int
     lib.hyphy_hip_fetch_device_scalar.argtypes = [vp, vp, C.POINTER(C.c_double)]
     lib.hyphy_hip_evaluate_device.restype = C.c_int
@@ -108,6 +110,10 @@ def load():
     lib.hyphy_hip_stream.argtypes = [vp]
     lib.hyphy_hip_set_stream.restype = C.c_int
     lib.hyphy_hip_set_stream.argtypes = [vp, vp]
+    lib.hyphy_hip_evaluate_built_allreduce.restype = C.c_int
+    lib.hyphy_hip_evaluate_built_allreduce.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, dp]
+    lib.hyphy_hip_last_allreduce_ms.restype = C.c_double
+    lib.hyphy_hip_last_allreduce_ms.argtypes = [vp]
     lib.hyphy_hip_last_timings.restype = C.c_int
     lib.hyphy_hip_last_timings.argtypes = [vp, dp]
     lib.hyphy_hip_schedule_info.restype = C.c_char_p
@@ -166,6 +172,17 @@ def plan_pattern_order(D: int, leaf_codes) -> np.ndarray:
     if load().hyphy_hip_plan_pattern_order(int(D), lc.shape[0], lc.shape[1], _l(lc), _l(out)):
         raise HipError("plan_pattern_order: bad arguments")
     return out
+
+
+def plan_schedule(flat_parents, L: int, kernel: int = 1, chain_m: int = 0, ntiles: int = 64, reroot: bool = False) -> dict:
+    """Host-only: compile the steady-state full-pass schedule of a 61-state partition of this shape and decode its join
+    table the way the kernels do (include/hyphy_hip.h: hyphy_hip_plan_schedule)."""
+    fp = np.ascontiguousarray(flat_parents, dtype=np.int64)
+    info = np.zeros(8, dtype=np.int64)
+    if load().hyphy_hip_plan_schedule(int(L), len(fp) - int(L), _l(fp), int(kernel), int(chain_m), int(ntiles), int(bool(reroot)), _l(info)):
+        raise HipError("plan_schedule: bad arguments")
+    keys = ("chain", "programs", "entries", "max_slot", "max_need", "decode_errors", "rerooted", "trunk_nodes")
+    return dict(zip(keys, (int(v) for v in info)))
 
 
 def device_count() -> int:
@@ -361,6 +378,34 @@ class HipPartition:
                 _check(rc)
             return out.value
         return step
+
+    def prepare_built_allreduce_step(self, update_nodes, q_nodes, root_freqs, coeffs: np.ndarray, cat: int = -1):
+        """Zero-argument callable: ``build_q(coeffs)`` + ``evaluate_built_allreduce`` -> log-L of the WHOLE alignment on every
+        rank (local evaluation of this rank's pattern shard, one ncclAllReduce in the partition's stream, value back through
+        the host-mapped record).  Needs ``comm_init_rank`` first."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        assert coeffs.flags.c_contiguous and coeffs.dtype == np.float64
+        keep = (un, qn, rf, coeffs)
+        lib, h = self._lib, self._h
+        pun, pqn, prf, pco = _l(un), _l(qn), _d(rf), _d(coeffs)
+        nun, nqn, nco = len(un), len(qn), coeffs.shape[0]
+        out = C.c_double(0.0)
+        pout = C.byref(out)
+
+        def step(_keep=keep):
+            rc = lib.hyphy_hip_build_q(h, nco, pco)
+            if rc == 0:
+                rc = lib.hyphy_hip_evaluate_built_allreduce(h, cat, pun, nun, pqn, nqn, prf, pout)
+            if rc:
+                _check(rc)
+            return out.value
+        return step
+
+    def last_allreduce_ms(self) -> float:
+        """Event-timed duration of the last in-stream all-reduce (``set_all_timings(True)``), ms."""
+        return float(self._lib.hyphy_hip_last_allreduce_ms(self._h))
 
     def prepare_built_categories_step(self, update_nodes, q_nodes, weights, root_freqs, coeffs: np.ndarray):
         """``build_q`` (C*n_q coefficient rows, class-major) + ``evaluate_categories_built`` -> log-L."""

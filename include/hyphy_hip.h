@@ -141,8 +141,8 @@ int hyphy_hip_collect(hyphy_hip_partition *p, double *logl_out, double *site_lik
  *                          double, in the partition's stream).  hyphy_hip_allreduce_device is the bare in-stream sum
  *                          for callers of hyphy_hip_evaluate_device.
  *   one process, N GPUs:   hyphy_hip_create(device_count = N) + hyphy_hip_comm_init_all(p): with HYPHY_HIP_COMBINE=rccl
- *                          hyphy_hip_evaluate sums the shard partials by ONE group all-reduce instead of on the host
- *                          (default: host-side Neumaier combine, likefunc.cpp:11046-11093).
+ *                          hyphy_hip_evaluate / hyphy_hip_evaluate_built sum the shard partials by ONE group all-reduce
+ *                          instead of on the host (default: host-side Neumaier combine, likefunc.cpp:11046-11093).
  */
 int hyphy_hip_comm_unique_id(void *out128);
 int hyphy_hip_comm_init_rank(hyphy_hip_partition *p, const void *unique_id, int rank, int n_ranks);
@@ -151,6 +151,14 @@ int hyphy_hip_allreduce_device(hyphy_hip_partition *p, double *d_value);
 int hyphy_hip_evaluate_allreduce(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                                  const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
                                  const double *root_freqs, double *logl_out);
+/* ... behind hyphy_hip_build_q (template models; the step `bench.py --gpus N` times): local construction + exponentials +
+ * pruning + reduction, one ncclAllReduce of one double on the partition's stream, the sum back through the host-mapped
+ * record.  A rank whose local evaluation fails still joins the collective (with NaN) and then returns its error: no rank
+ * is left waiting.  hyphy_hip_last_allreduce_ms: event-timed duration of the last in-stream all-reduce while
+ * hyphy_hip_set_timing_detail is on (else 0). */
+int hyphy_hip_evaluate_built_allreduce(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                                       const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out);
+double hyphy_hip_last_allreduce_ms(const hyphy_hip_partition *p);
 
 /*
  * Same evaluation with device-resident inputs/outputs, enqueued asynchronously on the
@@ -344,9 +352,20 @@ const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p);
  *   hyphy_hip_plan_reroot       the path (internal indices, given root first) to the `candidate`-th (0, 1) height-minimising
  *                               node the steady-state passes may be rooted at (re-rooted schedules); returns the
  *                               number of nodes on the path, 0 if there is no such candidate, < 0 on bad arguments.
- *   hyphy_hip_plan_pattern_order  the device-side pattern order (order_out[j] = caller's pattern stored j-th). */
+ *   hyphy_hip_plan_pattern_order  the device-side pattern order (order_out[j] = caller's pattern stored j-th).
+ *   hyphy_hip_plan_schedule     compiles the steady-state full-pass schedule of a 61-state partition with `ntiles` 16-pattern
+ *                               tiles for `kernel` (0 workgroup per tile, 1 wave per tile, 2 row-split workgroups on chain
+ *                               schedules) and cut `chain_m` (> 0: chain schedule with sources of at most chain_m nodes, -1:
+ *                               level-peeled fragments, 0: the library's heuristic), optionally re-rooted, and decodes its join
+ *                               table the way the kernels do.  info_out[8] = {chain schedule (0/1), programs, schedule entries,
+ *                               largest matrix-image slot in the join table, most arrivals a node waits for, records that do not
+ *                               decode to the topology (must be 0), re-rooted (0/1), trunk nodes}.  Trees the packed join table
+ *                               cannot describe (> 65 535 internal nodes, image slots >= 2^15, > 255 internal children of one node)
+ *                               get a schedule without chains. */
 int64_t hyphy_hip_plan_reroot(int64_t L, int64_t I, const int64_t *flat_parents, int64_t candidate, int64_t *path_out, int64_t cap);
 int hyphy_hip_plan_pattern_order(int64_t D, int64_t L, int64_t S, const int64_t *leaf_codes, int64_t *order_out);
+int hyphy_hip_plan_schedule(int64_t L, int64_t I, const int64_t *flat_parents, int64_t kernel, int64_t chain_m, int64_t ntiles,
+                            int64_t reroot, int64_t *info_out);
 
 const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p);
 

@@ -375,6 +375,29 @@ def fullsize_partitions(name="full_gtr_32x50k_x8", taxa=32, sites=50000, n_part=
     print(f"{name}: logL = {res['logl']!r}  sum of partitions = {sum(part_ll)!r}")
 
 
+def fullsize_sweep(name="full_mg94_64x10k_sweep", taxa=64, codons=10000, seed=3, n=40, threads=16):
+    """The parameter points bench.py's timed loop visits on the headline workload (omega = 0.3 + 0.001 k, k = 1 .. n, every
+    branch at t = 0.05): the reference's log L at each of them, so that the TIMED path (hyphy_hip_build_q +
+    hyphy_hip_evaluate_built on the tuned / forced schedules) is held to the reference under `pytest -m gpu`, not only inside
+    bench.py's own parity block."""
+    syn = data.evolve(taxa, codons, 3, seed=seed, p_change=0.04)
+    flat = syn.flat
+    bt = {nm: 0.05 for nm in flat.branch_names()}
+    tmpl = models.mg94rev_template(POS_FREQS)
+    pi = models.f3x4_codon_freqs(POS_FREQS)
+    g = dict(R=0.3, **REV)
+    res = hbl.evaluate(names=flat.leaf_names, seqs=syn.seqs, newick=tree.to_newick(syn.tree), unit=3,
+                       model_block=hbl.codon_model_block(tmpl, pi), model_name="MGM", globals_=g, branch_t=bt,
+                       sweep=dict(param="R", start=0.3, step=0.001, n=n, record=n), threads=threads, per_site=False, timeout=3600.0)
+    sv = np.asarray(res["sweep_values"])
+    assert len(sv) == n
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="codon_sweep", taxa=taxa, sites=codons, seed=seed, p_change=0.04,
+                        states_crc=_crc(syn.states.astype(np.int16)), t=0.05, omega0=0.3, omega_step=0.001,
+                        rev=np.array([REV[k] for k in ("AC", "AT", "CG", "CT", "GT")]), pos_freqs=POS_FREQS,
+                        logl0=res["logl"], sweep_logl=sv)
+    print(f"{name}: logL(0.3) = {res['logl']!r}, {n} sweep points, last = {sv[-1]!r}")
+
+
 def fullsize_cases():
     fullsize_codon("full_mg94_32x5k", 32, 5000, seed=2)            # configs[1]
     fullsize_codon("full_mg94_64x10k", 64, 10000, seed=3)          # the headline metric's workload
@@ -389,6 +412,12 @@ def main():
         os.makedirs(OUT, exist_ok=True)
         mixture_case()
         mixture_case("codon_mix3", 20, 80, seed=43, omegas=(0.05, 0.8, 6.0), weights=(0.6, 0.3, 0.1))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        if not hbl.have_reference():
+            raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
+        os.makedirs(OUT, exist_ok=True)
+        fullsize_sweep()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
         if not hbl.have_reference():

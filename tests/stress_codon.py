@@ -18,7 +18,7 @@ for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
     taxa = int(rng.integers(4, 70))
     codons = int(rng.integers(20, 700))
-    kernel = str(int(rng.integers(0, 2)))
+    kernel = str(int(rng.integers(0, 3)))   # 0: workgroup per tile, 1: wave per tile, 2: row-split workgroups on chain schedules
     frag = int(rng.choice([2, 3, 5, 8, 13, 1000]))
     slots, persist = str(int(rng.choice([2, 3]))), str(rng.choice(["lazy", "always"]))
     chain_m = str(int(rng.choice([0, 1, 2, 3, 5])))   # wave-per-tile kernel: chain schedule with sources of <= m nodes (0: level-peeled fragments)

@@ -35,7 +35,7 @@ for case in range(n_cases):
     taxa = int(rng.integers(3, 90))
     sites = int(rng.integers(5, 3000 if D == 4 else 500))
     n_cat = int(rng.choice([1, 1, 2, 3, 4]))
-    kernel = os.environ.get("STRESS_KERNEL", str(int(rng.integers(0, 2))))
+    kernel = os.environ.get("STRESS_KERNEL", str(int(rng.integers(0, 3))))
     frag = os.environ.get("STRESS_FRAGMENT", str(int(rng.choice([2, 4, 7, 11, 1000]))))
     persist = os.environ.get("STRESS_CACHE", str(rng.choice(["lazy", "always"])))
     tiles = os.environ.get("STRESS_TILES", str(int(rng.choice([1, 1, 2, 3, 4]))))  # patterns tiles per workgroup (workgroup kernel)

@@ -1,0 +1,139 @@
+"""The N > 1 forms of the path on real devices, through the C-ABI — skipped on boxes with fewer than two GPUs:
+ * one process per GPU: hyphy_hip_comm_unique_id on rank 0 -> the 128 bytes to every rank -> hyphy_hip_comm_init_rank ->
+   hyphy_hip_build_q + hyphy_hip_evaluate_built_allreduce (what `bench.py --gpus N` times);
+ * one process, N devices: hyphy_hip_create(device_count = N), shard partials combined on the host or by one RCCL group
+   all-reduce (HYPHY_HIP_COMBINE=rccl behind hyphy_hip_comm_init_all).
+Both against the single-device evaluation of the whole alignment."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _hip(min_devices):
+    from hyphy_amd import hip
+    if hip.device_count() < min_devices:
+        pytest.skip(f"needs {min_devices} GPUs")
+    return hip
+
+
+def _single_device_values(hip):
+    import multi_gpu_rank as mg
+    syn, pd, T, pi, tb = mg.build_case()
+    nodes = np.arange(syn.flat.n_branches, dtype=np.int64)
+    vals = []
+    with hip.HipPartition(61, syn.flat.flat_parents, syn.flat.L, pd.leaf_codes, None, pd.pattern_freq) as part:
+        part.set_q_templates(T)
+        co = mg.coeffs_for(tb, mg.OMEGAS[0])
+        step = part.prepare_built_step(nodes, nodes, pi, co)
+        for om in mg.OMEGAS:
+            co[:] = mg.coeffs_for(tb, om)
+            vals.append(step())
+    return vals
+
+
+def _run_ranks(world, tmp_path, extra_env=None):
+    uid = str(tmp_path / "uid.bin")
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"rank{r}.json")
+        outs.append(out)
+        env = dict(os.environ, **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multi_gpu_rank.py"), str(r), str(world), uid, out],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung (collective not matched?)")
+    for p, lg in zip(procs, logs):
+        assert p.returncode == 0, lg[-3000:]
+    return [json.load(open(o)) for o in outs]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_one_process_per_gpu_allreduce_through_the_c_abi(world, tmp_path):
+    hip = _hip(world)
+    want = _single_device_values(hip)
+    res = _run_ranks(world, tmp_path)
+    for r in res:
+        got = np.array(r["values"]).reshape(len(want), 2)
+        for k, w in enumerate(want):
+            assert abs(got[k, 0] - w) <= 1e-12 * abs(w) and abs(got[k, 1] - w) <= 1e-12 * abs(w), (r["rank"], k, got[k], w)
+    # every rank returns the same bits (one all-reduce result)
+    assert all(res[0]["values"] == r["values"] for r in res[1:])
+
+
+def test_a_failing_rank_does_not_leave_the_others_in_the_collective(tmp_path):
+    _hip(2)
+    res = _run_ranks(2, tmp_path, extra_env={"FAIL_RANK": "1"})
+    by_rank = {r["rank"]: r["failure_case"] for r in res}
+    assert by_rank[1].startswith("error:") and "twice" in by_rank[1], by_rank
+    assert by_rank[0] == "nan", by_rank     # rank 0's own evaluation was fine; the sum carries rank 1's NaN
+
+
+@pytest.mark.parametrize("combine", ["host", "rccl"])
+@pytest.mark.parametrize("n_dev", [2, 8])
+def test_single_process_multi_device_combine(n_dev, combine, monkeypatch):
+    hip = _hip(n_dev)
+    import multi_gpu_rank as mg
+    want = _single_device_values(hip)
+    monkeypatch.setenv("HYPHY_HIP_COMBINE", combine)
+    syn, pd, T, pi, tb = mg.build_case()
+    nodes = np.arange(syn.flat.n_branches, dtype=np.int64)
+    with hip.HipPartition(61, syn.flat.flat_parents, syn.flat.L, pd.leaf_codes, None, pd.pattern_freq, device_count=n_dev) as part:
+        part.set_q_templates(T)
+        if combine == "rccl":
+            part.comm_init_all()
+        co = mg.coeffs_for(tb, mg.OMEGAS[0])
+        step = part.prepare_built_step(nodes, nodes, pi, co)
+        for om, w in zip(mg.OMEGAS, want):
+            co[:] = mg.coeffs_for(tb, om)
+            for _ in range(2):
+                got = step()
+                assert abs(got - w) <= 1e-12 * abs(w), (n_dev, combine, om, got, w)
+        # host-supplied matrices through hyphy_hip_evaluate take the same combine
+        Q = np.einsum("bk,kij->bij", co, T)
+        idx = np.arange(61)
+        Q[:, idx, idx] = 0.0
+        Q[:, idx, idx] = -Q.sum(2)
+        got = part.evaluate(nodes, nodes, Q, pi)
+        assert abs(got - want[-1]) <= 1e-12 * abs(want[-1])
+
+
+def test_one_rank_communicator_on_one_gpu():
+    """What a single-GPU box can check of the N > 1 step: the same entry point on a one-rank communicator."""
+    hip = _hip(1)
+    import multi_gpu_rank as mg
+    want = _single_device_values(hip)
+    syn, pd, T, pi, tb = mg.build_case()
+    nodes = np.arange(syn.flat.n_branches, dtype=np.int64)
+    with hip.HipPartition(61, syn.flat.flat_parents, syn.flat.L, pd.leaf_codes, None, pd.pattern_freq) as part:
+        part.set_q_templates(T)
+        part.comm_init_rank(hip.HipPartition.comm_unique_id(), 0, 1)
+        co = mg.coeffs_for(tb, mg.OMEGAS[0])
+        step = part.prepare_built_allreduce_step(nodes, nodes, pi, co)
+        for om, w in zip(mg.OMEGAS, want):
+            co[:] = mg.coeffs_for(tb, om)
+            for _ in range(2):
+                got = step()
+                assert abs(got - w) <= 1e-13 * abs(w), (om, got, w)
+        part.set_all_timings(True)
+        step()
+        assert part.last_allreduce_ms() > 0.0
+        part.set_all_timings(False)
+        bad = nodes.copy()
+        bad[1] = bad[0]
+        with pytest.raises(hip.HipError, match="twice"):      # a local failure still completes the collective and reports itself
+            part.prepare_built_allreduce_step(nodes, bad, pi, co)()
+        assert abs(step() - want[-1]) <= 1e-13 * abs(want[-1])  # ... and the partition is usable afterwards

@@ -71,19 +71,23 @@ def test_logl_and_sites_match_reference(name):
         assert sc.max() > 0  # the rescaling branch was really exercised
 
 
-@pytest.mark.parametrize("kernel", ["1"])
+@pytest.mark.parametrize("kernel,chain_m", [("1", None), ("2", "2"), ("2", "5")])
 @pytest.mark.parametrize("name", ["codon_small", "codon_ambig", "codon_deep", "codon_wide"])
-def test_wave_kernels_match_reference(name, kernel, monkeypatch):
+def test_wave_kernels_match_reference(name, kernel, chain_m, monkeypatch):
     """The goldens are small shards (the library would pick the workgroup-per-tile kernel): force the
-    wave-per-tile kernel (register hand-over, chained fragments) through the same checks, including the downloaded
-    conditionals of every internal node."""
+    wave-per-tile kernel (register hand-over, chained fragments) and the row-split workgroups on chain schedules
+    (kernel 2: joins through global memory, every product split over four waves) through the same checks, including the
+    downloaded conditionals of every internal node."""
     from oracle import oracle
     monkeypatch.setenv("HYPHY_HIP_KERNEL", kernel)
+    if chain_m:
+        monkeypatch.setenv("HYPHY_HIP_CHAIN_M", chain_m)
+        monkeypatch.setenv("HYPHY_HIP_POISON", "1")
     fx = common.load(name)
     nodes = common.all_nodes(fx)
     Q = common.fixture_Q(fx)
     with _mk(fx) as part:
-        assert part.prune_kernel_name() == "prune_wave_kernel"
+        assert part.prune_kernel_name() == ("prune_wave_kernel" if kernel == "1" else "prune_mfma_kernel")
         ll, sl, sc = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
         cache, counts = part.download_partials()
     ref = float(fx["logl"])
@@ -938,8 +942,9 @@ def test_rccl_allreduce_entry_points_single_rank():
         assert abs(a - b) <= 1e-13 * abs(b)
 
 
+@pytest.mark.parametrize("kernel", ["1", "2"])
 @pytest.mark.parametrize("n_tiles", [41, 48, 7])
-def test_chain_joins_within_and_across_xcds(n_tiles, monkeypatch):
+def test_chain_joins_within_and_across_xcds(n_tiles, kernel, monkeypatch):
     """Chain schedules hand edge products between waves of ONE launch through global memory (write-through stores, drained,
     then an agent-scope arrival; the last arriver reads with L1-bypassing loads).  Workgroup b runs on XCD b mod 8 and
     the grid is (tiles, classes, sources): sibling chains of a tile sit n_tiles x (source distance) workgroups apart —
@@ -947,7 +952,7 @@ def test_chain_joins_within_and_across_xcds(n_tiles, monkeypatch):
     (m = 1: the most joins), poisoned allocations, 24 evaluations with changing parameters each against the oracle."""
     from hyphy_amd import data, models, tree
     from oracle import oracle
-    monkeypatch.setenv("HYPHY_HIP_KERNEL", "1")
+    monkeypatch.setenv("HYPHY_HIP_KERNEL", kernel)   # 1: one wave per chain, 2: a workgroup of four row-split waves per chain
     monkeypatch.setenv("HYPHY_HIP_CHAIN_M", "1")
     monkeypatch.setenv("HYPHY_HIP_POISON", "1")
     rng = np.random.default_rng(100 + n_tiles)
@@ -1024,8 +1029,9 @@ def test_sorted_patterns_are_invisible_to_the_caller(monkeypatch):
         assert np.allclose(got[5], ref[5], rtol=1e-12, atol=0), label
 
 
+@pytest.mark.parametrize("kernel", ["1", "2"])
 @pytest.mark.parametrize("shape", ["caterpillar", "long caterpillar", "random"])
-def test_rerooted_schedules_match_oracle_without_reversibility(shape, monkeypatch):
+def test_rerooted_schedules_match_oracle_without_reversibility(shape, kernel, monkeypatch):
     """Re-rooted schedules (api.hip: rr_path) hang the computation from the node that minimises the tree's height and walk the
     edges between the given root and that node with transposed matrices, pi folded in on the old root's edge.  Nothing about
     that needs a reversible model: random NON-reversible rate matrices and root frequencies that are not their stationary
@@ -1035,7 +1041,7 @@ def test_rerooted_schedules_match_oracle_without_reversibility(shape, monkeypatc
     from hyphy_amd import data, tree
     from oracle import oracle
     monkeypatch.setenv("HYPHY_HIP_REROOT", "1")
-    monkeypatch.setenv("HYPHY_HIP_KERNEL", "1")
+    monkeypatch.setenv("HYPHY_HIP_KERNEL", kernel)
     monkeypatch.setenv("HYPHY_HIP_CHAIN_M", "3")
     monkeypatch.setenv("HYPHY_HIP_POISON", "1")
     rng = np.random.default_rng(2024)

@@ -1,5 +1,6 @@
-"""Host-side decisions of hyphy_hip_create that need no device (C-ABI: hyphy_hip_plan_reroot, hyphy_hip_plan_pattern_order):
-the node steady-state passes may be re-rooted at, and the device-side pattern order."""
+"""Host-side decisions of hyphy_hip_create that need no device (C-ABI: hyphy_hip_plan_reroot, hyphy_hip_plan_pattern_order,
+hyphy_hip_plan_schedule): the node steady-state passes may be re-rooted at, the device-side pattern order, and the join
+table of chain schedules as the kernels decode it."""
 import collections
 
 import numpy as np
@@ -77,3 +78,67 @@ def test_pattern_order_is_a_permutation_grouped_by_majority_state():
         assert cols == sorted(cols)
     # short alignments keep the caller's order
     assert hip.plan_pattern_order(D, codes[:, :20]).tolist() == list(range(20))
+
+
+def _flat_caterpillar(L):
+    """Post-order parents of a caterpillar with L leaves and a trifurcating root (L - 2 internal nodes)."""
+    I = L - 2
+    fp = np.empty(L + I, dtype=np.int64)
+    fp[0] = fp[1] = 0                      # the cherry at the far end
+    for k in range(1, I):
+        fp[L + k - 1] = k                  # internal node k - 1 hangs below internal node k
+        fp[k + 1] = k                      # ... together with leaf k + 1
+    fp[L - 1] = I - 1                      # the root's third child
+    fp[L + I - 1] = -1
+    return fp
+
+
+def test_chain_schedule_join_table_decodes_for_every_kernel_and_cut():
+    """prune.hip decodes jn[n].x as parent | image slot << 16 (negative: root) and jn[n].y & 0xff as the arrivals a node waits
+    for: every record of every cut must decode to the topology the schedule was built on — random trees, both chain kernels,
+    re-rooted and not."""
+    rng = np.random.default_rng(5)
+    seen_chain = seen_rr = 0
+    for trial in range(60):
+        n = int(rng.integers(6, 200))
+        flat = tree.flatten(tree.caterpillar_tree(n) if trial % 6 == 0 else tree.random_tree(n, rng, trifurcating_root=bool(rng.integers(0, 2))))
+        for kernel in (1, 2):
+            for m in (1, 3, 8):
+                for rr in (False, True):
+                    info = hip.plan_schedule(flat.flat_parents, flat.L, kernel=kernel, chain_m=m, ntiles=int(rng.integers(1, 700)), reroot=rr)
+                    assert info["decode_errors"] == 0, (trial, kernel, m, rr, info)
+                    if info["chain"]:
+                        seen_chain += 1
+                        assert info["max_slot"] < 32768 and info["max_need"] <= 255
+                    seen_rr += info["rerooted"]
+    assert seen_chain > 300 and seen_rr > 20
+
+
+def test_trees_beyond_the_packed_join_table_get_no_chain_schedule():
+    """r02 ADVICE: parent | slot << 16 in one signed int goes negative (= "root") once an image slot reaches 2^15, i.e. for
+    trees of roughly 10 000 taxa and more (twin slots of re-rooted schedules first), and arrivals are an 8-bit field.  Such trees
+    must fall back to a cut that needs no join table instead of silently truncating the pass."""
+    ok = hip.plan_schedule(_flat_caterpillar(9000), 9000, kernel=1, chain_m=12, ntiles=4)
+    assert ok["chain"] == 1 and ok["decode_errors"] == 0 and ok["max_slot"] < 32768
+    big = hip.plan_schedule(_flat_caterpillar(12000), 12000, kernel=1, chain_m=12, ntiles=4)
+    assert big["chain"] == 0 and big["programs"] >= 1
+    big_rr = hip.plan_schedule(_flat_caterpillar(11000), 11000, kernel=2, chain_m=5, ntiles=4, reroot=True)
+    assert big_rr["chain"] == 0
+    # a star of 300 cherries below the root: 300 internal children of one node
+    L, I = 600, 301
+    fp = np.empty(L + I, dtype=np.int64)
+    for k in range(300):
+        fp[2 * k] = fp[2 * k + 1] = k
+        fp[L + k] = 300
+    fp[L + 300] = -1
+    star = hip.plan_schedule(fp, L, kernel=1, chain_m=1, ntiles=16)
+    assert star["chain"] == 0
+    fp2 = fp[: 2 * 200 + 201].copy()       # 200 cherries: fits
+    L2 = 400
+    fp2 = np.empty(L2 + 201, dtype=np.int64)
+    for k in range(200):
+        fp2[2 * k] = fp2[2 * k + 1] = k
+        fp2[L2 + k] = 200
+    fp2[L2 + 200] = -1
+    star2 = hip.plan_schedule(fp2, L2, kernel=1, chain_m=1, ntiles=16)
+    assert star2["chain"] == 1 and star2["max_need"] == 200 and star2["decode_errors"] == 0

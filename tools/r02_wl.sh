@@ -11,7 +11,7 @@ import json, sys
 tag, path = sys.argv[1], sys.argv[2]
 try:
     j = json.loads([l for l in open(path) if l.startswith("{")][-1]); r = j["roofline"]
-    print(f"{tag:18s} {j['value']:9.1f} evals/s  step {j['ms_per_step']*1e3:8.1f} us  {r['kernel']} {r['kernel_ms']*1e3:8.1f} us  {r['achieved']:8.2f} {r['unit']}  frac {r['frac']:.3f}  expm {r['expm_ms']}  reduce {r['reduce_ms']}")
+    print(f"{tag:18s} {j['value']:9.1f} evals/s  step {j['ms_per_step']*1e3:8.1f} us  {r['kernel']} {r['kernel_ms']*1e3:8.1f} us  {r['achieved']:8.2f} {r['unit']}  frac {(r['frac'] if r['frac'] is not None else float('nan')):.3f}  expm {r['expm_ms']}  reduce {r['reduce_ms']}")
 except Exception as e:
     print(f"{tag:18s} FAILED ({e})")
 PY
