@@ -721,7 +721,14 @@ def main():
                 par["per_site_max_abs_dlogl"] = float(np.max(np.abs(gpu_site - ref["site_logl"])))
                 par["per_site_sites"] = int(len(gpu_site))
             out["parity"] = par
-        print(json.dumps(out))
+        # (RCCL prints its version banner through C stdio: flush that first, so that the JSON line is the LAST line on stdout)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     part.close()
     if multi:
         dist.destroy_process_group()

@@ -300,6 +300,10 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
   static const int timing_every = getenv("HYPHY_HIP_TIMING_EVERY") ? std::max(1, atoi(getenv("HYPHY_HIP_TIMING_EVERY"))) : 1;
   const bool stamp = timing_every == 1 || (s.eval_count++ % (uint64_t)timing_every) == 0;
   const size_t ring_slot = (size_t)(s.ring_count % kTimingRing) * 2;
+  if (stamp && !s.ring[ring_slot]) {  // (the ring's events are made on first use: a short-lived partition never pays for 2 048 of them)
+    HIPCHK(hipEventCreate(&s.ring[ring_slot]));
+    HIPCHK(hipEventCreate(&s.ring[ring_slot + 1]));
+  }
   if (stamp) HIPCHK(hipEventRecord(s.ring[ring_slot], s.stream));
   if (p->all_timings) HIPCHK(hipEventRecord(s.ev[1], s.stream));
   int n_ops = 0;  // longest program
@@ -748,7 +752,6 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     s.stream = s.own_stream;
     for (auto &e : s.ev) hipEventCreate(&e);
     s.ring.assign(2 * kTimingRing, nullptr);
-    for (auto &e : s.ring) hipEventCreate(&e);
     A_(s.codes, (size_t)L * s.S_pad * sizeof(int16_t));
     if (!p->nuc) {
       A_(s.codes_tile, (size_t)L * s.S_pad * sizeof(int16_t));

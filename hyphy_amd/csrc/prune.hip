@@ -528,6 +528,9 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
       it.cnt = __hip_atomic_load(a.hand_cnt + ((size_t)child * a.ntiles + tile) * 32 + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     Payload pimg;
+#ifdef HYPHY_TRUNK_PRIO
+    __builtin_amdgcn_s_setprio(HYPHY_TRUNK_PRIO);  // (experiment: see the wave-per-tile kernel)
+#endif
     // `s_early[k & 1]`: arrival counter of level k's parent, sampled by thread 0 a whole level ahead (while the node below is
     // finalised: the round trip is covered) and agreed on through LDS.  If every sibling had arrived by then, this workgroup
     // WILL be the last arriver: it skips its own deposit and has the siblings' deposits in flight under its own product.
@@ -1009,6 +1012,10 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
     // own product) knows it will be last: it skips its own deposit and streams the sibling's deposit in under its
     // MFMAs, so that a join costs the critical path one counter read instead of a ~4 us hand-off.
     int c = prg.w;
+    // (experiment, -DHYPHY_TRUNK_PRIO=3: trunk waves carry their tile's critical path — let them win the SIMD's issue arbitration)
+#ifdef HYPHY_TRUNK_PRIO
+    __builtin_amdgcn_s_setprio(HYPHY_TRUNK_PRIO);
+#endif
     int early = -1;  // arrival counter of c's parent, sampled (lane 0) while c itself was still being finalised
     for (;;) {
       const int4 jc = jn[c];  // x = parent (internal index) | matrix-image slot of the edge c -> parent << 16; -1: c is the root
@@ -1448,21 +1455,37 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
       const int lf = (o.z >> (16 * i)) & 0xffff;
 #pragma unroll
       for (int q = 0; q < NP; q++) {
-        code[i][q] = 0;
-        if (i < nl) {
-          if (PIN && lf == a.pin_leaf) code[i][q] = (int)a.pin[s0 + 256 * q];  // (pinned leaf: its states replace the data)
-          else code[i][q] = (int)a.codes[(size_t)lf * S_pad + s0 + 256 * q];
-        }
+        // (always requested — an internal entry's word names leaf 0 — so that the code is straight-line)
+        const int16_t *src = (PIN && lf == a.pin_leaf) ? a.pin : a.codes + (size_t)(lf < a.L ? lf : 0) * S_pad;  // (pinned leaf: its states replace the data)
+        const int c = (int)src[s0 + 256 * q];
+        code[i][q] = i < nl ? c : 0;
       }
     }
   };
-  // columns 0..2 of an internal child's matrix = the first 12 doubles of its TRANSPOSED copy (PTm: [branch][state j][row i]);
-  // uniform address: three 32-byte scalar loads.  Leaf entries need no matrix here (LDS lookup).
+  // Everything the loop fetches ahead — schedule words, matrices, leaf codes — goes through VECTOR loads, although the first
+  // two are wave-uniform: scalar loads return out of order and share their counter with LDS, so any use of one drains
+  // every scalar load AND every LDS access in flight (s_waitcnt lgkmcnt(0)) — with the matrix of the NEXT entry just
+  // requested that was a full L2 round trip per entry, the bulk of the r03 first cut's 1 000 cycles per entry.  The
+  // vector-memory counter is in order: the compiler waits for exactly the loads an entry needs.  `vz` is a zero the
+  // compiler cannot see through (keeps uniform addresses off the scalar path).
+  unsigned vz = 0;
+  asm volatile("" : "+v"(vz));
+  auto load_op = [&](int idx) -> int4 { return ops[(unsigned)idx + vz]; };
+  auto scalar_op = [](const int4 &v) -> int4 {
+    return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z),
+                     __builtin_amdgcn_readfirstlane(v.w));
+  };
+  // columns 0..2 of a child's matrix = the first 12 doubles of its TRANSPOSED copy (PTm: [branch][state j][row i]);
+  // requested for every entry (a leaf group's are simply not used: straight-line code, exact wait counts)
   auto load_P = [&](const int4 &o, double (&P)[12]) {
-    if ((o.x & 3) == OPK_LEAF) return;
-    const double *src = PTm + (size_t)o.z * 16;
+    const int child = (o.x & 3) == OPK_LEAF ? (o.z & 0xffff) : o.z;
+    const f64x2 *src = reinterpret_cast<const f64x2 *>(PTm + (size_t)child * 16) + vz;
 #pragma unroll
-    for (int e = 0; e < 12; e++) P[e] = src[e];
+    for (int e = 0; e < 6; e++) {
+      const f64x2 v = src[e];
+      P[2 * e] = v[0];
+      P[2 * e + 1] = v[1];
+    }
   };
   // one schedule entry: `code` = this thread's leaf codes (leaf entries), P = columns 0..2 of the child's transition matrix
   auto entry = [&](const int4 &op, const double (&P)[12], const int (&code)[2][NP]) {
@@ -1600,25 +1623,25 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
   };
   // Software pipeline, unrolled by two: matrix and leaf codes of entry i + 1 are requested before entry i is processed.
   // Programs are padded to an even entry count and followed by two no-op entries.
-  // (schedule words two entries ahead: their scalar load has returned by the time they address the matrix / code loads)
-  int4 opA = ops[0], opB = ops[1];
+  // (schedule words two entries ahead: their load has returned by the time they address the matrix / code loads)
+  int4 opA = scalar_op(load_op(0)), vB = load_op(1);
   double PA[12], PB[12];
-#pragma unroll
-  for (int e = 0; e < 12; e++) PA[e] = PB[e] = 0.;
   int cA[2][NP], cB[2][NP];
   load_P(opA, PA);
   codes_of(opA, cA);
   for (int oi = 0; oi < a.n_ops; oi += 2) {
-    const int4 opC = ops[oi + 2];
+    const int4 vC = load_op(oi + 2);
+    const int4 opB = scalar_op(vB);
     load_P(opB, PB);
     codes_of(opB, cB);
     entry(opA, PA, cA);
-    const int4 opD = ops[oi + 3];
+    const int4 vD = load_op(oi + 3);
+    const int4 opC = scalar_op(vC);
     load_P(opC, PA);
     codes_of(opC, cA);
     entry(opB, PB, cB);
     opA = opC;
-    opB = opD;
+    vB = vD;
   }
   // root: L_s = sum_k root[s][k] pi[k]; this workgroup's share of sum_s f_s log L_s and of the integer scaler sum
   double term = 0.;
@@ -1953,7 +1976,7 @@ static int nuc2_np(const NucArgs &a) {
   if (!prune_nuc_takes_leaf_pairs(a.L) || !a.PT) return 0;
   if (forced == 1 || a.S_pad % 512 != 0) return 1;
   if (forced == 2) return 2;
-  return a.S_pad >= 512 * 4 * 256 ? 2 : 1;  // two patterns per thread once that still leaves >= 4 workgroups per CU
+  return 1;  // (measured: one pattern per thread and four workgroups per CU beat two patterns and two workgroups at every size)
 }
 static size_t nuc2_lds(const NucArgs &a, int np) {
   return (size_t)a.L * 16 * sizeof(double) + (size_t)kNucParkSlots * np * 256 * (4 * sizeof(double) + sizeof(int));

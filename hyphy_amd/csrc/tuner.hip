@@ -1,4 +1,8 @@
 // Run-time schedule tuner of libhyphy_hip.so and the launch of the current schedule (shared with the evaluation path).
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "partition.h"
 
 namespace hyhip {
@@ -116,6 +120,31 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   p->tune_report.clear();
   Cand best{1, -1, 0, -1};
   double best_ms = 1e30;
+  // What was chosen for the same tree, shard size and class batch earlier in this process is taken over without timing
+  // anything: analyses that create one likelihood function after another on the same tree (FEL: one per site) tune once.
+  // (HYPHY_HIP_TUNE_CACHE=0: every partition measures for itself.)
+  struct Key {
+    int64_t D, L, I, ntiles, classes, forced;
+    uint64_t topo;
+    bool operator<(const Key &o) const {
+      return std::tie(D, L, I, ntiles, classes, forced, topo) < std::tie(o.D, o.L, o.I, o.ntiles, o.classes, o.forced, o.topo);
+    }
+  };
+  static std::map<Key, Cand> cache;
+  static std::mutex cache_mutex;
+  static const bool cache_on = !(getenv("HYPHY_HIP_TUNE_CACHE") && atoi(getenv("HYPHY_HIP_TUNE_CACHE")) == 0);
+  uint64_t topo = 1469598103934665603ull;  // FNV-1a over the parent vector
+  for (int64_t v : p->parents) topo = (topo ^ (uint64_t)v) * 1099511628211ull;
+  const Key key{p->D, p->L, p->I, s.ntiles, n_cat_batch, p->kernel_forced ? p->variant : -1, topo};
+  if (cache_on) {
+    std::lock_guard<std::mutex> lock(cache_mutex);
+    auto hit = cache.find(key);
+    if (hit != cache.end() && apply(hit->second)) {
+      p->tune_report = "(same tree, shard size and class batch as an earlier partition of this process) -> " + label(hit->second);
+      if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] schedule tuner (%d classes per launch): %s\n", n_cat_batch, p->tune_report.c_str());
+      return 0;
+    }
+  }
   // ---- first stage: the cut, per kernel ----
   std::vector<Cand> stage1;
   const int forced = p->kernel_forced ? p->variant : -1;  // HYPHY_HIP_KERNEL / T > 1: only that kernel's cuts compete
@@ -179,6 +208,10 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
       }
   }
   apply(best);  // (leaves kernel, slot budget, instantiation, cut and re-rooting path set; the caller rebuilds the schedule)
+  if (cache_on) {
+    std::lock_guard<std::mutex> lock(cache_mutex);
+    cache[key] = best;
+  }
   p->tune_report += " -> " + label(best);
   if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] schedule tuner (%d classes per launch): %s\n", n_cat_batch, p->tune_report.c_str());
   return 0;

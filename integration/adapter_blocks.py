@@ -11,6 +11,8 @@ HELPERS = r'''
 #include <map>
 #include <unordered_map>
 #include <cstdlib>
+#include <string>
+#include <unistd.h>
 struct _HyHipPart {
   hyphy_hip_partition *part = nullptr;
   std::unordered_map<const void *, long> code_of;  // _CalcNode* -> node code (flatLeaves, then flatTree)
@@ -41,6 +43,7 @@ struct _HyHipPart {
     long cat = 0;
     std::vector<long> probe, skipped;        // node codes
     long verify = -1;
+    double verify_dist = 0., skipped_dist = 0.;  // relative distance of the verification row / of the farthest skipped row from the probes
   } call;
   long n_template_evals = 0, n_skipped = 0;
   // mixture mode (explicit-form models: P_b = sum_m w_m Exp(Q_bm), weights built from GLOBAL variables only): per rate
@@ -52,6 +55,11 @@ struct _HyHipPart {
   std::vector<std::vector<double>> mix_q;         // per class: [B][M][D*D]
   std::vector<std::vector<double>> mix_w;         // per class: [M] weights of the matrices stashed last
   long n_mixture_evals = 0;
+  // SPMD site sharding (one host process per GPU, every process runs the same batch file: HYPHY_HIP_WORLD / HYPHY_HIP_RANK,
+  // or the MPI rank of a HYPHYMPI build with HYPHY_HIP_MPI_SHARD=1): this process holds patterns [lo, hi) of the partition
+  // and every evaluation ends in ONE ncclAllReduce of the partition log-likelihood (hyphy_hip_evaluate*_allreduce)
+  bool spmd = false;
+  long spmd_rank = 0, spmd_world = 1;
 };
 static std::map<const void *, std::vector<_HyHipPart>> _hyhip_lfs;
 static std::map<const void *, std::pair<const void *, long>> _hyhip_tree_owner;  // _TheTree* -> (lf, partition index)
@@ -121,6 +129,45 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   for (long s = 0; s < S; s++) freq[s] = theFilter->theFrequencies.get(s);
   for (size_t k = 0; k < (size_t)L * S; k++) codes[k] = leaf_codes[k];
   const long n_amb = (long)ambigs->get_used() / D;
+  // Size policy: a 4-state partition of a few patterns is evaluated faster by the host than a kernel can be launched
+  // (61-state partitions are worth it from ONE pattern on: the host spends ~10 ms per evaluation exponentiating the
+  // 2L-3 rate matrices of a 64-taxon tree, the device 25 us — profiles/r03_adapter_rate.jsonl).  HYPHY_HIP_MIN_PATTERNS overrides.
+  {
+    const char *mp = getenv("HYPHY_HIP_MIN_PATTERNS");
+    const long min_patterns = mp ? atol(mp) : (D <= 4 ? 64L : 1L);
+    if (S < min_patterns) {
+      if (getenv("HYPHY_HIP_VERBOSE"))
+        fprintf(stderr, "[hyphy_hip] partition %lu: %ld patterns < HYPHY_HIP_MIN_PATTERNS = %ld -> host path\n", i, S, min_patterns);
+      return;
+    }
+  }
+  // SPMD site sharding: this process keeps patterns [lo, hi)
+  long spmd_world = 1, spmd_rank = 0;
+  bool spmd = false;
+  if (const char *w = getenv("HYPHY_HIP_WORLD")) {
+    spmd_world = atol(w);
+    spmd_rank = getenv("HYPHY_HIP_RANK") ? atol(getenv("HYPHY_HIP_RANK")) : 0;
+    spmd = spmd_world >= 1 && spmd_rank >= 0 && spmd_rank < spmd_world;
+  }
+#ifdef __HYPHYMPI__
+  else if (getenv("HYPHY_HIP_MPI_SHARD") && hy_mpi_node_count > 1) {
+    spmd_world = hy_mpi_node_count;
+    spmd_rank = hy_mpi_node_rank;
+    spmd = true;
+  }
+#endif
+  if (spmd && (n_parts > 1 || cT->categoryCount > 1)) spmd = false;  // (one partition, one rate class: the site-sharded config)
+  if (spmd) {
+    const long lo = S * spmd_rank / spmd_world, hi = S * (spmd_rank + 1) / spmd_world, Sl = hi - lo;
+    if (Sl < 1) return;
+    std::vector<int64_t> c2((size_t)L * Sl), f2(Sl);
+    for (long l = 0; l < L; l++)
+      for (long k = 0; k < Sl; k++) c2[(size_t)l * Sl + k] = codes[(size_t)l * S + lo + k];
+    for (long k = 0; k < Sl; k++) f2[k] = freq[lo + k];
+    codes.swap(c2);
+    freq.swap(f2);
+  }
+  const long S_dev = (long)freq.size();
   // Partition -> device(s).  HYPHY_HIP_DEVICES=a-b (or HYPHY_HIP_DEVICE=a, or every visible device): a likelihood
   // function with several partitions puts partition i on device a + i mod n (config "multi-partition -> N GPUs",
   // the evaluations are enqueued together by the pre-pass in Compute); a single partition is site-sharded over
@@ -142,13 +189,63 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
       dev_n = ndev > 0 ? ndev : 1;
     }
   }
-  const int my_first = n_parts > 1 ? dev_first + (int)(i % (unsigned long)dev_n) : dev_first;
-  const int my_count = n_parts > 1 ? 1 : dev_n;
-  int rc = hyphy_hip_create(&hp.part, D, S, L, I, cT->categoryCount, parents.data(), codes.data(),
+  int my_first = n_parts > 1 ? dev_first + (int)(i % (unsigned long)dev_n) : dev_first;
+  int my_count = n_parts > 1 ? 1 : dev_n;
+  if (spmd) {  // one device per process: local rank -> device (HYPHY_HIP_LOCAL_RANK, else the rank itself), within the device range
+    const long local = getenv("HYPHY_HIP_LOCAL_RANK") ? atol(getenv("HYPHY_HIP_LOCAL_RANK")) : spmd_rank;
+    const int ndev_all = hyphy_hip_device_count();
+    const int span = (getenv("HYPHY_HIP_DEVICES") || getenv("HYPHY_HIP_DEVICE")) ? dev_n : (ndev_all > 0 ? ndev_all : 1);
+    my_first = dev_first + (int)(local % span);
+    my_count = 1;
+  }
+  int rc = hyphy_hip_create(&hp.part, D, S_dev, L, I, cT->categoryCount, parents.data(), codes.data(),
                             n_amb ? ambigs->theData : nullptr, n_amb, freq.data(), my_first, my_count);
+  if (rc == 0 && spmd) {
+    // the RCCL unique id: made by rank 0, broadcast by the host's own means — MPI in a HYPHYMPI build, else a file
+    // (HYPHY_HIP_UID_FILE) that rank 0 writes and the others wait for
+    char uid[128];
+    bool have = false;
+#ifdef __HYPHYMPI__
+    if (!getenv("HYPHY_HIP_WORLD")) {
+      if (spmd_rank == 0) have = hyphy_hip_comm_unique_id(uid) == 0;
+      MPI_Bcast(uid, 128, MPI_CHAR, 0, MPI_COMM_WORLD);
+      have = true;
+    }
+#endif
+    if (!have) {
+      const char *path = getenv("HYPHY_HIP_UID_FILE");
+      if (spmd_world == 1) {
+        have = hyphy_hip_comm_unique_id(uid) == 0;
+      } else if (path && spmd_rank == 0) {
+        have = hyphy_hip_comm_unique_id(uid) == 0;
+        std::string tmp = std::string(path) + ".tmp";
+        FILE *fh = have ? fopen(tmp.c_str(), "wb") : nullptr;
+        if (fh) {
+          fwrite(uid, 1, 128, fh);
+          fclose(fh);
+          rename(tmp.c_str(), path);
+        } else have = false;
+      } else if (path) {
+        for (int tries = 0; tries < 6000 && !have; tries++) {  // (up to ~10 minutes: rank 0 may still be parsing its batch file)
+          FILE *fh = fopen(path, "rb");
+          if (fh) {
+            have = fread(uid, 1, 128, fh) == 128;
+            fclose(fh);
+          }
+          if (!have) usleep(100000);
+        }
+      }
+    }
+    if (!have || hyphy_hip_comm_init_rank(hp.part, uid, (int)spmd_rank, (int)spmd_world) != 0) {
+      ReportWarning(_String("hyphy_hip: SPMD site sharding could not set up its communicator (") & hyphy_hip_last_error() & "); host path");
+      hyphy_hip_destroy(hp.part);
+      hp.part = nullptr;
+      return;
+    }
+  }
   if (rc == 0 && getenv("HYPHY_HIP_VERBOSE"))
-    fprintf(stderr, "[hyphy_hip] partition %lu of %lu -> device %d%s (%ld states, %ld patterns, %ld leaves)\n", i, n_parts, my_first,
-            my_count > 1 ? " (+ site shards on the following devices)" : "", D, S, L);
+    fprintf(stderr, "[hyphy_hip] partition %lu of %lu -> device %d%s (%ld states, %ld patterns, %ld leaves)%s\n", i, n_parts, my_first,
+            my_count > 1 ? " (+ site shards on the following devices)" : "", D, S_dev, L, spmd ? " [SPMD site shard, RCCL all-reduce per evaluation]" : "");
   if (rc != 0) {  // > 0: unsupported here -> the CPU path keeps working; < 0: report and use the CPU path
     hp.part = nullptr;
     ReportWarning(_String("hyphy_hip_create: ") & hyphy_hip_last_error());
@@ -164,6 +261,9 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   hp.cat_arg.assign(n_cat, -1L);
   hp.n_stale = 0;
   hp.pending = hp.pre_done = false;
+  hp.spmd = spmd;
+  hp.spmd_rank = spmd_rank;
+  hp.spmd_world = spmd_world;
   hp.tmpl_state.assign(n_cat, getenv("HYPHY_HIP_TEMPLATES") && !strcmp(getenv("HYPHY_HIP_TEMPLATES"), "0") ? -1 : 0);
   hp.tmpl_K = 0;
   hp.tmpl_refs.Clear();
@@ -173,7 +273,7 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   hp.tmpl_uploaded.assign(n_cat, 0);
   hp.tmpl_device_cat = -1;
   hp.call = _HyHipPart::Call();
-  hp.mix_state.assign(n_cat, getenv("HYPHY_HIP_MIXTURES") && !strcmp(getenv("HYPHY_HIP_MIXTURES"), "0") ? -1 : 0);
+  hp.mix_state.assign(n_cat, (spmd || (getenv("HYPHY_HIP_MIXTURES") && !strcmp(getenv("HYPHY_HIP_MIXTURES"), "0"))) ? -1 : 0);
   hp.mix_M = 0;
   hp.mix_probe = -1;
   for (_Formula *f : hp.mix_wf) delete f;
@@ -355,10 +455,25 @@ static bool _hyphy_hip_skip_handler(_TheTree *t, long catID, _CalcNode *node, un
     }
     return false;  // dependent on the probes so far and no basis yet: the dense way
   }
-  if (hp.call.verify < 0) {
+  // A branch whose local parameters EQUAL a probe's has the probe's rate matrix (same model, same globals): skipping it
+  // assumes nothing about linearity.  The first branch that differs goes through RecomputeMatrix and verifies the
+  // templates; how far it sits from the probes says how much that verification is worth for the others (r02 ADVICE: with
+  // every branch length equal the check used to pass vacuously).
+  double dist = 1e300;
+  for (long pc : hp.call.probe) {
+    double d = 0.;
+    for (long k = 0; k < K; k++) {
+      const double a = X[(size_t)pc * K + k], b = X[(size_t)code * K + k];
+      d = fmax(d, a == b ? 0. : fabs(a - b) / fmax(fabs(a), fabs(b)));
+    }
+    dist = fmin(dist, d);
+  }
+  if (dist > 0. && hp.call.verify < 0) {
     hp.call.verify = code;
+    hp.call.verify_dist = dist;
     return false;
   }
+  hp.call.skipped_dist = fmax(hp.call.skipped_dist, dist);
   hp.call.skipped.push_back(code);
   hp.n_skipped++;
   return true;
@@ -539,7 +654,12 @@ static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, 
   const long K = hp.tmpl_K;
   if (hp.call.active && hp.call.cat == cat) {
     // template call: K probes + one verification node were recomputed, hp.call.skipped were not
-    bool ok = (long)hp.call.probe.size() == K && hp.call.verify >= 0;
+    // verify < 0: every skipped branch duplicates a probe (nothing to verify, nothing assumed)
+    bool ok = (long)hp.call.probe.size() == K;
+    // a verification taken closer than 1 % to the probes says little about branches that sit farther away: this call
+    // (only) takes the skipped matrices the normal way
+    const bool weak = hp.call.verify >= 0 && hp.call.skipped_dist > 0. && hp.call.verify_dist < 0.01 &&
+                      hp.call.skipped_dist > 4. * hp.call.verify_dist;
     std::vector<double> M;
     if (ok) {
       double Xp[16];
@@ -549,20 +669,23 @@ static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, 
         Qp.push_back(hp.qstash[cat].data() + (size_t)hp.call.probe[i] * DD);
       }
       ok = _hyhip_solve_templates(K, DD, Xp, Qp, M) &&
-           _hyhip_template_error(K, D, hp.tmpl_x[cat].data() + (size_t)hp.call.verify * K, M,
-                                 hp.qstash[cat].data() + (size_t)hp.call.verify * DD) < 1e-11;
+           (hp.call.verify < 0 || _hyhip_template_error(K, D, hp.tmpl_x[cat].data() + (size_t)hp.call.verify * K, M,
+                                                        hp.qstash[cat].data() + (size_t)hp.call.verify * DD) < 1e-11);
     }
-    if (ok) {
+    if (ok && !weak) {
       hp.tmpl_M[cat].swap(M);
       hp.tmpl_uploaded[cat] = 0;
       for (long code : hp.call.probe) mark(code, 2);
-      mark(hp.call.verify, 2);
+      if (hp.call.verify >= 0) mark(hp.call.verify, 2);
       for (long code : hp.call.skipped) mark(code, 2);
       _hyhip_deferred += (long)hp.call.skipped.size();
     } else {
       // not linear after all (or no usable probes): the skipped matrices the normal way, and never again for this class
-      hp.tmpl_state[cat] = -1;
-      ReportWarning("hyphy_hip: rate matrices are not linear in the branch parameters; template mode switched off");
+      // (a merely weak verification keeps the mode for later calls)
+      if (!ok) {
+        hp.tmpl_state[cat] = -1;
+        ReportWarning("hyphy_hip: rate matrices are not linear in the branch parameters; template mode switched off");
+      }
       for (long code : hp.call.skipped) {
         _List lq;
         _SimpleList lt;
@@ -683,6 +806,7 @@ static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catI
   }
   double ll = 0.;
   int rc = 0;
+  if (hp.spmd && (siteRes || scc || go_async)) return 1;  // (per-pattern outputs live on several ranks: this call stays on the host)
   if (n_mixture > 0 && (n_mixture < n_q || go_async)) {  // mixed with other kinds (rare): the host's own matrices for everything
     _hyphy_hip_flush_part(hp, t);
     n_pending = n_template = n_mixture = 0;
@@ -723,7 +847,10 @@ static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catI
     for (long k = 0; k < n_q; k++)
       for (long j = 0; j < K; j++) hp.pbuf[(size_t)k * K + j] = hp.tmpl_x[cat][(size_t)hp.qnodes[k] * K + j];
     if (rc == 0) rc = hyphy_hip_build_q(hp.part, n_q, hp.pbuf.data());
-    if (rc == 0)
+    if (rc == 0 && hp.spmd)
+      rc = hyphy_hip_evaluate_built_allreduce(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(),
+                                              n_q, t->GetProbs(), &ll);
+    else if (rc == 0)
       rc = hyphy_hip_evaluate_built_sites(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(),
                                           n_q, t->GetProbs(), &ll, siteRes, (int64_t *)scc);
     if (rc < 0) {
@@ -766,6 +893,9 @@ static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catI
     rc = hyphy_hip_evaluate_async(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(), n_q,
                                   hp.pbuf.data(), rate_matrices ? 0 : 1, t->GetProbs());
     if (rc == 0) hp.pending = true;
+  } else if (hp.spmd) {
+    rc = hyphy_hip_evaluate_allreduce(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(), n_q,
+                                      hp.pbuf.data(), /* q_is_probability = */ rate_matrices ? 0 : 1, t->GetProbs(), &ll);
   } else {
     rc = hyphy_hip_evaluate(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(), n_q,
                             hp.pbuf.data(), /* q_is_probability = */ rate_matrices ? 0 : 1, t->GetProbs(), &ll, siteRes,
@@ -819,6 +949,7 @@ static bool _hyphy_hip_prepass_result(const void *lf, long index, hyFloat *value
 static int _hyphy_hip_pinned(const void *lf, long index, _TheTree *t, long catID, _SimpleList &branches, _List &matrices,
                              long node_code, long const *states, hyFloat *siteRes, long *scc, hyFloat *result) {
   _HyHipPart &hp = _hyhip_lfs[lf][index];
+  if (hp.spmd) return 1;  // (pinned evaluations are per-pattern: host path)
   int rc = hyphy_hip_set_pinned_states(hp.part, node_code, (const int64_t *)states);
   if (rc != 0) return rc > 0 ? rc : 1;
   rc = _hyphy_hip_compute(lf, index, t, catID, branches, matrices, siteRes, scc, result);
@@ -830,6 +961,7 @@ static int _hyphy_hip_pinned(const void *lf, long index, _TheTree *t, long catID
 // reference's own policy state machine (computedLocalUpdatePolicy, likefunc.cpp:10886-10948)
 static int _hyphy_hip_cache_build(const void *lf, long index, long catID, long node) {
   _HyHipPart &hp = _hyhip_lfs[lf][index];
+  if (hp.spmd) return 1;  // (the cached evaluation has no all-reduce entry point: the policy keeps evaluating normally)
   int rc = hyphy_hip_branch_cache_build(hp.part, catID, node);
   if (rc < 0) ReportWarning(_String("hyphy_hip_branch_cache_build: ") & hyphy_hip_last_error());
   return rc;

@@ -1,0 +1,100 @@
+"""Through-the-host rates of the configurations that are NOT the headline one: the patched hyphy binary
+(integration/_build/hyphy_hip, HYPHY_HIP=1) runs HBL written by oracle/hbl.py —
+  cat3      64 taxa x 10 000 codons, MG94 with a 3-class omega category variable (BUSTED-shaped, weighted-sum category mode):
+            LFCompute sweep of the global scaling R;
+  mix3      the same alignment under the reference's EXPLICIT-FORM 3-component branch-site mixture
+            ("Exp(Q1)*W1+Exp(Q2)*W2+Exp(Q3)*(1-W1-W2)"): LFCompute sweep of W1 with device exponentials forced (mode B, mixture mode);
+  manylf    N single-codon likelihood functions on the 64-taxon tree (what FEL does per site): create, 50 LFCompute calls with R
+            swept, destroy — through the device, through the device with the adapter's size policy (default), and on the CPU.
+One JSON line per measurement.  Usage (GPU box): python tests/adapter_rate2.py [cat3,mix3,manylf] [n_evals] [n_lfs]"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import bench
+from hyphy_amd import data, models, tree as htree
+from oracle import hbl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_BIN = os.path.join(ROOT, "integration", "_build", "hyphy_hip")
+which = (sys.argv[1] if len(sys.argv) > 1 else "cat3,mix3,manylf").split(",")
+n_evals = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
+n_lfs = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+ENV = dict(HYPHY_HIP="1", HYPHY_HIP_VERBOSE="1", **{k: v for k, v in os.environ.items() if k.startswith("HYPHY_HIP_")})
+
+wl = bench.WORKLOADS["mg94_64x10k"]
+syn = data.evolve(wl["taxa"], wl["sites"], 3, seed=wl["seed"], p_change=0.04)
+tmpl = models.mg94rev_template(bench.POS_FREQS)
+pi = models.f3x4_codon_freqs(bench.POS_FREQS)
+bt = {nm: 0.05 for nm in syn.flat.branch_names()}
+common = dict(names=syn.flat.leaf_names, seqs=syn.seqs, newick=htree.to_newick(syn.tree), unit=3, model_name="MGM", branch_t=bt,
+              per_site=False, timeout=1800.0)
+
+
+def emit(tag, host, res, count, t0, extra=None):
+    secs = max(res.get("sweep_seconds", 0.0), 1.0)   # (HBL's Time(1) has 1 s resolution)
+    mode = [ln for ln in res.get("stdout", "").split("\n") if "mode:" in ln or "template analysis" in ln or "explicit-form" in ln]
+    print(json.dumps({"case": tag, "host": host, "evals": count, "sweep_seconds": secs, "evals_per_s": count / secs, "logl": res["logl"],
+                      "wall": time.time() - t0, "adapter_says": mode[-2:], **(extra or {})}), flush=True)
+
+
+if "cat3" in which:
+    block = hbl.codon_model_block(tmpl, pi, omega="R*cc")
+    cat = dict(name="cc", weights=[0.7, 0.25, 0.05], values=[0.1 / 0.3, 1.0 / 0.3, 5.0 / 0.3])
+    for host, binary, env, count in (("adapter", HIP_BIN, ENV, n_evals), ("reference 16 threads", None, None, max(6, n_evals // 200))):
+        t0 = time.time()
+        res = hbl.evaluate(model_block=block, globals_=dict(R=0.3, **bench.REV), category=cat,
+                           sweep=dict(param="R", start=0.3, step=0.0001, n=count), threads=(1 if binary else 16), binary=binary, extra_env=env, **common)
+        emit("cat3_64x10k", host, res, count, t0)
+
+if "mix3" in which:
+    block = hbl.codon_mixture_model_block(tmpl, pi, ["R1", "R2", "R3"], ["W1", "W2", "(1-W1-W2)"])
+    g = dict(R1=0.1, R2=1.0, R3=5.0, W1=0.6, W2=0.3, **bench.REV)
+    for host, binary, env, count in (("adapter", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), max(200, n_evals // 4)),
+                                      ("reference 16 threads", None, None, max(4, n_evals // 600))):
+        t0 = time.time()
+        res = hbl.evaluate(model_block=block, globals_=g, upper_bounds=dict(W1=1.0, W2=1.0),
+                           sweep=dict(param="W1", start=0.5, step=0.00001, n=count), threads=(1 if binary else 16), binary=binary, extra_env=env, **common)
+        emit("mix3_64x10k", host, res, count, t0)
+
+if "manylf" in which:
+    # N single-codon likelihood functions, 50 evaluations each (FEL's shape: one LF per site)
+    tmp = tempfile.mkdtemp(prefix="hymany_")
+    fasta = os.path.join(tmp, "aln.fasta")
+    hbl.write_fasta(fasta, syn.flat.leaf_names, [s[: 3 * n_lfs] for s in syn.seqs])
+    outp = os.path.join(tmp, "out.txt")
+    L = ["VERBOSITY_LEVEL = -1;", "PRINT_DIGITS = 17;"] + [f"global {k} = {v!r};" for k, v in dict(R=0.3, **bench.REV).items()]
+    L.append(hbl.codon_model_block(tmpl, pi))
+    L.append("UseModel (MGM);")
+    L.append(f"Tree givenTree = {htree.to_newick(syn.tree)};")
+    L.append(f'DataSet ds = ReadDataFile ("{fasta}");')
+    for nm, t in bt.items():
+        L.append(f"givenTree.{nm}.t = {t!r};")
+    L.append("tot_ = 0; t0_ = Time (1);")
+    L.append(f"for (s_ = 0; s_ < {n_lfs}; s_ += 1) {{")
+    L.append('  DataSetFilter sf_ = CreateFilter (ds, 3, "" + (3*s_) + "-" + (3*s_+2), "", "TAA,TAG,TGA");')
+    L.append("  LikelihoodFunction slf_ = (sf_, givenTree);")
+    L.append("  LFCompute (slf_, LF_START_COMPUTE);")
+    L.append("  for (k_ = 0; k_ < 50; k_ += 1) { R = 0.3 + 0.001*k_; LFCompute (slf_, r_); }")
+    L.append("  LFCompute (slf_, LF_DONE_COMPUTE);")
+    L.append("  tot_ += r_;")
+    L.append("}")
+    L.append("t1_ = Time (1);")
+    L.append(f'fprintf ("{outp}", CLEAR_FILE, "LOGL ", Format (tot_, 30, 17), "\\n", "SWEEP_SECONDS ", Format (t1_-t0_, 20, 6), "\\n");')
+    script = "\n".join(L) + "\n"
+    for host, binary, env in (("adapter, every LF on the device", HIP_BIN, dict(ENV, HYPHY_HIP_MIN_PATTERNS="0", HYPHY_HIP_VERBOSE="0")),
+                              ("adapter, default size policy", HIP_BIN, dict(ENV, HYPHY_HIP_VERBOSE="0")),
+                              ("reference 1 thread", None, None)):
+        t0 = time.time()
+        try:
+            stdout = hbl.run_script(script, tmp, cpus=1, timeout=1800.0, binary=binary, extra_env=env)
+            res = hbl.parse_output(outp)
+            res["stdout"] = stdout
+            emit("manylf_64taxa_1codon_x50", host, res, 50 * n_lfs, t0, extra={"likelihood_functions": n_lfs})
+        except Exception as e:  # (report and go on: the other hosts still run)
+            print(json.dumps({"case": "manylf", "host": host, "error": str(e)[-600:]}), flush=True)

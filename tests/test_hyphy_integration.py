@@ -321,3 +321,56 @@ def test_hbl_explicit_form_mixture_through_device():
     cpu = hbl.evaluate(sweep=sweep, per_site=False, **case)
     gpu = hbl.evaluate(sweep=sweep, per_site=False, binary=HIP_BIN, extra_env=dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), **case)
     assert np.max(np.abs(gpu["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10
+
+
+def test_hbl_spmd_site_shard_one_rank_through_device():
+    """SPMD site sharding of the adapter (one host process per GPU, every process runs the same batch file,
+    HYPHY_HIP_WORLD / HYPHY_HIP_RANK): with a world of ONE — what a single-GPU box can run — the partition goes
+    through hyphy_hip_comm_init_rank and every evaluation through hyphy_hip_evaluate*_allreduce; LFCompute, a sweep in mode B
+    (template mode: hyphy_hip_evaluate_built_allreduce) and a complete Optimize must give the unmodified binary's numbers."""
+    _need_binaries()
+    from oracle import hbl
+    fx = common.load("codon_wide")
+    case = _case("codon", 64, 60, 15)
+    env = dict(ENV, HYPHY_HIP_WORLD="1", HYPHY_HIP_RANK="0")
+    res = hbl.evaluate(binary=HIP_BIN, extra_env=env, per_site=False, **case)
+    assert "SPMD site shard" in res["stdout"], res["stdout"][-1500:]
+    assert _device_calls(res["stdout"]) > 0
+    ref = float(fx["logl"])
+    assert abs(res["logl"] - ref) <= 1e-10 * abs(ref)
+    sweep = dict(param="R", start=0.3, step=0.01, n=12, record=12)
+    cpu = hbl.evaluate(sweep=sweep, per_site=False, **case)
+    gpu = hbl.evaluate(sweep=sweep, per_site=False, binary=HIP_BIN, extra_env=dict(env, HYPHY_HIP_DEVICE_EXPM="always"), **case)
+    assert np.max(np.abs(gpu["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10
+    cpu = hbl.evaluate(optimize=True, per_site=False, **case)
+    gpu = hbl.evaluate(optimize=True, per_site=False, binary=HIP_BIN, extra_env=env, **case)
+    assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3, (gpu["opt_logl"], cpu["opt_logl"])
+
+
+def test_hbl_spmd_site_shard_two_ranks(tmp_path):
+    """The same with two host processes on two GPUs (skipped on smaller boxes): both run the same batch file, each holds half
+    of the patterns, the RCCL unique id travels through a file, both report the whole alignment's log-likelihood."""
+    _need_binaries()
+    from hyphy_amd import hip
+    from oracle import hbl
+    if hip.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import threading
+    fx = common.load("codon_wide")
+    case = _case("codon", 64, 60, 15)
+    uid = str(tmp_path / "uid.bin")
+    out = {}
+
+    def run(rank):
+        env = dict(ENV, HYPHY_HIP_WORLD="2", HYPHY_HIP_RANK=str(rank), HYPHY_HIP_UID_FILE=uid)
+        out[rank] = hbl.evaluate(binary=HIP_BIN, extra_env=env, per_site=False, sweep=dict(param="R", start=0.3, step=0.01, n=8, record=8), **case)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    ref = float(fx["logl"])
+    for r in (0, 1):
+        assert abs(out[r]["logl"] - ref) <= 1e-10 * abs(ref), (r, out[r]["logl"], ref)
+    assert np.array_equal(out[0]["sweep_values"], out[1]["sweep_values"])
