@@ -177,6 +177,10 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
   tr.lap("ops+pi");
   if (p->all_timings) HIPCHK(hipEventRecord(s.ev[0], s.stream));
   tr.lap("event0");
+  int n_ops_planned = 0;  // longest program: > 0 means a pruning launch follows
+  for (const auto &pr : p->programs) n_ops_planned = std::max(n_ops_planned, pr.n);
+  ExpmArgs folded_expm;
+  bool have_folded = false;
   if (n_q > 0) {
     // n_cat_batch > 1: the matrices of ALL rate classes in one expm launch, class-major; destination
     // slot of matrix (c, k) is c*B + q_nodes[k] relative to class 0's image arrays
@@ -288,8 +292,14 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       if (covered == k) s.twins_dirty = false;           // every twin rewritten by this launch (with the current pi)
     }
     tr.lap("slots+q");
-    const bool coeffs_consumed = launch_expm(ea, s.stream);
-    if (q_from_templates && d_logl_out && s.coeff_slot >= 0 && !coeffs_consumed) {  // asynchronous caller: guard the ring slot until the kernel has run
+    bool coeffs_consumed = false;
+    if (p->nuc && prune_nuc_folds_expm((int)p->L, s.S_pad, n_ops_planned) && !(q_from_templates && !ea.coeffs)) {
+      folded_expm = ea;  // (4 states, small shard: the pruning launch computes the exponentials itself)
+      have_folded = true;
+    } else {
+      coeffs_consumed = launch_expm(ea, s.stream);
+    }
+    if (q_from_templates && d_logl_out && s.coeff_slot >= 0 && !coeffs_consumed && !have_folded) {  // asynchronous caller: guard the ring slot until the kernel has run
       HIPCHK(hipEventRecord(s.coeff_ev[s.coeff_slot], s.stream));
       s.coeff_busy[s.coeff_slot] = true;
     }
@@ -335,7 +345,11 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     na.wg_cnt = s.wg_cnt;
     na.wg_flag = s.wg_flag;
     n_wg = prune_nuc_grid(na);
-    launch_prune_nuc(na, s.stream);
+    launch_prune_nuc(na, s.stream, have_folded ? &folded_expm : nullptr);
+    if (have_folded && folded_expm.templates && d_logl_out && s.coeff_slot >= 0) {  // (the ring slot is read by THIS launch)
+      HIPCHK(hipEventRecord(s.coeff_ev[s.coeff_slot], s.stream));
+      s.coeff_busy[s.coeff_slot] = true;
+    }
   } else {
     if (p->rr_active && p->chain && s.twins_dirty) refresh_twins(p, s);
     PruneArgs pa = base_prune_args(p, s, cat, n_cat_batch);
@@ -853,6 +867,19 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
 
 namespace hyhip {
 
+// An uncollected hyphy_hip_evaluate_async owns the host-mapped result record: every entry point that is about to write it
+// (or to wait on it) finishes the pending evaluation first (include/hyphy_hip.h: "any other evaluation entry point ...").
+int finish_pending_async(hyphy_hip_partition *p) {
+  if (!p->async_pending) return 0;
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    s.seq_wait = 0.;
+  }
+  p->async_pending = false;
+  return 0;
+}
+
 int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                        const int64_t *q_nodes, int64_t n_q, const double *q, bool q_on_device, int q_is_probability,
                        const double *root_freqs, double *d_logl_out, bool reduce, bool floor_log, bool batch,
@@ -860,14 +887,7 @@ int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes
   if (!p) return fail("partition == NULL");
   if (cat < 0) cat = 0;
   if (cat >= p->C) return fail("rate class out of range");
-  if (p->async_pending) {  // (an uncollected asynchronous evaluation: its result record is about to be overwritten)
-    for (Shard &s : p->shards) {
-      HIPCHK(hipSetDevice(s.device));
-      HIPCHK(hipStreamSynchronize(s.stream));
-      s.seq_wait = 0.;
-    }
-    p->async_pending = false;
-  }
+  if (finish_pending_async(p)) return -1;
   if (batch) {  // all classes in one launch: bookkeeping is shared, keyed on class 0
     if (p->nuc) return fail("internal: class batching is for the MFMA path");
     cat = 0;
@@ -950,6 +970,7 @@ __global__ void publish_scalar_kernel(const double *__restrict__ value, double *
   }
 }
 int publish_and_collect(hyphy_hip_partition *p, const double *d_value, double *value_out) {
+  if (finish_pending_async(p)) return -1;
   Shard &s = p->shards[0];
   HIPCHK(hipSetDevice(s.device));
   double *rec = s.d_hout ? s.d_hout : s.out;
@@ -1392,6 +1413,7 @@ int hyphy_hip_branch_cache_evaluate(hyphy_hip_partition *p, int64_t cat, int64_t
   if (p->bc_node[cat] < 0 || p->bc_node[cat] != node)
     return fail("branch cache: no cache resident for this branch (call hyphy_hip_branch_cache_build after an evaluation)");
   if (!q_dense) return fail("null matrix pointer");
+  if (finish_pending_async(p)) return -1;
   const int L = (int)p->L, I = (int)p->I, C = (int)p->C;
   const int64_t B = p->B, D = p->D;
   const int DP = p->DP;
@@ -1611,6 +1633,7 @@ static int site_fits_common(hyphy_hip_partition *p, int64_t n_sets, int64_t n_gr
     return fail("site fits: bad set / group / mixture-component count");
   if (!branch_group || !branch_coeffs || !site_mult || !root_freqs || !site_logl_out || (n_mix > 1 && !site_weights))
     return fail("site fits: null argument");
+  if (finish_pending_async(p)) return -1;
   const int64_t D = p->D, B = p->B, K = p->K, S = p->S;
   const int L = (int)p->L, I = (int)p->I, DP = p->DP, NW = p->NW;
   const int NKK = 4 * NW, TILE = NKK * 64;

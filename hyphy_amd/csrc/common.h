@@ -45,7 +45,8 @@ __host__ __device__ inline int frag_index(int kk, int lane) { return (((kk >> 1)
 //      bit  6    OPF_AMBIG   (leaf group) some leaf of the group carries ambiguity codes in this shard
 //      bit  7    OPF_INREGS  (nucleotide kernel only) child is the node finalised by the previous entry
 //                OPF_NOPERSIST (MFMA kernels, OPF_LAST entries) lazy persistence: do not store the finalised parent
-//      bits 8-14 number of leaves in a leaf group
+//      bits 8-13 number of leaves in a leaf group
+//      bit  14   OPF_NOSCALE (wave-per-tile kernel, OPF_LAST entries) no rescaling test at this node (schedule.hip: thin_rescale_tests)
 //      bit  15   OPF_PUBLISH (wave-per-tile kernel, OPF_LAST entries) the finalised parent is the root of a fragment that
 //                another workgroup of this launch consumes — publish it with sc1 stores.  (Its own bit: the last entry
 //                of a fragment root may itself be an internal-global entry, with or without OPF_HANDOFF.)
@@ -239,7 +240,8 @@ void launch_mix_images(const double *P, const int *off, const double *w, const i
                        double *PTg, double *Prow, hipStream_t stream, double *PTrow = nullptr);
 void launch_site_fit(const SiteFitArgs &a, hipStream_t stream);
 void launch_prune_mfma(const PruneArgs &a, hipStream_t stream);
-void launch_prune_nuc(const NucArgs &a, hipStream_t stream);
+void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex = nullptr);  // ex: matrix exponentials folded into the launch
+bool prune_nuc_folds_expm(int L, int S_pad, int n_ops);
 void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,
                         double *out_logl, double *out_cnt, const int *status, hipStream_t stream, double seq = 0.);
 void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *wg_flag, int n, double *out_logl,

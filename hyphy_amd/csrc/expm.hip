@@ -11,6 +11,7 @@
 // (matrix.cpp:5703-5721): on the GPU a dense 64^3 MFMA product is cheaper than CSR bookkeeping
 // (SURVEY §2.1 K10).  With ||Q/2^p|| <= 1/4 the truncation error is < 2.5e-18.
 #include "common.h"
+#include "expm4.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -145,8 +146,9 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
 
   bool diag_pending = false;  // (uniform) fused construction: the diagonal of Q is still zero in LDS
   if (a.templates) {
-    // fused device-side rate-matrix construction: Q = sum_k c_k T_k, then the diagonal by column-order
-    // subtraction (the order of _Matrix::MultByFreqs, matrix.cpp:1664-1674).  Every load of a thread is
+    // fused device-side rate-matrix construction: Q = sum_k c_k T_k; the diagonal = -(row sum) comes out of the segmented norm
+    // pass below (partial sums combined by shuffles: it can differ from the serial column order of _Matrix::MultByFreqs,
+    // matrix.cpp:1664-1674, in the last bit).  Every load of a thread is
     // independent of the others (clamped index + mask instead of a branch), so the whole build costs one
     // memory round trip instead of one per element.
     constexpr int EPT = DP * DP / NTHR;  // elements per thread (DP*DP is a multiple of the block size)
@@ -930,125 +932,12 @@ __global__ __launch_bounds__(512) void expm64_kernel(ExpmArgs a, CoefInline ci) 
 // ---------------------------------------------------------------------------------------------
 // 4-state specialisation: one thread per matrix, everything in registers.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mm4(const double *A, const double *B, double *C) {
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      double s = 0.;
-#pragma unroll
-      for (int k = 0; k < 4; k++) s = fma(A[4 * i + k], B[4 * k + j], s);
-      C[4 * i + j] = s;
-    }
-}
-
-__device__ __forceinline__ bool diag_fix4(double *R) {
-  bool ok = true;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const double s = (R[4 * i] + R[4 * i + 1]) + (R[4 * i + 2] + R[4 * i + 3]);
-    if (s != s || R[5 * i] > 1.) ok = false;
-    R[5 * i] += 1. - s;
-  }
-  return ok;
-}
-
 __global__ void expm_nuc_kernel(ExpmArgs a) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= a.n) return;
   const int slot = a.slots ? a.slots[m] : m;
-  double Q[16], R[16];
-  if (a.templates) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      double d = 0.;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (j == i) continue;
-        double v = 0.;
-        for (int k = 0; k < a.K; k++) v += a.coeffs[(size_t)m * a.K + k] * a.templates[(size_t)k * 16 + 4 * i + j];
-        Q[4 * i + j] = v;
-        d -= v;
-      }
-      Q[5 * i] = d;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 16; k++) Q[k] = a.Q[(size_t)m * 16 + k];
-  }
-  if (a.is_prob) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) R[k] = Q[k];
-  } else {
-    double rmax = 0., cmax = 0.;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      double rs = 0., cs = 0.;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        rs += fabs(Q[4 * i + j]);
-        cs += fabs(Q[4 * j + i]);
-      }
-      rmax = fmax(rmax, rs);
-      cmax = fmax(cmax, cs);
-    }
-    const double mnorm = rmax * cmax;
-    int p = 0;
-    if (mnorm > 0.) {
-      const double s = 4. * sqrt(mnorm);
-      if (s > 1.) p = ilogb(s) + 1;
-    }
-    bool done = false, failed = !(mnorm < 1e300);
-    for (int attempt = 0; attempt < 48 && !done && !failed; attempt++) {
-      const double scale = ldexp(1.0, -p);
-      double X[16], T[16], T2[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) X[k] = Q[k] * scale;
-      // Horner: R = I + X (I + X/2 (I + X/3 (... (I + X/12))))
-#pragma unroll
-      for (int k = 0; k < 16; k++) T[k] = X[k] * (1.0 / 12.0);
-#pragma unroll
-      for (int d = 0; d < 4; d++) T[5 * d] += 1.0;
-      for (int k = 11; k >= 1; k--) {
-        mm4(X, T, T2);
-        const double f = 1.0 / (double)k;
-#pragma unroll
-        for (int e = 0; e < 16; e++) T[e] = T2[e] * f;
-#pragma unroll
-        for (int d = 0; d < 4; d++) T[5 * d] += 1.0;
-      }
-#pragma unroll
-      for (int k = 0; k < 16; k++) R[k] = T[k];
-      if (!diag_fix4(R)) {
-        p += 7;
-        if (p > 900) failed = true;
-        continue;
-      }
-      double last_diff = 0.;
-      for (int s = 0; s < p; s++) {
-        mm4(R, R, T);
-        double diff = 0.;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-          diff = fmax(diff, fabs(T[k] - R[k]));
-          R[k] = T[k];
-        }
-        if (diff < 2.220446049250313e-16 * 1.e3 || (s >= 10 && diff > last_diff * 100.)) break;
-        last_diff = diff;
-      }
-      if (p > 0 && !diag_fix4(R)) {
-        p += 7;
-        if (p > 900) failed = true;
-        continue;
-      }
-      done = true;
-    }
-    if (!done) {  // (as in the MFMA kernel: sticky status + NaN matrix, so that this evaluation's log-L is NaN)
-      atomicOr(a.status, 1);
-#pragma unroll
-      for (int k = 0; k < 16; k++) R[k] = NAN;
-    }
-  }
+  double R[16];
+  expm4_one(a, m, R);
   if (a.Prow) {
 #pragma unroll
     for (int k = 0; k < 16; k++) a.Prow[(size_t)slot * 16 + k] = R[k];

@@ -276,6 +276,7 @@ int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes
                 int64_t n_q, const double *q, bool q_on_device, int q_is_probability, const double *root_freqs,
                 double *d_logl_out, bool reduce, bool floor_log, bool batch = false, bool force_persist = false,
                 const MixSpec *mix = nullptr);
+int finish_pending_async(hyphy_hip_partition *p);
 int collect_status(hyphy_hip_partition *p);
 int publish_and_collect(hyphy_hip_partition *p, const double *d_value, double *value_out);  // (single-shard partitions)
 void record_timings(hyphy_hip_partition *p);

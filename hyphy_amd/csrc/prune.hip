@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "expm4.h"
 
 #ifndef HYPHY_OCC
 #define HYPHY_OCC 3  // waves per SIMD the T = 1 pruning kernel is compiled for
@@ -1426,9 +1427,12 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
 // Same schedule format, same exponent bookkeeping, same outputs as prune_nuc_kernel (which stays for trees whose leaf
 // matrices do not fit LDS).
 // ---------------------------------------------------------------------------------------------
-template <int NP, bool PIN>
+// FOLD: the matrix exponentials of this evaluation are computed HERE, by the first threads of every workgroup (each writes the
+// transposed copies it reads itself; workgroup 0 also leaves the row-major ones), instead of by a launch of their own in
+// front — for shards of a few hundred workgroups the 10 us of that launch were a fifth of the step, 2 us of one wave are not.
+template <int NP, bool PIN, bool FOLD = false>
 __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict__ ops, const double *__restrict__ PTm,
-                                                         NucArgs a) {
+                                                         NucArgs a, ExpmArgs ex) {
   constexpr int WGP = 256 * NP;  // patterns per workgroup
   extern __shared__ __align__(16) double nlds[];
   double *PT = nlds;                                                   // [L][4 states][4 rows]
@@ -1437,6 +1441,21 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
   const int tid = threadIdx.x;
   const size_t S_pad = a.S_pad;
   const int s0 = blockIdx.x * WGP + tid;  // pattern q of this thread: s0 + 256 q
+  if constexpr (FOLD) {
+    for (int m = tid; m < ex.n; m += 256) {
+      double R[16];
+      expm4_one(ex, m, R);
+      const int slot = ex.slots ? ex.slots[m] : m;
+      if (blockIdx.x == 0 && ex.Prow) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) ex.Prow[(size_t)slot * 16 + k] = R[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++) ex.PTrow[(size_t)slot * 16 + k] = R[4 * (k & 3) + (k >> 2)];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's copies have reached L2 before any of its waves reads them
+    __syncthreads();
+  }
   for (int idx = tid; idx < a.L * 16; idx += 256) PT[idx] = PTm[idx];  // (leaves are branches 0 .. L-1)
   __syncthreads();
   double acc[NP][4], b[NP][4];
@@ -1455,37 +1474,22 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
       const int lf = (o.z >> (16 * i)) & 0xffff;
 #pragma unroll
       for (int q = 0; q < NP; q++) {
-        // (always requested — an internal entry's word names leaf 0 — so that the code is straight-line)
-        const int16_t *src = (PIN && lf == a.pin_leaf) ? a.pin : a.codes + (size_t)(lf < a.L ? lf : 0) * S_pad;  // (pinned leaf: its states replace the data)
-        const int c = (int)src[s0 + 256 * q];
-        code[i][q] = i < nl ? c : 0;
+        code[i][q] = 0;
+        if (i < nl) {
+          if (PIN && lf == a.pin_leaf) code[i][q] = (int)a.pin[s0 + 256 * q];  // (pinned leaf: its states replace the data)
+          else code[i][q] = (int)a.codes[(size_t)lf * S_pad + s0 + 256 * q];
+        }
       }
     }
   };
-  // Everything the loop fetches ahead — schedule words, matrices, leaf codes — goes through VECTOR loads, although the first
-  // two are wave-uniform: scalar loads return out of order and share their counter with LDS, so any use of one drains
-  // every scalar load AND every LDS access in flight (s_waitcnt lgkmcnt(0)) — with the matrix of the NEXT entry just
-  // requested that was a full L2 round trip per entry, the bulk of the r03 first cut's 1 000 cycles per entry.  The
-  // vector-memory counter is in order: the compiler waits for exactly the loads an entry needs.  `vz` is a zero the
-  // compiler cannot see through (keeps uniform addresses off the scalar path).
-  unsigned vz = 0;
-  asm volatile("" : "+v"(vz));
-  auto load_op = [&](int idx) -> int4 { return ops[(unsigned)idx + vz]; };
-  auto scalar_op = [](const int4 &v) -> int4 {
-    return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z),
-                     __builtin_amdgcn_readfirstlane(v.w));
-  };
-  // columns 0..2 of a child's matrix = the first 12 doubles of its TRANSPOSED copy (PTm: [branch][state j][row i]);
-  // requested for every entry (a leaf group's are simply not used: straight-line code, exact wait counts)
+  // columns 0..2 of a child's matrix = the first 12 doubles of its TRANSPOSED copy (PTm: [branch][state j][row i]): uniform
+  // address, three 32-byte scalar loads, requested one entry ahead.  (Tried and measured slower: the same through vector
+  // loads — 96 bytes x 64 lanes per entry made the kernel TA-bound, 205 vs 120 us at 10^6 sites; schedule words through
+  // vector loads + readfirstlane, 38 vs 27 us at 50 000 sites.)
   auto load_P = [&](const int4 &o, double (&P)[12]) {
-    const int child = (o.x & 3) == OPK_LEAF ? (o.z & 0xffff) : o.z;
-    const f64x2 *src = reinterpret_cast<const f64x2 *>(PTm + (size_t)child * 16) + vz;
+    const double *src = PTm + (size_t)((o.x & 3) == OPK_LEAF ? (o.z & 0xffff) : o.z) * 16;
 #pragma unroll
-    for (int e = 0; e < 6; e++) {
-      const f64x2 v = src[e];
-      P[2 * e] = v[0];
-      P[2 * e + 1] = v[1];
-    }
+    for (int e = 0; e < 12; e++) P[e] = src[e];
   };
   // one schedule entry: `code` = this thread's leaf codes (leaf entries), P = columns 0..2 of the child's transition matrix
   auto entry = [&](const int4 &op, const double (&P)[12], const int (&code)[2][NP]) {
@@ -1623,25 +1627,23 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
   };
   // Software pipeline, unrolled by two: matrix and leaf codes of entry i + 1 are requested before entry i is processed.
   // Programs are padded to an even entry count and followed by two no-op entries.
-  // (schedule words two entries ahead: their load has returned by the time they address the matrix / code loads)
-  int4 opA = scalar_op(load_op(0)), vB = load_op(1);
+  // (schedule words two entries ahead: their scalar load has returned by the time they address the matrix / code loads)
+  int4 opA = ops[0], opB = ops[1];
   double PA[12], PB[12];
   int cA[2][NP], cB[2][NP];
   load_P(opA, PA);
   codes_of(opA, cA);
   for (int oi = 0; oi < a.n_ops; oi += 2) {
-    const int4 vC = load_op(oi + 2);
-    const int4 opB = scalar_op(vB);
+    const int4 opC = ops[oi + 2];
     load_P(opB, PB);
     codes_of(opB, cB);
     entry(opA, PA, cA);
-    const int4 vD = load_op(oi + 3);
-    const int4 opC = scalar_op(vC);
+    const int4 opD = ops[oi + 3];
     load_P(opC, PA);
     codes_of(opC, cA);
     entry(opB, PB, cB);
     opA = opC;
-    vB = vD;
+    opB = opD;
   }
   // root: L_s = sum_k root[s][k] pi[k]; this workgroup's share of sum_s f_s log L_s and of the integer scaler sum
   double term = 0.;
@@ -1982,7 +1984,14 @@ static size_t nuc2_lds(const NucArgs &a, int np) {
   return (size_t)a.L * 16 * sizeof(double) + (size_t)kNucParkSlots * np * 256 * (4 * sizeof(double) + sizeof(int));
 }
 
-void launch_prune_nuc(const NucArgs &a, hipStream_t stream) {
+// true when launch_prune_nuc can take the evaluation's matrix exponentials along (ex != nullptr): the r03 kernel on a shard of
+// at most two workgroups per CU
+bool prune_nuc_folds_expm(int L, int S_pad, int n_ops) {
+  static const bool on = !(getenv("HYPHY_HIP_NUC_FOLD") && atoi(getenv("HYPHY_HIP_NUC_FOLD")) == 0);
+  return on && n_ops > 0 && prune_nuc_takes_leaf_pairs(L) && nuc_forced() != 2 && S_pad % 256 == 0 && S_pad / 256 <= 512;
+}
+
+void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex) {
   if (a.n_ops <= 0) return;
   const bool pin = a.pin_leaf >= 0 || a.pin_inode >= 0;
   const int np = nuc2_np(a);
@@ -2000,16 +2009,25 @@ void launch_prune_nuc(const NucArgs &a, hipStream_t stream) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     attr_done[dev] = true;
   }
   const dim3 grid(a.S_pad / (256 * np)), block(256);
   const size_t lds = nuc2_lds(a, np);
+  ExpmArgs none;
+  none.n = 0;
+  if (ex && ex->n > 0 && np == 1) {
+    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, true>), grid, block, lds, stream, a.ops, a.PT, a, *ex);
+    else hipLaunchKernelGGL((prune_nuc2_kernel<1, false, true>), grid, block, lds, stream, a.ops, a.PT, a, *ex);
+    return;
+  }
   if (np == 2) {
-    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<2, true>), grid, block, lds, stream, a.ops, a.PT, a);
-    else hipLaunchKernelGGL((prune_nuc2_kernel<2, false>), grid, block, lds, stream, a.ops, a.PT, a);
+    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<2, true>), grid, block, lds, stream, a.ops, a.PT, a, none);
+    else hipLaunchKernelGGL((prune_nuc2_kernel<2, false>), grid, block, lds, stream, a.ops, a.PT, a, none);
   } else {
-    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true>), grid, block, lds, stream, a.ops, a.PT, a);
-    else hipLaunchKernelGGL((prune_nuc2_kernel<1, false>), grid, block, lds, stream, a.ops, a.PT, a);
+    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true>), grid, block, lds, stream, a.ops, a.PT, a, none);
+    else hipLaunchKernelGGL((prune_nuc2_kernel<1, false>), grid, block, lds, stream, a.ops, a.PT, a, none);
   }
 }
 
