@@ -582,7 +582,7 @@ int hyphy_hip_prune_launches(hyphy_hip_partition *p) { return p ? (int)std::max<
 
 const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p) {
   if (!p) return "";
-  if (p->nuc) return "prune_nuc_kernel";
+  if (p->nuc) return p->nuc_leaf_pairs ? "prune_nuc2_kernel" : "prune_nuc_kernel";
   return p->variant == 1 ? "prune_wave_kernel" : "prune_mfma_kernel";  // (variant 2: the same kernel on a chain schedule)
 }
 

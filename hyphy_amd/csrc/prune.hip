@@ -1987,7 +1987,7 @@ static size_t nuc2_lds(const NucArgs &a, int np) {
 // true when launch_prune_nuc can take the evaluation's matrix exponentials along (ex != nullptr): the r03 kernel on a shard of
 // at most two workgroups per CU
 bool prune_nuc_folds_expm(int L, int S_pad, int n_ops) {
-  static const bool on = !(getenv("HYPHY_HIP_NUC_FOLD") && atoi(getenv("HYPHY_HIP_NUC_FOLD")) == 0);
+  static const bool on = getenv("HYPHY_HIP_NUC_FOLD") && atoi(getenv("HYPHY_HIP_NUC_FOLD")) != 0;  // (opt-in: measured neutral, 45.5 vs 45.6 us per step at 50 000 sites)
   return on && n_ops > 0 && prune_nuc_takes_leaf_pairs(L) && nuc_forced() != 2 && S_pad % 256 == 0 && S_pad / 256 <= 512;
 }
 
