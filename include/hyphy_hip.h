@@ -97,6 +97,12 @@ void hyphy_hip_destroy(hyphy_hip_partition *p);
  *   site_scaler_out optional [S] == the siteCorrections slice: c_s.  Only differences of c_s
  *                   between rate classes and sum_s f_s c_s are observable upstream
  *                   (likefunc2.cpp:736-770, 828-853, 1484-1506).
+ *
+ * Reproducibility: steady-state full passes run on chain schedules whose joins multiply the children of a node in the
+ * order in which their workgroups arrive, and the schedule itself is chosen by timing (HYPHY_HIP_TUNE): the same inputs can
+ * give log-likelihoods that differ in the last bits (<= a few 1e-16 relative) between runs and between ranks.  The reference's
+ * CPU path is deterministic for a fixed thread count; a host that needs bit-identical repeats sets
+ * HYPHY_HIP_TUNE=0 HYPHY_HIP_CUT=levels (fixed order, no joins; ~25 % slower at the headline size).
  */
 int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                        const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,

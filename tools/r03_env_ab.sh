@@ -12,7 +12,7 @@ tag, path = sys.argv[1], sys.argv[2]
 try:
     j = json.loads([l for l in open(path) if l.startswith("{")][-1]); r = j["roofline"]
     ex = r.get("expm_ms"); rd = r.get("reduce_ms")
-    print(f"{tag:44s} {j['value']:9.1f} evals/s  step {j['ms_per_step']*1e3:8.1f} us  prune {r['kernel_ms']*1e3:8.1f} us  frac {r['frac']:.3f}"
+    print(f"{tag:44s} {j['value']:9.1f} evals/s  step {j['ms_per_step']*1e3:8.1f} us  prune {r['kernel_ms']*1e3:8.1f} us  frac {(r['frac'] if r.get('frac') is not None else float('nan')):.3f}"
           f"  expm {ex*1e3 if ex else float('nan'):6.1f}  reduce {rd*1e3 if rd else float('nan'):5.1f}  logL {j['logl_last']!r}")
 except Exception as e:
     print(f"{tag:44s} FAILED ({e})")
