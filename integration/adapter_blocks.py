@@ -34,6 +34,8 @@ struct _HyHipPart {
   long tmpl_K = 0;
   _SimpleList tmpl_refs;                     // template-variable references every conforming node must show (iVariables odd entries)
   long tmpl_model = -1;
+  std::string tmpl_dep_sig;                  // constraints on dependent locals every conforming node must carry (see _hyhip_dep_signature)
+  std::unordered_map<const void *, char> dep_ok;
   std::vector<std::vector<double>> tmpl_M;   // per class: [K][D*D] current templates (off-diagonal entries are what counts)
   std::vector<std::vector<double>> tmpl_x;   // per class: [B][K] latest local-parameter rows
   std::vector<char> tmpl_uploaded;           // per class: tmpl_M is what the device holds
@@ -268,6 +270,8 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   hp.tmpl_K = 0;
   hp.tmpl_refs.Clear();
   hp.tmpl_model = -1;
+  hp.tmpl_dep_sig.clear();
+  hp.dep_ok.clear();
   hp.tmpl_M.assign(n_cat, std::vector<double>());
   hp.tmpl_x.assign(n_cat, std::vector<double>());
   hp.tmpl_uploaded.assign(n_cat, 0);
@@ -302,9 +306,36 @@ static bool _hyphy_hip_active(const void *lf, long index) {
 // RecomputeMatrix: K probes give the templates M_k of THIS evaluation, one more verifies them (1e-11 relative), all the
 // others are skipped and reach the device as K coefficients (hyphy_hip_build_q).  A failed verification recomputes
 // the skipped matrices the normal way and switches the mode off for the rate class.
-static bool _hyhip_conforms(const _HyHipPart &hp, _CalcNode *n) {
+// Constrained (dependent) local parameters — "givenTree.N.nonSynRate := R*givenTree.N.synRate", the usual way a global omega
+// enters a codon model — are fine as long as EVERY branch carries the same constraints: the text of each constraint with the
+// branch's own name prefix removed, plus the template variable it binds to.  With identical constraints the dependents are the
+// same function of (the branch's independent locals, the globals) on every branch, so the numerical linearity test in the
+// independent locals covers them; branch-specific constraints (foreground / background omega classes) give different
+// signatures and keep the dense path.
+static std::string _hyhip_dep_signature(_CalcNode *n) {
+  std::string sig;
+  if (!n->dVariables || !n->dVariables->lLength) return sig;
+  const std::string prefix = std::string(n->GetName()->get_str()) + ".";
+  for (unsigned long k = 0; k + 1 < n->dVariables->lLength; k += 2) {
+    _Variable *v = LocateVar(n->dVariables->list_data[k]);
+    if (!v) return "?";
+    _String *fs = v->GetFormulaString(kFormulaStringConversionNormal);
+    std::string text(fs->get_str());
+    DeleteObject(fs);
+    for (size_t pos = text.find(prefix); pos != std::string::npos; pos = text.find(prefix, pos)) text.erase(pos, prefix.size());
+    sig += std::to_string(n->dVariables->list_data[k + 1]) + "=" + text + ";";
+  }
+  return sig;
+}
+static bool _hyhip_conforms(_HyHipPart &hp, _CalcNode *n) {
   if (n->HasExplicitFormModel() || n->GetModelIndex() != hp.tmpl_model) return false;
-  if (n->dVariables && n->dVariables->lLength) return false;
+  if (n->dVariables && n->dVariables->lLength) {
+    auto it = hp.dep_ok.find(n);
+    if (it == hp.dep_ok.end()) it = hp.dep_ok.emplace(n, _hyhip_dep_signature(n) == hp.tmpl_dep_sig ? 1 : 0).first;
+    if (!it->second) return false;
+  } else if (!hp.tmpl_dep_sig.empty()) {
+    return false;
+  }
   if (!n->iVariables || (long)n->iVariables->lLength != 2 * hp.tmpl_K) return false;
   for (long k = 0; k < hp.tmpl_K; k++)
     if (n->iVariables->list_data[2 * k + 1] != hp.tmpl_refs.list_data[k]) return false;
@@ -708,6 +739,8 @@ static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, 
         hp.tmpl_model = first->GetModelIndex();
         hp.tmpl_refs.Clear();
         for (long k = 0; k < K0; k++) hp.tmpl_refs << first->iVariables->list_data[2 * k + 1];
+        hp.tmpl_dep_sig = _hyhip_dep_signature(first);
+        hp.dep_ok.clear();
       }
       std::vector<long> codes;
       bool all_conform = true;

@@ -374,3 +374,63 @@ def test_hbl_spmd_site_shard_two_ranks(tmp_path):
     for r in (0, 1):
         assert abs(out[r]["logl"] - ref) <= 1e-10 * abs(ref), (r, out[r]["logl"], ref)
     assert np.array_equal(out[0]["sweep_values"], out[1]["sweep_values"])
+
+
+def _run_constrained_local_model(binary=None, env=None, optimize=False, sweep=None, branch_specific=False):
+    """MG94 written the way HyPhy's own codon models carry a global omega: two LOCAL parameters per branch (synRate,
+    nonSynRate) and the constraint `givenTree.N.nonSynRate := R*givenTree.N.synRate` on every branch — nonSynRate is a
+    DEPENDENT local.  branch_specific: every third branch is constrained through a second global R2 instead (foreground /
+    background omega classes): the constraints then differ between branches."""
+    import tempfile
+    from hyphy_amd import data, models, tree
+    from oracle import hbl, make_golden as mg
+    syn = data.evolve(16, 60, 3, seed=31)
+    bt = mg.branch_lengths(syn.flat, 38, 0.02, 0.12)
+    lines = ["MGQ = {61,61};"]
+    for (i, j, name, ns, pf) in models.mg94rev_template(mg.POS_FREQS):
+        parts = ([name] if name != "AG" else []) + ["nonSynRate" if ns else "synRate", repr(float(pf))]
+        lines.append(f"MGQ[{i}][{j}] := {'*'.join(parts)};")
+    lines.append("vectorOfFrequencies = {\n" + ",\n".join("{" + repr(float(v)) + "}" for v in models.f3x4_codon_freqs(mg.POS_FREQS)) + "};")
+    lines.append("Model MGM = (MGQ, vectorOfFrequencies, 0);")
+    tmp = tempfile.mkdtemp(prefix="hydep_")
+    fasta, outp = os.path.join(tmp, "aln.fasta"), os.path.join(tmp, "out.txt")
+    hbl.write_fasta(fasta, syn.flat.leaf_names, syn.seqs)
+    g = dict(R=0.3, **mg.REV)
+    if branch_specific:
+        g["R2"] = 0.3   # (equal at the start: the classes only separate once a parameter moves)
+    txt = hbl.build_script(fasta=fasta, newick=tree.to_newick(syn.tree), unit=3, model_block="\n".join(lines), model_name="MGM",
+                           globals_=g, branch_t=bt, out_path=outp, per_site=False, optimize=optimize, sweep=sweep)
+    for k, (nm, t) in enumerate(bt.items()):
+        om = "R2" if (branch_specific and k % 3 == 0) else "R"
+        txt = txt.replace(f"givenTree.{nm}.t = {hbl._fmt(t)};",
+                          f"givenTree.{nm}.synRate = {hbl._fmt(t)}; givenTree.{nm}.nonSynRate := {om}*givenTree.{nm}.synRate;")
+    assert ".t = " not in txt
+    out = hbl.run_script(txt, tmp, binary=binary, extra_env=env)
+    res = hbl.parse_output(outp)
+    res["stdout"] = out
+    return res
+
+
+def test_hbl_template_mode_with_constrained_dependent_locals():
+    """r03: template mode also takes models whose branches carry DEPENDENT locals, provided every branch carries the same
+    constraints.  Global-omega MG94 with `nonSynRate := R*synRate` per branch: a sweep of R in mode B and a
+    complete Optimize through template mode (K = 1) against the unmodified binary; with branch-specific constraints (two omega
+    classes that are equal at the start and separate during the sweep) the adapter must NOT use templates."""
+    _need_binaries()
+    sweep = dict(param="R", start=0.3, step=0.02, n=15, record=15)
+    envB = dict(ENV, HYPHY_HIP_DEVICE_EXPM="always")
+    cpu = _run_constrained_local_model(sweep=sweep)
+    gpu = _run_constrained_local_model(binary=HIP_BIN, env=envB, sweep=sweep)
+    n_eval, K, n_skip = _template_evals(gpu["stdout"])
+    assert K == 1 and n_eval >= 10 and n_skip > 0, gpu["stdout"][-1000:]
+    assert np.max(np.abs(gpu["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10
+    cpu = _run_constrained_local_model(optimize=True)
+    gpu = _run_constrained_local_model(binary=HIP_BIN, env=ENV, optimize=True)
+    assert _template_evals(gpu["stdout"])[0] > 5, gpu["stdout"][-1000:]
+    assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3
+    # two omega classes: same rows, different constraints -> different matrices on branches with equal locals
+    cpu = _run_constrained_local_model(sweep=sweep, branch_specific=True)
+    gpu = _run_constrained_local_model(binary=HIP_BIN, env=envB, sweep=sweep, branch_specific=True)
+    assert _template_evals(gpu["stdout"])[0] == 0, gpu["stdout"][-1000:]
+    assert _device_calls(gpu["stdout"]) > 10
+    assert np.max(np.abs(gpu["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10
