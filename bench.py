@@ -406,18 +406,42 @@ def main():
     if not single:
         part.set_stream(stream.cuda_stream)
     d_logl = torch.zeros(2, dtype=torch.float64, device="cuda")
+    collective_note = None
     if collective == "cabi":
-        # the library's own communicator: rank 0 makes the id, the 128 bytes travel through torch.distributed's store
+        # the library's own communicator: rank 0 makes the id, the 128 bytes travel through torch.distributed's store.
+        # Safety net for the first run on a multi-GPU box: if any rank cannot set it up, ALL ranks fall back to
+        # torch.distributed's all-reduce (agreed on by a MIN all-reduce of a flag) and the line says so.
+        ok, why = 1, ""
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(hip.HipPartition.comm_unique_id()), dtype=torch.uint8))
+        try:
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(hip.HipPartition.comm_unique_id()), dtype=torch.uint8))
+        except Exception as e:
+            ok, why = 0, f"comm_unique_id: {e}"
         if multi:
-            dist.broadcast(uid, src=0)
-        part.comm_init_rank(bytes(uid.cpu().numpy().tobytes()), rank, N if multi else 1)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+            if ok:
+                dist.broadcast(uid, src=0)
+        if ok:
+            try:
+                part.comm_init_rank(bytes(uid.cpu().numpy().tobytes()), rank, N if multi else 1)
+            except Exception as e:
+                ok, why = 0, f"comm_init_rank: {e}"
+            if multi:
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+        if not ok:
+            collective = "torch" if multi else "none"
+            collective_note = "C-ABI communicator not available (" + (why or "another rank failed") + "): fell back to torch.distributed.all_reduce"
+            sys.stderr.write(f"[bench] rank {rank}: {collective_note}\n")
     coeffs = np.empty((B * n_classes, 2))
     coeffs[:, 0] = np.tile(tb, n_classes)
     class_omega = np.array([0.1, 1.0, 5.0][:n_classes]) / 0.3 if n_classes > 1 else np.array([1.0])
     class_w = np.array([0.7, 0.25, 0.05])
+    ar_step = None
     if n_classes > 1:
         cat_step = part.prepare_built_categories_step(nodes, nodes, class_w, pi, coeffs)
     else:
@@ -453,6 +477,13 @@ def main():
         return None
 
     ll0 = step(0)
+    if ar_step is not None and not np.isfinite(ll0):
+        # (the all-reduced value is the same on every rank, so every rank takes this branch or none does)
+        collective_note = "hyphy_hip_evaluate_built_allreduce returned a non-finite value on the first evaluation: fell back to torch.distributed.all_reduce"
+        sys.stderr.write(f"[bench] rank {rank}: {collective_note}\n")
+        ar_step = None
+        collective = "torch" if multi else "none"
+        ll0 = step(0)
     # device preheat (clock ramp): the same number of steps on every rank (a step contains a collective when N > 1)
     t_pre = time.perf_counter()
     for _ in range(3):
@@ -673,6 +704,7 @@ def main():
                                        f"site-shard x{N}, one process, shard partials combined by {args.combine}" if single and N > 1 else "single GPU"),
                        "collective": ({"cabi": "hyphy_hip_evaluate_built_allreduce (in-stream ncclAllReduce of one double, C-ABI communicator)",
                                        "torch": "torch.distributed.all_reduce on the partition's stream", "none": None}[collective]),
+                       **({"collective_note": collective_note} if collective_note else {}),
                        "patterns_rank0": int(S_rank),
                        "step": "device Q build + expm of all branches + full pruning pass + reduction" +
                                (" + RCCL all-reduce" if (multi or collective == "cabi") else "") + ", log-L returned to host every step"},
