@@ -729,10 +729,7 @@ __global__ __launch_bounds__(512) void expm64_kernel(ExpmArgs a, CoefInline ci) 
 #pragma unroll
         for (int c = 0; c < NTW; c++) R[c] = Rf[c];
       }
-      __syncthreads();
-      if (H > 1) {
-        // (a matrix that left panel mode: this workgroup writes every row — the generic image loops below, panel = all)
-      }
+      __syncthreads();  // (H > 1: a matrix that left panel mode — this workgroup writes every row below)
     } else {
       // ================= panel mode (p = 0): rows [64/H * panel, ...) of the polynomial =================
       if (H == 2) {

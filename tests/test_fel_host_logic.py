@@ -131,3 +131,12 @@ def test_meme_driver_bookkeeping():
     bc = np.stack([np.full(B, 0.2), np.full(B, 0.1)], axis=1)
     again = part.site_fits_evaluate_mixture(group, bc, sm[None], sw[None], pi)[0]
     assert np.allclose(again, res.logl_alt, rtol=0, atol=1e-9)
+
+
+def test_bench_reads_the_measured_instruction_peak_from_the_committed_microbenchmark():
+    """bench.py's `instruction_peak_measured` is read from profiles/r01_ubench_mfma_f64.txt (no literals in the line)."""
+    import bench
+    peak, src = bench.measured_instruction_peak()
+    assert src == "profiles/r01_ubench_mfma_f64.txt" and 45.0 < peak < 55.0
+    flops, bytes_ = bench.alg_work(61, 9974, 64, 62)
+    assert flops == 4642198820 and bytes_ == 599317712      # SURVEY 8d at the headline size (DESIGN 4.1)
