@@ -132,6 +132,12 @@ PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
   pa.chain = 0;
   pa.jn = nullptr;
   pa.deposits = nullptr;
+  pa.red_out = nullptr;  // (fused final combine: enqueue_eval turns it on for the launch that finalises the roots)
+  pa.red_rec = nullptr;
+  pa.red_status = nullptr;
+  pa.red_seq = 0.;
+  pa.red_done = nullptr;
+  pa.red_n = 0;
   return pa;
 }
 
@@ -306,21 +312,24 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     tr.lap("launch_expm");
     }
   }
-  // kernel-duration stamps: every evaluation by default; HYPHY_HIP_TIMING_EVERY=n keeps one in n
-  static const int timing_every = getenv("HYPHY_HIP_TIMING_EVERY") ? std::max(1, atoi(getenv("HYPHY_HIP_TIMING_EVERY"))) : 1;
-  const bool stamp = timing_every == 1 || (s.eval_count++ % (uint64_t)timing_every) == 0;
+  // kernel-duration stamps (an event pair around the pruning launches: two barrier packets, ~5 us of stream time at the
+  // headline size): one evaluation in 16 by default — an optimiser's sweep should not pay for a profile nobody reads —,
+  // HYPHY_HIP_TIMING_EVERY=n keeps one in n (bench.py: 4, the rocprofv3 runs: 1)
+  static const int timing_every = getenv("HYPHY_HIP_TIMING_EVERY") ? std::max(1, atoi(getenv("HYPHY_HIP_TIMING_EVERY"))) : 16;
+  const bool stamp = timing_every == 1 || p->all_timings || (s.eval_count++ % (uint64_t)timing_every) == 0;
   const size_t ring_slot = (size_t)(s.ring_count % kTimingRing) * 2;
   if (stamp && !s.ring[ring_slot]) {  // (the ring's events are made on first use: a short-lived partition never pays for 2 048 of them)
     HIPCHK(hipEventCreate(&s.ring[ring_slot]));
     HIPCHK(hipEventCreate(&s.ring[ring_slot + 1]));
   }
+  if (p->all_timings) HIPCHK(hipEventRecord(s.ev[1], s.stream));  // (before the ring's stamp: the exponentials' interval ends here)
   if (stamp) HIPCHK(hipEventRecord(s.ring[ring_slot], s.stream));
-  if (p->all_timings) HIPCHK(hipEventRecord(s.ev[1], s.stream));
   int n_ops = 0;  // longest program
   for (const auto &pr : p->programs) n_ops = std::max(n_ops, pr.n);
   double *site_lik = s.site_lik + (size_t)cat * s.S_pad;
   int32_t *site_cnt = s.site_cnt + (size_t)cat * s.S_pad;
   int n_wg = 0;
+  bool fused_reduce = false;
   if (p->nuc) {
     NucArgs na;
     na.ops = s.ops + (p->programs.empty() ? 0 : p->programs[0].off);
@@ -376,10 +385,29 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     pa.chain = p->chain ? 1 : 0;
     pa.jn = s.jn;
     pa.deposits = s.deposits;
+    // Fused final combine: the launch that finalises the roots also sums the per-tile partial sums and publishes the record —
+    // the last root-finalising wave does what wg_reduce_kernel would do in a launch of its own (prune.hip: publish_partial).
+    // Saves 1.5-3 us per evaluation of a small shard (below two tiles per CU; 64 x 1 250: 69.1 -> 67.7 us, 32 x 5 000: 79.8 ->
+    // 77.0); at the headline size the gain shrinks to ~1 us while the pruning kernel's own duration grows by the 3-4 us of the
+    // serial tail, so larger shards keep the separate kernel.  HYPHY_HIP_FUSED_REDUCE=0/1 forces either.
+    const char *fuse_env = getenv("HYPHY_HIP_FUSED_REDUCE");
+    const bool fuse_on = fuse_env ? atoi(fuse_env) != 0 : s.ntiles <= 2 * s.cus;
+    if (fuse_on && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && !pa.timeline) {
+      double *rec = s.d_hout ? s.d_hout : s.out;
+      fused_reduce = true;
+      pa.red_out = d_logl_out ? d_logl_out : rec;
+      pa.red_rec = d_logl_out ? s.out + 1 : rec + 1;
+      pa.red_status = d_logl_out ? nullptr : s.status;
+      pa.red_seq = next_seq(s, !d_logl_out);
+      pa.red_done = s.frag_ctr + (size_t)p->C * (p->I + 2) * s.ntiles - 1;  // (a word of the arrival counters no schedule indexes; zero between launches)
+      pa.red_n = n_wg;
+    }
+    double *const red_out = pa.red_out;
     for (size_t lv = 0; lv < p->levels.size(); lv++) {  // one launch per level of subtree fragments
       pa.prog = s.prog + p->levels[lv].first;
       pa.n_prog = p->levels[lv].count;
       pa.do_root = (lv + 1 == p->levels.size()) ? 1 : 0;
+      pa.red_out = pa.do_root ? red_out : nullptr;
       launch_prune_mfma(pa, s.stream);
     }
     if (pa.timeline) {  // tracing only: synchronous dump of the per-entry s_memtime stamps
@@ -415,7 +443,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     s.ring_count++;
   }
   if (p->all_timings) HIPCHK(hipEventRecord(s.ev[2], s.stream));
-  if (reduce) {
+  if (reduce && !fused_reduce) {
     // synchronous entry points: the result record goes straight to host-mapped pinned memory (a
     // posted PCIe write from the kernel) — an SDMA device-to-host copy after the kernels costs far more
     double *rec = s.d_hout ? s.d_hout : s.out;
@@ -814,9 +842,9 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     A_(s.status, sizeof(int32_t));  // set by the expm kernel when a matrix fails
     A_(s.weights, (size_t)C * sizeof(double));
     s.wg_cap = p->nuc ? (s.S_pad + 255) / 256 : s.ntiles;
-    A_(s.wg_sum, (size_t)C * s.wg_cap * sizeof(double));  // x C: rate-class batching writes one row per class
-    A_(s.wg_cnt, (size_t)C * s.wg_cap * sizeof(long long));
-    A_(s.wg_flag, (size_t)C * s.wg_cap * sizeof(int));
+    A_(s.wg_sum, ((size_t)C * s.wg_cap + 4) * sizeof(double));  // x C: rate-class batching writes one row per class; + 4: the fused
+    A_(s.wg_cnt, ((size_t)C * s.wg_cap + 4) * sizeof(long long));  // final combine reads them with 16-byte loads
+    A_(s.wg_flag, ((size_t)C * s.wg_cap + 4) * sizeof(int));
 #undef A_
     s.h_small_cap = (size_t)std::max<int64_t>(std::max<int64_t>(DP, C), 64);
     if (hipHostMalloc((void **)&s.h_ops, ops_capacity(p) * sizeof(int4)) != hipSuccess ||

@@ -122,6 +122,15 @@ struct PruneArgs {
   int ablate;                // DIAGNOSTIC ONLY (HYPHY_HIP_ABLATE bitmask, results invalid): 1 no MFMA, 2 no barrier,
                              // 4 no persist stores, 8 no leaf gathers, 16 no operand prefetch, 32 no LDS exchange
   long long *timeline;       // optional tracing: [kTraceWG][NW][n_ops][4] s_memtime stamps (HYPHY_HIP_TIMELINE)
+  // fused final combine (r03): the wave that finalises the LAST root of the launch sums the per-tile partial sums itself
+  // (fixed order, compensated) and publishes the result record — no reduction kernel behind the pruning launch.
+  // red_out == nullptr: off (the caller launches wg_reduce_kernel).
+  double *red_out;           // [1] log-L
+  double *red_rec;           // [3] scaler sum, expm status, sequence word (the host spins on it when red_seq != 0)
+  const int *red_status;     // expm status word of the shard (or nullptr)
+  double red_seq;
+  int *red_done;             // arrivals of finalised roots (zero between launches)
+  int red_n;                 // roots the launch finalises = entries of wg_sum
 };
 constexpr int kTraceWG = 8;
 constexpr int kNucParkSlots = 4;  // LDS parking slots of the 4-state kernel (nodes whose parent is not the next entry)

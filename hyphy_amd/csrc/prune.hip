@@ -94,6 +94,100 @@ __device__ __forceinline__ void st16_agent(double *ubase, unsigned byte_off, f64
   __builtin_amdgcn_raw_buffer_store_b128(v, agent_rsrc(ubase), byte_off, 0, 16);
 }
 
+// A root-finalising wave's share of the log-likelihood sum (all 64 lanes active, values wave-uniform): entry `idx` of the
+// per-tile partial sums.  PruneArgs::red_out == nullptr: plain stores, wg_reduce_kernel combines them behind the launch.
+// Otherwise (r03, fused final combine) the partials go out with agent-scope stores, the wave arrives at red_done, and the
+// LAST arriver of the launch reads all red_n partials back (sc1 loads, all in flight together; entries past red_n read as
+// zero through the buffer bounds), sums them in a FIXED order — lane l takes entries 128 j + 2 l, 128 j + 2 l + 1 for
+// j = 0, 1, .. with a Kahan sum, then a compensated shuffle tree over the lanes — and publishes the result record exactly
+// like wg_reduce_kernel does (same flags, same record, same sequence word).  The order of arrival decides only WHO sums.
+__device__ __forceinline__ void publish_partial(const PruneArgs &a, int idx, double wsum, long long wcnt, int wflag, int lane) {
+  if (a.red_out == nullptr) {
+    if (lane == 0) {
+      a.wg_sum[idx] = wsum;
+      a.wg_cnt[idx] = wcnt;
+      a.wg_flag[idx] = wflag;
+    }
+    return;
+  }
+  if (lane == 0) {
+    __hip_atomic_store(a.wg_sum + idx, wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.wg_cnt + idx, wcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.wg_flag + idx, wflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (payload written through before the arrival: the protocol of the chain joins)
+  int old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(a.red_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __builtin_amdgcn_readfirstlane(old);
+  asm volatile("" ::: "memory");
+  if (old + 1 < a.red_n) return;
+  if (lane == 0) __hip_atomic_store(a.red_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+  const int n = a.red_n;
+  // (bounds rounded up to whole 16-byte accesses — the arrays are allocated 4 entries longer than any n —, entries >= n masked below)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.wg_sum, 0, ((n + 1) & ~1) * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(a.wg_cnt, 0, ((n + 1) & ~1) * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(a.wg_flag, 0, ((n + 3) & ~3) * 4, 0x00020000);
+  double sum = 0., comp = 0.;
+  long long c = 0;
+  int fl = 0;
+  constexpr int U = 4;
+  for (int base = 0; base < n; base += 128 * U) {
+    u32x4_t vs[U], vc[U];
+    u32x4_t vf[U / 2];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      vs[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(base + 128 * j + 2 * lane) * 8u, 0, 16);
+      vc[j] = __builtin_amdgcn_raw_buffer_load_b128(rc, (unsigned)(base + 128 * j + 2 * lane) * 8u, 0, 16);
+    }
+#pragma unroll
+    for (int j = 0; j < U / 2; j++) vf[j] = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)(base + 256 * j + 4 * lane) * 4u, 0, 16);
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      f64x2 x;
+      long long cc[2];
+      __builtin_memcpy(&x, &vs[j], 16);
+      __builtin_memcpy(cc, &vc[j], 16);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const bool in = base + 128 * j + 2 * lane + h < n;
+        const double y = (in ? x[h] : 0.) - comp;  // Kahan
+        const double t = sum + y;
+        comp = (t - sum) - y;
+        sum = t;
+        c += in ? cc[h] : 0ll;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < U / 2; j++)
+#pragma unroll
+      for (int h = 0; h < 4; h++)
+        if (base + 256 * j + 4 * lane + h < n) fl |= (int)vf[j][h];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double b0 = __shfl_down(sum, off), bc = __shfl_down(comp, off);
+    const long long cc = __shfl_down(c, off);
+    fl |= __shfl_down(fl, off);
+    const double t = sum + b0;
+    const double e = (fabs(sum) >= fabs(b0)) ? (sum - t) + b0 : (b0 - t) + sum;  // sum + b0 = t + e exactly
+    comp = comp + bc - e;
+    sum = t;
+    c += cc;
+  }
+  if (lane == 0) {
+    double r = (sum - comp) - kLogScaler * (double)c;
+    if (fl & 2) r = NAN;
+    else if (fl & 1) r = -INFINITY;
+    a.red_out[0] = r;
+    a.red_rec[0] = (double)c;
+    a.red_rec[1] = a.red_status ? (double)*a.red_status : 0.;
+    if (a.red_seq != 0.) {  // host spins on this word instead of waiting for the stream (record complete before it)
+      __threadfence_system();
+      reinterpret_cast<volatile double *>(a.red_rec)[2] = a.red_seq;
+    }
+  }
+}
+
 // Operand bundle fetched one schedule entry ahead: 16 doubles per lane, either the A-operand image
 // of the next internal edge's transition matrix or the gathered columns of the next leaf group.
 struct Payload {
@@ -147,11 +241,7 @@ __device__ __forceinline__ void root_epilogue(const PruneArgs &a, const double *
       wcnt += __shfl_xor(wcnt, off);
       wflag |= __shfl_xor(wflag, off);
     }
-    if (lane == 0) {
-      a.wg_sum[blockIdx.x] = wsum;
-      a.wg_cnt[blockIdx.x] = wcnt;
-      a.wg_flag[blockIdx.x] = wflag;
-    }
+    publish_partial(a, (int)blockIdx.x, wsum, wcnt, wflag, lane);
   }
 }
 
@@ -1133,11 +1223,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
       wcnt += __shfl_xor(wcnt, off);
       wflag |= __shfl_xor(wflag, off);
     }
-    if (lane == 0) {
-      a.wg_sum[tile0] = wsum;
-      a.wg_cnt[tile0] = wcnt;
-      a.wg_flag[tile0] = wflag;
-    }
+    publish_partial(a, tile0, wsum, wcnt, wflag, lane);
   }
   HYPHY_TRACE_FINISH(1)
 }

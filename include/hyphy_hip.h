@@ -341,7 +341,8 @@ int hyphy_hip_branch_cache_evaluate(hyphy_hip_partition *p, int64_t cat, int64_t
 /* Durations (ms) of the pruning launches of the last `n` evaluations, oldest first, from a ring of HIP
  * event pairs recorded on the partition's stream (shard 0).  Nothing is queried while evaluations run —
  * call this after the timed region.  Returns the number of entries written (<= n, <= 1024).
- * Environment HYPHY_HIP_TIMING_EVERY=k stamps one evaluation in k (default 1: every evaluation). */
+ * "Evaluations" here are the STAMPED ones: the library stamps one evaluation in k (environment HYPHY_HIP_TIMING_EVERY=k,
+ * default 16; the first evaluation of a partition is always stamped) — an event pair costs ~5 us of stream time. */
 int64_t hyphy_hip_prune_timings(hyphy_hip_partition *p, double *out_ms, int64_t n);
 /* Pruning-kernel launches per evaluation under the current schedule (forest scheduling cuts a full
  * evaluation into levels of subtree fragments, one launch per level; partial updates use one). */

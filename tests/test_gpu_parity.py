@@ -1107,3 +1107,55 @@ def test_rerooted_schedules_match_oracle_without_reversibility(shape, kernel, mo
         if np.isfinite(want):
             assert abs(got - want) <= RTOL * abs(want), (shape, "pinned", got, want)
         check("after pin", np.zeros(0, dtype=np.int64), np.zeros((0, D, D)))
+
+
+@pytest.mark.parametrize("kernel,n_tiles", [("0", 37), ("1", 131), ("2", 131), ("1", 700), ("1", 513)])
+def test_fused_final_combine_equals_the_reduction_kernel(kernel, n_tiles, monkeypatch):
+    """r03: the pruning launch sums the per-tile partial sums itself (prune.hip: publish_partial — the last root-finalising
+    wave of the launch does what wg_reduce_kernel does in a launch of its own; HYPHY_HIP_FUSED_REDUCE=0 restores the separate
+    kernel).  Tile counts below one load batch (37, 131), across several (700) and odd just past a batch boundary (513):
+    the fused sum must equal the per-site values summed on the host and the separate kernel's result to rounding, must not
+    depend on which wave arrives last (repeated evaluations: fixed summation order -> the chain joins' order is the only
+    run-to-run freedom, 1e-13), and -inf / the scaler sum must come through."""
+    from hyphy_amd import data, models, tree
+    monkeypatch.setenv("HYPHY_HIP_KERNEL", kernel)
+    if kernel != "0":
+        monkeypatch.setenv("HYPHY_HIP_CHAIN_M", "3")
+    monkeypatch.setenv("HYPHY_HIP_POISON", "1")
+    rng = np.random.default_rng(7000 + n_tiles)
+    root = tree.random_tree(24, rng, trifurcating_root=True)
+    flat = tree.flatten(root)
+    S = n_tiles * 16 - 5
+    states = rng.integers(0, 61, size=(flat.L, S))
+    base = rng.integers(0, 61, size=S)
+    states = np.where(rng.random((flat.L, S)) < 0.3, states, base[None, :])
+    pd = data.from_states(states, 61, compress_patterns=False)
+    pf = np.array([[0.3, 0.2, 0.25, 0.25], [0.2, 0.3, 0.3, 0.2], [0.25, 0.25, 0.2, 0.3]])
+    rev = dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4)
+    pi = models.f3x4_codon_freqs(pf)
+    B = flat.n_branches
+    nodes = np.arange(B, dtype=np.int64)
+    tb = rng.uniform(0.01, 0.4, B)
+    freq = rng.integers(1, 4, size=S).astype(np.float64)
+    hip = _hip()
+    with hip.HipPartition(61, flat.flat_parents, flat.L, pd.leaf_codes, None, freq) as part:
+        for k in range(6):
+            Q = models.mg94rev_Q_batch(tb * (1.0 + 0.3 * k), 0.2 + 0.2 * k, rev, pf)
+            monkeypatch.setenv("HYPHY_HIP_FUSED_REDUCE", "1")
+            fused = part.evaluate(nodes, nodes, Q, pi)
+            fused2, lik, sc = part.evaluate(nodes, nodes, Q, pi, per_site=True)
+            monkeypatch.setenv("HYPHY_HIP_FUSED_REDUCE", "0")
+            plain = part.evaluate(nodes, nodes, Q, pi)
+            host = float(np.sum(freq * (np.log(lik) - sc * 64 * np.log(2.0))))
+            assert np.isfinite(fused)
+            assert abs(fused - fused2) <= 1e-13 * abs(fused), (k, fused, fused2)
+            assert abs(fused - plain) <= 1e-13 * abs(plain), (k, fused, plain)
+            assert abs(fused - host) <= 1e-12 * abs(host), (k, fused, host)
+        monkeypatch.setenv("HYPHY_HIP_FUSED_REDUCE", "1")
+        P = np.tile(np.eye(61), (B, 1, 1))   # identity transitions: any variable pattern is impossible
+        assert part.evaluate(nodes, nodes, P, pi, q_is_probability=True) == -np.inf
+        Q = models.mg94rev_Q_batch(tb, 0.5, rev, pf)
+        a = part.evaluate(nodes, nodes, Q, pi)   # (and the arrival counter was left at zero by the -inf launch)
+        monkeypatch.setenv("HYPHY_HIP_FUSED_REDUCE", "0")
+        b = part.evaluate(nodes, nodes, Q, pi)
+        assert np.isfinite(a) and abs(a - b) <= 1e-13 * abs(b)
