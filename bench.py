@@ -359,6 +359,7 @@ def main():
     dist = None
     single = bool(args.single_process)
     multi = N > 1 and not single           # one process per GPU
+    share = multi and bool(os.environ.get("HYPHY_BENCH_SHARE_DEVICE"))
     if single:
         if world != 1:
             raise SystemExit("--single-process is one process driving N devices: do not launch it with torch.distributed.run")
@@ -368,11 +369,21 @@ def main():
             raise SystemExit(f"--gpus {N} needs WORLD_SIZE={N} (launch with torch.distributed.run)")
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl")   # == RCCL on ROCm (barriers, timing gather, the id broadcast)
+        if share:
+            # DIAGNOSTIC (HYPHY_BENCH_SHARE_DEVICE=1): N ranks on ONE device — a 1-GPU box walks the N > 1 code of this file
+            # (sharding, fall-backs, per-rank gather, the line).  RCCL refuses two ranks on a device, so the control plane is
+            # gloo and the sum goes through torch.distributed; the numbers mean nothing, the line says so.
+            local = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl")   # == RCCL on ROCm (barriers, timing gather, the id broadcast)
     import torch
     torch.cuda.set_device(local if multi else 0)
+    ctl = "cpu" if share else "cuda"       # where the control-plane tensors (flags, counts, timings) live
     collective = args.collective
+    if share:
+        collective = "torch"
     if collective == "auto":
         collective = "cabi" if multi else "none"
     if single or (N == 1 and collective == "torch"):
@@ -419,7 +430,7 @@ def main():
         except Exception as e:
             ok, why = 0, f"comm_unique_id: {e}"
         if multi:
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
             if ok:
@@ -430,7 +441,7 @@ def main():
             except Exception as e:
                 ok, why = 0, f"comm_init_rank: {e}"
             if multi:
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = int(flag.item())
         if not ok:
@@ -458,6 +469,10 @@ def main():
             np.multiply(tb, omega, out=coeffs[:, 1])   # nonSynRate = omega * synRate on every branch (one numpy call: < 1 us)
         if n_classes > 1:
             v = cat_step()         # build_q (3 x 125 matrices) + expm + batched pruning + mixing + reduction
+            if share:
+                t = torch.tensor([v], dtype=torch.float64)
+                dist.all_reduce(t)
+                return float(t.item())
             if multi:              # (classes are mixed per site on the rank that owns the site; the partial log-Ls add up)
                 d_logl[0] = v
                 hdist.allreduce_logl(d_logl[:1])
@@ -468,6 +483,10 @@ def main():
         if (not multi) and sync and not os.environ.get("HYPHY_BENCH_DEVICE_STEP"):
             return sync_step()     # build_q + evaluate_built: log-L returned by the C-ABI call itself (all shards if --single-process)
         enqueue()      # device-side Q for every branch, then expm + pruning + reduction (C-ABI calls)
+        if share:      # (diagnostic: the sum over ranks through a host tensor and gloo)
+            t = torch.tensor([fetch()], dtype=torch.float64)
+            dist.all_reduce(t)
+            return float(t.item())
         if multi:
             hdist.allreduce_logl(d_logl[:1])                   # one RCCL all-reduce per evaluation (torch.distributed)
         if sync:
@@ -506,13 +525,13 @@ def main():
         torch.cuda.synchronize()
         dtc = time.perf_counter() - tc0
         if multi:
-            tcm = torch.tensor([dtc], dtype=torch.float64, device="cuda")
+            tcm = torch.tensor([dtc], dtype=torch.float64, device=ctl)
             dist.all_reduce(tcm, op=dist.ReduceOp.MAX)
             dtc = float(tcm.item())
         value_cold = args.steps / dtc
     n_pre = int(min(20000, max(0.0, args.preheat_s) / max(per, 1e-6)))
     if multi:
-        cnt = torch.tensor([n_pre], dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([n_pre], dtype=torch.int64, device=ctl)
         dist.broadcast(cnt, src=0)
         n_pre = int(cnt.item())
     for _ in range(n_pre):
@@ -562,12 +581,12 @@ def main():
         t_ar = None
     per_rank = None
     if multi:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=ctl)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         # every rank's own numbers (the line is printed by rank 0): shard size, kernel / expm / reduction / all-reduce ms
         mine = torch.tensor([float(hi - lo), t_prune / max(1, args.steps), t_exp or 0.0, t_red or 0.0, t_ar or 0.0],
-                            dtype=torch.float64, device="cuda")
+                            dtype=torch.float64, device=ctl)
         allr = [torch.zeros_like(mine) for _ in range(N)]
         dist.all_gather(allr, mine)
         per_rank = [dict(rank=r, patterns=int(v[0].item()), kernel_ms=float(v[1].item()), expm_ms=float(v[2].item()),
@@ -705,6 +724,7 @@ def main():
                        "collective": ({"cabi": "hyphy_hip_evaluate_built_allreduce (in-stream ncclAllReduce of one double, C-ABI communicator)",
                                        "torch": "torch.distributed.all_reduce on the partition's stream", "none": None}[collective]),
                        **({"collective_note": collective_note} if collective_note else {}),
+                       **({"DIAGNOSTIC": "HYPHY_BENCH_SHARE_DEVICE: all ranks ran on ONE device over gloo — the N > 1 code path was walked, the rate means nothing"} if share else {}),
                        "patterns_rank0": int(S_rank),
                        "step": "device Q build + expm of all branches + full pruning pass + reduction" +
                                (" + RCCL all-reduce" if (multi or collective == "cabi") else "") + ", log-L returned to host every step"},

@@ -137,3 +137,31 @@ def test_one_rank_communicator_on_one_gpu():
         with pytest.raises(hip.HipError, match="twice"):      # a local failure still completes the collective and reports itself
             part.prepare_built_allreduce_step(nodes, bad, pi, co)()
         assert abs(step() - want[-1]) <= 1e-13 * abs(want[-1])  # ... and the partition is usable afterwards
+
+
+def test_bench_two_ranks_sharing_one_device_walk_the_multi_rank_code(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU) has never met a multi-GPU box.
+    HYPHY_BENCH_SHARE_DEVICE=1 (diagnostic) puts both ranks on device 0 over gloo, so a 1-GPU box runs the N > 1 code of
+    bench.py — pattern sharding, the per-evaluation sum across ranks, barrier/max timing, the per-rank gather, the line — and
+    the summed log-L must equal the single-device value of the same sweep point."""
+    _hip(1)
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    common = ["--workload", "mg94_64x1250", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-traffic", "--preheat-s", "0", "--cold-s", "0"]
+    env = dict(os.environ, HYPHY_BENCH_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert two.returncode == 0, (two.stdout + two.stderr)[-3000:]
+    line2 = json.loads([ln for ln in two.stdout.split("\n") if ln.startswith("{")][-1])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=dict(os.environ),
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, (one.stdout + one.stderr)[-3000:]
+    line1 = json.loads([ln for ln in one.stdout.split("\n") if ln.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and "DIAGNOSTIC" in line2["config"]
+    assert len(line2["per_rank"]) == 2 and sum(r["patterns"] for r in line2["per_rank"]) == line1["config"]["patterns_rank0"]
+    assert all(r["kernel_ms"] > 0 for r in line2["per_rank"])
+    assert abs(line2["logl_last"] - line1["logl_last"]) <= 1e-12 * abs(line1["logl_last"]), (line2["logl_last"], line1["logl_last"])
+    assert line2["scaling"] == "strong" and line2["value"] > 0
