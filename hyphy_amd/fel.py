@@ -236,8 +236,9 @@ def meme(part, tested: Sequence[bool], syn_lengths, nonsyn_lengths, root_freqs, 
     /root/reference/res/TemplateBatchFiles/SelectionAnalyses/MEME.bf: on the tested branches every site has two
     non-synonymous rate classes, beta_minus <= alpha with weight q and beta_plus (unconstrained) with weight 1 - q, mixed
     per BRANCH (P_b = q exp(Q_b^-) + (1 - q) exp(Q_b^+): the explicit-form route), untested branches evolve with
-    (alpha, beta_nuisance) (MEME.bf:71-79, 487-508).  Null: beta_plus <= alpha.  Test statistic against the 0.33 chi2_0 + 0.30 chi2_1 + 0.37 chi2_2
-    mixture used by MEME.  Lockstep Nelder-Mead over hyphy_hip_site_fits_evaluate_mixture."""
+    (alpha, beta_nuisance) (MEME.bf:71-79, 487-508; the reference scales EVERY site rate by the branch's total length MLE, MEME.bf:837-845: pass that as both
+    coefficient vectors to reproduce it).  Null: beta_plus <= alpha (the reference: beta_plus := alpha where the alternative has
+    beta_plus > alpha, no test otherwise, MEME.bf:1432-1436).  p-value 2/3 - 2/3 (0.45 F_chi2_1 + 0.55 F_chi2_2) (MEME.bf:1656).  Lockstep Nelder-Mead over hyphy_hip_site_fits_evaluate_mixture."""
     from scipy.stats import chi2
     tested = np.asarray(tested, dtype=bool)
     group = np.where(tested, 0, 1).astype(np.int64)
@@ -290,6 +291,6 @@ def meme(part, tested: Sequence[bool], syn_lengths, nonsyn_lengths, root_freqs, 
         u_alt[take], f_alt[take] = u2[take], f2[take]
         a_alt, bm_alt, bp_alt, q_alt, bn_alt = theta_of(u_alt, False)
     lrt = np.maximum(0.0, 2.0 * (f_alt - f_null))
-    pv = np.where(lrt > 0, 0.30 * chi2.sf(lrt, 1) + 0.37 * chi2.sf(lrt, 2), 1.0)
+    pv = (2.0 / 3.0) * (0.45 * chi2.sf(lrt, 1) + 0.55 * chi2.sf(lrt, 2))   # MEME.bf:1656 (2/3 at LRT = 0)
     return MemeResult(alpha=a_alt, beta_minus=bm_alt, beta_plus=bp_alt, weight_minus=q_alt, beta_nuisance=bn_alt, logl_alt=f_alt, logl_null=f_null,
                       lrt=lrt, p_value=pv, launches=launches[0])

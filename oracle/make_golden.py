@@ -20,6 +20,8 @@ Cases (SURVEY §8c "Fixtures to commit"):
   codon_mix2/3  branch-site mixtures in the reference's explicit form (sum_m w_m Exp(Q_m) on every branch): BUSTED / BS-REL shape
   ref_smallcodon  the reference's own known-answer test SimpleOptimizations/SmallCodon.bf (data + expected log L)
   ref_fluHA       real data of SimpleOptimizations/IntermediateNuc.bf (HKY85, 349 influenza sequences: the 4-state path)
+  ref_fel_12x60   (python -m oracle.make_golden fel) the reference's unmodified FEL.bf on a 12 x 60 codon alignment: per-site
+                  alpha / beta / LRT / p-value table + the global fit its site phase starts from
 """
 from __future__ import annotations
 
@@ -289,6 +291,95 @@ def reference_test_case_nuc(name="ref_fluHA"):
 # per-site log L (all sites up to 10 000 codons, 2 000 sampled sites beyond).
 #     python -m oracle.make_golden fullsize
 # ---------------------------------------------------------------------------------------------------------------
+def fel_case(name="ref_fel_12x60", n_taxa=12, n_codons=60, seed=91, branches="Internal", threads=8, analysis="FEL"):
+    """The reference's OWN FEL analysis (res/TemplateBatchFiles/SelectionAnalyses/FEL.bf, unmodified, run by the unmodified
+    binary) on a synthetic alignment: nucleotide GTR fit -> global MG94xREV fit -> one single-site likelihood function per
+    site, alpha / beta_test / beta_nuisance optimised under the alternative and under beta_test := alpha, LRT and p-value
+    (FEL.bf:593-1000).  A two-line wrapper executes FEL.bf and then prints `fel.final_partitioned_mg_results` (the global
+    fit the site phase starts from: per-branch synonymous rates, the theta's, omega) next to FEL's own JSON.
+    The fixture holds the inputs of the site phase (tree, per-site codon states, which branches are tested, the global
+    MLEs, position frequencies recovered from the CF3x4 vector: the product form is exact) and the reference's per-site
+    table [alpha, beta, alpha=beta, LRT, p-value]; tests/test_gpu_parity.py::test_fel_driver_matches_the_reference_fel
+    runs hyphy_amd/fel.py on the device against it.  The reconstructed global model is checked here against the reference's
+    global log-likelihood with the CPU oracle before anything is written.
+    analysis="MEME": the same for MEME.bf (per-site two-class branch-site mixture on the tested branches; table columns
+    alpha, beta-, p-, beta+, p+, LRT, p-value, MEME LogL, FEL LogL — the last two are the site's log-likelihoods at the
+    reference's optima: a likelihood-level anchor for hyphy_amd/fel.py::meme)."""
+    import json
+    import re
+    import subprocess
+    import tempfile
+    from oracle import oracle
+    syn = data.evolve(n_taxa, n_codons, 3, seed=seed, p_change=0.10)
+    flat = syn.flat
+    tmp = tempfile.mkdtemp(prefix="felref_")
+    hbl.write_fasta(os.path.join(tmp, "aln.fasta"), flat.leaf_names, syn.seqs)
+    with open(os.path.join(tmp, "tree.nwk"), "w") as fh:
+        fh.write(tree.to_newick(syn.tree) + ";\n")
+    fel_bf = f"/root/reference/res/TemplateBatchFiles/SelectionAnalyses/{analysis}.bf"
+    with open(os.path.join(tmp, "wrap.bf"), "w") as fh:
+        fh.write(f'ExecuteAFile ("{fel_bf}");\nfprintf ("{tmp}/dump.txt", CLEAR_FILE, {analysis.lower()}.final_partitioned_mg_results);\n')
+    r = subprocess.run([hbl.REF_BIN, "LIBPATH=/root/reference/res", f"CPU={threads}", os.path.join(tmp, "wrap.bf"),
+                        "--alignment", os.path.join(tmp, "aln.fasta"), "--tree", os.path.join(tmp, "tree.nwk"), "--code", "Universal",
+                        "--branches", branches] + (["--srv", "Yes", "--ci", "No"] if analysis == "FEL" else []) +
+                       ["--pvalue", "0.1", "--resample", "0", "--output", os.path.join(tmp, "fel.json")], capture_output=True, text=True, timeout=3600)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout[-3000:] + r.stderr[-2000:])
+    d = open(os.path.join(tmp, "dump.txt")).read()
+    num = r"([-0-9.e+]+)"
+    logl = float(re.search(r'"LogL":' + num, d).group(1))
+    syn_rate = {m.group(1): float(m.group(2)) for m in re.finditer(
+        r'"(\w+)":\{\s*"MLE":[-0-9.e+]+,\s*"non-synonymous rate":\{.*?\},\s*"synonymous rate":\{\s*"ID":"alpha",\s*"MLE":' + num, d, re.S)}
+    total_len = {m.group(1): float(m.group(2)) for m in re.finditer(r'"(\w+)":\{\s*"MLE":' + num + r',\s*"non-synonymous rate"', d)}
+    theta = {m.group(1) + m.group(2): float(m.group(3)) for m in re.finditer(
+        r'"Substitution rate from nucleotide (\w) to nucleotide (\w)":\{\s*"ID":"[^"]+",\s*"MLE":' + num, d)}
+    om_t = float(re.search(r'rate ratio for \*test\*":\{\s*"ID":"[^"]+",\s*"MLE":' + num, d).group(1))
+    m_bg = re.search(r'rate ratio for \*background\*":\{\s*"ID":"[^"]+",\s*"MLE":' + num, d)
+    om_b = float(m_bg.group(1)) if m_bg else om_t
+    j = json.load(open(os.path.join(tmp, "fel.json")))
+    efv = np.array(j["fits"]["Global MG94xREV"]["Equilibrium frequencies"]).ravel()
+    A = np.zeros((61, 13))
+    for row, c in enumerate(models.sense_codons()):
+        for pos in range(3):
+            A[row, 4 * pos + "ACGT".index(c[pos])] = 1.0
+    A[:, 12] = 1.0
+    x = np.linalg.lstsq(A, np.log(efv), rcond=None)[0]
+    pf = np.exp(x[:12]).reshape(3, 4)
+    pf /= pf.sum(1, keepdims=True)
+    pi = models.f3x4_codon_freqs(pf)
+    assert np.abs(pi - efv).max() < 1e-14, "CF3x4 vector is not of product form?"
+    names = flat.branch_names()
+    ts = np.array([syn_rate[n] for n in names])
+    tested = np.array([j["tested"]["0"][n] == "test" for n in names])
+    rev = np.array([theta["AC"], theta["AT"], theta["CG"], theta["CT"], theta["GT"]])
+    revd = dict(AC=rev[0], AT=rev[1], CG=rev[2], CT=rev[3], GT=rev[4])
+    assert theta["AG"] == 1.0
+    Q = np.stack([models.mg94rev_Q(ts[b], om_t if tested[b] else om_b, revd, pf) for b in range(len(names))])
+    pd = data.compress(syn.seqs, 3)
+    op = oracle.OraclePartition(61, flat.flat_parents, flat.L, pd.leaf_codes, pd.ambig, pd.pattern_freq)
+    nodes = np.arange(len(names), dtype=np.int64)
+    op.set_P(nodes, oracle.expm(Q, True))
+    mine = op.compute_block(nodes, pi)
+    assert abs(mine - logl) <= 1e-10 * abs(logl), (mine, logl)   # the reconstructed global model IS the reference's
+    full = np.array(j["MLE"]["content"]["0"], dtype=np.float64)
+    heads = ["alpha", "beta", "alpha=beta", "LRT", "p-value"]
+    table = full[:, :5]
+    if analysis == "MEME":
+        heads = ["alpha", "beta-", "p-", "beta+", "p+", "LRT", "p-value", "MEME LogL", "FEL LogL"]
+        assert "MEME LogL" in j["MLE"]["headers"][9][0] and "FEL LogL" in j["MLE"]["headers"][10][0]
+        table = full[:, [0, 1, 2, 3, 4, 5, 6, 9, 10]]
+    assert table.shape[0] == n_codons
+    sites = data.from_states(syn.states, 61, compress_patterns=False)
+    fx = dict(kind="codon", D=61, L=flat.L, flat_parents=flat.flat_parents, leaf_codes=sites.leaf_codes, tested=tested,
+              syn_rate=ts, branch_length=np.array([total_len[n] for n in names]), rev=rev, omega_test=om_t, omega_background=om_b, pos_freqs=pf, root_freqs=pi, global_logl=logl,
+              fel_table=table, fel_headers=np.array(heads), analysis=np.array(analysis),
+              names=np.array(flat.leaf_names), seqs=np.array(syn.seqs), newick=np.array(tree.to_newick(syn.tree)),
+              branches=np.array(branches))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(f"{name}: global logL {logl!r} (oracle on the reconstructed model: {mine!r}); {int(tested.sum())} of {len(names)} branches tested; "
+          f"{int((table[:, 6 if analysis == 'MEME' else 4] <= 0.1).sum())} sites at p <= 0.1")
+
+
 def _crc(a):
     import zlib
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff
@@ -412,6 +503,13 @@ def main():
         os.makedirs(OUT, exist_ok=True)
         mixture_case()
         mixture_case("codon_mix3", 20, 80, seed=43, omegas=(0.05, 0.8, 6.0), weights=(0.6, 0.3, 0.1))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "fel":
+        if not hbl.have_reference():
+            raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
+        os.makedirs(OUT, exist_ok=True)
+        fel_case()
+        fel_case("ref_meme_12x60", analysis="MEME")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
         if not hbl.have_reference():

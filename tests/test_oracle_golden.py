@@ -177,3 +177,57 @@ def test_explicit_form_mixture_matches_reference(name):
     assert abs(ll - float(fx["logl"])) <= 1e-11 * abs(float(fx["logl"]))
     site = part.site_log_likelihoods(common.all_nodes(fx), fx["root_freqs"])[fx["site_to_pattern"]]
     assert np.max(np.abs(site - fx["site_logl"]) / np.abs(fx["site_logl"])) < 1e-11
+
+
+def _selection_site_logl(fx, site, alpha, beta_tested, beta_untested, coeff):
+    """log L of ONE site of a FEL / MEME fixture under site rates (alpha, beta) x per-branch coefficient (CPU oracle)."""
+    from hyphy_amd import models
+    T = np.zeros((2, 61, 61))
+    rv = dict(zip(("AC", "AT", "CG", "CT", "GT"), fx["rev"]), AG=1.0)
+    for (i, j, name, ns, f) in models.mg94rev_template(fx["pos_freqs"]):
+        T[1 if ns else 0, i, j] = rv[name] * f
+    B = len(coeff)
+    Q = np.zeros((B, 61, 61))
+    for b in range(B):
+        Q[b] = coeff[b] * (alpha * T[0] + (beta_tested if fx["tested"][b] else beta_untested) * T[1])
+        np.fill_diagonal(Q[b], 0.0)
+        np.fill_diagonal(Q[b], -Q[b].sum(1))
+    op = oracle.OraclePartition(61, fx["flat_parents"], int(fx["L"]), fx["leaf_codes"][:, site:site + 1], None, np.ones(1))
+    nodes = np.arange(B, dtype=np.int64)
+    op.set_P(nodes, oracle.expm(Q, True))
+    return op.compute_block(nodes, fx["root_freqs"])
+
+
+def test_reference_fel_fixture_is_consistent_with_the_oracle():
+    """tests/golden/ref_fel_12x60.npz (the reference's own FEL.bf table): at the reference's per-site MLEs the CPU oracle's
+    site log-likelihood under the alternative is at least the one under the reference's null estimate minus LRT/2 — i.e.
+    the stored alpha / beta / alpha=beta / LRT columns describe the model this repo rebuilds (site rates x the branch's
+    synonymous-rate MLE, FEL.bf:565-571)."""
+    fx = common.load("ref_fel_12x60")
+    ref = fx["fel_table"]
+    checked = 0
+    for site in range(ref.shape[0]):
+        a, b, ab, lrt = ref[site, :4]
+        if lrt < 0.3:
+            continue
+        # (untested branches: the nuisance rate is not in the table; maximise over a small grid on both sides)
+        alt = max(_selection_site_logl(fx, site, a, b, bn, fx["syn_rate"]) for bn in (0.0, 0.3, 1.0, 3.0))
+        null = max(_selection_site_logl(fx, site, ab, ab, bn, fx["syn_rate"]) for bn in (0.0, 0.3, 1.0, 3.0))
+        assert abs(2.0 * (alt - null) - lrt) <= 0.35, (site, alt, null, lrt)
+        checked += 1
+    assert checked >= 10
+
+
+def test_reference_meme_null_fit_stalls_where_alpha_is_zero():
+    """Why tests/test_gpu_parity.py::test_meme_driver_matches_the_reference_meme does not compare LRTs at every site: where
+    the alternative has alpha = 0 the reference restarts its null (beta+ := alpha) from alpha = 1e-4 (MEME.bf:1432-1436) and
+    at some sites never leaves it.  Site 3 of the fixture: reported null = MEME LogL - LRT/2 = -28.69, while the same
+    constrained model reaches -19.76 on a coarse grid (one rate class, beta+ = alpha)."""
+    fx = common.load("ref_meme_12x60")
+    ref = fx["fel_table"]
+    site = 3
+    assert ref[site, 0] <= 1e-3 and ref[site, 5] > 15.0
+    reported_null = ref[site, 7] - ref[site, 5] / 2.0
+    best = max(_selection_site_logl(fx, site, a, a, bn, fx["branch_length"]) for a in (1.0, 2.0, 3.0, 4.0) for bn in (1.0, 2.0, 4.0))
+    assert best > reported_null + 8.0, (best, reported_null)
+    assert best <= ref[site, 7] + 1e-6       # (and the null stays below the alternative)
