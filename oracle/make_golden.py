@@ -20,6 +20,8 @@ Cases (SURVEY §8c "Fixtures to commit"):
   codon_mix2/3  branch-site mixtures in the reference's explicit form (sum_m w_m Exp(Q_m) on every branch): BUSTED / BS-REL shape
   ref_smallcodon  the reference's own known-answer test SimpleOptimizations/SmallCodon.bf (data + expected log L)
   ref_fluHA       real data of SimpleOptimizations/IntermediateNuc.bf (HKY85, 349 influenza sequences: the 4-state path)
+  ref_busted_16x150 (python -m oracle.make_golden busted) the reference's unmodified BUSTED.bf on a simulated 16 x 150 codon
+                  alignment: MLEs of the unconstrained branch-site mixture + the log L at them (explicit-form path)
   ref_fel_12x60   (python -m oracle.make_golden fel) the reference's unmodified FEL.bf on a 12 x 60 codon alignment: per-site
                   alpha / beta / LRT / p-value table + the global fit its site phase starts from
 """
@@ -380,6 +382,114 @@ def fel_case(name="ref_fel_12x60", n_taxa=12, n_codons=60, seed=91, branches="In
           f"{int((table[:, 6 if analysis == 'MEME' else 4] <= 0.1).sum())} sites at p <= 0.1")
 
 
+def _simulate_site_classes(flat, t, omegas, weights, rev, pf, n_codons, seed):
+    """Codon alignment evolved on `flat` under MG94xREV with a per-SITE omega class (our own sampler: root state from the
+    CF3x4 vector, child state from the row of P_b^(class) — enough signal for BUSTED to infer a non-degenerate mixture)."""
+    from oracle import oracle
+    rng = np.random.default_rng(seed)
+    pi = models.f3x4_codon_freqs(pf)
+    B = flat.n_branches
+    P = [oracle.expm(np.stack([models.mg94rev_Q(t[b], om, rev, pf) for b in range(B)]), True) for om in omegas]
+    n_nodes = B + 1
+    states = np.zeros((n_nodes, n_codons), dtype=np.int64)
+    cls = rng.choice(len(omegas), size=n_codons, p=np.asarray(weights))
+    root = n_nodes - 1
+    states[root] = rng.choice(61, size=n_codons, p=pi / pi.sum())
+    for node in range(B - 1, -1, -1):          # (parents have larger flat indices than their children)
+        par = flat.L + int(flat.flat_parents[node])
+        for s_ in range(n_codons):
+            row = np.maximum(P[cls[s_]][node][states[par, s_]], 0.0)
+            states[node, s_] = rng.choice(61, p=row / row.sum())
+    cod = models.sense_codons()
+    return ["".join(cod[k] for k in states[leaf]) for leaf in range(flat.L)], states[:flat.L]
+
+
+def busted_case(name="ref_busted_16x150", n_taxa=16, n_codons=150, seed=131, branches="Internal", threads=8):
+    """The reference's OWN BUSTED analysis (res/TemplateBatchFiles/SelectionAnalyses/BUSTED.bf, unmodified, unmodified binary;
+    --srv No, 3 omega classes) on an alignment simulated with site classes omega = 0.1 / 1 / 8.  A two-line wrapper executes
+    BUSTED.bf and prints `busted.full_model`: the MLEs of the unconstrained branch-site model — per-branch t, theta's, and for
+    the test and the background set three omegas with their stick-breaking weights.  Fixture: alignment + tree + those MLEs +
+    the reference's log L at them.  The model is the explicit-form mixture P_b = sum_k w_k Exp(Q_b(omega_k))
+    (libv3/models/codon/BS_REL.bf) — the CPU oracle must reproduce the log L from the reconstruction before the fixture is
+    written; tests/test_gpu_parity.py::test_busted_fit_of_the_reference_evaluates_on_the_device holds
+    hyphy_hip_evaluate_mixture to it."""
+    import json
+    import re
+    import subprocess
+    import tempfile
+    from oracle import oracle
+    rng = np.random.default_rng(seed)
+    root = tree.random_tree(n_taxa, rng, trifurcating_root=True)
+    flat = tree.flatten(root)
+    t_sim = rng.uniform(0.05, 0.3, flat.n_branches)
+    seqs, _ = _simulate_site_classes(flat, t_sim, (0.1, 1.0, 8.0), (0.5, 0.35, 0.15), REV, POS_FREQS, n_codons, seed + 1)
+    tmp = tempfile.mkdtemp(prefix="bustedref_")
+    hbl.write_fasta(os.path.join(tmp, "aln.fasta"), flat.leaf_names, seqs)
+    with open(os.path.join(tmp, "tree.nwk"), "w") as fh:
+        fh.write(tree.to_newick(root) + ";\n")
+    bf = "/root/reference/res/TemplateBatchFiles/SelectionAnalyses/BUSTED.bf"
+    with open(os.path.join(tmp, "wrap.bf"), "w") as fh:
+        fh.write(f'ExecuteAFile ("{bf}");\nfprintf ("{tmp}/dump.txt", CLEAR_FILE, busted.full_model);\n')
+    r = subprocess.run([hbl.REF_BIN, "LIBPATH=/root/reference/res", f"CPU={threads}", os.path.join(tmp, "wrap.bf"),
+                        "--alignment", os.path.join(tmp, "aln.fasta"), "--tree", os.path.join(tmp, "tree.nwk"), "--code", "Universal",
+                        "--branches", branches, "--srv", "No", "--rates", "3", "--starting-points", "1",
+                        "--output", os.path.join(tmp, "busted.json")], capture_output=True, text=True, timeout=7200)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout[-3000:] + r.stderr[-2000:])
+    d = open(os.path.join(tmp, "dump.txt")).read()
+    num = r"([-0-9.e+]+)"
+    logl = float(re.search(r'"LogL":' + num, d).group(1))
+    tb = {m.group(1): float(m.group(2)) for m in re.finditer(r'"(\w+)":\{\s*"MLE":[-0-9.e+]+,\s*"synonymous rate":\{\s*"ID":"t",\s*"MLE":' + num, d, re.S)}
+    def g(idname):
+        return float(re.search(r'"ID":"' + re.escape(idname) + r'",\s*"MLE":' + num, d).group(1))
+    rev = np.array([g("busted.test.theta_" + k) for k in ("AC", "AT", "CG", "CT", "GT")])
+    om = {st: np.array([g(f"busted.{st}.omega{k}") for k in (1, 2, 3)]) for st in ("test", "background")}
+    w = {}
+    for st in ("test", "background"):
+        a0, a1 = g(f"busted.{st}.bsrel_mixture_aux_0"), g(f"busted.{st}.bsrel_mixture_aux_1")
+        w[st] = np.array([a0, (1.0 - a0) * a1, (1.0 - a0) * (1.0 - a1)])     # stick breaking (BS_REL.bf)
+    j = json.load(open(os.path.join(tmp, "busted.json")))
+    efv = np.array(j["fits"]["MG94xREV with separate rates for branch sets"]["Equilibrium frequencies"]).ravel()   # (CF3x4: the same vector for every codon model of the run)
+    A = np.zeros((61, 13))
+    for row, c in enumerate(models.sense_codons()):
+        for pos in range(3):
+            A[row, 4 * pos + "ACGT".index(c[pos])] = 1.0
+    A[:, 12] = 1.0
+    pf = np.exp(np.linalg.lstsq(A, np.log(efv), rcond=None)[0][:12]).reshape(3, 4)
+    pf /= pf.sum(1, keepdims=True)
+    pi = models.f3x4_codon_freqs(pf)
+    assert np.abs(pi - efv).max() < 1e-14
+    names = flat.branch_names()
+    ts = np.array([tb[n] for n in names])
+    tested = np.array([j["tested"]["0"][n] == "test" for n in names])
+    revd = dict(zip(("AC", "AT", "CG", "CT", "GT"), rev))
+    B = len(names)
+    Qc = np.zeros((B, 3, 61, 61))
+    W = np.zeros((B, 3))
+    for b in range(B):
+        st = "test" if tested[b] else "background"
+        W[b] = w[st]
+        for k in range(3):
+            Qc[b, k] = models.mg94rev_Q(ts[b], om[st][k], revd, pf)
+    pd = data.compress(seqs, 3)
+    op = oracle.OraclePartition(61, flat.flat_parents, flat.L, pd.leaf_codes, pd.ambig, pd.pattern_freq)
+    nodes = np.arange(B, dtype=np.int64)
+    Pm = sum(W[:, k, None, None] * oracle.expm(Qc[:, k], True) for k in range(3))
+    op.set_P(nodes, Pm)
+    mine = op.compute_block(nodes, pi)
+    assert abs(mine - logl) <= 1e-9 * abs(logl), (mine, logl)
+    fits = {k: float(v["Log Likelihood"]) for k, v in j["fits"].items()}
+    fx = dict(kind="codon_mixture", D=61, L=flat.L, flat_parents=flat.flat_parents, leaf_codes=pd.leaf_codes, ambig=pd.ambig,
+              pattern_freq=pd.pattern_freq, site_to_pattern=pd.site_to_pattern, tested=tested, t=ts, rev=rev,
+              omega_test=om["test"], omega_background=om["background"], weights_test=w["test"], weights_background=w["background"],
+              pos_freqs=pf, root_freqs=pi, logl=logl, json_unconstrained_logl=fits.get("Unconstrained model", np.nan),
+              json_constrained_logl=fits.get("Constrained model", np.nan), p_value=float(j["test results"]["p-value"]),
+              names=np.array(flat.leaf_names), seqs=np.array(seqs), newick=np.array(tree.to_newick(root)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(f"{name}: unconstrained logL {logl!r} (oracle on the reconstructed mixture: {mine!r}); test omegas {om['test']} weights {w['test']}; "
+          f"background omegas {om['background']} weights {w['background']}; BUSTED p = {fx['p_value']}")
+
+
 def _crc(a):
     import zlib
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff
@@ -510,6 +620,12 @@ def main():
         os.makedirs(OUT, exist_ok=True)
         fel_case()
         fel_case("ref_meme_12x60", analysis="MEME")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "busted":
+        if not hbl.have_reference():
+            raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
+        os.makedirs(OUT, exist_ok=True)
+        busted_case()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
         if not hbl.have_reference():

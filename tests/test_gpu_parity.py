@@ -1218,3 +1218,24 @@ def test_meme_driver_matches_the_reference_meme():
     assert np.abs(res.lrt - lrt_ref)[ok].max() <= 0.25, np.abs(res.lrt - lrt_ref)[ok].max()
     assert np.abs(res.p_value - ref[:, 6])[ok].max() <= 0.09
     assert np.abs(res.lrt[~fitted]).max() <= 1e-6      # (sites without substitutions: no test in either)
+
+
+def test_busted_fit_of_the_reference_evaluates_on_the_device():
+    """The unconstrained model of the reference's OWN BUSTED.bf (unmodified batch file + binary, `python -m
+    oracle.make_golden busted`: 16 taxa x 150 codons simulated with site classes; test and background branches each with three
+    omegas and stick-breaking weights) through hyphy_hip_evaluate_mixture at the reference's MLEs: its log L to 1e-10, and the
+    per-site values against the oracle's explicitly mixed matrices."""
+    from oracle import oracle
+    fx = common.load("ref_busted_16x150")
+    Qc, W = common.busted_components(fx)
+    nodes = common.all_nodes(fx)
+    with _mk(fx) as part:
+        ll, lik, sc = part.evaluate_mixture(nodes, nodes, Qc, W, fx["root_freqs"], per_site=True)
+    ref = float(fx["logl"])
+    assert abs(ll - ref) <= RTOL * abs(ref), (ll, ref)
+    P = sum(W[:, k, None, None] * oracle.expm(Qc[:, k], True) for k in range(3))
+    op = oracle.OraclePartition(61, fx["flat_parents"], int(fx["L"]), fx["leaf_codes"], fx["ambig"], fx["pattern_freq"])
+    op.set_P(nodes, P)
+    want = op.site_log_likelihoods(nodes, fx["root_freqs"])
+    got = np.log(lik) - sc * 64 * np.log(2.0)
+    assert np.max(np.abs(got - want) / np.abs(want)) < RTOL

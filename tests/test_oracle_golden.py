@@ -231,3 +231,20 @@ def test_reference_meme_null_fit_stalls_where_alpha_is_zero():
     best = max(_selection_site_logl(fx, site, a, a, bn, fx["branch_length"]) for a in (1.0, 2.0, 3.0, 4.0) for bn in (1.0, 2.0, 4.0))
     assert best > reported_null + 8.0, (best, reported_null)
     assert best <= ref[site, 7] + 1e-6       # (and the null stays below the alternative)
+
+
+def test_reference_busted_fit_matches_the_oracle():
+    """tests/golden/ref_busted_16x150.npz: the MLEs of the unconstrained model of the reference's OWN BUSTED.bf run and its log L
+    at them (`python -m oracle.make_golden busted`).  The restatement's exponentials mixed per branch with the test / background
+    weights reproduce it; the JSON's rounded copy of the same fit agrees, and the constrained fit lies below."""
+    fx = common.load("ref_busted_16x150")
+    Qc, W = common.busted_components(fx)
+    P = sum(W[:, k, None, None] * oracle.expm(Qc[:, k], sparse_hint=True) for k in range(3))
+    part = _partition(fx)
+    nodes = common.all_nodes(fx)
+    part.set_P(nodes, P)
+    ll = part.compute_block(nodes, fx["root_freqs"])
+    assert abs(ll - float(fx["logl"])) <= 1e-10 * abs(float(fx["logl"]))
+    assert abs(float(fx["json_unconstrained_logl"]) - float(fx["logl"])) < 0.05      # (the JSON stores the fit before the last polish)
+    assert float(fx["json_constrained_logl"]) < float(fx["logl"])
+    assert abs(W.sum(1) - 1.0).max() < 1e-12 and fx["tested"].sum() not in (0, len(fx["tested"]))
