@@ -392,7 +392,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     // serial tail, so larger shards keep the separate kernel.  HYPHY_HIP_FUSED_REDUCE=0/1 forces either.
     const char *fuse_env = getenv("HYPHY_HIP_FUSED_REDUCE");
     const bool fuse_on = fuse_env ? atoi(fuse_env) != 0 : s.ntiles <= 2 * s.cus;
-    if (fuse_on && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && !pa.timeline) {
+    if (fuse_on && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && !pa.timeline && prune_fuses_reduce(pa)) {
       double *rec = s.d_hout ? s.d_hout : s.out;
       fused_reduce = true;
       pa.red_out = d_logl_out ? d_logl_out : rec;

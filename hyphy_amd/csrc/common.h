@@ -256,6 +256,7 @@ void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const d
 void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *wg_flag, int n, double *out_logl,
                       double *out_cnt, const int *status, hipStream_t stream, double seq = 0.);
 int prune_mfma_grid(const PruneArgs &a);
+bool prune_fuses_reduce(const PruneArgs &a);  // launch_prune_mfma has a fused-combine instantiation for this launch form
 int prune_nuc_grid(const NucArgs &a);
 bool prune_nuc_takes_leaf_pairs(int L);  // the kernel launch_prune_nuc picks for L leaves reads leaf groups of two
 void launch_mix_categories(const double *site_lik /*[C][S_pad]*/, const int32_t *site_cnt, const double *weights_dev,

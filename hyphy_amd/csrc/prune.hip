@@ -101,8 +101,11 @@ __device__ __forceinline__ void st16_agent(double *ubase, unsigned byte_off, f64
 // zero through the buffer bounds), sums them in a FIXED order — lane l takes entries 128 j + 2 l, 128 j + 2 l + 1 for
 // j = 0, 1, .. with a Kahan sum, then a compensated shuffle tree over the lanes — and publishes the result record exactly
 // like wg_reduce_kernel does (same flags, same record, same sequence word).  The order of arrival decides only WHO sums.
+// FUSE is a template parameter of the kernels: the combine's registers must not exist in the builds that do not use it (inlined
+// behind a run-time test it cost the production wave kernel 15 scratch instructions and 3 us of 119 at the headline size).
+template <bool FUSE>
 __device__ __forceinline__ void publish_partial(const PruneArgs &a, int idx, double wsum, long long wcnt, int wflag, int lane) {
-  if (a.red_out == nullptr) {
+  if (!FUSE || a.red_out == nullptr) {
     if (lane == 0) {
       a.wg_sum[idx] = wsum;
       a.wg_cnt[idx] = wcnt;
@@ -110,6 +113,7 @@ __device__ __forceinline__ void publish_partial(const PruneArgs &a, int idx, dou
     }
     return;
   }
+  if constexpr (FUSE) {
   if (lane == 0) {
     __hip_atomic_store(a.wg_sum + idx, wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(a.wg_cnt + idx, wcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -186,6 +190,7 @@ __device__ __forceinline__ void publish_partial(const PruneArgs &a, int idx, dou
       reinterpret_cast<volatile double *>(a.red_rec)[2] = a.red_seq;
     }
   }
+  }  // FUSE
 }
 
 // Operand bundle fetched one schedule entry ahead: 16 doubles per lane, either the A-operand image
@@ -198,7 +203,7 @@ struct Payload {
 // sum_s f_s log L_s (tree_evaluator.cpp:4046-4128) and of the integer scaler sum (likefunc.cpp:11123).
 // `rootv` = the root's unscaled conditional tiles in LDS (fragment layout), `rscale`/`rcnt` = this wave's
 // copy of the root's per-site scale and 2^64-exponent ([T][16]).
-template <int NW, int T>
+template <int NW, int T, bool FUSE = false>
 __device__ __forceinline__ void root_epilogue(const PruneArgs &a, const double *rootv0, const double *rscale,
                                               const int *rcntv, int tile0, int w, int lane) {
   constexpr int NKK = 4 * NW, TILE = NKK * 64;
@@ -241,7 +246,7 @@ __device__ __forceinline__ void root_epilogue(const PruneArgs &a, const double *
       wcnt += __shfl_xor(wcnt, off);
       wflag |= __shfl_xor(wflag, off);
     }
-    publish_partial(a, (int)blockIdx.x, wsum, wcnt, wflag, lane);
+    publish_partial<FUSE>(a, (int)blockIdx.x, wsum, wcnt, wflag, lane);
   }
 }
 
@@ -261,7 +266,7 @@ __device__ __forceinline__ void root_epilogue(const PruneArgs &a, const double *
 // instead of 64 from one wave), the waves agree on every arrival through one LDS word, and each wave deposits / fetches only
 // its own 16 rows.  A tile's critical path is then (height of the tree) x (a quarter of the wave kernel's edge latency):
 // what small shards — a rank's share of an alignment at 4 or 8 GPUs — are bound by.
-template <int NW, int T, bool CLDS, bool TRACE, int ABL = 0, bool CHAIN = false>
+template <int NW, int T, bool CLDS, bool TRACE, int ABL = 0, bool CHAIN = false, bool FUSE = false>
 __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_kernel(const int4 *__restrict__ ops,
                                                                                PruneArgs a) {
   static_assert(!CHAIN || T == 1, "chain schedules: one tile per workgroup");
@@ -300,6 +305,9 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
   __shared__ int slot_cnt[NS][NW][T][16];
   extern __shared__ __align__(16) int16_t codes_lds[];  // CLDS: [L][T*16] leaf codes
 
+  if constexpr (CHAIN) {
+    if ((int)blockIdx.x >= a.ntiles) return;  // (tile dimension padded to a multiple of 8: launch_prune_T)
+  }
   const int lane = threadIdx.x & 63, g = lane >> 4, sl = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR: scalar bases
   const int tile0 = blockIdx.x * T;
@@ -736,11 +744,11 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
       finalise((lastx & (OPF_NOPERSIST | OPF_LAST)) | (cur ? OPF_PARITY : 0) | (cur << 16), par, nullptr, false, []() {});
       c = par;
     }
-    root_epilogue<NW, T>(a, xbuf + (size_t)cur * T * TILE, &slot_scale[cur][w][0][0], &slot_cnt[cur][w][0][0], tile0, w, lane);
+    root_epilogue<NW, T, FUSE>(a, xbuf + (size_t)cur * T * TILE, &slot_scale[cur][w][0][0], &slot_cnt[cur][w][0][0], tile0, w, lane);
     return;
   }
   if (a.do_root)
-    root_epilogue<NW, T>(a, xbuf + (size_t)a.root_slot * T * TILE, &slot_scale[a.root_slot][w][0][0],
+    root_epilogue<NW, T, FUSE>(a, xbuf + (size_t)a.root_slot * T * TILE, &slot_scale[a.root_slot][w][0][0],
                          &slot_cnt[a.root_slot][w][0][0], tile0, w, lane);
 }
 
@@ -792,9 +800,10 @@ __device__ __forceinline__ double row_sum4(double x) {
 // PRE: a sibling's deposit is streamed into registers under the wave's own product (32 registers).
 // APF: the first A-operand chunk of the NEXT edge product is requested during the last k-step of the current one (the
 //      schedule names it), so that an edge does not start with an exposed L2 round trip.
-template <int NW, int NP, bool CLDS, bool TRACE = false, bool LB = false, int OCC = HYPHY_OCC3, bool PRE = true, bool APF = false>
+template <int NW, int NP, bool CLDS, bool TRACE = false, bool LB = false, int OCC = HYPHY_OCC3, bool PRE = true, bool APF = false, bool FUSE = false>
 __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restrict__ ops, const int4 *__restrict__ prog,
                                                                              const int4 *__restrict__ jn, PruneArgs a) {
+  if (a.chain && (int)blockIdx.x >= a.ntiles) return;  // (tile dimension padded to a multiple of 8: launch_prune_T)
   [[maybe_unused]] long long tr_t[3] = {0, 0, 0};
   [[maybe_unused]] int tr_levels = 0;
   HYPHY_TRACE_STAMP(0)
@@ -1223,7 +1232,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
       wcnt += __shfl_xor(wcnt, off);
       wflag |= __shfl_xor(wflag, off);
     }
-    publish_partial(a, tile0, wsum, wcnt, wflag, lane);
+    publish_partial<FUSE>(a, tile0, wsum, wcnt, wflag, lane);
   }
   HYPHY_TRACE_FINISH(1)
 }
@@ -1955,9 +1964,15 @@ __global__ void unpack_partials_kernel(const double *__restrict__ partials, int 
 
 template <int NW, bool CLDS>
 void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
-  const dim3 grid(a.ntiles / a.T, a.n_cat > 0 ? a.n_cat : 1, a.n_prog > 0 ? a.n_prog : 1), block(64 * NW);
+  // Chain grids (tiles, classes, sources): workgroup b runs on XCD b mod 8 and the grid is linearised x-fastest, so with the
+  // tile dimension padded to a multiple of 8 (the surplus workgroups retire at once) every chain of a tile — and so every
+  // join of its trunk — sits on ONE XCD: deposits and arrival counters are then L2 hits instead of trips to memory.
+  // (HYPHY_HIP_XCD_PAD=0: the bare tile count.)
+  static const bool xcd_pad = !(getenv("HYPHY_HIP_XCD_PAD") && atoi(getenv("HYPHY_HIP_XCD_PAD")) == 0);
+  const int gx_chain = (a.chain && a.T == 1 && xcd_pad && !a.timeline) ? ((a.ntiles + 7) & ~7) : a.ntiles / a.T;
+  const dim3 grid(a.chain ? gx_chain : a.ntiles / a.T, a.n_cat > 0 ? a.n_cat : 1, a.n_prog > 0 ? a.n_prog : 1), block(64 * NW);
   const size_t lds = CLDS ? (size_t)a.L * a.T * 16 * sizeof(int16_t) : 0;
-  const dim3 gridw = a.chain ? dim3(a.ntiles, a.n_cat > 0 ? a.n_cat : 1, a.n_prog > 0 ? a.n_prog : 1)   // chains: source-major
+  const dim3 gridw = a.chain ? dim3(gx_chain, a.n_cat > 0 ? a.n_cat : 1, a.n_prog > 0 ? a.n_prog : 1)   // chains: source-major
                              : dim3(a.n_prog > 0 ? a.n_prog : 1, a.n_cat > 0 ? a.n_cat : 1, a.ntiles);  // fragments: tile-major
   if (a.variant == 1 && a.T == 1) {  // wave-per-tile kernel: one wave per workgroup
     const dim3 block1(64);
@@ -1993,6 +2008,12 @@ void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
     return;
   }
   if (a.variant == 2 && a.chain && a.T == 1) {  // row-split workgroups on a chain schedule: grid = (tiles, classes, sources)
+    if constexpr (NW == 4 && CLDS) {
+      if (a.red_out) {
+        hipLaunchKernelGGL((prune_mfma_kernel<4, 1, true, false, 0, true, true>), grid, block, lds, stream, a.ops, a);
+        return;
+      }
+    }
     hipLaunchKernelGGL((prune_mfma_kernel<NW, 1, CLDS, false, 0, true>), grid, block, lds, stream, a.ops, a);
     return;
   }
@@ -2013,6 +2034,12 @@ void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
   }
   switch (a.T) {
     case 1:
+      if constexpr (NW == 4 && CLDS) {
+        if (a.red_out) {
+          hipLaunchKernelGGL((prune_mfma_kernel<4, 1, true, false, 0, false, true>), grid, block, lds, stream, a.ops, a);
+          break;
+        }
+      }
       hipLaunchKernelGGL((prune_mfma_kernel<NW, 1, CLDS, false>), grid, block, lds, stream, a.ops, a);
       break;
     case 2:
@@ -2130,6 +2157,15 @@ void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *
 }
 
 int prune_mfma_grid(const PruneArgs &a) { return a.ntiles / a.T; }
+
+// true when launch_prune_mfma has an instantiation with the fused final combine for this launch form (PruneArgs::red_out):
+// 49-64 states with the leaf codes in LDS, one tile per workgroup, the row-split kernels (workgroup per tile, team)
+bool prune_fuses_reduce(const PruneArgs &a) {
+  // (not the wave-per-tile kernel: at 231 VGPRs the combine's registers push 15 spill instructions into its main loop —
+  //  what the fusion saves on a small shard, the spills cost)
+  if (a.NW != 4 || !a.codes_in_lds || a.T != 1 || a.timeline || a.ablate) return false;
+  return a.variant == 0 || (a.variant == 2 && a.chain);
+}
 
 void launch_transpose_frag(const double *src_image, double *dst_image, const double *row_scale, int NW, hipStream_t stream) {
   hipLaunchKernelGGL(transpose_frag_kernel, dim3(1), dim3(256), 0, stream, src_image, dst_image, row_scale, NW);

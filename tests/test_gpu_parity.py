@@ -1109,11 +1109,12 @@ def test_rerooted_schedules_match_oracle_without_reversibility(shape, kernel, mo
         check("after pin", np.zeros(0, dtype=np.int64), np.zeros((0, D, D)))
 
 
-@pytest.mark.parametrize("kernel,n_tiles", [("0", 37), ("1", 131), ("2", 131), ("1", 700), ("1", 513)])
+@pytest.mark.parametrize("kernel,n_tiles", [("0", 37), ("2", 131), ("2", 700), ("0", 513), ("1", 131)])
 def test_fused_final_combine_equals_the_reduction_kernel(kernel, n_tiles, monkeypatch):
     """r03: the pruning launch sums the per-tile partial sums itself (prune.hip: publish_partial — the last root-finalising
     wave of the launch does what wg_reduce_kernel does in a launch of its own; HYPHY_HIP_FUSED_REDUCE=0 restores the separate
-    kernel).  Tile counts below one load batch (37, 131), across several (700) and odd just past a batch boundary (513):
+    kernel; the row-split kernels have the fused instantiation, the wave-per-tile kernel — case "1" — keeps the separate
+    kernel whatever the variable says).  Tile counts below one load batch (37, 131), across several (700) and odd just past a batch boundary (513):
     the fused sum must equal the per-site values summed on the host and the separate kernel's result to rounding, must not
     depend on which wave arrives last (repeated evaluations: fixed summation order -> the chain joins' order is the only
     run-to-run freedom, 1e-13), and -inf / the scaler sum must come through."""
