@@ -181,8 +181,10 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
       const Cand c{1, ranked[1][k].second, 2, -1};
       const double t = time_it(c);
       if (err) return -1;
-      // (2 % margin over the first stage: at equal tuner times the production pass of the 2-waves build is the faster one)
-      if (t >= 0. && t < 0.98 * stage1_ms && t < best_ms) {
+      // (5 % margin over the first stage: at equal tuner times the production pass of the 2-waves build is the faster one —
+      //  at the headline size the tuner's back-to-back passes put this build 0-3 % ahead and production runs it 3-5 us
+      //  behind (122-125 against 119 us); where it really wins the margin is 6 % (128 x 100 k) to 9 % (three batched classes))
+      if (t >= 0. && t < 0.95 * stage1_ms && t < best_ms) {
         best_ms = t;
         best = c;
         wave_wv = 2;
