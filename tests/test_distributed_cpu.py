@@ -121,3 +121,64 @@ def test_two_rank_site_sharding_with_rate_classes():
         assert p.exitcode == 0
     ref = float(common.load("codon_cat3")["logl"])
     assert abs(total - ref) <= 1e-11 * abs(ref)
+
+
+def _worker_classes_spread(rank, world, port, out_q):
+    """Rate classes dealt over ranks (SURVEY 8e-iii second form; the reference's MPI category mode, likefunc2.cpp:595-696):
+    every rank holds the whole alignment, evaluates classes c = rank mod world, one all-gather of the per-site rows, every
+    rank mixes."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    fx = common.load("codon_cat3")
+    C = len(fx["cat_weights"])
+    part = oracle.OraclePartition(int(fx["D"]), fx["flat_parents"], int(fx["L"]), fx["leaf_codes"], fx["ambig"], fx["pattern_freq"], C)
+    nodes = common.all_nodes(fx)
+    calls = []
+
+    def evaluate_class(c):
+        calls.append(c)
+        part.set_P(nodes, oracle.expm(common.fixture_Q(fx, float(fx["cat_values"][c])), True), cat=c)
+        return part.site_block(nodes, fx["root_freqs"], cat=c)
+
+    ll = hdist.evaluate_classes_spread(evaluate_class, fx["cat_weights"], fx["pattern_freq"], rank, world)
+    out_q.put((rank, ll, calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rate_classes_spread_over_ranks(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_classes_spread, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = float(common.load("codon_cat3")["logl"])
+    for rank, ll, calls in got:
+        assert abs(ll - ref) <= 1e-11 * abs(ref), (rank, ll, ref)
+        assert calls == hdist.local_classes(3, rank, world)      # every class evaluated exactly once, on its owner
+    assert len({ll for _, ll, _ in got}) == 1                      # the same bits on every rank
+
+
+def test_mix_classes_matches_the_oracle_mixing_with_exponents_and_floor():
+    """hdist.mix_classes against the restatement of PopulateConditionalProbabilities / SumUpSiteLikelihoods on rows with
+    different 2^64-exponents per class and a pattern whose mixed likelihood is zero (the myLog floor)."""
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    C, S = 4, 50
+    lik = rng.uniform(1e-8, 1.0, size=(C, S))
+    sc = rng.integers(0, 3, size=(C, S))
+    lik[:, 7] = 0.0
+    w = np.array([0.4, 0.3, 0.2, 0.1])
+    f = rng.integers(1, 5, size=S)
+    want, _, _ = oracle.mix_categories(w, lik, sc, f)
+    got = float(hdist.mix_classes(w, torch.from_numpy(lik), torch.from_numpy(sc), f))
+    assert abs(got - want) <= 1e-12 * abs(want), (got, want)
+    assert hdist.local_classes(5, 1, 2) == [1, 3] and hdist.local_classes(2, 2, 3) == []

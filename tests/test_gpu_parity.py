@@ -1240,3 +1240,25 @@ def test_busted_fit_of_the_reference_evaluates_on_the_device():
     want = op.site_log_likelihoods(nodes, fx["root_freqs"])
     got = np.log(lik) - sc * 64 * np.log(2.0)
     assert np.max(np.abs(got - want) / np.abs(want)) < RTOL
+
+
+def test_rate_classes_spread_mode_on_the_device_single_rank():
+    """hyphy_amd/dist.py::evaluate_classes_spread (SURVEY 8e-iii second form: class c on rank c mod world, one all-gather of
+    the per-site rows, every rank mixes) with a world of one and the tensors on the GPU: the per-class, per-site outputs of
+    hyphy_hip_evaluate(cat = c) mixed by torch ops must equal the library's own batched category evaluation and the
+    reference's log L.  (World sizes 2 and 3: tests/test_distributed_cpu.py over gloo.)"""
+    import torch
+    from hyphy_amd import dist as hdist
+    fx = common.load("codon_cat3")
+    C = len(fx["cat_weights"])
+    nodes = common.all_nodes(fx)
+    Q = np.stack([common.fixture_Q(fx, float(v)) for v in fx["cat_values"]])
+    ref = float(fx["logl"])
+    with _mk(fx, C) as part:
+        def evaluate_class(c):
+            return part.evaluate(nodes, nodes, Q[c], fx["root_freqs"], cat=c, per_site=True)[1:]
+        ll = hdist.evaluate_classes_spread(evaluate_class, fx["cat_weights"], fx["pattern_freq"], 0, 1, device="cuda")
+        batched = part.evaluate_categories(nodes, nodes, Q, fx["cat_weights"], fx["root_freqs"])
+    assert abs(ll - ref) <= RTOL * abs(ref), (ll, ref)
+    assert abs(ll - batched) <= 1e-12 * abs(batched), (ll, batched)
+    assert torch.cuda.is_available()
