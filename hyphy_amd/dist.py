@@ -112,7 +112,7 @@ def allgather_classes(lik_local, sc_local, n_classes: int, rank: int, world: int
 def evaluate_classes_spread(evaluate_class, weights, pattern_freq, rank: int, world: int, device=None, group=None):
     """One evaluation of a C-class model with the classes dealt over the ranks.  ``evaluate_class(c)`` returns this rank's
     per-pattern (likelihood [S], exponent [S]) of class c over the WHOLE alignment (``HipPartition.evaluate(..., cat=c,
-    per_site=True)[1:]`` on a GPU rank; the oracle in the CPU tests); ``device``: where the collective's tensors live
+    per_site=True)[1:]`` on a GPU rank; a CPU stand-in in the gloo tests); ``device``: where the collective's tensors live
     ("cuda" for RCCL).  Returns log L (float), identical on every rank."""
     import torch
     C = len(weights)
