@@ -205,6 +205,7 @@ struct ExpmArgs {
   const double *coeffs;      // [n][K]
   int K;
   int prof;                  // diagnostic: workgroup 0 stamps its phases (HYPHY_HIP_EXPM_PROF)
+  int fixed_degree = 0;      // expm64_kernel: 1 = always degree 12 (HYPHY_HIP_EXPM_DEGREE=12); 0 = degree from the scaled norm
   // re-rooted schedules (api.hip: reroot_path): matrix j of twin_src (a slot number) also leaves the TRANSPOSED image
   // M[r][c] = P[c][r] (times twin_pi[c] for j == 0, the edge that leaves the old root) in slot twin_dst0 + j of Pfrag
   int n_twin = 0;

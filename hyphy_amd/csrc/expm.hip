@@ -431,6 +431,14 @@ __global__ __launch_bounds__(64 * NT * CS) void expm_mfma_kernel(ExpmArgs a) {
 // the input is not a rate matrix) is reported as failure right away; the full-mode restart with a 2^7 larger scale would
 // square its way back to the same matrix and fail after the retries (matrix.cpp:5854-5864).
 // ---------------------------------------------------------------------------------------------
+// Degree of the Taylor polynomial from the norm of the (scaled) matrix: 3 nb with nb blocks of Paterson-Stockmeyer in X^3.
+// Remainder ||X||^(m+1) / (m+1)!: 12 for ||X|| <= 1/4 (2.4e-18), 9 for <= 0.11 (7e-17), 6 for <= 1/64 (4.5e-17) — each block
+// less is one product less behind X^2 and X^3 (a third of the Horner part at the headline's ||Q t|| = 0.10).
+__device__ __forceinline__ int taylor_blocks(double scaled_norm, int fixed_degree) {
+  if (fixed_degree) return 4;
+  return scaled_norm <= 0.015625 ? 2 : (scaled_norm <= 0.11 ? 3 : 4);
+}
+
 template <int NTW>
 __device__ __forceinline__ void load_tiles(const double *__restrict__ M, f64x4 (&f)[NTW], int rb, int ct0, int g, int sl) {
   constexpr int LD = 65;
@@ -631,11 +639,12 @@ __global__ __launch_bounds__(512) void expm64_kernel(ExpmArgs a, CoefInline ci) 
             for (int r = 0; r < 4; r++)
               if (fc0 + c == fw && sl == 4 * r + g) f[c][r] += dv;
         };
+        const int nb = taylor_blocks(norm * scale, a.fixed_degree);  // degree 3 nb from the scaled norm (uniform)
 #pragma unroll
-        for (int c = 0; c < 2; c++) acc[c] = kInvFact[10] * Xr[c] + kInvFact[11] * X2[c] + kInvFact[12] * X3[c];
-        add_diag(acc, kInvFact[9]);
+        for (int c = 0; c < 2; c++) acc[c] = kInvFact[3 * nb - 2] * Xr[c] + kInvFact[3 * nb - 1] * X2[c] + kInvFact[3 * nb] * X3[c];
+        add_diag(acc, kInvFact[3 * nb - 3]);
 #pragma unroll 1
-        for (int blk = 2; blk >= 0; blk--) {
+        for (int blk = nb - 2; blk >= 0; blk--) {
           __syncthreads();  // previous readers of Ys are done (and Zs is complete on the first pass)
           store_tiles<2>(Ys, acc, fw, fc0, g, sl);
           __syncthreads();
@@ -740,6 +749,7 @@ __global__ __launch_bounds__(512) void expm64_kernel(ExpmArgs a, CoefInline ci) 
         ct0 = wv & 3;
         active = wv < 4;
       }
+      const int nb = taylor_blocks(norm, a.fixed_degree);  // (p = 0: the matrix is unscaled; uniform over the workgroup and its siblings)
       f64x4 X2f[2], X3f[2];
       mm64<2>(Xs, Xs, X2f, fw, fc0, g, sl);
       store_tiles<2>(Ys, X2f, fw, fc0, g, sl);
@@ -761,11 +771,11 @@ __global__ __launch_bounds__(512) void expm64_kernel(ExpmArgs a, CoefInline ci) 
         load_tiles<NTW>(Ys, X2p, rb, ct0, g, sl);
         load_tiles<NTW>(Zs, X3p, rb, ct0, g, sl);
 #pragma unroll
-        for (int c = 0; c < NTW; c++) acc[c] = kInvFact[10] * Xp[c] + kInvFact[11] * X2p[c] + kInvFact[12] * X3p[c];
-        add_diag(acc, kInvFact[9]);
+        for (int c = 0; c < NTW; c++) acc[c] = kInvFact[3 * nb - 2] * Xp[c] + kInvFact[3 * nb - 1] * X2p[c] + kInvFact[3 * nb] * X3p[c];
+        add_diag(acc, kInvFact[3 * nb - 3]);
       }
 #pragma unroll 1
-      for (int blk = 2; blk >= 0; blk--) {
+      for (int blk = nb - 2; blk >= 0; blk--) {
         __syncthreads();  // every wave has its tiles of X^2 (first pass) / has read the previous panel
         if (active) store_tiles<NTW>(Ys, acc, rb, ct0, g, sl);
         __syncthreads();
@@ -1086,6 +1096,8 @@ bool launch_expm(const ExpmArgs &a, hipStream_t stream) {
       // Coefficients of the fused construction in the kernel-argument block when they fit: `coeffs` is host-mapped
       // memory and is dereferenced HERE, on the host — the caller staged it before this call (hyphy_hip_build_q).
       ExpmArgs b = a;
+      static const bool fixed12 = getenv("HYPHY_HIP_EXPM_DEGREE") && atoi(getenv("HYPHY_HIP_EXPM_DEGREE")) == 12;
+      b.fixed_degree = fixed12 ? 1 : 0;
       CoefInline ci;
       static const int coef_mode = getenv("HYPHY_HIP_COEF_INLINE") ? atoi(getenv("HYPHY_HIP_COEF_INLINE")) : 1;
       if (b.templates_pad && b.coeffs_host && coef_mode && (size_t)b.n * b.K <= (size_t)kCoefInline) {

@@ -1262,3 +1262,23 @@ def test_rate_classes_spread_mode_on_the_device_single_rank():
     assert abs(ll - ref) <= RTOL * abs(ref), (ll, ref)
     assert abs(ll - batched) <= 1e-12 * abs(batched), (ll, batched)
     assert torch.cuda.is_available()
+
+
+def test_expm_degree_follows_the_norm_without_losing_accuracy():
+    """expm64_kernel picks the Taylor degree from the scaled infinity norm (12 / 9 / 6 for <= 1/4, 0.11, 1/64: one
+    Paterson-Stockmeyer block less each).  Codon rate matrices scaled to sit just below and just above every threshold, and the
+    headline's own (||Q t|| = 0.10): against the restatement of the reference's Taylor-to-convergence exponential, 2e-15
+    absolute on every entry and row sums of 1 to 1e-14 — the same as the fixed degree 12 gives."""
+    from hyphy_amd import models
+    from oracle import oracle
+    hip = _hip()
+    pf = np.array([[0.3, 0.2, 0.25, 0.25], [0.2, 0.3, 0.3, 0.2], [0.25, 0.25, 0.2, 0.3]])
+    rev = dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4)
+    Q0 = models.mg94rev_Q(1.0, 0.7, rev, pf)
+    n0 = np.abs(Q0).sum(1).max()
+    norms = [0.9 / 64, 1.0 / 64 * 0.9999, 1.1 / 64, 0.10, 0.1099, 0.1101, 0.12, 0.2499, 0.2501, 0.4, 1e-6]
+    Q = np.stack([Q0 * (nm / n0) for nm in norms])
+    P = hip.expm_batch(Q)
+    Po = oracle.expm(Q, True)
+    assert np.max(np.abs(P - Po)) < 2e-15, np.max(np.abs(P - Po), axis=(1, 2))
+    assert np.max(np.abs(P.sum(2) - 1.0)) < 1e-14
