@@ -1968,7 +1968,8 @@ void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
   // tile dimension padded to a multiple of 8 (the surplus workgroups retire at once) every chain of a tile — and so every
   // join of its trunk — sits on ONE XCD: deposits and arrival counters are then L2 hits instead of trips to memory.
   // (HYPHY_HIP_XCD_PAD=0: the bare tile count.)
-  static const bool xcd_pad = !(getenv("HYPHY_HIP_XCD_PAD") && atoi(getenv("HYPHY_HIP_XCD_PAD")) == 0);
+  const char *pad_env = getenv("HYPHY_HIP_XCD_PAD");  // (read per launch: the tests run both placements in one process)
+  const bool xcd_pad = !(pad_env && atoi(pad_env) == 0);
   const int gx_chain = (a.chain && a.T == 1 && xcd_pad && !a.timeline) ? ((a.ntiles + 7) & ~7) : a.ntiles / a.T;
   const dim3 grid(a.chain ? gx_chain : a.ntiles / a.T, a.n_cat > 0 ? a.n_cat : 1, a.n_prog > 0 ? a.n_prog : 1), block(64 * NW);
   const size_t lds = CLDS ? (size_t)a.L * a.T * 16 * sizeof(int16_t) : 0;

@@ -951,9 +951,9 @@ def test_rccl_allreduce_entry_points_single_rank():
         assert abs(a - b) <= 1e-13 * abs(b)
 
 
-@pytest.mark.parametrize("kernel", ["1", "2"])
+@pytest.mark.parametrize("kernel,pad", [("1", "0"), ("2", "0"), ("1", "1")])
 @pytest.mark.parametrize("n_tiles", [41, 48, 7])
-def test_chain_joins_within_and_across_xcds(n_tiles, kernel, monkeypatch):
+def test_chain_joins_within_and_across_xcds(n_tiles, kernel, pad, monkeypatch):
     """Chain schedules hand edge products between waves of ONE launch through global memory (write-through stores, drained,
     then an agent-scope arrival; the last arriver reads with L1-bypassing loads).  Workgroup b runs on XCD b mod 8 and
     the grid is (tiles, classes, sources): sibling chains of a tile sit n_tiles x (source distance) workgroups apart —
@@ -962,6 +962,10 @@ def test_chain_joins_within_and_across_xcds(n_tiles, kernel, monkeypatch):
     from hyphy_amd import data, models, tree
     from oracle import oracle
     monkeypatch.setenv("HYPHY_HIP_KERNEL", kernel)   # 1: one wave per chain, 2: a workgroup of four row-split waves per chain
+    # pad = "0": the bare (tiles, classes, sources) grid, where the tile count decides which joins cross XCDs (the text above);
+    # pad = "1" (the default since late r03): tile dimension padded to a multiple of 8, every join inside one XCD, surplus
+    # workgroups retire at once
+    monkeypatch.setenv("HYPHY_HIP_XCD_PAD", pad)
     monkeypatch.setenv("HYPHY_HIP_CHAIN_M", "1")
     monkeypatch.setenv("HYPHY_HIP_POISON", "1")
     rng = np.random.default_rng(100 + n_tiles)
