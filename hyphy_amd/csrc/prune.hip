@@ -1525,14 +1525,22 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
 // FOLD: the matrix exponentials of this evaluation are computed HERE, by the first threads of every workgroup (each writes the
 // transposed copies it reads itself; workgroup 0 also leaves the row-major ones), instead of by a launch of their own in
 // front — for shards of a few hundred workgroups the 10 us of that launch were a fifth of the step, 2 us of one wave are not.
-template <int NP, bool PIN, bool FOLD = false>
+// LP (late r03): the schedule words and the transposed matrices of ALL branches are copied to LDS once per workgroup and every
+// per-entry fetch is an LDS read (uniform address, one entry / two entries ahead as before).  Scalar loads return out of order
+// and share their counter with LDS: every wait for a leaf's LDS lookup or for this entry's matrix is an lgkmcnt(0) that also
+// waits for the scalar loads just issued for the NEXT entry — with (less than) one wave per SIMD that exposed a scalar-load
+// latency per entry.  LDS reads return in order: the waits become partial.  Costs ~7 wide LDS reads per entry and wave, so
+// only shards of at most two workgroups per CU use it (launch_prune_nuc); the 10^6-site launches keep the scalar path.
+template <int NP, bool PIN, bool FOLD = false, bool LP = false>
 __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict__ ops, const double *__restrict__ PTm,
                                                          NucArgs a, ExpmArgs ex) {
   constexpr int WGP = 256 * NP;  // patterns per workgroup
   extern __shared__ __align__(16) double nlds[];
-  double *PT = nlds;                                                   // [L][4 states][4 rows]
-  double *park = nlds + (size_t)a.L * 16;                              // [slot][NP][4][256]
+  const int nPT = LP ? a.L + a.root_inode : a.L;                       // matrices kept in LDS (LP: every branch)
+  double *PT = nlds;                                                   // [nPT][4 states][4 rows]
+  double *park = nlds + (size_t)nPT * 16;                              // [slot][NP][4][256]
   int *park_cnt = reinterpret_cast<int *>(park + kNucParkSlots * NP * 4 * 256);  // [slot][NP][256]
+  [[maybe_unused]] int4 *ops_l = reinterpret_cast<int4 *>(park_cnt + kNucParkSlots * NP * 256);  // LP: [n_ops + 4]
   const int tid = threadIdx.x;
   const size_t S_pad = a.S_pad;
   const int s0 = blockIdx.x * WGP + tid;  // pattern q of this thread: s0 + 256 q
@@ -1551,8 +1559,23 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's copies have reached L2 before any of its waves reads them
     __syncthreads();
   }
-  for (int idx = tid; idx < a.L * 16; idx += 256) PT[idx] = PTm[idx];  // (leaves are branches 0 .. L-1)
+  for (int idx = tid; idx < nPT * 16; idx += 256) PT[idx] = PTm[idx];  // (leaves are branches 0 .. L-1)
+  if constexpr (LP) {
+    for (int idx = tid; idx < a.n_ops + 4; idx += 256) ops_l[idx] = ops[idx < a.n_ops + 2 ? idx : a.n_ops + 1];
+  }
   __syncthreads();
+  auto fetch_op = [&](int k) -> int4 {
+    if constexpr (LP) {
+      int4 o = ops_l[k];  // (uniform address; the words steer branches: back into scalar registers)
+      o.x = __builtin_amdgcn_readfirstlane(o.x);
+      o.y = __builtin_amdgcn_readfirstlane(o.y);
+      o.z = __builtin_amdgcn_readfirstlane(o.z);
+      o.w = __builtin_amdgcn_readfirstlane(o.w);
+      return o;
+    } else {
+      return ops[k];
+    }
+  };
   double acc[NP][4], b[NP][4];
   int cnt[NP], bcnt[NP];
 #pragma unroll
@@ -1582,9 +1605,19 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
   // loads — 96 bytes x 64 lanes per entry made the kernel TA-bound, 205 vs 120 us at 10^6 sites; schedule words through
   // vector loads + readfirstlane, 38 vs 27 us at 50 000 sites.)
   auto load_P = [&](const int4 &o, double (&P)[12]) {
-    const double *src = PTm + (size_t)((o.x & 3) == OPK_LEAF ? (o.z & 0xffff) : o.z) * 16;
+    const int br = (o.x & 3) == OPK_LEAF ? (o.z & 0xffff) : o.z;
+    if constexpr (LP) {
+      const f64x2 *src = reinterpret_cast<const f64x2 *>(PT + (size_t)br * 16);
 #pragma unroll
-    for (int e = 0; e < 12; e++) P[e] = src[e];
+      for (int e = 0; e < 6; e++) {
+        const f64x2 v = src[e];
+        P[2 * e] = v[0], P[2 * e + 1] = v[1];
+      }
+    } else {
+      const double *src = PTm + (size_t)br * 16;
+#pragma unroll
+      for (int e = 0; e < 12; e++) P[e] = src[e];
+    }
   };
   // one schedule entry: `code` = this thread's leaf codes (leaf entries), P = columns 0..2 of the child's transition matrix
   auto entry = [&](const int4 &op, const double (&P)[12], const int (&code)[2][NP]) {
@@ -1723,17 +1756,17 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
   // Software pipeline, unrolled by two: matrix and leaf codes of entry i + 1 are requested before entry i is processed.
   // Programs are padded to an even entry count and followed by two no-op entries.
   // (schedule words two entries ahead: their scalar load has returned by the time they address the matrix / code loads)
-  int4 opA = ops[0], opB = ops[1];
+  int4 opA = fetch_op(0), opB = fetch_op(1);
   double PA[12], PB[12];
   int cA[2][NP], cB[2][NP];
   load_P(opA, PA);
   codes_of(opA, cA);
   for (int oi = 0; oi < a.n_ops; oi += 2) {
-    const int4 opC = ops[oi + 2];
+    const int4 opC = fetch_op(oi + 2);
     load_P(opB, PB);
     codes_of(opB, cB);
     entry(opA, PA, cA);
-    const int4 opD = ops[oi + 3];
+    const int4 opD = fetch_op(oi + 3);
     load_P(opC, PA);
     codes_of(opC, cA);
     entry(opB, PB, cB);
@@ -2094,8 +2127,9 @@ static int nuc2_np(const NucArgs &a) {
   if (forced == 2) return 2;
   return 1;  // (measured: one pattern per thread and four workgroups per CU beat two patterns and two workgroups at every size)
 }
-static size_t nuc2_lds(const NucArgs &a, int np) {
-  return (size_t)a.L * 16 * sizeof(double) + (size_t)kNucParkSlots * np * 256 * (4 * sizeof(double) + sizeof(int));
+static size_t nuc2_lds(const NucArgs &a, int np, bool lp = false) {
+  return (size_t)(lp ? a.L + a.root_inode : a.L) * 16 * sizeof(double) +
+         (size_t)kNucParkSlots * np * 256 * (4 * sizeof(double) + sizeof(int)) + (lp ? (size_t)(a.n_ops + 4) * sizeof(int4) : 0);
 }
 
 // true when launch_prune_nuc can take the evaluation's matrix exponentials along (ex != nullptr): the r03 kernel on a shard of
@@ -2115,10 +2149,13 @@ void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex) 
     return;
   }
   static bool attr_done[64];
+  constexpr int cap_bytes = 112 * 1024;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!attr_done[dev]) {  // (2 patterns per thread: 74 KiB of parking + up to 32 KiB of leaf matrices)
-    const int cap = 112 * 1024;
+    const int cap = cap_bytes;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
@@ -2131,6 +2168,21 @@ void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex) 
   const size_t lds = nuc2_lds(a, np);
   ExpmArgs none;
   none.n = 0;
+  // schedule words + every branch's matrix from LDS (LP): shards of at most two workgroups per CU
+  static int cus_n[64];
+  if (!cus_n[dev]) {
+    hipDeviceProp_t pr;
+    cus_n[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  const char *lp_env = getenv("HYPHY_HIP_NUC_LP");
+  const bool lp = np == 1 && !(ex && ex->n > 0) && (lp_env ? atoi(lp_env) != 0 : (int)grid.x <= 2 * cus_n[dev]) &&
+                  nuc2_lds(a, 1, true) <= (size_t)cap_bytes;
+  if (lp) {
+    const size_t ldl = nuc2_lds(a, 1, true);
+    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, false, true>), grid, block, ldl, stream, a.ops, a.PT, a, none);
+    else hipLaunchKernelGGL((prune_nuc2_kernel<1, false, false, true>), grid, block, ldl, stream, a.ops, a.PT, a, none);
+    return;
+  }
   if (ex && ex->n > 0 && np == 1) {
     if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, true>), grid, block, lds, stream, a.ops, a.PT, a, *ex);
     else hipLaunchKernelGGL((prune_nuc2_kernel<1, false, true>), grid, block, lds, stream, a.ops, a.PT, a, *ex);

@@ -1286,3 +1286,24 @@ def test_expm_degree_follows_the_norm_without_losing_accuracy():
     Po = oracle.expm(Q, True)
     assert np.max(np.abs(P - Po)) < 2e-15, np.max(np.abs(P - Po), axis=(1, 2))
     assert np.max(np.abs(P.sum(2) - 1.0)) < 1e-14
+
+
+@pytest.mark.parametrize("lp", ["0", "1"])
+@pytest.mark.parametrize("name", ["nuc_small", "nuc_ambig", "nuc_wide"])
+def test_four_state_kernel_with_and_without_the_lds_schedule(name, lp, monkeypatch):
+    """prune_nuc2_kernel fetches schedule words and internal-edge matrices through scalar loads (large shards) or from an LDS
+    copy (LP: shards of at most two workgroups per CU, the default at these sizes); HYPHY_HIP_NUC_LP forces either.  Both
+    against the reference's log L and per-site values."""
+    monkeypatch.setenv("HYPHY_HIP_NUC_LP", lp)
+    fx = common.load(name)
+    Q = common.fixture_Q(fx)
+    nodes = common.all_nodes(fx)
+    with _mk(fx) as part:
+        assert part.prune_kernel_name() == "prune_nuc2_kernel"
+        ll, lik, sc = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+        again = part.evaluate(nodes, nodes, Q, fx["root_freqs"])      # (steady state: lazy persistence)
+    ref = float(fx["logl"])
+    assert abs(ll - ref) <= RTOL * abs(ref), (ll, ref)
+    assert again == ll
+    site = (np.log(lik) - sc * 64 * np.log(2.0))[fx["site_to_pattern"]]
+    assert np.max(np.abs(site - fx["site_logl"]) / np.abs(fx["site_logl"])) < RTOL
