@@ -354,6 +354,18 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     na.wg_cnt = s.wg_cnt;
     na.wg_flag = s.wg_flag;
     n_wg = prune_nuc_grid(na);
+    {  // fused final combine (see the codon branch below): the small-shard instantiation of the 4-state kernel carries it
+      const char *fuse_env = getenv("HYPHY_HIP_FUSED_REDUCE");
+      if (!(fuse_env && atoi(fuse_env) == 0) && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && prune_nuc_fuses_reduce(na, have_folded)) {
+        double *rec = s.d_hout ? s.d_hout : s.out;
+        fused_reduce = true;
+        na.red_out = d_logl_out ? d_logl_out : rec;
+        na.red_rec = d_logl_out ? s.out + 1 : rec + 1;
+        na.red_status = d_logl_out ? nullptr : s.status;
+        na.red_seq = next_seq(s, !d_logl_out);
+        na.red_done = s.wg_flag + (size_t)p->C * s.wg_cap + 3;  // (the spare words behind the flags; zeroed at creation)
+      }
+    }
     launch_prune_nuc(na, s.stream, have_folded ? &folded_expm : nullptr);
     if (have_folded && folded_expm.templates && d_logl_out && s.coeff_slot >= 0) {  // (the ring slot is read by THIS launch)
       HIPCHK(hipEventRecord(s.coeff_ev[s.coeff_slot], s.stream));
@@ -845,6 +857,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     A_(s.wg_sum, ((size_t)C * s.wg_cap + 4) * sizeof(double));  // x C: rate-class batching writes one row per class; + 4: the fused
     A_(s.wg_cnt, ((size_t)C * s.wg_cap + 4) * sizeof(long long));  // final combine reads them with 16-byte loads
     A_(s.wg_flag, ((size_t)C * s.wg_cap + 4) * sizeof(int));
+    hipMemset(s.wg_flag + (size_t)C * s.wg_cap, 0, 4 * sizeof(int));  // (the last word: arrival counter of the 4-state kernel's fused combine)
 #undef A_
     s.h_small_cap = (size_t)std::max<int64_t>(std::max<int64_t>(DP, C), 64);
     if (hipHostMalloc((void **)&s.h_ops, ops_capacity(p) * sizeof(int4)) != hipSuccess ||

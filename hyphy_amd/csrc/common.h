@@ -156,6 +156,12 @@ struct NucArgs {
   double *wg_sum;
   long long *wg_cnt;
   int *wg_flag;
+  // fused final combine (see PruneArgs): nullptr = off
+  double *red_out = nullptr;
+  double *red_rec = nullptr;
+  const int *red_status = nullptr;
+  double red_seq = 0.;
+  int *red_done = nullptr;   // arrivals of workgroups (zero between launches)
 };
 
 constexpr int kSiteFitParkSlots = 1;  // wave-private LDS parking slots of the per-site fit kernel (8 KiB each at D = 61); nodes
@@ -252,6 +258,7 @@ void launch_site_fit(const SiteFitArgs &a, hipStream_t stream);
 void launch_prune_mfma(const PruneArgs &a, hipStream_t stream);
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex = nullptr);  // ex: matrix exponentials folded into the launch
 bool prune_nuc_folds_expm(int L, int S_pad, int n_ops);
+bool prune_nuc_fuses_reduce(const NucArgs &a, bool folded);  // launch_prune_nuc will run the instantiation that carries the fused final combine
 void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,
                         double *out_logl, double *out_cnt, const int *status, hipStream_t stream, double seq = 0.);
 void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *wg_flag, int n, double *out_logl,

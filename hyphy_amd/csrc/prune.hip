@@ -103,6 +103,8 @@ __device__ __forceinline__ void st16_agent(double *ubase, unsigned byte_off, f64
 // like wg_reduce_kernel does (same flags, same record, same sequence word).  The order of arrival decides only WHO sums.
 // FUSE is a template parameter of the kernels: the combine's registers must not exist in the builds that do not use it (inlined
 // behind a run-time test it cost the production wave kernel 15 scratch instructions and 3 us of 119 at the headline size).
+__device__ __forceinline__ void combine_partials(double *wg_sum, long long *wg_cnt, int *wg_flag, int n, double *red_out,
+                                                 double *red_rec, const int *red_status, double red_seq, int lane);
 template <bool FUSE>
 __device__ __forceinline__ void publish_partial(const PruneArgs &a, int idx, double wsum, long long wcnt, int wflag, int lane) {
   if (!FUSE || a.red_out == nullptr) {
@@ -126,11 +128,20 @@ __device__ __forceinline__ void publish_partial(const PruneArgs &a, int idx, dou
   asm volatile("" ::: "memory");
   if (old + 1 < a.red_n) return;
   if (lane == 0) __hip_atomic_store(a.red_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
-  const int n = a.red_n;
+  combine_partials(a.wg_sum, a.wg_cnt, a.wg_flag, a.red_n, a.red_out, a.red_rec, a.red_status, a.red_seq, lane);
+  }  // FUSE
+}
+
+// The last arriver's part of the fused final combine (one full wave): n partial sums read back with sc1 loads, fixed-order
+// compensated sum, result record published like wg_reduce_kernel's.  Shared by the codon kernels' publish_partial and the
+// 4-state kernel's epilogue.
+__device__ __forceinline__ void combine_partials(double *wg_sum, long long *wg_cnt, int *wg_flag, int n, double *red_out,
+                                                 double *red_rec, const int *red_status, double red_seq, int lane) {
+  {
   // (bounds rounded up to whole 16-byte accesses — the arrays are allocated 4 entries longer than any n —, entries >= n masked below)
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.wg_sum, 0, ((n + 1) & ~1) * 8, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(a.wg_cnt, 0, ((n + 1) & ~1) * 8, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(a.wg_flag, 0, ((n + 3) & ~3) * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wg_sum, 0, ((n + 1) & ~1) * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(wg_cnt, 0, ((n + 1) & ~1) * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(wg_flag, 0, ((n + 3) & ~3) * 4, 0x00020000);
   double sum = 0., comp = 0.;
   long long c = 0;
   int fl = 0;
@@ -182,15 +193,15 @@ __device__ __forceinline__ void publish_partial(const PruneArgs &a, int idx, dou
     double r = (sum - comp) - kLogScaler * (double)c;
     if (fl & 2) r = NAN;
     else if (fl & 1) r = -INFINITY;
-    a.red_out[0] = r;
-    a.red_rec[0] = (double)c;
-    a.red_rec[1] = a.red_status ? (double)*a.red_status : 0.;
-    if (a.red_seq != 0.) {  // host spins on this word instead of waiting for the stream (record complete before it)
+    red_out[0] = r;
+    red_rec[0] = (double)c;
+    red_rec[1] = red_status ? (double)*red_status : 0.;
+    if (red_seq != 0.) {  // host spins on this word instead of waiting for the stream (record complete before it)
       __threadfence_system();
-      reinterpret_cast<volatile double *>(a.red_rec)[2] = a.red_seq;
+      reinterpret_cast<volatile double *>(red_rec)[2] = red_seq;
     }
   }
-  }  // FUSE
+  }
 }
 
 // Operand bundle fetched one schedule entry ahead: 16 doubles per lane, either the A-operand image
@@ -1814,6 +1825,27 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
     rf[tid >> 6] = fl;
   }
   __syncthreads();
+  if constexpr (LP) {
+    if (a.red_out && a.n_ops > 0) {  // fused final combine (small shards): the last workgroup to arrive sums all partials
+      if (tid < 64) {                // (wave 0, all lanes: the same protocol as the codon kernels' publish_partial)
+        if (tid == 0) {
+          __hip_atomic_store(a.wg_sum + blockIdx.x, (rs[0] + rs[1]) + (rs[2] + rs[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a.wg_cnt + blockIdx.x, (rc[0] + rc[1]) + (rc[2] + rc[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a.wg_flag + blockIdx.x, rf[0] | rf[1] | rf[2] | rf[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int old = 0;
+        if (tid == 0) old = __hip_atomic_fetch_add(a.red_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        asm volatile("" ::: "memory");
+        if (old + 1 == (int)gridDim.x) {
+          if (tid == 0) __hip_atomic_store(a.red_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+          combine_partials(a.wg_sum, a.wg_cnt, a.wg_flag, (int)gridDim.x, a.red_out, a.red_rec, a.red_status, a.red_seq, tid);
+        }
+      }
+      return;
+    }
+  }
   if (tid == 0 && a.n_ops > 0) {
     a.wg_sum[blockIdx.x] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
     a.wg_cnt[blockIdx.x] = (rc[0] + rc[1]) + (rc[2] + rc[3]);
@@ -2132,11 +2164,29 @@ static size_t nuc2_lds(const NucArgs &a, int np, bool lp = false) {
          (size_t)kNucParkSlots * np * 256 * (4 * sizeof(double) + sizeof(int)) + (lp ? (size_t)(a.n_ops + 4) * sizeof(int4) : 0);
 }
 
+static bool nuc_uses_lp(const NucArgs &a, int np, bool folded, int dev) {
+  static int cus_n[64];
+  if (!cus_n[dev]) {
+    hipDeviceProp_t pr;
+    cus_n[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  const char *lp_env = getenv("HYPHY_HIP_NUC_LP");
+  return np == 1 && !folded && (lp_env ? atoi(lp_env) != 0 : a.S_pad / 256 <= 2 * cus_n[dev]) && nuc2_lds(a, 1, true) <= (size_t)(112 * 1024);
+}
+
 // true when launch_prune_nuc can take the evaluation's matrix exponentials along (ex != nullptr): the r03 kernel on a shard of
 // at most two workgroups per CU
 bool prune_nuc_folds_expm(int L, int S_pad, int n_ops) {
   static const bool on = getenv("HYPHY_HIP_NUC_FOLD") && atoi(getenv("HYPHY_HIP_NUC_FOLD")) != 0;  // (opt-in: measured neutral, 45.5 vs 45.6 us per step at 50 000 sites)
   return on && n_ops > 0 && prune_nuc_takes_leaf_pairs(L) && nuc_forced() != 2 && S_pad % 256 == 0 && S_pad / 256 <= 512;
+}
+
+// true when launch_prune_nuc will pick the LDS-schedule instantiation (LP) — the one that can also carry the fused final
+// combine (NucArgs::red_out) — for this launch
+bool prune_nuc_fuses_reduce(const NucArgs &a, bool folded) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  return a.n_ops > 0 && nuc_uses_lp(a, nuc2_np(a), folded, dev);
 }
 
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex) {
@@ -2169,14 +2219,7 @@ void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex) 
   ExpmArgs none;
   none.n = 0;
   // schedule words + every branch's matrix from LDS (LP): shards of at most two workgroups per CU
-  static int cus_n[64];
-  if (!cus_n[dev]) {
-    hipDeviceProp_t pr;
-    cus_n[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-  }
-  const char *lp_env = getenv("HYPHY_HIP_NUC_LP");
-  const bool lp = np == 1 && !(ex && ex->n > 0) && (lp_env ? atoi(lp_env) != 0 : (int)grid.x <= 2 * cus_n[dev]) &&
-                  nuc2_lds(a, 1, true) <= (size_t)cap_bytes;
+  const bool lp = nuc_uses_lp(a, np, ex && ex->n > 0, dev);
   if (lp) {
     const size_t ldl = nuc2_lds(a, 1, true);
     if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, false, true>), grid, block, ldl, stream, a.ops, a.PT, a, none);

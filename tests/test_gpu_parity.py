@@ -1302,8 +1302,17 @@ def test_four_state_kernel_with_and_without_the_lds_schedule(name, lp, monkeypat
         assert part.prune_kernel_name() == "prune_nuc2_kernel"
         ll, lik, sc = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
         again = part.evaluate(nodes, nodes, Q, fx["root_freqs"])      # (steady state: lazy persistence)
+        # the LDS-schedule build also carries the fused final combine (last workgroup sums the partials): against the
+        # separate reduction kernel, and -inf must come through it
+        monkeypatch.setenv("HYPHY_HIP_FUSED_REDUCE", "0")
+        plain = part.evaluate(nodes, nodes, Q, fx["root_freqs"])
+        monkeypatch.setenv("HYPHY_HIP_FUSED_REDUCE", "1")
+        P = np.tile(np.eye(4), (len(nodes), 1, 1))
+        assert part.evaluate(nodes, nodes, P, fx["root_freqs"], q_is_probability=True) == -np.inf
+        after = part.evaluate(nodes, nodes, Q, fx["root_freqs"])
     ref = float(fx["logl"])
     assert abs(ll - ref) <= RTOL * abs(ref), (ll, ref)
     assert again == ll
+    assert abs(plain - ll) <= 1e-13 * abs(ll) and after == ll
     site = (np.log(lik) - sc * 64 * np.log(2.0))[fx["site_to_pattern"]]
     assert np.max(np.abs(site - fx["site_logl"]) / np.abs(fx["site_logl"])) < RTOL
