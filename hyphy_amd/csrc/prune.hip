@@ -1555,7 +1555,7 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
   const int tid = threadIdx.x;
   const size_t S_pad = a.S_pad;
   const int s0 = blockIdx.x * WGP + tid;  // pattern q of this thread: s0 + 256 q
-  if constexpr (FOLD) {
+  if constexpr (FOLD && !LP) {
     for (int m = tid; m < ex.n; m += 256) {
       double R[16];
       expm4_one(ex, m, R);
@@ -1573,6 +1573,25 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
   for (int idx = tid; idx < nPT * 16; idx += 256) PT[idx] = PTm[idx];  // (leaves are branches 0 .. L-1)
   if constexpr (LP) {
     for (int idx = tid; idx < a.n_ops + 4; idx += 256) ops_l[idx] = ops[idx < a.n_ops + 2 ? idx : a.n_ops + 1];
+  }
+  if constexpr (FOLD && LP) {
+    // this evaluation's exponentials straight into the LDS copy every entry reads (behind the copy of the resident matrices:
+    // branches that did not change keep theirs); workgroup 0 also leaves the global copies for later partial updates
+    __syncthreads();
+    for (int m = tid; m < ex.n; m += 256) {
+      double R[16];
+      expm4_one(ex, m, R);
+      const int slot = ex.slots ? ex.slots[m] : m;
+#pragma unroll
+      for (int k = 0; k < 16; k++) PT[slot * 16 + k] = R[4 * (k & 3) + (k >> 2)];
+      if (blockIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          if (ex.Prow) ex.Prow[(size_t)slot * 16 + k] = R[k];
+          ex.PTrow[(size_t)slot * 16 + k] = R[4 * (k & 3) + (k >> 2)];
+        }
+      }
+    }
   }
   __syncthreads();
   auto fetch_op = [&](int k) -> int4 {
@@ -2171,13 +2190,15 @@ static bool nuc_uses_lp(const NucArgs &a, int np, bool folded, int dev) {
     cus_n[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
   }
   const char *lp_env = getenv("HYPHY_HIP_NUC_LP");
-  return np == 1 && !folded && (lp_env ? atoi(lp_env) != 0 : a.S_pad / 256 <= 2 * cus_n[dev]) && nuc2_lds(a, 1, true) <= (size_t)(112 * 1024);
+  (void)folded;
+  return np == 1 && (lp_env ? atoi(lp_env) != 0 : a.S_pad / 256 <= 2 * cus_n[dev]) && nuc2_lds(a, 1, true) <= (size_t)(112 * 1024);
 }
 
 // true when launch_prune_nuc can take the evaluation's matrix exponentials along (ex != nullptr): the r03 kernel on a shard of
 // at most two workgroups per CU
 bool prune_nuc_folds_expm(int L, int S_pad, int n_ops) {
-  static const bool on = getenv("HYPHY_HIP_NUC_FOLD") && atoi(getenv("HYPHY_HIP_NUC_FOLD")) != 0;  // (opt-in: measured neutral, 45.5 vs 45.6 us per step at 50 000 sites)
+  const char *fe = getenv("HYPHY_HIP_NUC_FOLD");
+  const bool on = fe && atoi(fe) != 0;  // (opt-in: measured neutral, 45.5 vs 45.6 us per step at 50 000 sites)
   return on && n_ops > 0 && prune_nuc_takes_leaf_pairs(L) && nuc_forced() != 2 && S_pad % 256 == 0 && S_pad / 256 <= 512;
 }
 
@@ -2206,6 +2227,8 @@ void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex) 
     const int cap = cap_bytes;
     hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     hipFuncSetAttribute(reinterpret_cast<const void *>(prune_nuc2_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
@@ -2222,6 +2245,11 @@ void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex) 
   const bool lp = nuc_uses_lp(a, np, ex && ex->n > 0, dev);
   if (lp) {
     const size_t ldl = nuc2_lds(a, 1, true);
+    if (ex && ex->n > 0) {  // (with this evaluation's exponentials folded in)
+      if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, true, true>), grid, block, ldl, stream, a.ops, a.PT, a, *ex);
+      else hipLaunchKernelGGL((prune_nuc2_kernel<1, false, true, true>), grid, block, ldl, stream, a.ops, a.PT, a, *ex);
+      return;
+    }
     if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, false, true>), grid, block, ldl, stream, a.ops, a.PT, a, none);
     else hipLaunchKernelGGL((prune_nuc2_kernel<1, false, false, true>), grid, block, ldl, stream, a.ops, a.PT, a, none);
     return;

@@ -1288,13 +1288,14 @@ def test_expm_degree_follows_the_norm_without_losing_accuracy():
     assert np.max(np.abs(P.sum(2) - 1.0)) < 1e-14
 
 
-@pytest.mark.parametrize("lp", ["0", "1"])
+@pytest.mark.parametrize("lp,fold", [("0", "0"), ("1", "0"), ("1", "1"), ("0", "1")])
 @pytest.mark.parametrize("name", ["nuc_small", "nuc_ambig", "nuc_wide"])
-def test_four_state_kernel_with_and_without_the_lds_schedule(name, lp, monkeypatch):
+def test_four_state_kernel_with_and_without_the_lds_schedule(name, lp, fold, monkeypatch):
     """prune_nuc2_kernel fetches schedule words and internal-edge matrices through scalar loads (large shards) or from an LDS
     copy (LP: shards of at most two workgroups per CU, the default at these sizes); HYPHY_HIP_NUC_LP forces either.  Both
     against the reference's log L and per-site values."""
     monkeypatch.setenv("HYPHY_HIP_NUC_LP", lp)
+    monkeypatch.setenv("HYPHY_HIP_NUC_FOLD", fold)   # 1: this evaluation's 4 x 4 exponentials computed inside the pruning launch
     fx = common.load(name)
     Q = common.fixture_Q(fx)
     nodes = common.all_nodes(fx)
