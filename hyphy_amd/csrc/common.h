@@ -135,6 +135,24 @@ struct PruneArgs {
 constexpr int kTraceWG = 8;
 constexpr int kNucParkSlots = 4;  // LDS parking slots of the 4-state kernel (nodes whose parent is not the next entry)
 
+constexpr int kCoefInline = 400;  // coefficients that fit the kernel-argument block (n * K doubles)
+struct CoefInline {
+  double c[kCoefInline];
+};
+struct CoefNone {  // (kernels that take the coefficient block only in some instantiations)
+  int unused;
+};
+template <bool ON>
+struct CoefArg {
+  typedef CoefNone type;
+};
+template <>
+struct CoefArg<true> {
+  typedef CoefInline type;
+};
+struct ExpmArgs;
+bool fill_coef_inline(ExpmArgs &b, CoefInline &ci);  // expm.hip
+
 struct NucArgs {
   const int4 *ops;
   int n_ops;

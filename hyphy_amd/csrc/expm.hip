@@ -477,10 +477,6 @@ __device__ __forceinline__ void mm64(const double *__restrict__ Lm, const double
   for (int c = 0; c < NTW; c++) d[c] += e[c];
 }
 
-constexpr int kCoefInline = 400;  // coefficients that fit the kernel-argument block (n * K doubles)
-struct CoefInline {
-  double c[kCoefInline];
-};
 
 template <int H>
 __global__ __launch_bounds__(512) void expm64_kernel(ExpmArgs a, CoefInline ci) {
@@ -939,12 +935,14 @@ __global__ __launch_bounds__(512) void expm64_kernel(ExpmArgs a, CoefInline ci) 
 // ---------------------------------------------------------------------------------------------
 // 4-state specialisation: one thread per matrix, everything in registers.
 // ---------------------------------------------------------------------------------------------
+// (coefficients from the ring slot: a 3.2 KB kernel-argument block costs this 61-thread launch more than the PCIe read —
+//  measured 11-15 against 9.8 us event-timed)
 __global__ void expm_nuc_kernel(ExpmArgs a) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= a.n) return;
   const int slot = a.slots ? a.slots[m] : m;
   double R[16];
-  expm4_one(a, m, R);
+  expm4_one(a, m, R, a.coeffs);
   if (a.Prow) {
 #pragma unroll
     for (int k = 0; k < 16; k++) a.Prow[(size_t)slot * 16 + k] = R[k];
@@ -1033,6 +1031,19 @@ void expm_read_profile(long long out[8]) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g
 
 // returns true when the coefficients of a fused construction travelled in the kernel-argument block (the caller's staging
 // buffer is free again on return), false when the kernel will read them from `coeffs` when it executes
+// Coefficients of the fused rate-matrix construction into the kernel-argument block when they fit: `coeffs_host` is the host's
+// view of the (host-mapped) ring slot and is dereferenced HERE, by the caller's thread — staged before this call
+// (hyphy_hip_build_q).  true: the launch no longer reads the ring slot.
+bool fill_coef_inline(ExpmArgs &b, CoefInline &ci) {
+  static const int coef_mode = getenv("HYPHY_HIP_COEF_INLINE") ? atoi(getenv("HYPHY_HIP_COEF_INLINE")) : 1;
+  b.coef_inline = 0;
+  if (b.templates && b.coeffs_host && coef_mode && (size_t)b.n * b.K <= (size_t)kCoefInline) {
+    memcpy(ci.c, b.coeffs_host, (size_t)b.n * b.K * sizeof(double));
+    b.coef_inline = 1;
+  }
+  return b.coef_inline != 0;
+}
+
 bool launch_expm(const ExpmArgs &a, hipStream_t stream) {
   if (a.n <= 0) return false;
   if (a.D == 4 && !a.Pfrag && !a.PTg) {
@@ -1099,11 +1110,7 @@ bool launch_expm(const ExpmArgs &a, hipStream_t stream) {
       static const bool fixed12 = getenv("HYPHY_HIP_EXPM_DEGREE") && atoi(getenv("HYPHY_HIP_EXPM_DEGREE")) == 12;
       b.fixed_degree = fixed12 ? 1 : 0;
       CoefInline ci;
-      static const int coef_mode = getenv("HYPHY_HIP_COEF_INLINE") ? atoi(getenv("HYPHY_HIP_COEF_INLINE")) : 1;
-      if (b.templates_pad && b.coeffs_host && coef_mode && (size_t)b.n * b.K <= (size_t)kCoefInline) {
-        memcpy(ci.c, b.coeffs_host, (size_t)b.n * b.K * sizeof(double));
-        b.coef_inline = 1;
-      }
+      if (b.templates_pad) fill_coef_inline(b, ci);
       switch (H) {
         case 4: hipLaunchKernelGGL((expm64_kernel<4>), dim3(4 * b.n), dim3(512), lds64, stream, b, ci); break;
         case 2: hipLaunchKernelGGL((expm64_kernel<2>), dim3(2 * b.n), dim3(512), lds64, stream, b, ci); break;

@@ -1,6 +1,6 @@
 // 4-state matrix exponential: one thread, everything in registers (shared by expm_nuc_kernel and — folded into the pruning
-// launch of small shards — prune_nuc2_kernel).  Same contract as the MFMA kernels: scaling by a power of two, degree-12 Taylor
-// (Horner), diag_populator before and after the squarings, restart with a 2^7 larger scale when a diagonal exceeds 1, early
+// launch of small shards — prune_nuc2_kernel).  Same contract as the MFMA kernels: scaling by a power of two, Taylor polynomial of
+// degree 12 / 9 / 6 by the scaled norm (Paterson-Stockmeyer), diag_populator before and after the squarings, restart with a 2^7 larger scale when a diagonal exceeds 1, early
 // exit from the squarings, sticky status + NaN matrix on failure (matrix.cpp:5537-5951).
 #pragma once
 #include "common.h"
@@ -31,7 +31,8 @@ __device__ __forceinline__ bool diag_fix4(double *R) {
 }
 
 // exp of matrix m of the batch `a` (rate matrix given, built from templates, or — is_prob — a transition matrix passed through)
-__device__ __forceinline__ void expm4_one(const ExpmArgs &a, int m, double (&R)[16]) {
+// `coef`: the [n][K] coefficients of the fused construction (the ring slot, or the copy in the kernel-argument block)
+__device__ __forceinline__ void expm4_one(const ExpmArgs &a, int m, double (&R)[16], const double *coef) {
   double Q[16];
   if (a.templates) {
 #pragma unroll
@@ -41,7 +42,7 @@ __device__ __forceinline__ void expm4_one(const ExpmArgs &a, int m, double (&R)[
       for (int j = 0; j < 4; j++) {
         if (j == i) continue;
         double v = 0.;
-        for (int k = 0; k < a.K; k++) v += a.coeffs[(size_t)m * a.K + k] * a.templates[(size_t)k * 16 + 4 * i + j];
+        for (int k = 0; k < a.K; k++) v += coef[(size_t)m * a.K + k] * a.templates[(size_t)k * 16 + 4 * i + j];
         Q[4 * i + j] = v;
         d -= v;
       }
@@ -76,24 +77,29 @@ __device__ __forceinline__ void expm4_one(const ExpmArgs &a, int m, double (&R)[
     bool done = false, failed = !(mnorm < 1e300);
     for (int attempt = 0; attempt < 48 && !done && !failed; attempt++) {
       const double scale = ldexp(1.0, -p);
-      double X[16], T[16], T2[16];
+      double X[16], T[16], X2[16], X3[16];
 #pragma unroll
       for (int k = 0; k < 16; k++) X[k] = Q[k] * scale;
-      // Horner: R = I + X (I + X/2 (I + X/3 (... (I + X/12))))
+      // Paterson-Stockmeyer in X^3, degree 3 nb chosen from the scaled norm like the 64-state kernel (expm.hip: taylor_blocks;
+      // sqrt(||X||_1 ||X||_inf) bounds the 2-norm, so the same remainder bound holds): 5 / 4 / 3 products of 4 x 4 instead of the
+      // 11 of a plain Horner scheme (late r03: one thread's 704 dependent multiply-adds were 2.3 us of a 7.8 us launch).
+      const double sn = sqrt(mnorm) * scale;
+      const int nb = sn <= 0.015625 ? 2 : (sn <= 0.11 ? 3 : 4);
+      mm4(X, X, X2);
+      mm4(X2, X, X3);
+      constexpr double kF[13] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                                 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600};
 #pragma unroll
-      for (int k = 0; k < 16; k++) T[k] = X[k] * (1.0 / 12.0);
+      for (int e = 0; e < 16; e++) R[e] = kF[3 * nb - 2] * X[e] + kF[3 * nb - 1] * X2[e] + kF[3 * nb] * X3[e];
 #pragma unroll
-      for (int d = 0; d < 4; d++) T[5 * d] += 1.0;
-      for (int k = 11; k >= 1; k--) {
-        mm4(X, T, T2);
-        const double f = 1.0 / (double)k;
+      for (int d = 0; d < 4; d++) R[5 * d] += kF[3 * nb - 3];
+      for (int blk = nb - 2; blk >= 0; blk--) {
+        mm4(R, X3, T);
 #pragma unroll
-        for (int e = 0; e < 16; e++) T[e] = T2[e] * f;
+        for (int e = 0; e < 16; e++) R[e] = T[e] + kF[3 * blk + 1] * X[e] + kF[3 * blk + 2] * X2[e];
 #pragma unroll
-        for (int d = 0; d < 4; d++) T[5 * d] += 1.0;
+        for (int d = 0; d < 4; d++) R[5 * d] += kF[3 * blk];
       }
-#pragma unroll
-      for (int k = 0; k < 16; k++) R[k] = T[k];
       if (!diag_fix4(R)) {
         p += 7;
         if (p > 900) failed = true;

@@ -1544,7 +1544,7 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
 // only shards of at most two workgroups per CU use it (launch_prune_nuc); the 10^6-site launches keep the scalar path.
 template <int NP, bool PIN, bool FOLD = false, bool LP = false>
 __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict__ ops, const double *__restrict__ PTm,
-                                                         NucArgs a, ExpmArgs ex) {
+                                                         NucArgs a, ExpmArgs ex, typename CoefArg<FOLD>::type ci) {
   constexpr int WGP = 256 * NP;  // patterns per workgroup
   extern __shared__ __align__(16) double nlds[];
   const int nPT = LP ? a.L + a.root_inode : a.L;                       // matrices kept in LDS (LP: every branch)
@@ -1558,7 +1558,7 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
   if constexpr (FOLD && !LP) {
     for (int m = tid; m < ex.n; m += 256) {
       double R[16];
-      expm4_one(ex, m, R);
+      expm4_one(ex, m, R, ex.coef_inline ? ci.c : ex.coeffs);
       const int slot = ex.slots ? ex.slots[m] : m;
       if (blockIdx.x == 0 && ex.Prow) {
 #pragma unroll
@@ -1580,7 +1580,7 @@ __global__ __launch_bounds__(256) void prune_nuc2_kernel(const int4 *__restrict_
     __syncthreads();
     for (int m = tid; m < ex.n; m += 256) {
       double R[16];
-      expm4_one(ex, m, R);
+      expm4_one(ex, m, R, ex.coef_inline ? ci.c : ex.coeffs);
       const int slot = ex.slots ? ex.slots[m] : m;
 #pragma unroll
       for (int k = 0; k < 16; k++) PT[slot * 16 + k] = R[4 * (k & 3) + (k >> 2)];
@@ -2197,8 +2197,10 @@ static bool nuc_uses_lp(const NucArgs &a, int np, bool folded, int dev) {
 // true when launch_prune_nuc can take the evaluation's matrix exponentials along (ex != nullptr): the r03 kernel on a shard of
 // at most two workgroups per CU
 bool prune_nuc_folds_expm(int L, int S_pad, int n_ops) {
+  // (late r03: on by default — with the Paterson-Stockmeyer 4 x 4 exponential and the coefficients in the kernel-argument block the
+  //  folded launch is 41 us per step at 50 000 sites against 42.5-43 with a launch of its own; HYPHY_HIP_NUC_FOLD=0 turns it off)
   const char *fe = getenv("HYPHY_HIP_NUC_FOLD");
-  const bool on = fe && atoi(fe) != 0;  // (opt-in: measured neutral, 45.5 vs 45.6 us per step at 50 000 sites)
+  const bool on = !(fe && atoi(fe) == 0);
   return on && n_ops > 0 && prune_nuc_takes_leaf_pairs(L) && nuc_forced() != 2 && S_pad % 256 == 0 && S_pad / 256 <= 512;
 }
 
@@ -2241,30 +2243,36 @@ void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex) 
   const size_t lds = nuc2_lds(a, np);
   ExpmArgs none;
   none.n = 0;
+  CoefInline ci;          // (contents only matter to the folded launches, which fill it below; copied into the kernel arguments at launch)
+  ExpmArgs exb;
+  if (ex && ex->n > 0) {
+    exb = *ex;
+    fill_coef_inline(exb, ci);
+  }
   // schedule words + every branch's matrix from LDS (LP): shards of at most two workgroups per CU
   const bool lp = nuc_uses_lp(a, np, ex && ex->n > 0, dev);
   if (lp) {
     const size_t ldl = nuc2_lds(a, 1, true);
     if (ex && ex->n > 0) {  // (with this evaluation's exponentials folded in)
-      if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, true, true>), grid, block, ldl, stream, a.ops, a.PT, a, *ex);
-      else hipLaunchKernelGGL((prune_nuc2_kernel<1, false, true, true>), grid, block, ldl, stream, a.ops, a.PT, a, *ex);
+      if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, true, true>), grid, block, ldl, stream, a.ops, a.PT, a, exb, ci);
+      else hipLaunchKernelGGL((prune_nuc2_kernel<1, false, true, true>), grid, block, ldl, stream, a.ops, a.PT, a, exb, ci);
       return;
     }
-    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, false, true>), grid, block, ldl, stream, a.ops, a.PT, a, none);
-    else hipLaunchKernelGGL((prune_nuc2_kernel<1, false, false, true>), grid, block, ldl, stream, a.ops, a.PT, a, none);
+    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, false, true>), grid, block, ldl, stream, a.ops, a.PT, a, none, CoefNone{0});
+    else hipLaunchKernelGGL((prune_nuc2_kernel<1, false, false, true>), grid, block, ldl, stream, a.ops, a.PT, a, none, CoefNone{0});
     return;
   }
   if (ex && ex->n > 0 && np == 1) {
-    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, true>), grid, block, lds, stream, a.ops, a.PT, a, *ex);
-    else hipLaunchKernelGGL((prune_nuc2_kernel<1, false, true>), grid, block, lds, stream, a.ops, a.PT, a, *ex);
+    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true, true>), grid, block, lds, stream, a.ops, a.PT, a, exb, ci);
+    else hipLaunchKernelGGL((prune_nuc2_kernel<1, false, true>), grid, block, lds, stream, a.ops, a.PT, a, exb, ci);
     return;
   }
   if (np == 2) {
-    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<2, true>), grid, block, lds, stream, a.ops, a.PT, a, none);
-    else hipLaunchKernelGGL((prune_nuc2_kernel<2, false>), grid, block, lds, stream, a.ops, a.PT, a, none);
+    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<2, true>), grid, block, lds, stream, a.ops, a.PT, a, none, CoefNone{0});
+    else hipLaunchKernelGGL((prune_nuc2_kernel<2, false>), grid, block, lds, stream, a.ops, a.PT, a, none, CoefNone{0});
   } else {
-    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true>), grid, block, lds, stream, a.ops, a.PT, a, none);
-    else hipLaunchKernelGGL((prune_nuc2_kernel<1, false>), grid, block, lds, stream, a.ops, a.PT, a, none);
+    if (pin) hipLaunchKernelGGL((prune_nuc2_kernel<1, true>), grid, block, lds, stream, a.ops, a.PT, a, none, CoefNone{0});
+    else hipLaunchKernelGGL((prune_nuc2_kernel<1, false>), grid, block, lds, stream, a.ops, a.PT, a, none, CoefNone{0});
   }
 }
 

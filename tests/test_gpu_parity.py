@@ -1286,6 +1286,16 @@ def test_expm_degree_follows_the_norm_without_losing_accuracy():
     Po = oracle.expm(Q, True)
     assert np.max(np.abs(P - Po)) < 2e-15, np.max(np.abs(P - Po), axis=(1, 2))
     assert np.max(np.abs(P.sum(2) - 1.0)) < 1e-14
+    # the 4-state exponential (expm4.h, one thread per matrix) follows the same rule on sqrt(||X||_1 ||X||_inf)
+    Q4 = models.nuc_rev_Q(1.0, dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4), np.array([0.35, 0.15, 0.2, 0.3]))
+    n4 = np.sqrt(np.abs(Q4).sum(1).max() * np.abs(Q4).sum(0).max())
+    Qs = np.stack([Q4 * (nm / n4) for nm in norms + [3.0, 40.0]])
+    P4 = hip.expm_batch(Qs)
+    P4o = oracle.expm(Qs, False)
+    err4 = np.max(np.abs(P4 - P4o), axis=(1, 2))
+    assert err4[:len(norms)].max() < 2e-15, err4            # no squarings (|| <= 1/4) or one (0.4)
+    assert err4[len(norms):].max() < 5e-14, err4            # 5 and 8 squarings: the reference goldens' tolerance
+    assert np.max(np.abs(P4.sum(2) - 1.0)) < 1e-14
 
 
 @pytest.mark.parametrize("lp,fold", [("0", "0"), ("1", "0"), ("1", "1"), ("0", "1")])
