@@ -937,7 +937,7 @@ __global__ __launch_bounds__(512) void expm64_kernel(ExpmArgs a, CoefInline ci) 
 // ---------------------------------------------------------------------------------------------
 // (coefficients from the ring slot: a 3.2 KB kernel-argument block costs this 61-thread launch more than the PCIe read —
 //  measured 11-15 against 9.8 us event-timed)
-__global__ void expm_nuc_kernel(ExpmArgs a) {
+__global__ __launch_bounds__(64) void expm_nuc_kernel(ExpmArgs a) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= a.n) return;
   const int slot = a.slots ? a.slots[m] : m;

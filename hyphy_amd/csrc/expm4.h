@@ -7,6 +7,9 @@
 
 namespace hyhip {
 
+static __constant__ double kInvFact4[13] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                                            1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600};
+
 __device__ __forceinline__ void mm4(const double *A, const double *B, double *C) {
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -87,8 +90,7 @@ __device__ __forceinline__ void expm4_one(const ExpmArgs &a, int m, double (&R)[
       const int nb = sn <= 0.015625 ? 2 : (sn <= 0.11 ? 3 : 4);
       mm4(X, X, X2);
       mm4(X2, X, X3);
-      constexpr double kF[13] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
-                                 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600};
+      const double *kF = kInvFact4;  // (a __constant__ table: a local array indexed by nb would live in scratch memory)
 #pragma unroll
       for (int e = 0; e < 16; e++) R[e] = kF[3 * nb - 2] * X[e] + kF[3 * nb - 1] * X2[e] + kF[3 * nb] * X3[e];
 #pragma unroll
