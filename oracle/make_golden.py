@@ -619,6 +619,7 @@ def main():
             raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
         os.makedirs(OUT, exist_ok=True)
         fel_case()
+        fel_case("ref_fel_10x48_all", n_taxa=10, n_codons=48, seed=203, branches="All")   # (every branch tested: no nuisance rate)
         fel_case("ref_meme_12x60", analysis="MEME")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "busted":

@@ -19,8 +19,8 @@ def templates(rev, pf):
     return T
 
 
-def run(max_iter=400):
-    fx = common.load("ref_fel_12x60")
+def run(max_iter=400, name="ref_fel_12x60"):
+    fx = common.load(name)
     S = fx["leaf_codes"].shape[1]
     with hip.HipPartition(61, fx["flat_parents"], int(fx["L"]), fx["leaf_codes"], None, np.ones(S, dtype=np.int64)) as part:
         part.set_q_templates(templates(fx["rev"], fx["pos_freqs"]))
@@ -58,7 +58,7 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "meme":
     sys.exit(0)
 
 if __name__ == "__main__":
-    fx, glob, res = run()
+    fx, glob, res = run(name=sys.argv[1] if len(sys.argv) > 1 else "ref_fel_12x60")
     ref = fx["fel_table"]
     print("global logL: device", glob, "reference", float(fx["global_logl"]))
     print("launches", res.launches)
