@@ -22,6 +22,8 @@ Cases (SURVEY §8c "Fixtures to commit"):
   ref_fluHA       real data of SimpleOptimizations/IntermediateNuc.bf (HKY85, 349 influenza sequences: the 4-state path)
   ref_busted_16x150 (python -m oracle.make_golden busted) the reference's unmodified BUSTED.bf on a simulated 16 x 150 codon
                   alignment: MLEs of the unconstrained branch-site mixture + the log L at them (explicit-form path)
+  ref_fubar_12x60 (python -m oracle.make_golden fubar) the reference's unmodified FUBAR.bf: site log-likelihoods of a 12 x 60 codon
+                  alignment on its 10 x 10 (alpha, beta) grid, recovered from FUBAR's cache file (per-site batched evaluation)
   ref_fel_12x60   (python -m oracle.make_golden fel) the reference's unmodified FEL.bf on a 12 x 60 codon alignment: per-site
                   alpha / beta / LRT / p-value table + the global fit its site phase starts from
 """
@@ -490,6 +492,123 @@ def busted_case(name="ref_busted_16x150", n_taxa=16, n_codons=150, seed=131, bra
           f"background omegas {om['background']} weights {w['background']}; BUSTED p = {fx['p_value']}")
 
 
+def _hbl_matrix(text, key_pos):
+    """The numeric matrix printed by HBL behind position `key_pos` of `text` ("{ {a, b} {c, d} }" with arbitrary white space)."""
+    i = text.index("{", key_pos)
+    depth, j = 0, i
+    while True:
+        ch = text[j]
+        if ch == "{":
+            depth += 1
+        elif ch == "}":
+            depth -= 1
+            if depth == 0:
+                break
+        j += 1
+    body = text[i + 1:j]
+    rows = [r for r in body.replace("\n", " ").split("}") if "{" in r]
+    return np.array([[float(x) for x in r.split("{")[1].split(",")] for r in rows])
+
+
+def fubar_case(name="ref_fubar_12x60", n_taxa=12, n_codons=60, seed=91, grid=10, threads=8):
+    """The reference's OWN FUBAR analysis (res/TemplateBatchFiles/SelectionAnalyses/FUBAR.bf, unmodified, unmodified binary): its
+    grid phase evaluates the site log-likelihoods of the alignment under MG94xREV at every point (alpha, beta) of a grid x grid
+    rate grid — site rates x per-branch (synonymous, non-synonymous) factors taken from the nucleotide GTR fit — which is exactly
+    the shape of hyphy_hip_site_fits_evaluate (one parameter set per grid point).  FUBAR's cache file keeps that matrix as per-site
+    softmax columns + log normalisers (modules/grid_compute.ibf: ConvertToConditionals), so the raw site log-likelihoods are
+    recovered as log(conditional) + scaler.  A two-line wrapper also prints `fubar.pass1.mle` (the per-branch factors, theta's).
+    Fixture: per-site codon states, tree, factors, theta's, position frequencies, the grid, and the reference's [grid point][site]
+    log-likelihood matrix; a sample of entries is checked against the CPU oracle before anything is written."""
+    import json
+    import re
+    import subprocess
+    import tempfile
+    from oracle import oracle
+    syn = data.evolve(n_taxa, n_codons, 3, seed=seed, p_change=0.10)
+    flat = syn.flat
+    tmp = tempfile.mkdtemp(prefix="fubarref_")
+    hbl.write_fasta(os.path.join(tmp, "aln.fasta"), flat.leaf_names, syn.seqs)
+    with open(os.path.join(tmp, "tree.nwk"), "w") as fh:
+        fh.write(tree.to_newick(syn.tree) + ";\n")
+    bf = "/root/reference/res/TemplateBatchFiles/SelectionAnalyses/FUBAR.bf"
+    with open(os.path.join(tmp, "wrap.bf"), "w") as fh:
+        # (the factors are read back AFTER the run, from the constraints the grid phase left on the tree: FUBAR re-applies its first-pass
+        #  estimates through the model's set-branch-length hook, a root finder whose answer differs from the values it printed
+        #  before by a few 1e-7 relative)
+        fh.write(f'ExecuteAFile ("{bf}");\nfubar.after = estimators.ExtractMLEs ("fubar.lf.codon", fubar.model_id_to_object);\n'
+                 f'fprintf ("{tmp}/dump.txt", CLEAR_FILE, fubar.after);\n')
+    r = subprocess.run([hbl.REF_BIN, "LIBPATH=/root/reference/res", f"CPU={threads}", os.path.join(tmp, "wrap.bf"),
+                        "--alignment", os.path.join(tmp, "aln.fasta"), "--tree", os.path.join(tmp, "tree.nwk"), "--code", "Universal",
+                        "--grid", str(grid), "--method", "Variational-Bayes", "--cache", os.path.join(tmp, "fubar.cache"),
+                        "--output", os.path.join(tmp, "fubar.json")], capture_output=True, text=True, timeout=3600)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout[-3000:] + r.stderr[-2000:])
+    d = open(os.path.join(tmp, "dump.txt")).read()
+    c = open(os.path.join(tmp, "fubar.cache")).read()
+    num = r"([-0-9.e+]+)"
+    alpha_b = {m.group(1): float(m.group(2)) for m in re.finditer(
+        r'"(\w+)":\{\s*"MLE":[-0-9.e+]+,\s*"non-synonymous rate":\{.*?\},\s*"synonymous rate":\{\s*"ID":"alpha",\s*"MLE":[-0-9.e+]+,\s*'
+        r'"constraint":"fubar\.scaler\.alpha\*' + num + '"', d, re.S)}
+    beta_b = {m.group(1): float(m.group(2)) for m in re.finditer(
+        r'"(\w+)":\{\s*"MLE":[-0-9.e+]+,\s*"non-synonymous rate":\{\s*"ID":"beta",\s*"MLE":[-0-9.e+]+,\s*"constraint":"fubar\.scaler\.beta\*' + num + '"', d, re.S)}
+    assert len(alpha_b) == flat.n_branches and len(beta_b) == flat.n_branches, (len(alpha_b), len(beta_b))
+    theta = {m.group(1) + m.group(2): float(m.group(3)) for m in re.finditer(
+        r'"Substitution rate from nucleotide (\w) to nucleotide (\w)":\{\s*"ID":"[^"]+",\s*"MLE":' + num, d)}
+    efv = _hbl_matrix(d, d.index("{", d.index('"EFV"')) + 1).ravel()      # ("EFV": {"<model id>": <matrix>})
+    assert efv.shape == (61,), efv.shape
+    A = np.zeros((61, 13))
+    for row, cdn in enumerate(models.sense_codons()):
+        for pos in range(3):
+            A[row, 4 * pos + "ACGT".index(cdn[pos])] = 1.0
+    A[:, 12] = 1.0
+    pf = np.exp(np.linalg.lstsq(A, np.log(efv), rcond=None)[0][:12]).reshape(3, 4)
+    pf /= pf.sum(1, keepdims=True)
+    pi = models.f3x4_codon_freqs(pf)
+    assert np.abs(pi - efv).max() < 1e-14
+    cond = _hbl_matrix(c, c.index('"conditionals"', c.index('"conditionals"') + 5))   # [grid points][sites]
+    scal = _hbl_matrix(c, c.index('"scalers"')).ravel()
+    G = grid * grid
+    assert cond.shape == (G, n_codons) and scal.shape == (n_codons,), (cond.shape, scal.shape)
+    with np.errstate(divide="ignore"):
+        site_logl = np.log(cond) + scal[None, :]          # (-inf where the reference's softmax underflowed to 0)
+    j = json.load(open(os.path.join(tmp, "fubar.json")))
+    gridm = np.array(j["grid"], dtype=np.float64)[:, :2]
+    assert gridm.shape == (G, 2)
+    names = flat.branch_names()
+    ca = np.array([alpha_b[n] for n in names])
+    cb = np.array([beta_b[n] for n in names])
+    rev = np.array([theta["AC"], theta["AT"], theta["CG"], theta["CT"], theta["GT"]])
+    assert theta["AG"] == 1.0
+    sites = data.from_states(syn.states, 61, compress_patterns=False)
+    # a sample of (grid point, site) entries against the CPU oracle (explicit exponentials, one pattern)
+    T = np.zeros((2, 61, 61))
+    rv = dict(zip(("AC", "AT", "CG", "CT", "GT"), rev), AG=1.0)
+    for (i, jj, nm, ns, f) in models.mg94rev_template(pf):
+        T[1 if ns else 0, i, jj] = rv[nm] * f
+    nodes = np.arange(len(names), dtype=np.int64)
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for _ in range(40):
+        g, st = int(rng.integers(G)), int(rng.integers(n_codons))
+        if not np.isfinite(site_logl[g, st]) or cond[g, st] < 1e-12:
+            continue
+        Q = np.stack([gridm[g, 0] * ca[b] * T[0] + gridm[g, 1] * cb[b] * T[1] for b in range(len(names))])
+        for b in range(len(names)):
+            np.fill_diagonal(Q[b], 0.0)
+            np.fill_diagonal(Q[b], -Q[b].sum(1))
+        op = oracle.OraclePartition(61, flat.flat_parents, flat.L, sites.leaf_codes[:, st:st + 1], None, np.ones(1))
+        op.set_P(nodes, oracle.expm(Q, True))
+        mine = op.compute_block(nodes, pi)
+        worst = max(worst, abs(mine - site_logl[g, st]) / abs(mine))
+    assert worst < 1e-9, worst
+    fx = dict(kind="codon", D=61, L=flat.L, flat_parents=flat.flat_parents, leaf_codes=sites.leaf_codes, syn_factor=ca, nonsyn_factor=cb,
+              rev=rev, pos_freqs=pf, root_freqs=pi, grid=gridm, site_logl=site_logl, conditionals=cond, scalers=scal,
+              names=np.array(flat.leaf_names), seqs=np.array(syn.seqs), newick=np.array(tree.to_newick(syn.tree)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(f"{name}: {G} grid points x {n_codons} sites; {int(np.isfinite(site_logl).sum())} finite entries; "
+          f"sampled entries agree with the oracle to {worst:.1e}")
+
+
 def _crc(a):
     import zlib
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff
@@ -621,6 +740,12 @@ def main():
         fel_case()
         fel_case("ref_fel_10x48_all", n_taxa=10, n_codons=48, seed=203, branches="All")   # (every branch tested: no nuisance rate)
         fel_case("ref_meme_12x60", analysis="MEME")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "fubar":
+        if not hbl.have_reference():
+            raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
+        os.makedirs(OUT, exist_ok=True)
+        fubar_case()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "busted":
         if not hbl.have_reference():

@@ -44,3 +44,20 @@ def busted_components(fx):
         for k in range(3):
             Qc[b, k] = models.mg94rev_Q(t[b], float(om[k]), rev, fx["pos_freqs"])
     return Qc, W
+
+
+def fubar_site_fit_args(fx, grid_points=None, sites=None):
+    """Arguments of hyphy_hip_site_fits_evaluate for a `ref_fubar_*` fixture: one branch group, per-branch (synonymous, non-synonymous)
+    factors, and one parameter set per grid point — every site of a set carries that point's (alpha, beta).
+    Returns (templates [2, 61, 61], branch_group [B], branch_coeffs [B, 2], site_mult [n, S, 1, 2], leaf_codes [L, S], expected [n, S])."""
+    from hyphy_amd import models
+    rev = dict(zip(REV_KEYS, (float(x) for x in fx["rev"])), AG=1.0)
+    T = np.zeros((2, 61, 61))
+    for (i, j, name, ns, f) in models.mg94rev_template(fx["pos_freqs"]):
+        T[1 if ns else 0, i, j] = rev[name] * f
+    gp = np.arange(fx["grid"].shape[0]) if grid_points is None else np.asarray(grid_points)
+    st = np.arange(fx["leaf_codes"].shape[1]) if sites is None else np.asarray(sites)
+    B = len(fx["syn_factor"])
+    coeffs = np.ascontiguousarray(np.stack([fx["syn_factor"], fx["nonsyn_factor"]], axis=1))
+    mult = np.ascontiguousarray(np.broadcast_to(fx["grid"][gp][:, None, None, :], (len(gp), len(st), 1, 2)))
+    return T, np.zeros(B, dtype=np.int64), coeffs, mult, np.ascontiguousarray(fx["leaf_codes"][:, st]), fx["site_logl"][np.ix_(gp, st)]

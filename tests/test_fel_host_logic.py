@@ -140,3 +140,19 @@ def test_bench_reads_the_measured_instruction_peak_from_the_committed_microbench
     assert src == "profiles/r01_ubench_mfma_f64.txt" and 45.0 < peak < 55.0
     flops, bytes_ = bench.alg_work(61, 9974, 64, 62)
     assert flops == 4642198820 and bytes_ == 599317712      # SURVEY 8d at the headline size
+
+
+def test_fubar_fixture_through_the_site_fit_interface():
+    """tests/golden/ref_fubar_12x60.npz (site log-likelihoods of the reference's own FUBAR.bf on its rate grid) through the
+    argument conventions of hyphy_hip_site_fits_evaluate — here with the numpy stand-in on a few grid points and sites (scipy's
+    expm, 61 states); the GPU test runs the same helper over the whole 100 x 60 matrix on the device."""
+    from tests import common
+    fx = common.load("ref_fubar_12x60")
+    gp, st = [0, 11, 37, 99], [0, 1, 7, 30]
+    T, group, coeffs, mult, codes, want = common.fubar_site_fit_args(fx, gp, st)
+    flat = tree.flat_from_parents(fx["flat_parents"], int(fx["L"]))
+    part = _NumpySiteFits(flat, codes, T)
+    got = part.site_fits_evaluate(group, coeffs, mult, fx["root_freqs"])
+    fin = np.isfinite(want)
+    assert fin.sum() >= 12
+    assert np.max(np.abs(got[fin] - want[fin]) / np.abs(want[fin])) < 1e-9

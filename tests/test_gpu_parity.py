@@ -1328,3 +1328,28 @@ def test_four_state_kernel_with_and_without_the_lds_schedule(name, lp, fold, mon
     assert abs(plain - ll) <= 1e-13 * abs(ll) and after == ll
     site = (np.log(lik) - sc * 64 * np.log(2.0))[fx["site_to_pattern"]]
     assert np.max(np.abs(site - fx["site_logl"]) / np.abs(fx["site_logl"])) < RTOL
+
+
+def test_site_fits_reproduce_the_reference_fubar_grid():
+    """The grid phase of the reference's OWN FUBAR.bf (unmodified batch file + binary, `python -m oracle.make_golden fubar`)
+    evaluates every site of the alignment at every (alpha, beta) of a 10 x 10 rate grid; its cache file keeps the matrix
+    (softmax columns + log normalisers).  hyphy_hip_site_fits_evaluate with one parameter set per grid point — the matrices
+    never formed, exp(Q) applied by uniformisation — must return the same [grid point][site] log-likelihoods: 1e-9 relative
+    wherever the reference's softmax did not underflow (5 489 of 6 000 entries), rates from 0 to 50 x the branch factors."""
+    hip = _hip()
+    fx = common.load("ref_fubar_12x60")
+    T, group, coeffs, mult, codes, want = common.fubar_site_fit_args(fx)
+    S = codes.shape[1]
+    with hip.HipPartition(61, fx["flat_parents"], int(fx["L"]), codes, None, np.ones(S, dtype=np.int64)) as part:
+        part.set_q_templates(T)
+        got = part.site_fits_evaluate(group, coeffs, mult, fx["root_freqs"])
+    assert got.shape == want.shape
+    fin = np.isfinite(want)
+    assert fin.sum() > 5000
+    assert np.max(np.abs(got[fin] - want[fin]) / np.abs(want[fin])) < 1e-9
+    # (and the conditionals FUBAR's inference consumes: per-site softmax over the grid)
+    g2 = np.where(np.isfinite(got), got, -np.inf)     # (alpha = beta = 0 at a variable site: likelihood 0)
+    mx = g2.max(0, keepdims=True)
+    cond = np.exp(g2 - mx)
+    cond /= cond.sum(0, keepdims=True)
+    assert np.max(np.abs(cond - fx["conditionals"])) < 1e-9
