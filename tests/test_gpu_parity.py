@@ -1353,3 +1353,28 @@ def test_site_fits_reproduce_the_reference_fubar_grid():
     cond = np.exp(g2 - mx)
     cond /= cond.sum(0, keepdims=True)
     assert np.max(np.abs(cond - fx["conditionals"])) < 1e-9
+
+
+def test_ordinary_per_site_evaluation_reproduces_the_reference_fubar_grid():
+    """The same FUBAR matrix the cheap way: a grid point gives every SITE the same rates, so one ordinary evaluation with per-site
+    outputs (hyphy_hip_evaluate: 21 exponentials + one pruning pass) yields a whole row of it — what an adapter-side FUBAR would
+    call 100-400 times; the per-site batched kernel is for analyses whose sites carry DIFFERENT rates (FEL, MEME).  Six grid
+    points, every site, 1e-9 relative."""
+    _hip()
+    fx = common.load("ref_fubar_12x60")
+    T, group, coeffs, mult, codes, want = common.fubar_site_fit_args(fx)
+    S, B = codes.shape[1], coeffs.shape[0]
+    nodes = np.arange(B, dtype=np.int64)
+    idx = np.arange(61)
+    with _hip().HipPartition(61, fx["flat_parents"], int(fx["L"]), codes, None, np.ones(S, dtype=np.int64)) as part:
+        for g in (11, 37, 55, 64, 99, 9):
+            a, b = fx["grid"][g]
+            Q = a * coeffs[:, 0, None, None] * T[0][None] + b * coeffs[:, 1, None, None] * T[1][None]
+            Q[:, idx, idx] = 0.0
+            Q[:, idx, idx] = -Q.sum(2)
+            ll, lik, sc = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+            got = np.log(lik) - sc * 64 * np.log(2.0)
+            fin = np.isfinite(want[g])
+            assert fin.sum() >= 40, (g, fin.sum())
+            assert np.max(np.abs(got[fin] - want[g][fin]) / np.abs(want[g][fin])) < 1e-9, g
+            assert abs(ll - got.sum()) <= 1e-10 * abs(ll)
