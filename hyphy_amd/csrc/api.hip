@@ -385,7 +385,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     const char *tl_path = getenv("HYPHY_HIP_TIMELINE");
     const bool tl_wave = p->variant == 1;  // wave-per-tile kernel: one record of 8 words per wave of the grid
     const size_t tl_waves = (size_t)s.ntiles * std::max(1, n_cat_batch) * std::max<size_t>(1, p->programs.size());
-    const size_t tl_n = tl_wave ? tl_waves * 8 : (size_t)kTraceWG * p->NW * std::max(1, n_ops) * 4;
+    const size_t tl_n = tl_wave ? tl_waves * 24 : (size_t)kTraceWG * p->NW * std::max(1, n_ops) * 4;
     if (tl_path && n_ops > 0 && s.T == 1) {
       HIPCHK(hipMalloc((void **)&pa.timeline, tl_n * sizeof(long long)));
       HIPCHK(hipMemsetAsync(pa.timeline, 0, tl_n * sizeof(long long), s.stream));
@@ -429,11 +429,14 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       hipFree(pa.timeline);
       if (tl_wave) {
         if (FILE *f = fopen(tl_path, "w")) {
-          fprintf(f, "# wave t_start t_prologue t_program t_end levels how hw_id xcc_id   (100 MHz ticks; grid = %s)\n",
+          fprintf(f, "# wave t_start t_prologue t_program t_end levels how hw_id xcc_id   (100 MHz ticks; grid = %s)  then shader cycles: "
+                     "16 phase buckets (prune.hip HYPHY_TR)\n",
                   p->chain ? "tiles x classes x sources" : "programs x classes x tiles");
           for (size_t k = 0; k < tl_waves; k++) {
-            const long long *r = &h[k * 8];
-            fprintf(f, "%zu %lld %lld %lld %lld %lld %lld %lld %lld\n", k, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+            const long long *r = &h[k * 24];
+            fprintf(f, "%zu", k);
+            for (int i = 0; i < 24; i++) fprintf(f, " %lld", r[i]);
+            fprintf(f, "\n");
           }
           fclose(f);
         }

@@ -794,13 +794,25 @@ __device__ __forceinline__ double row_sum4(double x) {
 #ifndef HYPHY_ABL
 #define HYPHY_ABL 0
 #endif
+// phase accounting of the TRACE build: every shader cycle of a wave goes to exactly one bucket (the time since the previous
+// mark goes to bucket b): 0 edge products, 1 their number, 2 leaf entries, 3 leaves, 4 finalisations, 5 trunk joins (arrival,
+// deposit), 6 child tiles fetched from global memory, 7 wave prologue, 8 schedule-entry decode (scalar loads of the entry),
+// 9 trunk bookkeeping before the edge (join records, arrival counter), 10 deposits multiplied in, 11 between entries and
+// their finalisation, 12 ahead of an edge product inside an entry, 13 root epilogue / retirement
+#define HYPHY_TR(b)                       \
+  if constexpr (TRACE) {                  \
+    const long long n_ = clock64();       \
+    tr_ph[b] += n_ - tr_last, tr_last = n_; \
+  }
 #define HYPHY_TRACE_STAMP(k) \
   if constexpr (TRACE) tr_t[k] = wall_clock64();
 #define HYPHY_TRACE_FINISH(how)                                                                                          \
   if constexpr (TRACE) {                                                                                                 \
     if (a.timeline && threadIdx.x == 0) {                                                                                \
-      long long *r_ = a.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;         \
+      long long *r_ = a.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 24;        \
       r_[0] = tr_t[0], r_[1] = tr_t[1], r_[2] = tr_t[2], r_[3] = wall_clock64(), r_[4] = tr_levels, r_[5] = (how);      \
+      HYPHY_TR(13)                                                                                                       \
+      for (int i_ = 0; i_ < 16; i_++) r_[8 + i_] = tr_ph[i_];                                                            \
       r_[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                                                 \
       r_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                                                \
     }                                                                                                                    \
@@ -817,6 +829,11 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
   if (a.chain && (int)blockIdx.x >= a.ntiles) return;  // (tile dimension padded to a multiple of 8: launch_prune_T)
   [[maybe_unused]] long long tr_t[3] = {0, 0, 0};
   [[maybe_unused]] int tr_levels = 0;
+  // TRACE: shader cycles (s_memtime) in [0] internal edge products, [1] their number, [2] leaf entries, [3] leaves,
+  // [4] finalisations, [5] trunk joins (arrival bookkeeping, deposits), [6] child tiles fetched from global memory
+  [[maybe_unused]] long long tr_ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] long long tr_last = 0;
+  if constexpr (TRACE) tr_last = clock64();
   HYPHY_TRACE_STAMP(0)
   // legacy grid = (leaf programs, classes, tiles): tile-major dispatch order, so that a tile's chained parent
   // programs start while other tiles still run their leaf fragments (no low-occupancy tail);
@@ -863,6 +880,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
   };
 
   HYPHY_TRACE_STAMP(1)
+  HYPHY_TR(7)
   const f64x4 ones = (f64x4){1., 1., 1., 1.}, zeros = (f64x4){0., 0., 0., 0.};
   f64x4 acc[NW], bch[NW];  // running product of the current parent / the node finalised last (scaled)
   f64x2 dreg[NKK / 2];     // chain schedules: a sibling's deposited edge product, fetched while this wave's own product runs
@@ -883,6 +901,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
   [[maybe_unused]] f64x2 Apre[NW];   // APF: first A chunk of branch `apre_branch`, requested under the previous product
   [[maybe_unused]] int apre_branch = -1;
   auto edge_product = [&](int branch, auto bsrc, const double *pre, const int *poll = nullptr, int next_branch = -1) {
+    HYPHY_TR(12)
     const double *pf = a.Pfrag + (size_t)((HYPHY_ABL & 1) ? (branch & abl_mask) : branch) * NW * TILE;  // uniform
     f64x4 D[NW];
 #pragma unroll
@@ -924,6 +943,11 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
     for (int w = 0; w < NW; w++) acc[w] *= D[w];
     if (HYPHY_ABL & 16) abl_after_edge = true;
     if (APF) apre_branch = next_branch;
+    if constexpr (TRACE) {
+      asm volatile("" ::"v"(acc[0][0]));  // (the stamp waits for the product)
+      tr_ph[1]++;
+    }
+    HYPHY_TR(0)
   };
   auto leaf_gather = [&](int lf, int c) {
     const double *bl = a.PTg + (size_t)lf * DP * DP;  // uniform; [code][w][g][r]
@@ -942,6 +966,8 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
   for (int oi = 0; oi < n_ops; oi++) {
     const int4 nxt = pops[oi + 1];
     const int kind = op.x & 3;
+    if constexpr (TRACE) asm volatile("" ::"s"(kind));
+    HYPHY_TR(8)
     // APF: the edge after this one, when the schedule's next entry is an internal edge (or, behind the run's last entry,
     // the caller's hint: the first trunk edge above a source)
     int nb = -1;
@@ -968,6 +994,11 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
           }, nullptr);
         }
       }
+      if constexpr (TRACE) {
+        asm volatile("" ::"v"(acc[0][0]));
+        tr_ph[3] += nl;
+      }
+      HYPHY_TR(2)
     } else if (kind == OPK_INTERNAL) {
       const int slot = (op.x >> 24) & 0xff;
       if (slot < 2) {  // the node finalised by the previous entry: operand straight from registers (LB: from its LDS tile)
@@ -1004,6 +1035,8 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
           acc[w] *= (f64x4){dreg[2 * w][0], dreg[2 * w][1], dreg[2 * w + 1][0], dreg[2 * w + 1][1]};
         cnt += dcnt;
       }
+      if constexpr (TRACE) asm volatile("" ::"v"(acc[0][0]));
+      HYPHY_TR(10)
     } else {
       // The child's tile is in global memory — the root of a child fragment finished by another workgroup
       // of this launch (agent-scope loads; its arrival was counted before this program started), or a node
@@ -1024,6 +1057,8 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
         for (int k2 = 0; k2 < NKK / 2; k2++)
           *reinterpret_cast<f64x2 *>(stage + (k2 * 64 + lane) * 2) = ld16(src, (unsigned)(k2 * 64 + lane) * 16u);
       }
+      if constexpr (TRACE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      HYPHY_TR(6)
       edge_product(op.z, [&](int k2) -> f64x2 { return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2); },
                    nullptr, nullptr, nb);
       cnt += ccnt;
@@ -1031,6 +1066,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
 
     if (op.x & OPF_LAST) {
       const int slot = (op.x >> 16) & 0xff;
+      HYPHY_TR(11)
       if (op.y == a.pin_inode) {  // pinned internal node: only the pinned state survives (tree_evaluator.cpp:589-594)
         const int ps = (int)a.pin[tile0 * 16 + sl];
 #pragma unroll
@@ -1089,6 +1125,8 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
       }
       bcnt = cnt;
       cnt = 0;
+      if constexpr (TRACE) asm volatile("" ::"v"(bch[0][0]));
+      HYPHY_TR(4)
     }
     op = nxt;
   }
@@ -1153,6 +1191,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
           }
         }
       }
+      HYPHY_TR(9)
       edge_product(jc.x >> 16, [&](int k2) -> f64x2 {
         if constexpr (LB) return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2);
         else return (f64x2){bch[k2 >> 1][(k2 & 1) * 2], bch[k2 >> 1][(k2 & 1) * 2 + 1]};
@@ -1203,6 +1242,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
       early = -1;
       if (jp.x >= 0 && (jn[jp.x & 0xffff].y & 0xff) > 1 && lane == 0)
         early = __hip_atomic_load(a.frag_ctr + (size_t)(jp.x & 0xffff) * a.ntiles + tile0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      HYPHY_TR(5)
       run_ops(ops + jp.z, jp.w, c, pre != nullptr, pre_cnt);
       if constexpr (TRACE) tr_levels += 1 + (pre ? 100 : 0);
       c = p;

@@ -31,3 +31,17 @@ for s_ in range(src.max() + 1):
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; se = (hw >> 13) & 7
 key = xcc * 100000 + se * 1000 + cu * 10 + simd
 print("distinct SIMDs used:", len(np.unique(key)), " distinct CUs:", len(np.unique(key // 10)))
+# phase cycles (records with 24 words, r04): where a wave's shader cycles go (prune.hip HYPHY_TR buckets)
+if a.shape[1] >= 25:
+    ph = a[:, 9:25]
+    names = {0: "edge products", 2: "leaf entries", 4: "finalisations", 5: "trunk joins (arrive/deposit)", 6: "child tiles from global memory",
+             7: "wave prologue", 8: "schedule-entry decode", 9: "trunk bookkeeping before the edge", 10: "deposits multiplied in",
+             11: "between entry and finalisation", 12: "ahead of an edge product", 13: "epilogue / retirement"}
+    tot = sum(ph[:, i].sum() for i in names)
+    nsimd = len(np.unique(key))
+    print(f"shader cycles, all waves: {tot/1e6:.1f} M = {tot/nsimd/1e3:.1f} k per SIMD used; mean clock {tot/np.sum(en-st)/1e3:.2f} GHz")
+    for i in names:
+        print(f"  {names[i]:36s} {ph[:, i].sum()/tot*100:5.1f} %   {ph[:, i].sum()/nsimd/1e3:7.1f} k cycles per SIMD")
+    ne, nl = ph[:, 1].sum(), ph[:, 3].sum()
+    print(f"  cycles per edge product {ph[:, 0].sum()/ne:.0f} ({ne:.0f} edges; 64 MFMAs each -> {ph[:, 0].sum()/ne/64:.1f} per MFMA);  per leaf {ph[:, 2].sum()/max(nl,1):.0f} ({nl:.0f})")
+    print(f"  MFMA issue floor: {ne*64/nsimd:.0f} MFMAs per SIMD x 69 cycles = {ne*64/nsimd*69/1e3:.1f} k cycles per SIMD")
