@@ -778,8 +778,13 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
         p->variant = 0;
         p->kernel_forced = true;
       }
-      p->n_slots_wave = 3;  // two "exchange" ids (register hand-over) + one wave-private LDS parking slot
-      if (const char *e = getenv("HYPHY_HIP_SLOTS")) p->n_slots_wave = atoi(e) == 2 ? 2 : 3;
+      // two "exchange" ids (register hand-over) + wave-private LDS parking slots: two where two tiles + the leaf codes fit an
+      // eighth of the CU's 160 KiB (eight waves per CU stay resident: 61 states up to 128 taxa), else one
+      {
+        const size_t tile_bytes = (size_t)p->NW * 4 * 64 * sizeof(double), codes_bytes = (size_t)p->L * 16 * sizeof(int16_t);
+        p->n_slots_wave = 2 * tile_bytes + codes_bytes <= 20480 ? 4 : 3;
+      }
+      if (const char *e = getenv("HYPHY_HIP_SLOTS")) p->n_slots_wave = std::max(2, std::min(4, atoi(e)));
       p->n_slots = p->variant == 1 ? p->n_slots_wave : lds_slots(T);
     }
     if (p->nuc) {

@@ -763,11 +763,17 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
                          &slot_cnt[a.root_slot][w][0][0], tile0, w, lane);
 }
 
-// sum over the four 16-lane rows of a wave (every lane ends up with the same value, same order)
+// sum over the four 16-lane rows of a wave (every lane ends up with the same value, same order): x[i] + x[i ^ 16], then
+// + x[i ^ 32], on gfx950's row / half swaps (v_permlane16_swap, v_permlane32_swap: pure VALU, no LDS round trip as a
+// ds_bpermute shuffle has; bit-identical to the shuffle form, a + b == b + a)
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double row_sum4(double x) {
-  x += __shfl_xor(x, 16);
-  x += __shfl_xor(x, 32);
-  return x;
+  unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  u32x2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  lo = __double2loint(x), hi = __double2hiint(x);
+  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -856,9 +862,14 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
     a.wg_flag += cat * a.cs_wg;
   }
   constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
-  __shared__ __align__(16) double park[(NP > 0 ? NP : 1) * TILE];  // parked nodes (scaled), fragment layout
-  __shared__ int park_cnt[(NP > 0 ? NP : 1)][16];
-  __shared__ __align__(16) double stage[TILE];  // a child tile fetched from global memory (bulk copy, then LDS operand)
+  // LDS of a wave: NP parked nodes (scaled, fragment layout) + the tile's leaf codes; LB builds also keep the node finalised last
+  // (and a child tile fetched from global memory) in `stage`.  r04: the other builds fetch child tiles straight into registers
+  // and keep the parked nodes' exponents in registers, so that two parking slots cost what one slot + the staging tile did
+  // (16 KiB + codes: eight waves per CU up to 128 taxa; r03's 8 + 8 KiB + 64 B + 4 KiB of codes admitted seven).
+  __shared__ __align__(16) double park[(NP > 0 ? NP : 1) * TILE];
+  __shared__ __align__(16) double stage_[LB ? TILE : 2];
+  double *const stage = stage_;
+  [[maybe_unused]] int pcnt[NP > 0 ? NP : 1];  // exponents of the parked nodes (this lane's site)
   extern __shared__ __align__(16) int16_t codes_lds[];  // CLDS: [L][16]
 
   const int lane = threadIdx.x, g = lane >> 4, sl = lane & 15;
@@ -883,18 +894,18 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
   HYPHY_TR(7)
   const f64x4 ones = (f64x4){1., 1., 1., 1.}, zeros = (f64x4){0., 0., 0., 0.};
   f64x4 acc[NW], bch[NW];  // running product of the current parent / the node finalised last (scaled)
-  f64x2 dreg[NKK / 2];     // chain schedules: a sibling's deposited edge product, fetched while this wave's own product runs
   int cnt = 0, bcnt = 0;
 #pragma unroll
   for (int w = 0; w < NW; w++) acc[w] = ones, bch[w] = zeros;
-#pragma unroll
-  for (int k = 0; k < NKK / 2; k++) dreg[k] = (f64x2){0., 0.};
 
   // acc[w'] *= sum_kk A[w'][kk] * B[kk]: `bsrc(k2)` yields the B operands of k-steps 2*k2, 2*k2 + 1.
   // Explicit two-stage software pipeline: the operands of step k2 + 1 are requested before the MFMAs of
   // step k2 are issued (sched_barrier: left alone, the scheduler sinks the loads below the MFMAs to save
   // registers and then waits for them with vmcnt(0) — eight exposed L2 round trips per edge).
-  // `pre` != nullptr (wave-uniform): one 16-byte agent-scope load of a sibling's deposit rides along with every step.
+  // `pre` != nullptr (wave-uniform): one 16-byte agent-scope load of a sibling's deposit rides along with every step and is
+  // multiplied into the (idle) running product two steps later, behind the wait for that step's A operands, which the in-order
+  // return of vector loads makes a wait for the deposit chunk too: no register image of the deposit exists (r04; the 32
+  // registers of r02's image kept the kernel on the 256-register edge).
   [[maybe_unused]] bool abl_after_edge = false;  // (HYPHY_ABL & 16: the first leaf behind an edge product is free)
   [[maybe_unused]] const int abl_mask = (a.ablate & 4096) ? 0 : -1;  // (HYPHY_ABL == 1 builds only)
   int polled = 0;  // (lane 0) arrival counter sampled near the end of an edge product, see the trunk loop
@@ -907,6 +918,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
 #pragma unroll
     for (int w = 0; w < NW; w++) D[w] = zeros;
     f64x2 Ac[NW], An[NW], bc, bn;
+    [[maybe_unused]] f64x2 dq[NKK / 2];  // deposit chunks in flight (three at a time)
     if (APF && apre_branch == branch) {
 #pragma unroll
       for (int w = 0; w < NW; w++) Ac[w] = Apre[w];
@@ -922,7 +934,10 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
         for (int w = 0; w < NW; w++) An[w] = (HYPHY_ABL & 2) ? Ac[w] : ld16(pf, (unsigned)((w * TILE + ((k2 + 1) * 64 + lane) * 2) * 8));
         bn = bsrc(k2 + 1);
       }
-      if (pre) dreg[k2] = ld16_agent(pre, (unsigned)(k2 * 64 + lane) * 16u);
+      if (pre) {
+        dq[k2] = ld16_agent(pre, (unsigned)(k2 * 64 + lane) * 16u);
+        if (k2 >= 2) acc[(k2 - 2) >> 1][((k2 - 2) & 1) * 2] *= dq[k2 - 2][0], acc[(k2 - 2) >> 1][((k2 - 2) & 1) * 2 + 1] *= dq[k2 - 2][1];
+      }
       if (APF && k2 == NKK / 2 - 1 && next_branch >= 0) {
         const double *pn = a.Pfrag + (size_t)next_branch * NW * TILE;  // uniform
 #pragma unroll
@@ -938,6 +953,11 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
 #pragma unroll
       for (int w = 0; w < NW; w++) Ac[w] = An[w];
       bc = bn;
+    }
+    if (pre) {
+#pragma unroll
+      for (int k2 = (NKK / 2 >= 2 ? NKK / 2 - 2 : 0); k2 < NKK / 2; k2++)
+        acc[k2 >> 1][(k2 & 1) * 2] *= dq[k2][0], acc[k2 >> 1][(k2 & 1) * 2 + 1] *= dq[k2][1];
     }
 #pragma unroll
     for (int w = 0; w < NW; w++) acc[w] *= D[w];
@@ -1009,7 +1029,9 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
         cnt += bcnt;
       } else {
         const double *src = park + (slot - 2) * TILE;
-        const int ccnt = park_cnt[slot - 2][sl];
+        int ccnt = pcnt[0];
+#pragma unroll
+        for (int q = 1; q < NP; q++) ccnt = (slot - 2 == q) ? pcnt[q] : ccnt;
         edge_product(op.z, [&](int k2) -> f64x2 {
           return *reinterpret_cast<const f64x2 *>(src + (k2 * 64 + lane) * 2);
         }, nullptr, nullptr, nb);
@@ -1020,19 +1042,20 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
       // stores, drained before its arrival was counted) by the wave that computed it — unless that wave is this one
       if (op.w != own) {
         const double *src = a.deposits + ((size_t)op.w * a.ntiles + tile0) * TILE;  // uniform
-        int dcnt = pre_cnt;
+        int dcnt = pre_cnt;  // (have_pre: the deposit went into acc under this wave's own product already)
         bool skip_load = have_pre;
         if constexpr (TRACE) skip_load = skip_load || (a.ablate & 512) != 0;
         if (!skip_load) {
           dcnt = __hip_atomic_load(a.hand_cnt + ((size_t)op.w * a.ntiles + tile0) * 32 + sl, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+          f64x2 dreg[NKK / 2];
 #pragma unroll
           for (int k2 = 0; k2 < NKK / 2; k2++) dreg[k2] = ld16_agent(src, (unsigned)(k2 * 64 + lane) * 16u);
+#pragma unroll
+          for (int w = 0; w < NW; w++)
+            acc[w] *= (f64x4){dreg[2 * w][0], dreg[2 * w][1], dreg[2 * w + 1][0], dreg[2 * w + 1][1]};
         }
         have_pre = false;
-#pragma unroll
-        for (int w = 0; w < NW; w++)
-          acc[w] *= (f64x4){dreg[2 * w][0], dreg[2 * w][1], dreg[2 * w + 1][0], dreg[2 * w + 1][1]};
         cnt += dcnt;
       }
       if constexpr (TRACE) asm volatile("" ::"v"(acc[0][0]));
@@ -1044,23 +1067,28 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
       // LDS first (all loads in flight together: ONE memory round trip instead of one per k-step).
       const double *src = a.partials + ((size_t)op.w * a.ntiles + tile0) * TILE;  // uniform
       int ccnt;
+      f64x2 gq[NKK / 2];  // the child's tile: the B-operand image, in registers (LB builds: through `stage`)
       if (op.x & OPF_HANDOFF) {
         ccnt = __hip_atomic_load(a.hand_cnt + ((size_t)op.w * a.ntiles + tile0) * 32 + sl, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int k2 = 0; k2 < NKK / 2; k2++)
-          *reinterpret_cast<f64x2 *>(stage + (k2 * 64 + lane) * 2) = ld16_agent(src, (unsigned)(k2 * 64 + lane) * 16u);
+        for (int k2 = 0; k2 < NKK / 2; k2++) gq[k2] = ld16_agent(src, (unsigned)(k2 * 64 + lane) * 16u);
       } else {
         if (op.x & OPF_GSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own stores visible in L2
         ccnt = a.counts[(size_t)op.w * S_pad + tile0 * 16 + sl];
 #pragma unroll
-        for (int k2 = 0; k2 < NKK / 2; k2++)
-          *reinterpret_cast<f64x2 *>(stage + (k2 * 64 + lane) * 2) = ld16(src, (unsigned)(k2 * 64 + lane) * 16u);
+        for (int k2 = 0; k2 < NKK / 2; k2++) gq[k2] = ld16(src, (unsigned)(k2 * 64 + lane) * 16u);
       }
       if constexpr (TRACE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       HYPHY_TR(6)
-      edge_product(op.z, [&](int k2) -> f64x2 { return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2); },
-                   nullptr, nullptr, nb);
+      if constexpr (LB) {
+#pragma unroll
+        for (int k2 = 0; k2 < NKK / 2; k2++) *reinterpret_cast<f64x2 *>(stage + (k2 * 64 + lane) * 2) = gq[k2];
+        edge_product(op.z, [&](int k2) -> f64x2 { return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2); },
+                     nullptr, nullptr, nb);
+      } else {
+        edge_product(op.z, [&](int k2) -> f64x2 { return gq[k2]; }, nullptr, nullptr, nb);
+      }
       cnt += ccnt;
     }
 
@@ -1121,7 +1149,8 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
           *reinterpret_cast<f64x2 *>(dst + ((2 * w) * 64 + lane) * 2) = (f64x2){bch[w][0], bch[w][1]};
           *reinterpret_cast<f64x2 *>(dst + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){bch[w][2], bch[w][3]};
         }
-        park_cnt[slot - 2][sl] = cnt;
+#pragma unroll
+        for (int q = 0; q < NP; q++) pcnt[q] = (slot - 2 == q) ? cnt : pcnt[q];
       }
       bcnt = cnt;
       cnt = 0;
@@ -2103,33 +2132,24 @@ void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
     const dim3 block1(64);
     const size_t lds1 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
     if (a.timeline && NW == 4 && CLDS) {  // tracing build (HYPHY_HIP_TIMELINE)
-      hipLaunchKernelGGL((prune_wave_kernel<4, 1, true, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      if (a.n_slots <= 3) hipLaunchKernelGGL((prune_wave_kernel<4, 1, true, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      else hipLaunchKernelGGL((prune_wave_kernel<4, 2, true, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
       return;
     }
-    if (NW == 4 && CLDS && a.wave_variant == 1) {  // experimental: finalised node in LDS, 2 waves per SIMD
-      if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 2, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
-      else hipLaunchKernelGGL((prune_wave_kernel<4, 1, true, false, true, 2, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
-      return;
-    }
-    if (NW == 4 && CLDS && a.wave_variant == 2 && a.n_slots <= 2) {  // experimental: ... 3 waves per SIMD, no register prefetch
+    // three waves per SIMD (the tuner's second stage): finalised node in LDS instead of 32 registers, no parking slot; 2 without,
+    // 3 with the deposit prefetch
+    if (NW == 4 && CLDS && a.wave_variant == 2 && a.n_slots <= 2) {
       hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 3, false>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
       return;
     }
-    if (NW == 4 && CLDS && a.wave_variant == 3 && a.n_slots <= 2) {  // experimental: ... 3 waves per SIMD, with the prefetch
+    if (NW == 4 && CLDS && a.wave_variant == 3 && a.n_slots <= 2) {
       hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 3, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
       return;
     }
-    if (NW == 4 && CLDS && a.wave_variant == 4) {  // experimental: finalised node in LDS + A-operand prefetch across edges
-      if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 2, true, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
-      else hipLaunchKernelGGL((prune_wave_kernel<4, 1, true, false, true, 2, true, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
-      return;
-    }
-    if (NW == 4 && CLDS && a.wave_variant == 5 && a.n_slots <= 2) {  // experimental: 3 waves per SIMD + A-operand prefetch
-      hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 3, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
-      return;
-    }
+    // production: two waves per SIMD, 0 / 1 / 2 parking slots in LDS (the schedule was compiled for a.n_slots - 2 of them)
     if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<NW, 0, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
-    else hipLaunchKernelGGL((prune_wave_kernel<NW, 1, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+    else if (a.n_slots == 3) hipLaunchKernelGGL((prune_wave_kernel<NW, 1, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+    else hipLaunchKernelGGL((prune_wave_kernel<NW, 2, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
     return;
   }
   if (a.variant == 2 && a.chain && a.T == 1) {  // row-split workgroups on a chain schedule: grid = (tiles, classes, sources)

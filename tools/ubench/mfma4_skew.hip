@@ -199,6 +199,52 @@ __global__ __launch_bounds__(64, OCC) void k(const double *__restrict__ imgs, in
   }
 }
 
+// r01's "instruction ceiling" kernel (tools/ubench_mfma_f64.hip: one operand pair, NACC in-place accumulators), compiled once
+// as it was (__launch_bounds__(256): the compiler puts the accumulators in AGPRs) and once with two waves per SIMD declared
+// (VGPR accumulators, the form every pruning kernel uses)
+template <int NACC, bool AG>
+__device__ __forceinline__ void kold_body(double *out, int iters, double a0, double b0) {
+  f64x4 acc[NACC];
+  for (int i = 0; i < NACC; i++) acc[i] = (f64x4){0, 0, 0, 0};
+  double a = a0 + threadIdx.x * 1e-9, b = b0;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = mfma16(a, b, acc[i]);
+  }
+  double s = 0;
+  for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s;
+}
+template <int NACC>
+__global__ __launch_bounds__(256) void kold_agpr(double *out, int iters, double a0, double b0) { kold_body<NACC, true>(out, iters, a0, b0); }
+template <int NACC>
+__global__ __launch_bounds__(256, 2) void kold_vgpr(double *out, int iters, double a0, double b0) { kold_body<NACC, false>(out, iters, a0, b0); }
+template <int NACC, bool AG>
+static void run_old(int wg_per_cu) {
+  double *d;
+  hipMalloc(&d, 8);
+  const int iters = 20000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  dim3 grid(256 * wg_per_cu), block(256);
+  auto go = [&](int it) {
+    if (AG) hipLaunchKernelGGL((kold_agpr<NACC>), grid, block, 0, 0, d, it, 1.0, 1e-3);
+    else hipLaunchKernelGGL((kold_vgpr<NACC>), grid, block, 0, 0, d, it, 1.0, 1e-3);
+  };
+  go(100);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  go(iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double n = (double)grid.x * 4 * iters * NACC;
+  printf("r01 kernel, %s accumulators, %dacc, waves/SIMD=%d: %.3f ms  %.1f TF\n", AG ? "AGPR" : "VGPR", NACC, wg_per_cu, ms, n * 2048.0 / ms / 1e9);
+  hipFree(d);
+}
+
 static int skew_state(int q, int lane) {
   const int b = (lane >> 2) & 3, i = lane >> 4;
   return 16 * (q >> 2) + 4 * (((q & 3) + b) & 3) + i;
@@ -321,6 +367,8 @@ int main() {
   double *d5;
   hipMalloc(&d5, 4096 * 8);
   hipMemcpy(d5, img5.data(), 4096 * 8, hipMemcpyHostToDevice);
+  run_old<4, true>(1), run_old<4, false>(1), run_old<4, true>(2), run_old<4, false>(2), run_old<4, true>(4);
+  if (getenv("OLD_ONLY")) return 0;
   for (int E : {60, 600, 6000}) {
     for (int waves : {1024, 2048}) {
       run<3, 2>("16x16x4 full (loads+mfma)", waves, E, d16, n_img, dv, P, v0);
