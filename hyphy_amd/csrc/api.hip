@@ -317,6 +317,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
   // HYPHY_HIP_TIMING_EVERY=n keeps one in n (bench.py: 4, the rocprofv3 runs: 1)
   static const int timing_every = getenv("HYPHY_HIP_TIMING_EVERY") ? std::max(1, atoi(getenv("HYPHY_HIP_TIMING_EVERY"))) : 16;
   const bool stamp = timing_every == 1 || p->all_timings || (s.eval_count++ % (uint64_t)timing_every) == 0;
+  s.last_stamped = stamp;
   const size_t ring_slot = (size_t)(s.ring_count % kTimingRing) * 2;
   if (stamp && !s.ring[ring_slot]) {  // (the ring's events are made on first use: a short-lived partition never pays for 2 048 of them)
     HIPCHK(hipEventCreate(&s.ring[ring_slot]));
@@ -559,9 +560,13 @@ void record_timings(hyphy_hip_partition *p) {
   float t;
   for (int k = 0; k < 3; k++) {
     t = 0.f;
-    if (k == 1 && s.ring_count > 0) {
-      const size_t slot = (size_t)((s.ring_count - 1) % kTimingRing) * 2;
-      if (hipEventElapsedTime(&t, s.ring[slot], s.ring[slot + 1]) == hipSuccess) p->timings[1] = t;
+    if (k == 1) {  // the pruning interval of THIS evaluation, or 0 when it carried no stamp (one evaluation in
+                   // HYPHY_HIP_TIMING_EVERY does; hyphy_hip_set_timing_detail stamps every one) — never an older evaluation's
+      p->timings[1] = 0.;
+      if (s.last_stamped && s.ring_count > 0) {
+        const size_t slot = (size_t)((s.ring_count - 1) % kTimingRing) * 2;
+        if (hipEventElapsedTime(&t, s.ring[slot], s.ring[slot + 1]) == hipSuccess) p->timings[1] = t;
+      }
       continue;
     }
     if (!p->all_timings) continue;

@@ -11,10 +11,14 @@ rccl_init_rank_fn g_rccl_init_rank = nullptr;
 
 int rccl_load() {
   if (g_rccl.lib) return 0;
-  void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) return fail(std::string("RCCL not available: ") + (dlerror() ? dlerror() : "librccl.so"));
+  // RTLD_LOCAL: a host process may carry a librccl of its own (PyTorch bundles one) — ours must not interpose on it.
+  void *h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) {
+    const char *e = dlerror();  // (ONE call: dlerror() clears the message it returns)
+    return fail(std::string("RCCL not available: ") + (e ? e : "librccl.so"));
+  }
   g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
   g_rccl_init_rank = (rccl_init_rank_fn)dlsym(h, "ncclCommInitRank");
   g_rccl.CommInitAll = (int (*)(void **, int, const int *))dlsym(h, "ncclCommInitAll");
@@ -117,20 +121,36 @@ int hyphy_hip_allreduce_device(hyphy_hip_partition *p, double *d_value) {
 // waiting in it; every rank then sees NaN and the failing one returns its own error.
 static int allreduce_and_fetch(hyphy_hip_partition *p, int local_rc, double *logl_out) {
   Shard &s = p->shards[0];
-  const std::string local_error = g_last_error;
-  if (hipSetDevice(s.device) != hipSuccess) return fail("hipSetDevice failed");
+  std::string local_error = g_last_error;
+  // Nothing returns before the all-reduce has been enqueued: the peers read their result by spinning on a host-mapped record
+  // and would never leave the collective.  Failures on the way (device selection, the NaN upload, timing events) only mark
+  // this rank as failed; the timing stamps are optional.
+  if (hipSetDevice(s.device) != hipSuccess && !local_rc) {
+    local_rc = fail("hipSetDevice failed");
+    local_error = g_last_error;
+  }
   if (local_rc) {
     static const double kNaN = NAN;
-    if (hipMemcpyAsync(s.ar_buf, &kNaN, sizeof(double), hipMemcpyHostToDevice, s.stream) != hipSuccess) return -1;
+    (void)hipMemcpyAsync(s.ar_buf, &kNaN, sizeof(double), hipMemcpyHostToDevice, s.stream);
   }
-  const bool stamp = p->all_timings;
+  bool stamp = p->all_timings;
   if (stamp) {
     for (auto &e : s.ev_ar)
-      if (!e) HIPCHK(hipEventCreate(&e));
-    HIPCHK(hipEventRecord(s.ev_ar[0], s.stream));
+      if (!e && hipEventCreate(&e) != hipSuccess) stamp = false;
+    if (stamp && hipEventRecord(s.ev_ar[0], s.stream) != hipSuccess) stamp = false;
   }
-  RCCLCHK(g_rccl.AllReduce(s.ar_buf, s.ar_buf, 1, kNcclDouble, kNcclSum, s.comm, s.stream));
-  if (stamp) HIPCHK(hipEventRecord(s.ev_ar[1], s.stream));
+  {
+    const int arc = g_rccl.AllReduce(s.ar_buf, s.ar_buf, 1, kNcclDouble, kNcclSum, s.comm, s.stream);
+    if (arc != 0) {  // could not even enqueue: the peers cannot be helped from here
+      const std::string why = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(arc) : "error");
+      if (local_rc) {
+        g_last_error = local_error + "; " + why;
+        return -1;
+      }
+      return fail(why);
+    }
+  }
+  if (stamp && hipEventRecord(s.ev_ar[1], s.stream) != hipSuccess) stamp = false;
   double v = 0.;
   const int rc = publish_and_collect(p, s.ar_buf, &v);  // (host-mapped record: no copy command, no stream synchronisation)
   if (stamp) {

@@ -153,6 +153,7 @@ struct Shard {
   std::vector<hipEvent_t> ring;  // kTimingRing pairs (start, end) around the pruning launches
   uint64_t ring_count = 0;       // evaluations stamped so far
   uint64_t eval_count = 0;
+  bool last_stamped = false;     // the most recent evaluation carried a kernel-duration stamp (hyphy_hip_last_timings)
   size_t partial_stride = 0;  // doubles per class
   // completion of the synchronous entry points: the reduction kernel writes a sequence number behind the result
   // record in host-mapped memory and the host spins on it (hipStreamSynchronize costs several microseconds more)

@@ -304,7 +304,10 @@ void *hyphy_hip_stream(hyphy_hip_partition *p);
 int hyphy_hip_set_stream(hyphy_hip_partition *p, void *stream);
 
 /* Per-call device timers of the last evaluation, milliseconds (SURVEY §5 tracing row):
- * out[0] = expm kernel(s), out[1] = pruning kernel, out[2] = root/site reduction. */
+ * out[0] = expm kernel(s), out[1] = pruning kernel, out[2] = root/site reduction.
+ * out[1] is 0 when the last evaluation carried no kernel-duration stamp (one evaluation in HYPHY_HIP_TIMING_EVERY, default 16,
+ * does; hyphy_hip_set_timing_detail(p, 1) stamps every evaluation) — it never reports an earlier evaluation's duration.
+ * out[0] and out[2] are measured only while timing detail is on. */
 int hyphy_hip_last_timings(hyphy_hip_partition *p, double out[3]);
 /* out[0] and out[2] are only stamped while the detail switch is on (two more event records per evaluation; the
  * environment variable HYPHY_HIP_ALL_TIMINGS sets its initial state); out[1] comes from the ring below. */

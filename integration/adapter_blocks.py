@@ -13,6 +13,8 @@ HELPERS = r'''
 #include <cstdlib>
 #include <string>
 #include <unistd.h>
+#include <sys/stat.h>
+#include <time.h>
 struct _HyHipPart {
   hyphy_hip_partition *part = nullptr;
   std::unordered_map<const void *, long> code_of;  // _CalcNode* -> node code (flatLeaves, then flatTree)
@@ -58,7 +60,7 @@ struct _HyHipPart {
   std::vector<std::vector<double>> mix_w;         // per class: [M] weights of the matrices stashed last
   long n_mixture_evals = 0;
   // SPMD site sharding (one host process per GPU, every process runs the same batch file: HYPHY_HIP_WORLD / HYPHY_HIP_RANK,
-  // or the MPI rank of a HYPHYMPI build with HYPHY_HIP_MPI_SHARD=1): this process holds patterns [lo, hi) of the partition
+  // set by the launcher, one ordinary host process per GPU): this process holds patterns [lo, hi) of the partition
   // and every evaluation ends in ONE ncclAllReduce of the partition log-likelihood (hyphy_hip_evaluate*_allreduce)
   bool spmd = false;
   long spmd_rank = 0, spmd_world = 1;
@@ -151,17 +153,17 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
     spmd_rank = getenv("HYPHY_HIP_RANK") ? atol(getenv("HYPHY_HIP_RANK")) : 0;
     spmd = spmd_world >= 1 && spmd_rank >= 0 && spmd_rank < spmd_world;
   }
-#ifdef __HYPHYMPI__
-  else if (getenv("HYPHY_HIP_MPI_SHARD") && hy_mpi_node_count > 1) {
-    spmd_world = hy_mpi_node_count;
-    spmd_rank = hy_mpi_node_rank;
-    spmd = true;
-  }
-#endif
+  // (A HYPHYMPI build is NOT a way into this mode: its ranks > 0 sit in the master/slave loop of src/mains/unix.cpp:1037-1042
+  //  and never run the batch file, so they would never reach this rendezvous.  SPMD here means: the launcher starts one
+  //  ordinary process per GPU with HYPHY_HIP_WORLD / HYPHY_HIP_RANK set.)
   if (spmd && (n_parts > 1 || cT->categoryCount > 1)) spmd = false;  // (one partition, one rate class: the site-sharded config)
+  if (spmd && S < spmd_world) {  // fewer patterns than ranks: EVERY rank takes the host path (S and the world are the same everywhere),
+    if (getenv("HYPHY_HIP_VERBOSE"))  // before anybody enters a collective
+      fprintf(stderr, "[hyphy_hip] partition %lu: %ld patterns < %ld ranks -> host path on every rank\n", i, S, spmd_world);
+    return;
+  }
   if (spmd) {
     const long lo = S * spmd_rank / spmd_world, hi = S * (spmd_rank + 1) / spmd_world, Sl = hi - lo;
-    if (Sl < 1) return;
     std::vector<int64_t> c2((size_t)L * Sl), f2(Sl);
     for (long l = 0; l < L; l++)
       for (long k = 0; k < Sl; k++) c2[(size_t)l * Sl + k] = codes[(size_t)l * S + lo + k];
@@ -203,36 +205,41 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   int rc = hyphy_hip_create(&hp.part, D, S_dev, L, I, cT->categoryCount, parents.data(), codes.data(),
                             n_amb ? ambigs->theData : nullptr, n_amb, freq.data(), my_first, my_count);
   if (rc == 0 && spmd) {
-    // the RCCL unique id: made by rank 0, broadcast by the host's own means — MPI in a HYPHYMPI build, else a file
+    // the RCCL unique id: made by rank 0, handed to the other ranks through a file
     // (HYPHY_HIP_UID_FILE) that rank 0 writes and the others wait for
+    // One rendezvous PER COMMUNICATOR: every process runs the same batch file, so the n-th SPMD set-up of this process pairs
+    // with the n-th of every other rank — the id travels in "<HYPHY_HIP_UID_FILE>.<n>".  Rank 0 removes a left-over of that
+    // name before it writes (atomic rename); the others accept only a file that is not older than their own process (a file
+    // from an earlier run of the same command is never taken for this run's id).
     char uid[128];
     bool have = false;
-#ifdef __HYPHYMPI__
-    if (!getenv("HYPHY_HIP_WORLD")) {
-      if (spmd_rank == 0) have = hyphy_hip_comm_unique_id(uid) == 0;
-      MPI_Bcast(uid, 128, MPI_CHAR, 0, MPI_COMM_WORLD);
-      have = true;
-    }
-#endif
-    if (!have) {
-      const char *path = getenv("HYPHY_HIP_UID_FILE");
+    static long spmd_generation = 0;
+    static const time_t proc_start = time(nullptr);
+    const long gen = spmd_generation++;
+    {
+      const char *base = getenv("HYPHY_HIP_UID_FILE");
+      const std::string path = base ? std::string(base) + "." + std::to_string(gen) : std::string();
       if (spmd_world == 1) {
         have = hyphy_hip_comm_unique_id(uid) == 0;
-      } else if (path && spmd_rank == 0) {
+      } else if (base && spmd_rank == 0) {
         have = hyphy_hip_comm_unique_id(uid) == 0;
-        std::string tmp = std::string(path) + ".tmp";
+        unlink(path.c_str());
+        const std::string tmp = path + ".tmp";
         FILE *fh = have ? fopen(tmp.c_str(), "wb") : nullptr;
         if (fh) {
-          fwrite(uid, 1, 128, fh);
+          have = fwrite(uid, 1, 128, fh) == 128;
           fclose(fh);
-          rename(tmp.c_str(), path);
+          if (have) have = rename(tmp.c_str(), path.c_str()) == 0;
         } else have = false;
-      } else if (path) {
+      } else if (base) {
         for (int tries = 0; tries < 6000 && !have; tries++) {  // (up to ~10 minutes: rank 0 may still be parsing its batch file)
-          FILE *fh = fopen(path, "rb");
-          if (fh) {
-            have = fread(uid, 1, 128, fh) == 128;
-            fclose(fh);
+          struct stat st;
+          if (stat(path.c_str(), &st) == 0 && st.st_mtime + 2 >= proc_start) {
+            FILE *fh = fopen(path.c_str(), "rb");
+            if (fh) {
+              have = fread(uid, 1, 128, fh) == 128;
+              fclose(fh);
+            }
           }
           if (!have) usleep(100000);
         }

@@ -646,6 +646,24 @@ def fullsize_codon(name, taxa, codons, seed, classes=None, threads=8):
     print(f"{name}: logL = {res['logl']!r}  sites stored {len(idx)}")
 
 
+def fullsize_nuc(name="full_hky_8x1k", taxa=8, sites=1000, seed=1, kappa=0.35, threads=1):
+    """configs[0]: HKY85 (transversions kappa x transitions, the parameterisation of the reference's IntermediateNuc.bf), 8 taxa x
+    1 000 sites — bench.py's `hky_8x1k` alignment at its stated size: scalar and per-site log L of the reference, and its log L at
+    the first sweep points of a global (kappa' = kappa + 0.001 k on the four transversion rates) as the adapter test uses them."""
+    syn = data.evolve(taxa, sites, 1, seed=seed, p_change=0.04)
+    flat = syn.flat
+    bt = {n: 0.05 for n in flat.branch_names()}
+    rev = models.hky85_rev(kappa)
+    res = hbl.evaluate(names=flat.leaf_names, seqs=syn.seqs, newick=tree.to_newick(syn.tree), unit=1,
+                       model_block=hbl.nuc_model_block(NUC_FREQS), model_name="NM", globals_=rev, branch_t=bt,
+                       threads=threads, timeout=600.0)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="nuc_full", taxa=taxa, sites=sites, seed=seed, p_change=0.04,
+                        states_crc=_crc(syn.states.astype(np.int16)), t=0.05, kappa=kappa,
+                        rev=np.array([rev[k] for k in ("AC", "AT", "CG", "CT", "GT")]), root_freqs=NUC_FREQS,
+                        logl=res["logl"], site_index=np.arange(sites), site_logl=res["site_logl"])
+    print(f"{name}: logL = {res['logl']!r}  sites stored {sites}")
+
+
 def fullsize_partitions(name="full_gtr_32x50k_x8", taxa=32, sites=50000, n_part=8, seed0=5, threads=8):
     """configs[4]: GARD-style multi-partition GTR — 8 partitions of 32 taxa x 50 000 sites, each with its own tree and
     alignment, ONE likelihood function over all of them (syntax precedent: res/TemplateBatchFiles/REL/MultiplePartitions.bf
@@ -725,6 +743,7 @@ def fullsize_cases():
                    classes=dict(weights=[0.7, 0.25, 0.05], values=[0.1 / 0.3, 1.0 / 0.3, 5.0 / 0.3]))
     fullsize_codon("full_mg94_128x100k", 128, 100000, seed=4)      # configs[3] (all 100 000 codons on one device in the test)
     fullsize_partitions()                                          # configs[4]
+    fullsize_nuc()                                                 # configs[0]
 
 
 def main():
@@ -758,6 +777,9 @@ def main():
             raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
         os.makedirs(OUT, exist_ok=True)
         fullsize_sweep()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize_hky":
+        fullsize_nuc()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
         if not hbl.have_reference():

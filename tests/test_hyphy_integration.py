@@ -71,6 +71,24 @@ def test_hbl_lfcompute_through_device_matches_reference_goldens(name, kind, taxa
     assert np.max(np.abs(res["site_logl"] - fx["site_logl"]) / np.abs(fx["site_logl"])) < 1e-10
 
 
+def test_hbl_hky_8x1k_at_stated_size_through_device():
+    """configs[0] at its stated size (HKY85, 8 taxa x 1 000 sites, bench.py's `hky_8x1k` alignment) through the real host:
+    LFCompute and the per-site values against the unmodified reference's (tests/golden/full_hky_8x1k.npz)."""
+    _need_binaries()
+    from hyphy_amd import data, models, tree
+    from oracle import hbl, make_golden as mg
+    fx = common.load("full_hky_8x1k")
+    syn = data.evolve(int(fx["taxa"]), int(fx["sites"]), 1, seed=int(fx["seed"]), p_change=float(fx["p_change"]))
+    bt = {n: float(fx["t"]) for n in syn.flat.branch_names()}
+    res = hbl.evaluate(binary=HIP_BIN, extra_env=ENV, names=syn.flat.leaf_names, seqs=syn.seqs, newick=tree.to_newick(syn.tree),
+                       unit=1, model_block=hbl.nuc_model_block(mg.NUC_FREQS), model_name="NM",
+                       globals_=dict(models.hky85_rev(float(fx["kappa"]))), branch_t=bt)
+    assert _device_calls(res["stdout"]) > 0, "the device path was not taken"
+    ref = float(fx["logl"])
+    assert abs(res["logl"] - ref) <= 1e-10 * abs(ref)
+    assert np.max(np.abs(res["site_logl"] - fx["site_logl"]) / np.abs(fx["site_logl"])) < 1e-10
+
+
 def test_hbl_rate_categories_through_device():
     """3 discrete rate classes: HyPhy's own PopulateConditionalProbabilities / SumUpSiteLikelihoods mix the
     per-class (l_s, c_s) pairs that the device returns through siteRes / siteCorrections."""
@@ -363,7 +381,10 @@ def test_hbl_spmd_site_shard_two_ranks(tmp_path):
 
     def run(rank):
         env = dict(ENV, HYPHY_HIP_WORLD="2", HYPHY_HIP_RANK=str(rank), HYPHY_HIP_UID_FILE=uid)
-        out[rank] = hbl.evaluate(binary=HIP_BIN, extra_env=env, per_site=False, sweep=dict(param="R", start=0.3, step=0.01, n=8, record=8), **case)
+        # (sweep inside an LF_START_COMPUTE bracket, then Optimize: two SetupLFCaches, i.e. two communicators per process —
+        #  each is a rendezvous of its own, "<uid file>.<n>")
+        out[rank] = hbl.evaluate(binary=HIP_BIN, extra_env=env, per_site=False, optimize=True,
+                                 sweep=dict(param="R", start=0.3, step=0.01, n=8, record=8), **case)
 
     th = [threading.Thread(target=run, args=(r,)) for r in (0, 1)]
     for t in th:
@@ -374,6 +395,7 @@ def test_hbl_spmd_site_shard_two_ranks(tmp_path):
     for r in (0, 1):
         assert abs(out[r]["logl"] - ref) <= 1e-10 * abs(ref), (r, out[r]["logl"], ref)
     assert np.array_equal(out[0]["sweep_values"], out[1]["sweep_values"])
+    assert out[0]["opt_logl"] == out[1]["opt_logl"]
 
 
 def _run_constrained_local_model(binary=None, env=None, optimize=False, sweep=None, branch_specific=False):
