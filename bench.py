@@ -60,13 +60,14 @@ HBM_ACHIEVABLE_GBS = 6300.0    # what a streaming kernel reaches (MI355X_MICROAR
 
 
 def measured_instruction_peak():
-    """Chip-wide rate v_mfma_f64_16x16x4_f64 sustains from one operand pair (tools/ubench_mfma_f64 under PMC): the best
-    'mfma only' line of the committed run, or None when the file is not there."""
+    """Chip-wide rate v_mfma_f64_16x16x4_f64 sustains with VGPR accumulators (tools/ubench/mfma4_skew.hip, committed run of r04):
+    the best VGPR line, or None when the file is not there.  (r01-r03 quoted 49 TFLOP/s from profiles/r01_ubench_mfma_f64.txt:
+    that microbenchmark had its accumulators in AGPRs, which halves the issue rate — profiles/r04_ubench_mfma_agpr_vs_vgpr.txt.)"""
     import re
-    path = os.path.join(ROOT, "profiles", "r01_ubench_mfma_f64.txt")
+    path = os.path.join(ROOT, "profiles", "r04_ubench_mfma_agpr_vs_vgpr.txt")
     try:
-        vals = [float(m.group(1)) for m in (re.search(r"^mfma only.*MFMA\s+([0-9.]+) TF", ln) for ln in open(path)) if m]
-        return (max(vals), "profiles/r01_ubench_mfma_f64.txt") if vals else (None, None)
+        vals = [float(m.group(1)) for m in (re.search(r"VGPR accumulators.*?([0-9.]+) TF", ln) for ln in open(path)) if m]
+        return (max(vals), "profiles/r04_ubench_mfma_agpr_vs_vgpr.txt") if vals else (None, None)
     except OSError:
         return None, None
 
@@ -94,6 +95,46 @@ def templates_for(unit):
             if i != j:
                 T[0, i, j] = rv[models.REV_NAMES[(min(i, j), max(i, j))]] * NUC_FREQS[j]
     return T, NUC_FREQS
+
+
+COLLECTIVE_LABEL = {"cabi": "hyphy_hip_evaluate_built_allreduce (in-stream ncclAllReduce of one double, C-ABI communicator)",
+                    "torch": "torch.distributed.all_reduce on the partition's stream", "none": None}
+PER_RANK_KEYS = ("patterns", "kernel_ms", "expm_ms", "reduce_ms", "allreduce_ms")
+
+
+def gather_per_rank(dist, ctl, world, patterns, kernel_ms, expm_ms, reduce_ms, allreduce_ms):
+    """Every rank's own numbers on every rank (the line is printed by rank 0): shard size and kernel / expm / reduction /
+    all-reduce milliseconds per step.  Only torch.distributed is touched: tests/test_distributed_cpu.py runs it over gloo."""
+    import torch
+    mine = torch.tensor([float(patterns), float(kernel_ms), float(expm_ms or 0.0), float(reduce_ms or 0.0), float(allreduce_ms or 0.0)],
+                        dtype=torch.float64, device=ctl)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    return [dict(rank=r, patterns=int(v[0].item()), **{k: float(v[i + 1].item()) for i, k in enumerate(PER_RANK_KEYS[1:])})
+            for r, v in enumerate(allr)]
+
+
+def max_over_ranks(dist, ctl, seconds):
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=ctl)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def multi_gpu_fields(world, collective, collective_note, per_rank, allreduce_ms, collective_ab):
+    """What the line of an N > 1 run carries on top of the N = 1 line: (config additions, roofline additions, top-level
+    additions).  `collective_ab`: ms per step of the SAME rank set with the library's in-stream all-reduce and with
+    torch.distributed's, measured back to back behind the timed region (None: not measured)."""
+    cfg = {"parallelism": f"site-shard x{world}, one process per GPU", "collective": COLLECTIVE_LABEL[collective]}
+    if collective_note:
+        cfg["collective_note"] = collective_note
+    roof = {}
+    if allreduce_ms is not None:
+        roof["allreduce_ms"] = allreduce_ms
+    top = {"per_rank": per_rank}
+    if collective_ab:
+        top["collective_ab"] = collective_ab
+    return cfg, roof, top
 
 
 def alg_work(D, S, L, I):
@@ -461,7 +502,7 @@ def main():
         sync_step = part.prepare_built_step(nodes, nodes, pi, coeffs)   # N == 1: synchronous C-ABI entry point
         ar_step = part.prepare_built_allreduce_step(nodes, nodes, pi, coeffs) if collective == "cabi" else None
 
-    def step(k, sync=True):
+    def step(k, sync=True, force_torch=False):
         omega = omega0 + 0.001 * k
         if n_classes > 1:
             coeffs[:, 1] = np.repeat(class_omega * omega, B) * coeffs[:, 0]
@@ -478,7 +519,7 @@ def main():
                 hdist.allreduce_logl(d_logl[:1])
                 v = float(d_logl[0].item())
             return v
-        if sync and ar_step is not None:
+        if sync and ar_step is not None and not force_torch:
             return ar_step()       # build_q + evaluate_built_allreduce: local pass, in-stream ncclAllReduce, value on every rank
         if (not multi) and sync and not os.environ.get("HYPHY_BENCH_DEVICE_STEP"):
             return sync_step()     # build_q + evaluate_built: log-L returned by the C-ABI call itself (all shards if --single-process)
@@ -580,17 +621,24 @@ def main():
     else:
         t_ar = None
     per_rank = None
+    collective_ab = None
     if multi:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=ctl)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        # every rank's own numbers (the line is printed by rank 0): shard size, kernel / expm / reduction / all-reduce ms
-        mine = torch.tensor([float(hi - lo), t_prune / max(1, args.steps), t_exp or 0.0, t_red or 0.0, t_ar or 0.0],
-                            dtype=torch.float64, device=ctl)
-        allr = [torch.zeros_like(mine) for _ in range(N)]
-        dist.all_gather(allr, mine)
-        per_rank = [dict(rank=r, patterns=int(v[0].item()), kernel_ms=float(v[1].item()), expm_ms=float(v[2].item()),
-                         reduce_ms=float(v[3].item()), allreduce_ms=float(v[4].item())) for r, v in enumerate(allr)]
+        dt = max_over_ranks(dist, ctl, dt)
+        per_rank = gather_per_rank(dist, ctl, N, hi - lo, t_prune / max(1, args.steps), t_exp, t_red, t_ar)
+        if ar_step is not None and n_classes == 1 and not share:
+            # both collectives in ONE run (which of the two costs less per step on this node?): 8 + 8 more steps
+            # behind the timed region, the library's in-stream all-reduce and torch.distributed's on the same stream
+            collective_ab = {}
+            for name, ft in (("cabi", False), ("torch", True), ("cabi_again", False)):
+                step(1, force_torch=ft)
+                dist.barrier()
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for k in range(8):
+                    step(k + 1, force_torch=ft)
+                dist.barrier()
+                torch.cuda.synchronize()
+                collective_ab[name + "_ms_per_step"] = 1e3 * max_over_ranks(dist, ctl, time.perf_counter() - ta) / 8
 
     branch_cache = None
     if args.branch_cache and n_classes == 1 and N == 1 and D > 4 and collective == "none":
@@ -664,13 +712,13 @@ def main():
                                 "HBM) does not exist — see traffic_rate_gbs (PMC) and valu_tflops")
         roof["kernel"] = part.prune_kernel_name()
         if bound == "mfma":
-            # measured ceiling of the instruction the kernel issues (tools/ubench_mfma_f64 under PMC,
-            # profiles/r01_ubench_mfma_f64.txt): v_mfma_f64_16x16x4_f64 sustains ~49 TFLOP/s chip-wide at 2.39 GHz
-            # (one per ~100 cycles per SIMD); `peak` stays the datasheet figure
+            # measured ceiling of the instruction the kernel issues (tools/ubench/mfma4_skew.hip): v_mfma_f64_16x16x4_f64 with VGPR
+            # accumulators sustains 73-78 TFLOP/s chip-wide from one operand pair and 66-72 with the kernel's own operand stream
+            # (profiles/r04_ubench_*.txt); `peak` stays the datasheet figure
             roof["instruction"] = "v_mfma_f64_16x16x4_f64"
             ipk, ipk_src = measured_instruction_peak()
             if ipk is not None:
-                roof["instruction_peak_measured"] = ipk   # TFLOP/s, one operand pair; site_fit_kernel sustains 48.7 in a real kernel
+                roof["instruction_peak_measured"] = ipk   # TFLOP/s, one operand pair, VGPR accumulators
                 roof["instruction_peak_source"] = ipk_src
         # forest scheduling: the pruning pass of ONE evaluation is `launches_per_step` launches of the same
         # kernel (levels of subtree fragments).  achieved = (algorithmic work of the pass / launches) / (mean
@@ -683,7 +731,7 @@ def main():
         roof["timed_steps_sampled"] = f"1 in {TIMING_EVERY}"
         roof["expm_ms"] = t_exp       # median of 8 event-timed steps after the timed region; None: not measured
         roof["reduce_ms"] = t_red
-        if t_ar is not None:
+        if t_ar is not None and not multi:
             roof["allreduce_ms"] = t_ar   # the in-stream ncclAllReduce of one double (same 8 steps)
         roof["alg_flops_per_step"] = flops
         roof["alg_bytes_per_step"] = bytes_
@@ -721,8 +769,7 @@ def main():
                        "unique_patterns": int(S_all), "branches": int(B), "rate_classes": n_classes,
                        "parallelism": (f"site-shard x{N}, one process per GPU" if multi else
                                        f"site-shard x{N}, one process, shard partials combined by {args.combine}" if single and N > 1 else "single GPU"),
-                       "collective": ({"cabi": "hyphy_hip_evaluate_built_allreduce (in-stream ncclAllReduce of one double, C-ABI communicator)",
-                                       "torch": "torch.distributed.all_reduce on the partition's stream", "none": None}[collective]),
+                       "collective": COLLECTIVE_LABEL[collective],
                        **({"collective_note": collective_note} if collective_note else {}),
                        **({"DIAGNOSTIC": "HYPHY_BENCH_SHARE_DEVICE: all ranks ran on ONE device over gloo — the N > 1 code path was walked, the rate means nothing"} if share else {}),
                        "patterns_rank0": int(S_rank),
@@ -730,10 +777,14 @@ def main():
                                (" + RCCL all-reduce" if (multi or collective == "cabi") else "") + ", log-L returned to host every step"},
             "logl_first": ll0, "logl_last": last,
             "roofline": roof,
-            **({"per_rank": per_rank} if per_rank else {}),
             **({"branch_cache": branch_cache} if branch_cache else {}),
             **({"site_fits": site_fits} if site_fits else {}),
         }
+        if multi:   # the N > 1 additions: which collective, every rank's numbers, the two collectives side by side
+            cfg_m, roof_m, top_m = multi_gpu_fields(N, collective, collective_note, per_rank, t_ar, collective_ab)
+            out["config"].update(cfg_m)
+            roof.update(roof_m)
+            out.update(top_m)
         if pipelined:
             out["value_pipelined_no_host_sync"] = pipelined
         if not args.no_cpu_baseline and N == 1 and n_classes == 1:

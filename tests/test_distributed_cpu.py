@@ -182,3 +182,50 @@ def test_mix_classes_matches_the_oracle_mixing_with_exponents_and_floor():
     got = float(hdist.mix_classes(w, torch.from_numpy(lik), torch.from_numpy(sc), f))
     assert abs(got - want) <= 1e-12 * abs(want), (got, want)
     assert hdist.local_classes(5, 1, 2) == [1, 3] and hdist.local_classes(2, 2, 3) == []
+
+
+def _worker_bench_line(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    # every rank contributes ITS numbers; the slowest rank's wall clock is the job's
+    table = bench.gather_per_rank(dist, "cpu", world, patterns=1000 + rank, kernel_ms=0.1 * (rank + 1), expm_ms=0.02, reduce_ms=0.005,
+                                  allreduce_ms=0.03 + 0.01 * rank)
+    dt = bench.max_over_ranks(dist, "cpu", 1.0 + rank)
+    if rank == 0:
+        out_q.put((table, dt))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_line_of_a_multi_gpu_run_carries_every_ranks_numbers():
+    """First-contact hardening for the 8-GPU box: the pieces of bench.py that only run at N > 1 — the
+    per-rank gather, the max-over-ranks clock and the line's N > 1 fields — over gloo with two ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bench_line, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    table, dt = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert dt == 2.0
+    assert [r["rank"] for r in table] == [0, 1] and [r["patterns"] for r in table] == [1000, 1001]
+    for r in table:
+        assert set(r) == {"rank", *bench.PER_RANK_KEYS}
+    assert table[1]["kernel_ms"] == pytest.approx(0.2) and table[1]["allreduce_ms"] == pytest.approx(0.04)
+    ab = {"cabi_ms_per_step": 0.21, "torch_ms_per_step": 0.25, "cabi_again_ms_per_step": 0.21}
+    cfg, roof, top = bench.multi_gpu_fields(2, "cabi", None, table, 0.03, ab)
+    assert "ncclAllReduce" in cfg["collective"] and "x2" in cfg["parallelism"] and "collective_note" not in cfg
+    assert roof == {"allreduce_ms": 0.03}
+    assert top["per_rank"] is table and top["collective_ab"] == ab
+    cfg, roof, top = bench.multi_gpu_fields(2, "torch", "C-ABI communicator not available", table, None, None)
+    assert "torch.distributed" in cfg["collective"] and cfg["collective_note"] and roof == {} and "collective_ab" not in top
