@@ -33,11 +33,19 @@ struct _HyHipPart {
   // template mode (SURVEY 8f-3 through the real host): Q_b = sum_k x_bk M_k(globals), x_b = the branch's independent local
   // parameters.  Per rate class: 0 not analysed yet, 1 enabled, -1 disabled (the model is not linear in its local parameters)
   std::vector<int> tmpl_state;
-  long tmpl_K = 0;
-  _SimpleList tmpl_refs;                     // template-variable references every conforming node must show (iVariables odd entries)
-  long tmpl_model = -1;
-  std::string tmpl_dep_sig;                  // constraints on dependent locals every conforming node must carry (see _hyhip_dep_signature)
-  std::unordered_map<const void *, char> dep_ok;
+  // Branch classes (r04): branches that share the model, the template variables of their independent locals and the text of
+  // their constraints (foreground / background omega: "fg.nonSynRate := omegaF*fg.synRate" vs "bg.nonSynRate := omegaB*...")
+  // form a GROUP with templates of its own; a branch's coefficient row is its K_g locals at the group's columns and zeros
+  // elsewhere, so the device sees ONE template model with tmpl_K = sum of the K_g columns.
+  struct Group {
+    long model = -1, K = 0, col = 0;
+    _SimpleList refs;                        // template-variable references of the group's nodes (iVariables odd entries)
+    std::string dep_sig;                     // constraints on dependent locals (see _hyhip_dep_signature)
+  };
+  std::vector<Group> tmpl_groups;
+  bool tmpl_groups_open = false;             // the learning call may still add groups
+  long tmpl_K = 0;                           // columns of a coefficient row = templates on the device
+  std::unordered_map<const void *, int> group_of;   // node -> group (-1: conforms to none), cached
   std::vector<std::vector<double>> tmpl_M;   // per class: [K][D*D] current templates (off-diagonal entries are what counts)
   std::vector<std::vector<double>> tmpl_x;   // per class: [B][K] latest local-parameter rows
   std::vector<char> tmpl_uploaded;           // per class: tmpl_M is what the device holds
@@ -45,9 +53,10 @@ struct _HyHipPart {
   struct Call {                              // one ExponentiateMatrices call in template mode
     bool active = false;
     long cat = 0;
-    std::vector<long> probe, skipped;        // node codes
-    long verify = -1;
-    double verify_dist = 0., skipped_dist = 0.;  // relative distance of the verification row / of the farthest skipped row from the probes
+    std::vector<std::vector<long>> probe;    // per group: node codes
+    std::vector<long> verify;                // per group: node code or -1
+    std::vector<double> verify_dist, skipped_dist;  // per group: relative distance of the verification row / of the farthest skipped row from the probes
+    std::vector<long> skipped;               // node codes
   } call;
   long n_template_evals = 0, n_skipped = 0;
   // mixture mode (explicit-form models: P_b = sum_m w_m Exp(Q_bm), weights built from GLOBAL variables only): per rate
@@ -275,10 +284,9 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   hp.spmd_world = spmd_world;
   hp.tmpl_state.assign(n_cat, getenv("HYPHY_HIP_TEMPLATES") && !strcmp(getenv("HYPHY_HIP_TEMPLATES"), "0") ? -1 : 0);
   hp.tmpl_K = 0;
-  hp.tmpl_refs.Clear();
-  hp.tmpl_model = -1;
-  hp.tmpl_dep_sig.clear();
-  hp.dep_ok.clear();
+  hp.tmpl_groups.clear();
+  hp.tmpl_groups_open = false;
+  hp.group_of.clear();
   hp.tmpl_M.assign(n_cat, std::vector<double>());
   hp.tmpl_x.assign(n_cat, std::vector<double>());
   hp.tmpl_uploaded.assign(n_cat, 0);
@@ -334,22 +342,65 @@ static std::string _hyhip_dep_signature(_CalcNode *n) {
   }
   return sig;
 }
-static bool _hyhip_conforms(_HyHipPart &hp, _CalcNode *n) {
-  if (n->HasExplicitFormModel() || n->GetModelIndex() != hp.tmpl_model) return false;
-  if (n->dVariables && n->dVariables->lLength) {
-    auto it = hp.dep_ok.find(n);
-    if (it == hp.dep_ok.end()) it = hp.dep_ok.emplace(n, _hyhip_dep_signature(n) == hp.tmpl_dep_sig ? 1 : 0).first;
-    if (!it->second) return false;
-  } else if (!hp.tmpl_dep_sig.empty()) {
-    return false;
+static bool _hyhip_invert(const double *rows, long K, double *inv);
+// group of a node (cached): same model, same template variables behind its independent locals, same constraint texts.
+// While the learning call is open a node that fits no group founds one (at most 4 groups, 8 columns in all).
+static int _hyhip_group(_HyHipPart &hp, _CalcNode *n) {
+  auto it = hp.group_of.find(n);
+  if (it != hp.group_of.end()) return it->second;
+  int g = -1;
+  if (!n->HasExplicitFormModel() && n->iVariables && n->iVariables->lLength >= 2 && n->iVariables->lLength <= 6) {
+    const long K = (long)n->iVariables->lLength / 2, model = n->GetModelIndex();
+    const std::string sig = (n->dVariables && n->dVariables->lLength) ? _hyhip_dep_signature(n) : std::string();
+    for (size_t k = 0; k < hp.tmpl_groups.size() && g < 0; k++) {
+      const _HyHipPart::Group &G = hp.tmpl_groups[k];
+      if (G.model != model || G.K != K || G.dep_sig != sig) continue;
+      bool same = true;
+      for (long j = 0; j < K && same; j++) same = n->iVariables->list_data[2 * j + 1] == G.refs.list_data[j];
+      if (same) g = (int)k;
+    }
+    if (g < 0 && hp.tmpl_groups_open && sig != "?" && hp.tmpl_groups.size() < 4 && hp.tmpl_K + K <= 8) {
+      _HyHipPart::Group G;
+      G.model = model;
+      G.K = K;
+      G.col = hp.tmpl_K;
+      G.dep_sig = sig;
+      for (long j = 0; j < K; j++) G.refs << n->iVariables->list_data[2 * j + 1];
+      hp.tmpl_groups.push_back(G);
+      hp.tmpl_K += K;
+      g = (int)hp.tmpl_groups.size() - 1;
+    }
   }
-  if (!n->iVariables || (long)n->iVariables->lLength != 2 * hp.tmpl_K) return false;
-  for (long k = 0; k < hp.tmpl_K; k++)
-    if (n->iVariables->list_data[2 * k + 1] != hp.tmpl_refs.list_data[k]) return false;
-  return true;
+  if (!hp.tmpl_groups_open) hp.group_of.emplace(n, g);   // (cached once the set of groups is final)
+  return g;
 }
-static void _hyhip_local_row(_CalcNode *n, long K, double *x) {
-  for (long k = 0; k < K; k++) x[k] = LocateVar(n->iVariables->list_data[2 * k])->Compute()->Value();
+// the branch's coefficient row: its independent locals at its group's columns, zeros elsewhere
+static void _hyhip_local_row(const _HyHipPart &hp, _CalcNode *n, int g, double *x) {
+  const _HyHipPart::Group &G = hp.tmpl_groups[g];
+  for (long k = 0; k < hp.tmpl_K; k++) x[k] = 0.;
+  for (long k = 0; k < G.K; k++) x[G.col + k] = LocateVar(n->iVariables->list_data[2 * k])->Compute()->Value();
+}
+// are the rows `codes` (+ optionally `extra`) of X independent in the columns of group G?  (Gram determinant, K <= 3)
+static bool _hyhip_rows_independent(const std::vector<double> &X, long Ktot, const _HyHipPart::Group &G, const std::vector<long> &codes,
+                                    long extra) {
+  double rows[16], gram[16], inv[16];
+  long n = 0;
+  for (long c : codes) {
+    for (long k = 0; k < G.K; k++) rows[n * G.K + k] = X[(size_t)c * Ktot + G.col + k];
+    n++;
+  }
+  if (extra >= 0) {
+    for (long k = 0; k < G.K; k++) rows[n * G.K + k] = X[(size_t)extra * Ktot + G.col + k];
+    n++;
+  }
+  if (n > G.K) return false;
+  for (long i = 0; i < n; i++)
+    for (long j = 0; j < n; j++) {
+      double gg = 0.;
+      for (long k = 0; k < G.K; k++) gg += rows[i * G.K + k] * rows[j * G.K + k];
+      gram[i * n + j] = gg;
+    }
+  return _hyhip_invert(gram, n, inv);
 }
 // rows [r][K] -> inverse of the K x K matrix (Gauss-Jordan, partial pivoting); false if (numerically) singular
 static bool _hyhip_invert(const double *rows, long K, double *inv) {
@@ -430,6 +481,27 @@ static bool _hyhip_solve_templates(long K, long DD, const double *Xp, const std:
     }
   return true;
 }
+// the same for ONE group: rows [G.col, G.col + G.K) of M (Ktot x DD) from the group's probes
+static bool _hyhip_solve_group(const std::vector<double> &X, long Ktot, long DD, const _HyHipPart::Group &G, const std::vector<long> &probe,
+                               const double *qstash, std::vector<double> &M) {
+  if ((long)probe.size() != G.K) return false;
+  double Xp[16], inv[16];
+  for (long i = 0; i < G.K; i++)
+    for (long k = 0; k < G.K; k++) Xp[i * G.K + k] = X[(size_t)probe[i] * Ktot + G.col + k];
+  if (!_hyhip_invert(Xp, G.K, inv)) return false;
+  if (M.size() != (size_t)Ktot * DD) M.assign((size_t)Ktot * DD, 0.);
+  for (long k = 0; k < G.K; k++) {
+    double *m = M.data() + (size_t)(G.col + k) * DD;
+    for (long e = 0; e < DD; e++) m[e] = 0.;
+    for (long i = 0; i < G.K; i++) {
+      const double f = inv[k * G.K + i];
+      if (f == 0.) continue;
+      const double *q = qstash + (size_t)probe[i] * DD;
+      for (long e = 0; e < DD; e++) m[e] += f * q[e];
+    }
+  }
+  return true;
+}
 static double _hyhip_template_error(long K, long D, const double *x, const std::vector<double> &M, const double *q) {
   const long DD = D * D;
   double err = 0., scale = 0.;
@@ -462,56 +534,47 @@ static bool _hyphy_hip_skip_handler(_TheTree *t, long catID, _CalcNode *node, un
   if (nodeID == 0) {
     hp.call = _HyHipPart::Call();
     hp.call.cat = cat;
-    hp.call.active = cat < (long)hp.tmpl_state.size() && hp.tmpl_state[cat] == 1 && (long)n_nodes >= hp.tmpl_K + 6;
+    const size_t ng = hp.tmpl_groups.size();
+    hp.call.active = cat < (long)hp.tmpl_state.size() && hp.tmpl_state[cat] == 1 && (long)n_nodes >= hp.tmpl_K + (long)ng + 5;
+    hp.call.probe.assign(ng, std::vector<long>());
+    hp.call.verify.assign(ng, -1L);
+    hp.call.verify_dist.assign(ng, 0.);
+    hp.call.skipped_dist.assign(ng, 0.);
   }
   if (!hp.call.active || hp.call.cat != cat) return false;
   auto itc = hp.code_of.find(node);
-  if (itc == hp.code_of.end() || !_hyhip_conforms(hp, node)) return false;  // (goes the dense way)
+  if (itc == hp.code_of.end()) return false;
+  const int g = _hyhip_group(hp, node);
+  if (g < 0) return false;  // (goes the dense way)
+  const _HyHipPart::Group &G = hp.tmpl_groups[g];
   const long code = itc->second, K = hp.tmpl_K;
   std::vector<double> &X = hp.tmpl_x[cat];
   if (X.empty()) X.assign(hp.code_of.size() * K, 0.);
-  _hyhip_local_row(node, K, X.data() + (size_t)code * K);
-  if ((long)hp.call.probe.size() < K) {  // a probe, if independent of the probes so far
-    double rows[16], inv[16];
-    const long np = (long)hp.call.probe.size();
-    // complete the candidate set with unit rows orthogonal enough only for K = 1 .. 4: test the rank by trial inversion of
-    // the (np + 1) x (np + 1) leading block in the candidate's own coordinates is overkill here — K is tiny: use the
-    // Gram determinant of the candidate rows
-    for (long i = 0; i < np; i++)
-      for (long k = 0; k < K; k++) rows[i * K + k] = X[(size_t)hp.call.probe[i] * K + k];
-    for (long k = 0; k < K; k++) rows[np * K + k] = X[(size_t)code * K + k];
-    double gram[16];
-    for (long i = 0; i <= np; i++)
-      for (long j = 0; j <= np; j++) {
-        double g = 0.;
-        for (long k = 0; k < K; k++) g += rows[i * K + k] * rows[j * K + k];
-        gram[i * (np + 1) + j] = g;
-      }
-    if (_hyhip_invert(gram, np + 1, inv)) {
-      hp.call.probe.push_back(code);
-      return false;
-    }
-    return false;  // dependent on the probes so far and no basis yet: the dense way
+  _hyhip_local_row(hp, node, g, X.data() + (size_t)code * K);
+  std::vector<long> &probe = hp.call.probe[g];
+  if ((long)probe.size() < G.K) {  // a probe of its group, if independent of the group's probes so far
+    if (_hyhip_rows_independent(X, K, G, probe, code)) probe.push_back(code);
+    return false;  // (dependent and no basis yet: the dense way)
   }
-  // A branch whose local parameters EQUAL a probe's has the probe's rate matrix (same model, same globals): skipping it
-  // assumes nothing about linearity.  The first branch that differs goes through RecomputeMatrix and verifies the
-  // templates; how far it sits from the probes says how much that verification is worth for the others (r02 ADVICE: with
-  // every branch length equal the check used to pass vacuously).
+  // A branch whose local parameters EQUAL a probe's has the probe's rate matrix (same group: same model, same constraints,
+  // same globals): skipping it assumes nothing about linearity.  The first branch of the group that differs goes through
+  // RecomputeMatrix and verifies the group's templates; how far it sits from the probes says how much that verification is worth
+  // for the others (r02 ADVICE: with every branch length equal the check used to pass vacuously).
   double dist = 1e300;
-  for (long pc : hp.call.probe) {
+  for (long pc : probe) {
     double d = 0.;
-    for (long k = 0; k < K; k++) {
-      const double a = X[(size_t)pc * K + k], b = X[(size_t)code * K + k];
+    for (long k = 0; k < G.K; k++) {
+      const double a = X[(size_t)pc * K + G.col + k], b = X[(size_t)code * K + G.col + k];
       d = fmax(d, a == b ? 0. : fabs(a - b) / fmax(fabs(a), fabs(b)));
     }
     dist = fmin(dist, d);
   }
-  if (dist > 0. && hp.call.verify < 0) {
-    hp.call.verify = code;
-    hp.call.verify_dist = dist;
+  if (dist > 0. && hp.call.verify[g] < 0) {
+    hp.call.verify[g] = code;
+    hp.call.verify_dist[g] = dist;
     return false;
   }
-  hp.call.skipped_dist = fmax(hp.call.skipped_dist, dist);
+  hp.call.skipped_dist[g] = fmax(hp.call.skipped_dist[g], dist);
   hp.call.skipped.push_back(code);
   hp.n_skipped++;
   return true;
@@ -691,30 +754,31 @@ static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, 
   _hyhip_deferred += parallel.lLength;
   const long K = hp.tmpl_K;
   if (hp.call.active && hp.call.cat == cat) {
-    // template call: K probes + one verification node were recomputed, hp.call.skipped were not
-    // verify < 0: every skipped branch duplicates a probe (nothing to verify, nothing assumed)
-    bool ok = (long)hp.call.probe.size() == K;
-    // a verification taken closer than 1 % to the probes says little about branches that sit farther away: this call
-    // (only) takes the skipped matrices the normal way
-    const bool weak = hp.call.verify >= 0 && hp.call.skipped_dist > 0. && hp.call.verify_dist < 0.01 &&
-                      hp.call.skipped_dist > 4. * hp.call.verify_dist;
-    std::vector<double> M;
-    if (ok) {
-      double Xp[16];
-      std::vector<const double *> Qp;
-      for (long i = 0; i < K; i++) {
-        for (long k = 0; k < K; k++) Xp[i * K + k] = hp.tmpl_x[cat][(size_t)hp.call.probe[i] * K + k];
-        Qp.push_back(hp.qstash[cat].data() + (size_t)hp.call.probe[i] * DD);
-      }
-      ok = _hyhip_solve_templates(K, DD, Xp, Qp, M) &&
-           (hp.call.verify < 0 || _hyhip_template_error(K, D, hp.tmpl_x[cat].data() + (size_t)hp.call.verify * K, M,
-                                                        hp.qstash[cat].data() + (size_t)hp.call.verify * DD) < 1e-11);
+    // template call: per group K_g probes + one verification node were recomputed, hp.call.skipped were not.
+    // verify < 0: every skipped branch of the group duplicates a probe (nothing to verify, nothing assumed); a group none of
+    // whose branches is dirty in this call keeps its templates of the last call (no row of this call refers to them).
+    bool ok = true, weak = false;
+    std::vector<double> M = hp.tmpl_M[cat];
+    std::vector<char> group_has_skipped(hp.tmpl_groups.size(), 0);
+    for (long code : hp.call.skipped) group_has_skipped[_hyhip_group(hp, (_CalcNode *)t->GetNodeFromFlatIndex(code))] = 1;
+    for (size_t g = 0; g < hp.tmpl_groups.size() && ok; g++) {
+      const _HyHipPart::Group &G = hp.tmpl_groups[g];
+      if (hp.call.probe[g].empty() && !group_has_skipped[g]) continue;
+      // a verification taken closer than 1 % to the probes says little about branches that sit farther away: this call
+      // (only) takes the skipped matrices the normal way
+      weak = weak || (hp.call.verify[g] >= 0 && hp.call.skipped_dist[g] > 0. && hp.call.verify_dist[g] < 0.01 &&
+                      hp.call.skipped_dist[g] > 4. * hp.call.verify_dist[g]);
+      ok = _hyhip_solve_group(hp.tmpl_x[cat], K, DD, G, hp.call.probe[g], hp.qstash[cat].data(), M) &&
+           (hp.call.verify[g] < 0 || _hyhip_template_error(K, D, hp.tmpl_x[cat].data() + (size_t)hp.call.verify[g] * K, M,
+                                                           hp.qstash[cat].data() + (size_t)hp.call.verify[g] * DD) < 1e-11);
     }
     if (ok && !weak) {
       hp.tmpl_M[cat].swap(M);
       hp.tmpl_uploaded[cat] = 0;
-      for (long code : hp.call.probe) mark(code, 2);
-      if (hp.call.verify >= 0) mark(hp.call.verify, 2);
+      for (size_t g = 0; g < hp.tmpl_groups.size(); g++) {
+        for (long code : hp.call.probe[g]) mark(code, 2);
+        if (hp.call.verify[g] >= 0) mark(hp.call.verify[g], 2);
+      }
       for (long code : hp.call.skipped) mark(code, 2);
       _hyhip_deferred += (long)hp.call.skipped.size();
     } else {
@@ -736,67 +800,57 @@ static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, 
     }
     hp.call = _HyHipPart::Call();
   } else if (cat < (long)hp.tmpl_state.size() && hp.tmpl_state[cat] == 0 && parallel.lLength >= 12) {
-    // first large call of this class: is the model linear in the branches' local parameters?  (all matrices are dense here)
-    _CalcNode *first = (_CalcNode *)nodesToDo(parallel.get(0));
+    // first large call of this class: is the model linear in the branches' local parameters, group by group?  (all matrices
+    // are dense here.)  The groups are founded by the first class that gets here and are final afterwards.
     int verdict = -1;
-    const long K0 = first->iVariables ? (long)first->iVariables->lLength / 2 : 0;
-    if (!first->HasExplicitFormModel() && K0 >= 1 && K0 <= 3 && (hp.tmpl_K == 0 || hp.tmpl_K == K0)) {
-      if (hp.tmpl_K == 0) {
-        hp.tmpl_K = K0;
-        hp.tmpl_model = first->GetModelIndex();
-        hp.tmpl_refs.Clear();
-        for (long k = 0; k < K0; k++) hp.tmpl_refs << first->iVariables->list_data[2 * k + 1];
-        hp.tmpl_dep_sig = _hyhip_dep_signature(first);
-        hp.dep_ok.clear();
-      }
-      std::vector<long> codes;
-      bool all_conform = true;
-      for (unsigned long id = 0; id < parallel.lLength && all_conform; id++) {
-        _CalcNode *nd = (_CalcNode *)nodesToDo(parallel.get(id));
-        all_conform = _hyhip_conforms(hp, nd);
-        codes.push_back(hp.code_of.at(nd));
-      }
-      if (all_conform) {
-        std::vector<double> &X = hp.tmpl_x[cat];
-        if (X.empty()) X.assign(hp.code_of.size() * K0, 0.);
-        for (unsigned long id = 0; id < parallel.lLength; id++)
-          _hyhip_local_row((_CalcNode *)nodesToDo(parallel.get(id)), K0, X.data() + (size_t)codes[id] * K0);
-        // greedy choice of K0 independent probes
+    const bool founding = hp.tmpl_groups.empty();
+    if (founding) {
+      hp.tmpl_groups_open = true;
+      hp.tmpl_K = 0;
+      hp.group_of.clear();
+    }
+    std::vector<long> codes;
+    std::vector<int> groups;
+    bool all_conform = true;
+    for (unsigned long id = 0; id < parallel.lLength && all_conform; id++) {
+      _CalcNode *nd = (_CalcNode *)nodesToDo(parallel.get(id));
+      const int g = _hyhip_group(hp, nd);
+      all_conform = g >= 0;
+      codes.push_back(hp.code_of.at(nd));
+      groups.push_back(g);
+    }
+    hp.tmpl_groups_open = false;
+    if (all_conform && hp.tmpl_K >= 1) {
+      const long K0 = hp.tmpl_K;
+      std::vector<double> &X = hp.tmpl_x[cat];
+      X.assign(hp.code_of.size() * K0, 0.);
+      for (unsigned long id = 0; id < parallel.lLength; id++)
+        _hyhip_local_row(hp, (_CalcNode *)nodesToDo(parallel.get(id)), groups[id], X.data() + (size_t)codes[id] * K0);
+      std::vector<double> M((size_t)K0 * DD, 0.);
+      bool solved = true;
+      for (size_t g = 0; g < hp.tmpl_groups.size() && solved; g++) {  // greedy choice of K_g independent probes per group
+        const _HyHipPart::Group &G = hp.tmpl_groups[g];
         std::vector<long> probe;
-        for (long code : codes) {
-          if ((long)probe.size() == K0) break;
-          double rows[16], gram[16], inv[16];
-          const long np = (long)probe.size();
-          for (long i = 0; i < np; i++)
-            for (long k = 0; k < K0; k++) rows[i * K0 + k] = X[(size_t)probe[i] * K0 + k];
-          for (long k = 0; k < K0; k++) rows[np * K0 + k] = X[(size_t)code * K0 + k];
-          for (long i = 0; i <= np; i++)
-            for (long j = 0; j <= np; j++) {
-              double g = 0.;
-              for (long k = 0; k < K0; k++) g += rows[i * K0 + k] * rows[j * K0 + k];
-              gram[i * (np + 1) + j] = g;
-            }
-          if (_hyhip_invert(gram, np + 1, inv)) probe.push_back(code);
-        }
-        if ((long)probe.size() == K0) {
-          double Xp[16];
-          std::vector<const double *> Qp;
-          for (long i = 0; i < K0; i++) {
-            for (long k = 0; k < K0; k++) Xp[i * K0 + k] = X[(size_t)probe[i] * K0 + k];
-            Qp.push_back(hp.qstash[cat].data() + (size_t)probe[i] * DD);
-          }
-          std::vector<double> M;
-          if (_hyhip_solve_templates(K0, DD, Xp, Qp, M)) {
-            double worst = 0.;
-            for (long code : codes)
-              worst = fmax(worst, _hyhip_template_error(K0, D, X.data() + (size_t)code * K0, M, hp.qstash[cat].data() + (size_t)code * DD));
-            verdict = worst < 1e-11 ? 1 : -1;
-            if (getenv("HYPHY_HIP_VERBOSE"))
-              fprintf(stderr, "[hyphy_hip] template analysis, class %ld: K = %ld local parameter(s), %ld branches, worst relative deviation from linearity %.2e -> %s\n",
-                      cat, K0, (long)codes.size(), worst, verdict == 1 ? "template mode" : "dense matrices");
-          } else verdict = 0;  // (dependent probes, e.g. every branch length equal to zero: try again next time)
-        } else verdict = 0;
+        for (size_t id = 0; id < codes.size() && (long)probe.size() < G.K; id++)
+          if (groups[id] == (int)g && _hyhip_rows_independent(X, K0, G, probe, codes[id])) probe.push_back(codes[id]);
+        solved = _hyhip_solve_group(X, K0, DD, G, probe, hp.qstash[cat].data(), M);
       }
+      if (solved) {
+        double worst = 0.;
+        for (long code : codes)
+          worst = fmax(worst, _hyhip_template_error(K0, D, X.data() + (size_t)code * K0, M, hp.qstash[cat].data() + (size_t)code * DD));
+        verdict = worst < 1e-11 ? 1 : -1;
+        if (verdict == 1) hp.tmpl_M[cat] = M;
+        if (getenv("HYPHY_HIP_VERBOSE"))
+          fprintf(stderr, "[hyphy_hip] template analysis, class %ld: %ld branch class(es), %ld template column(s), %ld branches, worst relative deviation from linearity %.2e -> %s\n",
+                  cat, (long)hp.tmpl_groups.size(), K0, (long)codes.size(), worst, verdict == 1 ? "template mode" : "dense matrices");
+      } else verdict = 0;  // (dependent probes, e.g. every branch length of a group equal to zero: try again next time)
+    }
+    if (verdict != 1 && founding) {  // nothing founded that later calls may rely on
+      hp.tmpl_groups.clear();
+      hp.tmpl_K = 0;
+      hp.group_of.clear();
+      for (auto &x : hp.tmpl_x) x.clear();
     }
     hp.tmpl_state[cat] = verdict;
   }

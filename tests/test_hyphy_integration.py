@@ -436,8 +436,7 @@ def _run_constrained_local_model(binary=None, env=None, optimize=False, sweep=No
 def test_hbl_template_mode_with_constrained_dependent_locals():
     """r03: template mode also takes models whose branches carry DEPENDENT locals, provided every branch carries the same
     constraints.  Global-omega MG94 with `nonSynRate := R*synRate` per branch: a sweep of R in mode B and a
-    complete Optimize through template mode (K = 1) against the unmodified binary; with branch-specific constraints (two omega
-    classes that are equal at the start and separate during the sweep) the adapter must NOT use templates."""
+    complete Optimize through template mode (K = 1) against the unmodified binary.  (Branch-specific constraints: the next test.)"""
     _need_binaries()
     sweep = dict(param="R", start=0.3, step=0.02, n=15, record=15)
     envB = dict(ENV, HYPHY_HIP_DEVICE_EXPM="always")
@@ -450,9 +449,31 @@ def test_hbl_template_mode_with_constrained_dependent_locals():
     gpu = _run_constrained_local_model(binary=HIP_BIN, env=ENV, optimize=True)
     assert _template_evals(gpu["stdout"])[0] > 5, gpu["stdout"][-1000:]
     assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3
-    # two omega classes: same rows, different constraints -> different matrices on branches with equal locals
+
+
+def test_hbl_template_mode_with_branch_classes():
+    """r04: foreground / background omega — how FEL, BUSTED and RELAX partition their branches (calcnode.cpp:526-704 evaluates the
+    dependents branch by branch).  Every third branch is constrained through R2, the others through R: two constraint signatures,
+    i.e. two branch classes with templates of their own (one coefficient column each).  Sweeps of either global (the classes are
+    equal at the start and separate during the sweep: branches with EQUAL local parameters then carry DIFFERENT matrices) and a
+    complete Optimize, in template mode, against the unmodified binary."""
+    _need_binaries()
+    envB = dict(ENV, HYPHY_HIP_DEVICE_EXPM="always")
+    for param in ("R", "R2"):
+        sweep = dict(param=param, start=0.3, step=0.02, n=15, record=15)
+        cpu = _run_constrained_local_model(sweep=sweep, branch_specific=True)
+        gpu = _run_constrained_local_model(binary=HIP_BIN, env=envB, sweep=sweep, branch_specific=True)
+        n_eval, K, n_skip = _template_evals(gpu["stdout"])
+        assert K == 2 and n_eval >= 10 and n_skip > 0, gpu["stdout"][-1500:]
+        assert "2 branch class(es)" in gpu["stdout"]
+        assert np.max(np.abs(gpu["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10
+    cpu = _run_constrained_local_model(optimize=True, branch_specific=True)
+    gpu = _run_constrained_local_model(binary=HIP_BIN, env=ENV, optimize=True, branch_specific=True)
+    assert _template_evals(gpu["stdout"])[0] > 5, gpu["stdout"][-1500:]
+    assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3
+    # dense mode B stays available and agrees (HYPHY_HIP_TEMPLATES=0)
+    sweep = dict(param="R2", start=0.3, step=0.02, n=6, record=6)
     cpu = _run_constrained_local_model(sweep=sweep, branch_specific=True)
-    gpu = _run_constrained_local_model(binary=HIP_BIN, env=envB, sweep=sweep, branch_specific=True)
-    assert _template_evals(gpu["stdout"])[0] == 0, gpu["stdout"][-1000:]
-    assert _device_calls(gpu["stdout"]) > 10
+    gpu = _run_constrained_local_model(binary=HIP_BIN, env=dict(envB, HYPHY_HIP_TEMPLATES="0"), sweep=sweep, branch_specific=True)
+    assert _template_evals(gpu["stdout"])[0] == 0 and _device_calls(gpu["stdout"]) > 4
     assert np.max(np.abs(gpu["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10

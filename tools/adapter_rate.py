@@ -1,12 +1,16 @@
-"""Through-the-host rates of the configurations that are NOT the headline one: the patched hyphy binary
-(integration/_build/hyphy_hip, HYPHY_HIP=1) runs HBL written by oracle/hbl.py —
+"""Through-the-host rates: the patched hyphy binary (integration/_build/hyphy_hip, HYPHY_HIP=1) runs HBL written
+by oracle/hbl.py, next to the unmodified reference —
+  headline  64 taxa x 10 000 codons, MG94 with one local parameter per branch (t) and a global omega: LFCompute sweep of R
+            (template mode), and the same with HYPHY_HIP_TEMPLATES=0 (dense mode B);
+  class2    the same alignment, MG94 with LOCAL synRate / nonSynRate and `nonSynRate := R*synRate` on the background branches,
+            `:= R2*synRate` on every third (foreground) branch — two branch classes (r04: template mode with a group per class);
   cat3      64 taxa x 10 000 codons, MG94 with a 3-class omega category variable (BUSTED-shaped, weighted-sum category mode):
             LFCompute sweep of the global scaling R;
   mix3      the same alignment under the reference's EXPLICIT-FORM 3-component branch-site mixture
             ("Exp(Q1)*W1+Exp(Q2)*W2+Exp(Q3)*(1-W1-W2)"): LFCompute sweep of W1 with device exponentials forced (mode B, mixture mode);
   manylf    N single-codon likelihood functions on the 64-taxon tree (what FEL does per site): create, 50 LFCompute calls with R
             swept, destroy — through the device, through the device with the adapter's size policy (default), and on the CPU.
-One JSON line per measurement.  Usage (GPU box): python tests/adapter_rate2.py [cat3,mix3,manylf] [n_evals] [n_lfs]"""
+One JSON line per measurement.  Usage (GPU box): python tools/adapter_rate.py [headline,class2,cat3,mix3,manylf] [n_evals] [n_lfs]"""
 import json
 import os
 import sys
@@ -22,7 +26,7 @@ from oracle import hbl
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIP_BIN = os.path.join(ROOT, "integration", "_build", "hyphy_hip")
-which = (sys.argv[1] if len(sys.argv) > 1 else "cat3,mix3,manylf").split(",")
+which = (sys.argv[1] if len(sys.argv) > 1 else "headline,class2,cat3,mix3,manylf").split(",")
 n_evals = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
 n_lfs = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 ENV = dict(HYPHY_HIP="1", HYPHY_HIP_VERBOSE="1", **{k: v for k, v in os.environ.items() if k.startswith("HYPHY_HIP_")})
@@ -42,6 +46,47 @@ def emit(tag, host, res, count, t0, extra=None):
     print(json.dumps({"case": tag, "host": host, "evals": count, "sweep_seconds": secs, "evals_per_s": count / secs, "logl": res["logl"],
                       "wall": time.time() - t0, "adapter_says": mode[-2:], **(extra or {})}), flush=True)
 
+
+if "headline" in which:
+    block = hbl.codon_model_block(tmpl, pi)
+    for host, binary, env, count in (("adapter (template mode)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals * 4),
+                                      ("adapter, HYPHY_HIP_TEMPLATES=0 (dense mode B)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always", HYPHY_HIP_TEMPLATES="0"), n_evals),
+                                      ("reference 16 threads", None, None, max(8, n_evals // 40))):
+        t0 = time.time()
+        res = hbl.evaluate(model_block=block, globals_=dict(R=0.3, **bench.REV), sweep=dict(param="R", start=0.3, step=0.0001, n=count),
+                           threads=(1 if binary else 16), binary=binary, extra_env=env, **common)
+        emit("mg94_64x10k", host, res, count, t0)
+
+if "class2" in which:
+    # MG94 with two local parameters per branch and branch-specific constraints: foreground / background omega
+    lines = ["MGQ = {61,61};"]
+    for (i, j, name, ns, pf) in tmpl:
+        parts = ([name] if name != "AG" else []) + ["nonSynRate" if ns else "synRate", repr(float(pf))]
+        lines.append(f"MGQ[{i}][{j}] := {'*'.join(parts)};")
+    lines.append("vectorOfFrequencies = {\n" + ",\n".join("{" + repr(float(v)) + "}" for v in pi) + "};")
+    lines.append("Model MGM = (MGQ, vectorOfFrequencies, 0);")
+    tmp = tempfile.mkdtemp(prefix="hyclass_")
+    fasta, outp = os.path.join(tmp, "aln.fasta"), os.path.join(tmp, "out.txt")
+    hbl.write_fasta(fasta, syn.flat.leaf_names, syn.seqs)
+    for host, binary, env, count, thr in (("adapter (template mode, one group per branch class)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals * 4, 1),
+                                           ("adapter, HYPHY_HIP_TEMPLATES=0 (dense mode B)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always", HYPHY_HIP_TEMPLATES="0"), n_evals, 1),
+                                           ("reference 16 threads", None, None, max(8, n_evals // 40), 16)):
+        t0 = time.time()
+        txt = hbl.build_script(fasta=fasta, newick=htree.to_newick(syn.tree), unit=3, model_block="\n".join(lines), model_name="MGM",
+                               globals_=dict(R=0.3, R2=0.5, **bench.REV), branch_t=bt, out_path=outp, per_site=False,
+                               sweep=dict(param="R", start=0.3, step=0.0001, n=count), threads=thr)
+        for k, (nm, t) in enumerate(bt.items()):
+            om = "R2" if k % 3 == 0 else "R"
+            txt = txt.replace(f"givenTree.{nm}.t = {hbl._fmt(t)};",
+                              f"givenTree.{nm}.synRate = {hbl._fmt(t)}; givenTree.{nm}.nonSynRate := {om}*givenTree.{nm}.synRate;")
+        assert ".t = " not in txt
+        try:
+            stdout = hbl.run_script(txt, tmp, cpus=thr, timeout=1800.0, binary=binary, extra_env=env)
+            res = hbl.parse_output(outp)
+            res["stdout"] = stdout
+            emit("mg94_two_omega_classes_64x10k", host, res, count, t0)
+        except Exception as e:
+            print(json.dumps({"case": "class2", "host": host, "error": str(e)[-600:]}), flush=True)
 
 if "cat3" in which:
     block = hbl.codon_model_block(tmpl, pi, omega="R*cc")
