@@ -203,8 +203,14 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     }
     if (mix) {
       // explicit-form branch-site mixtures: exponentiate every component, then mix into the branch's matrix images
-      if (q_on_device || q_is_prob || n_cat_batch != 1) return fail("mixture evaluation: host rate matrices, one class at a time");
+      // component rate matrices: dense from the host, or (q == the partition's own buffer behind hyphy_hip_build_q) formed inside
+      // the exponential kernel from the staged coefficient rows, one row per (branch, component)
+      const bool mix_built = q_on_device && q == s.qbuf && p->coeffs_pending;
+      if ((q_on_device && !mix_built) || q_is_prob || n_cat_batch != 1)
+        return fail("mixture evaluation: host rate matrices or hyphy_hip_build_q rows, one class at a time");
       const size_t n_tot = (size_t)mix->n_tot, DD = (size_t)D * D;
+      if (mix_built && s.coeff_rows != (int64_t)n_tot)
+        return fail("mixture evaluation: hyphy_hip_build_q staged a different number of rows than the components of this evaluation");
       if (s.mix_cap < n_tot || s.mix_nq_cap < (size_t)n_q) {
         HIPCHK(hipStreamSynchronize(s.stream));
         for (void *d : {(void *)s.mix_q, (void *)s.mix_p, (void *)s.mix_w, (void *)s.mix_off})
@@ -220,7 +226,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       }
       std::vector<int> off((size_t)n_q + 1, 0);
       for (int64_t k = 0; k < n_q; k++) off[k + 1] = off[k] + (int)mix->count[k];
-      HIPCHK(hipMemcpyAsync(s.mix_q, q, n_tot * DD * sizeof(double), hipMemcpyHostToDevice, s.stream));
+      if (!mix_built) HIPCHK(hipMemcpyAsync(s.mix_q, q, n_tot * DD * sizeof(double), hipMemcpyHostToDevice, s.stream));
       HIPCHK(hipMemcpyAsync(s.mix_w, mix->weights, n_tot * sizeof(double), hipMemcpyHostToDevice, s.stream));
       HIPCHK(hipMemcpyAsync(s.mix_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, s.stream));
       HIPCHK(hipStreamSynchronize(s.stream));  // (pageable sources; `off` goes out of scope)
@@ -234,11 +240,22 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       ea.templates = nullptr;
       ea.coeffs = nullptr;
       ea.K = 0;
+      if (mix_built) {
+        ea.templates = s.templates;
+        ea.templates_pad = s.templates_pad;
+        ea.coeffs = s.coeffs_cur ? s.coeffs_cur : s.coeffs;
+        ea.coeffs_host = (s.coeffs_cur && s.d_hcoeffs) ? s.h_coeffs + (s.coeffs_cur - s.d_hcoeffs) : nullptr;
+        ea.K = (int)p->K;
+      }
       ea.prof = 0;
       ea.Prow = s.mix_p;
       ea.Pfrag = nullptr;
       ea.PTg = nullptr;
-      launch_expm(ea, s.stream);
+      const bool mix_coeffs_consumed = launch_expm(ea, s.stream);
+      if (mix_built && d_logl_out && s.coeff_slot >= 0 && !mix_coeffs_consumed) {  // (asynchronous caller: guard the ring slot)
+        HIPCHK(hipEventRecord(s.coeff_ev[s.coeff_slot], s.stream));
+        s.coeff_busy[s.coeff_slot] = true;
+      }
       s.twins_dirty = true;  // (the mixing kernel writes matrix images without their twins)
       launch_mix_images(s.mix_p, s.mix_off, s.mix_w, d_slots, (int)n_q, (int)D,
                         p->nuc ? nullptr : s.Pfrag + (size_t)cat * B * DP * DP, p->nuc ? nullptr : s.PTg + (size_t)cat * B * DP * DP,
@@ -1081,6 +1098,33 @@ int hyphy_hip_evaluate_mixture(hyphy_hip_partition *p, int64_t cat, const int64_
   return 0;
 }
 
+/* The same with the component rate matrices formed ON THE DEVICE (r04): Q_(b,m) = sum_k x_(b,m),k T_k over the templates of
+ * hyphy_hip_set_q_templates / hyphy_hip_update_q_templates, one coefficient row per (branch of q_nodes, component) staged by
+ * hyphy_hip_build_q (n = sum of n_components rows, branch-major) — no dense matrix crosses PCIe.  BS-REL / BUSTED components
+ * differ in a global only (omega_m): component m of a branch with locals x_b is x_b at the columns of component m's templates. */
+int hyphy_hip_evaluate_mixture_built(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                                     const int64_t *q_nodes, int64_t n_q, const int64_t *n_components, const double *weights,
+                                     const double *root_freqs, double *logl_out, double *site_lik_out, int64_t *site_scaler_out) {
+  if (!p) return fail("partition == NULL");
+  if (!p->K) return fail("evaluate_mixture_built: templates not set");
+  if (n_q > 0 && (!n_components || !weights)) return fail("mixture evaluation: null argument");
+  if (n_q <= 0) return fail("evaluate_mixture_built: no matrices (use hyphy_hip_evaluate_built for a pure re-evaluation)");
+  MixSpec mix{n_components, weights, 0};
+  for (int64_t k = 0; k < n_q; k++) {
+    if (n_components[k] < 1 || n_components[k] > kMixRows) return fail("mixture evaluation: 1..16 components per branch");
+    mix.n_tot += n_components[k];
+  }
+  if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, &kOwnQBuffer, true, 0, root_freqs, nullptr, true, false, false, false, &mix))
+    return -1;
+  if (collect_status(p)) return -1;
+  std::vector<double> parts;
+  for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
+  record_timings(p);
+  if (logl_out) *logl_out = combine(parts);
+  if (site_lik_out || site_scaler_out) return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
+  return 0;
+}
+
 /* Asynchronous pair (partitions of one likelihood function on different devices / streams overlap: the host enqueues
  * every partition's evaluation before it waits for the first — the reference's partition loop, likefunc.cpp:2524-2589,
  * is serial).  The matrices are copied to a pinned staging buffer, so the caller's array is free on return. */
@@ -1576,9 +1620,11 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
     if (s.coeffs) hipFree(s.coeffs);
     s.templates = s.coeffs = nullptr;
     HIPCHK(hipMalloc((void **)&s.templates, (size_t)K * D * D * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&s.coeffs, (size_t)p->C * p->B * K * sizeof(double)));
+    // rows: one per (class, branch), or — mixtures built on the device — one per (branch, component), up to kMixRows components
+    const size_t coeff_rows_cap = (size_t)std::max<int64_t>(p->C, kMixRows) * p->B;
+    HIPCHK(hipMalloc((void **)&s.coeffs, coeff_rows_cap * K * sizeof(double)));
     if (s.h_coeffs) hipHostFree(s.h_coeffs);
-    HIPCHK(hipHostMalloc((void **)&s.h_coeffs, (size_t)4 * p->C * p->B * K * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&s.h_coeffs, (size_t)4 * coeff_rows_cap * K * sizeof(double)));
     if (hipHostGetDevicePointer((void **)&s.d_hcoeffs, s.h_coeffs, 0) != hipSuccess) s.d_hcoeffs = nullptr;
     s.coeffs_cur = nullptr;
     s.coeff_rows = 0;
@@ -1631,7 +1677,7 @@ int hyphy_hip_update_q_templates(hyphy_hip_partition *p, int64_t K, const double
 
 int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs) {
   if (!p || !p->K) return fail("build_q: templates not set");
-  if (n < 0 || n > p->C * p->B || !coeffs) return fail("build_q: bad arguments");
+  if (n < 0 || n > std::max<int64_t>(p->C, kMixRows) * p->B || !coeffs) return fail("build_q: bad arguments");
   Trace tr("build_q");
   // When the matrices are consumed by the next hyphy_hip_evaluate_device(q_buffer) — the normal use —
   // the construction is fused into the expm kernel (no Q round trip through HBM, one launch less).
@@ -1645,7 +1691,7 @@ int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs) {
       HIPCHK(hipEventSynchronize(s.coeff_ev[slot]));
       s.coeff_busy[slot] = false;
     }
-    double *stage = s.h_coeffs + (size_t)slot * (size_t)p->C * p->B * p->K;
+    double *stage = s.h_coeffs + (size_t)slot * (size_t)std::max<int64_t>(p->C, kMixRows) * p->B * p->K;
     memcpy(stage, coeffs, nbytes);
     s.coeff_slot = slot;
     s.coeff_rows = n;
@@ -1659,7 +1705,10 @@ int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs) {
       HIPCHK(hipMemcpyAsync(s.coeffs, stage, nbytes, hipMemcpyHostToDevice, s.stream));
     }
     tr.lap("memcpy");
-    if (!fuse) launch_build_q(s.templates, s.coeffs, (int)n, (int)p->K, (int)p->D, s.qbuf, s.stream);
+    if (!fuse) {
+      if (n > p->C * p->B) return fail("build_q: HYPHY_HIP_MATERIALIZE_Q holds at most one matrix per (class, branch)");
+      launch_build_q(s.templates, s.coeffs, (int)n, (int)p->K, (int)p->D, s.qbuf, s.stream);
+    }
     tr.lap("launch");
   }
   p->coeffs_pending = fuse;

@@ -254,6 +254,7 @@ inline int twin_slot0(const hyphy_hip_partition *p) { return (int)(p->B + (p->I 
 extern const double kOwnQBuffer;
 
 // branch-site mixture: matrix k of the evaluation is sum_m weights[off_k + m] exp(q[off_k + m]), count[k] components
+constexpr int64_t kMixRows = 16;  // most components of an explicit-form mixture per branch
 struct MixSpec {
   const int64_t *count;
   const double *weights;

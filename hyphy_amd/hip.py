@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("HYPHY_HIP_LIB") or os.path.join(HERE, "lib", "libhyph
 
 EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
-    "hyphy_hip_evaluate_device", "hyphy_hip_fetch_device_scalar", "hyphy_hip_plan_reroot", "hyphy_hip_plan_pattern_order", "hyphy_hip_plan_schedule", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_comm_unique_id", "hyphy_hip_comm_init_rank", "hyphy_hip_comm_init_all", "hyphy_hip_allreduce_device", "hyphy_hip_evaluate_allreduce", "hyphy_hip_evaluate_built_allreduce", "hyphy_hip_last_allreduce_ms", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
+    "hyphy_hip_evaluate_device", "hyphy_hip_fetch_device_scalar", "hyphy_hip_plan_reroot", "hyphy_hip_plan_pattern_order", "hyphy_hip_plan_schedule", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_evaluate_mixture_built", "hyphy_hip_comm_unique_id", "hyphy_hip_comm_init_rank", "hyphy_hip_comm_init_all", "hyphy_hip_allreduce_device", "hyphy_hip_evaluate_allreduce", "hyphy_hip_evaluate_built_allreduce", "hyphy_hip_last_allreduce_ms", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
@@ -68,6 +68,8 @@ def load():
     lib.hyphy_hip_evaluate_allreduce.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp, dp]
     lib.hyphy_hip_evaluate_mixture.restype = C.c_int
     lib.hyphy_hip_evaluate_mixture.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, lp, dp, dp, dp, dp, dp, lp]
+    lib.hyphy_hip_evaluate_mixture_built.restype = C.c_int
+    lib.hyphy_hip_evaluate_mixture_built.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, lp, dp, dp, dp, dp, lp]
     lib.hyphy_hip_evaluate_async.restype = C.c_int
     lib.hyphy_hip_evaluate_async.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp]
     lib.hyphy_hip_collect.restype = C.c_int
@@ -291,6 +293,24 @@ class HipPartition:
         sc = np.zeros(self.S, dtype=np.int64) if per_site else None
         _check(self._lib.hyphy_hip_evaluate_mixture(self._h, cat, _l(un), len(un), _l(qn), len(qn), _l(cnt), _d(q), _d(w),
                                                     _d(rf), C.byref(out), _d(sl), _l(sc)))
+        return (out.value, sl, sc) if per_site else out.value
+
+    def evaluate_mixture_built(self, update_nodes, q_nodes, coeffs, weights, root_freqs, cat: int = -1, per_site: bool = False):
+        """The same with the component rate matrices formed on the device from the uploaded templates: ``coeffs`` [n_q, M, K]
+        (one coefficient row per branch and component: ``hyphy_hip_build_q`` + ``hyphy_hip_evaluate_mixture_built``)."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        c = np.ascontiguousarray(coeffs, dtype=np.float64)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        assert c.ndim == 3 and w.shape == c.shape[:2] and c.shape[0] == len(qn)
+        cnt = np.full(len(qn), c.shape[1], dtype=np.int64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        out = C.c_double(0.0)
+        sl = np.zeros(self.S) if per_site else None
+        sc = np.zeros(self.S, dtype=np.int64) if per_site else None
+        _check(self._lib.hyphy_hip_build_q(self._h, c.shape[0] * c.shape[1], _d(c)))
+        _check(self._lib.hyphy_hip_evaluate_mixture_built(self._h, cat, _l(un), len(un), _l(qn), len(qn), _l(cnt), _d(w), _d(rf),
+                                                          C.byref(out), _d(sl), _l(sc)))
         return (out.value, sl, sc) if per_site else out.value
 
     def evaluate_async(self, update_nodes, q_nodes, q_dense, root_freqs, cat: int = -1, q_is_probability: bool = False):

@@ -124,6 +124,21 @@ int hyphy_hip_evaluate_mixture(hyphy_hip_partition *p, int64_t cat, const int64_
                                const double *root_freqs, double *logl_out, double *site_lik_out, int64_t *site_scaler_out);
 
 /*
+ * hyphy_hip_evaluate_mixture with the component rate matrices formed ON THE DEVICE (r04): BS-REL / BUSTED / RELAX components
+ * differ in GLOBAL parameters only (omega_m: res/TemplateBatchFiles/libv3/models/codon/BS_REL.bf:48), so component m of branch b is
+ * Q_(b,m) = sum_k x_(b,m),k T_k over the templates of hyphy_hip_set_q_templates / hyphy_hip_update_q_templates — the host's
+ * serial pass that evaluates every component's formulas for every branch (calcnode.cpp:526-704 behind
+ * variablecontainer.cpp:208-233) and the dense matrices over PCIe both go away.  Protocol: hyphy_hip_build_q(p, n, coeffs) with
+ * n = sum of n_components rows of K coefficients, branch-major (the components of q_nodes[0], then those of q_nodes[1], ...),
+ * then this call; the rows are consumed inside the exponential kernel (no rate matrix is ever materialised).  At most 16
+ * components per branch.  Everything else as hyphy_hip_evaluate_mixture.
+ */
+int hyphy_hip_evaluate_mixture_built(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                                     const int64_t *q_nodes, int64_t n_q, const int64_t *n_components /* [n_q] */,
+                                     const double *weights /* [sum n_components] */, const double *root_freqs, double *logl_out,
+                                     double *site_lik_out, int64_t *site_scaler_out);
+
+/*
  * The same evaluation split in two, so that the partitions of one likelihood function overlap (different devices, or
  * different streams of one device): enqueue every partition, then collect.  The reference's partition loop in
  * _LikelihoodFunction::Compute (src/core/likefunc.cpp:2524-2589) calls ComputeBlock(partID) serially and its MPI

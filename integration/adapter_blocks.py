@@ -68,6 +68,25 @@ struct _HyHipPart {
   std::vector<std::vector<double>> mix_q;         // per class: [B][M][D*D]
   std::vector<std::vector<double>> mix_w;         // per class: [M] weights of the matrices stashed last
   long n_mixture_evals = 0;
+  // mixture TEMPLATE mode (r04): the components of a BS-REL / BUSTED branch differ in global parameters only, so each is linear
+  // in the branch's own locals, Q_(b,m) = sum_k x_bk T^(m)_k: per call the host evaluates the component matrices of K probe
+  // branches + one verifier, every other branch reaches the device as its K locals (hyphy_hip_evaluate_mixture_built).
+  // Per rate class: 0 not analysed, 1 enabled, -1 disabled.
+  std::vector<int> mixT_state;
+  Group mixT_group;                               // what every explicit-form node must show (model, template variables, constraints)
+  std::unordered_map<const void *, char> mixT_ok;
+  std::vector<std::vector<double>> mixT_T;        // per class: [M][K][D*D] component templates of the last call
+  std::vector<std::vector<double>> mixT_x;        // per class: [B][K]
+  struct MCall {
+    bool active = false, broken = false;   // broken: a node outside the group turned up — this call goes the dense way
+    bool learning = false;                 // the adapter's learning call: every explicit-form node is recomputed by the host and its
+                                           // Exp() arguments are read behind it (`probe` lists them); the analysis runs at the end
+    long cat = 0, verify = -1;
+    long pending = -1;                     // recomputed node whose Exp() arguments are still to be read (behind its RecomputeMatrix)
+    std::vector<long> probe, skipped;
+    double verify_dist = 0., skipped_dist = 0.;
+  } mcall;
+  long n_mixT_evals = 0, n_mix_skipped = 0;
   // SPMD site sharding (one host process per GPU, every process runs the same batch file: HYPHY_HIP_WORLD / HYPHY_HIP_RANK,
   // set by the launcher, one ordinary host process per GPU): this process holds patterns [lo, hi) of the partition
   // and every evaluation ends in ONE ncclAllReduce of the partition log-likelihood (hyphy_hip_evaluate*_allreduce)
@@ -84,6 +103,7 @@ long _hyhip_calls = 0L, _hyhip_cached_calls = 0L, _hyhip_deferred = 0L;
 static int _hyhip_defer_depth = 0;
 extern bool (*_hyhip_defer_expm_hook)(_TheTree *, long, _List &, _List &, _SimpleList &, _SimpleList &, bool);  // tree.cpp copy
 extern bool (*_hyhip_skip_recompute_hook)(_TheTree *, long, _CalcNode *, unsigned long, unsigned long);  // tree.cpp copy
+extern bool _hyhip_force_defer_call;  // tree.cpp copy: offer this ExponentiateMatrices call to the adapter whatever its queue holds
 static int _hyhip_async_phase = 0;  // > 0: ComputeBlock enqueues the device evaluation and returns (pre-pass of Compute)
 static int _hyphy_hip_expm_mode(void) {
   static int mode = -1;
@@ -110,6 +130,9 @@ static void _hyphy_hip_teardown(const void *lf) {
     if (hp.part && getenv("HYPHY_HIP_VERBOSE") && hp.n_mixture_evals)
       fprintf(stderr, "[hyphy_hip] mixture mode: %ld evaluations exponentiated and mixed their %ld-component branch-site mixtures on the device\n",
               hp.n_mixture_evals, hp.mix_M);
+    if (hp.part && getenv("HYPHY_HIP_VERBOSE") && hp.n_mixT_evals)
+      fprintf(stderr, "[hyphy_hip] mixture template mode: %ld evaluations took their component rate matrices as coefficients (M = %ld, K = %ld), %ld RecomputeMatrix calls skipped\n",
+              hp.n_mixT_evals, hp.mix_M, hp.mixT_group.K, hp.n_mix_skipped);
     if (hp.part && getenv("HYPHY_HIP_VERBOSE") && hp.n_template_evals)
       fprintf(stderr, "[hyphy_hip] template mode: %ld evaluations took their rate matrices as coefficients (K = %ld), %ld RecomputeMatrix calls skipped\n",
               hp.n_template_evals, hp.tmpl_K, hp.n_skipped);
@@ -299,6 +322,12 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   hp.mix_wf.clear();
   hp.mix_q.assign(n_cat, std::vector<double>());
   hp.mix_w.assign(n_cat, std::vector<double>());
+  hp.mixT_state.assign(n_cat, (getenv("HYPHY_HIP_TEMPLATES") && !strcmp(getenv("HYPHY_HIP_TEMPLATES"), "0")) ? -1 : 0);
+  hp.mixT_group = _HyHipPart::Group();
+  hp.mixT_ok.clear();
+  hp.mixT_T.assign(n_cat, std::vector<double>());
+  hp.mixT_x.assign(n_cat, std::vector<double>());
+  hp.mcall = _HyHipPart::MCall();
   _hyhip_tree_owner[cT] = std::make_pair(lf, (long)i);
   if (_hyphy_hip_expm_mode() > 0) {
     _hyhip_defer_expm_hook = _hyphy_hip_defer_handler;
@@ -524,6 +553,101 @@ static _HyHipPart *_hyhip_part_of_tree(_TheTree *t) {
   return hp.part ? &hp : nullptr;
 }
 
+// explicit-form (mixture) nodes: does the node show the signature of the partition's mixture group?  (cached)
+static bool _hyhip_mix_conforms(_HyHipPart &hp, _CalcNode *n) {
+  auto it = hp.mixT_ok.find(n);
+  if (it != hp.mixT_ok.end()) return it->second != 0;
+  const _HyHipPart::Group &G = hp.mixT_group;
+  bool ok = n->HasExplicitFormModel() && n->GetModelIndex() == G.model && n->iVariables && (long)n->iVariables->lLength == 2 * G.K;
+  for (long k = 0; k < G.K && ok; k++) ok = n->iVariables->list_data[2 * k + 1] == G.refs.list_data[k];
+  if (ok) ok = ((n->dVariables && n->dVariables->lLength) ? _hyhip_dep_signature(n) : std::string()) == G.dep_sig;
+  hp.mixT_ok.emplace(n, ok ? 1 : 0);
+  return ok;
+}
+static void _hyhip_mix_row(_CalcNode *n, long K, double *x) {
+  for (long k = 0; k < K; k++) x[k] = LocateVar(n->iVariables->list_data[2 * k])->Compute()->Value();
+}
+// rows `codes` (+ `extra`) of X [.][K] independent?
+static bool _hyhip_mix_independent(const std::vector<double> &X, long K, const std::vector<long> &codes, long extra) {
+  _HyHipPart::Group G;
+  G.K = K;
+  G.col = 0;
+  return _hyhip_rows_independent(X, K, G, codes, extra);
+}
+// component templates from the probes: T[m][k] = sum_i inv(X_p)[k][i] Q_(probe_i, m); q_of(code, m) -> the stashed matrix
+template <typename QOf>
+static bool _hyhip_mix_solve(const std::vector<double> &X, long K, long M, long DD, const std::vector<long> &probe, QOf q_of, std::vector<double> &T) {
+  if ((long)probe.size() != K) return false;
+  double Xp[16], inv[16];
+  for (long i = 0; i < K; i++)
+    for (long k = 0; k < K; k++) Xp[i * K + k] = X[(size_t)probe[i] * K + k];
+  if (!_hyhip_invert(Xp, K, inv)) return false;
+  T.assign((size_t)M * K * DD, 0.);
+  for (long m = 0; m < M; m++)
+    for (long k = 0; k < K; k++) {
+      double *dst = T.data() + ((size_t)m * K + k) * DD;
+      for (long i = 0; i < K; i++) {
+        const double f = inv[k * K + i];
+        if (f == 0.) continue;
+        const double *q = q_of(probe[i], m);
+        for (long e = 0; e < DD; e++) dst[e] += f * q[e];
+      }
+    }
+  return true;
+}
+// worst relative deviation of one branch's M stashed component matrices from sum_k x_k T[m][k] (off-diagonal entries)
+template <typename QOf>
+static double _hyhip_mix_error(long K, long M, long D, const double *x, const std::vector<double> &T, long code, QOf q_of) {
+  const long DD = D * D;
+  double worst = 0.;
+  for (long m = 0; m < M; m++) {
+    const double *q = q_of(code, m);
+    double err = 0., scale = 0.;
+    for (long e = 0; e < DD; e++) {
+      if (e / D == e % D) continue;
+      double v = 0.;
+      for (long k = 0; k < K; k++) v += x[k] * T[((size_t)m * K + k) * DD + e];
+      err = fmax(err, fabs(v - q[e]));
+      scale = fmax(scale, fabs(q[e]));
+    }
+    worst = fmax(worst, scale > 0. ? err / scale : (err > 0. ? 1. : 0.));
+  }
+  return worst;
+}
+
+// The M component rate matrices of the node whose RecomputeMatrix ran last (its local parameters are still in the model's template
+// variables): the arguments of the formula's Exp() terms, evaluated the way _Formula::ExtractMatrixExpArguments does
+// (formula.cpp:2153-2214) but WITHOUT its cache comparison — the reference queues only the arguments that changed since the
+// formula's last evaluation, the adapter needs all of them for its probes whatever changed.
+static bool _hyhip_eval_exp_args(_Formula *f, long M, long D, double *dst) {
+  if (!f) return false;
+  long count = 0;
+  for (unsigned long i = 0UL; i + 1UL < f->theFormula.countitems(); i++) {
+    _Operation *this_op = f->GetIthTerm(i), *next_op = f->GetIthTerm(i + 1UL);
+    if (!next_op->CanResultsBeCached(this_op, true)) continue;
+    _Stack temp;
+    this_op->Execute(temp);
+    _Matrix *arg = (_Matrix *)temp.Pop(false);
+    if (!arg || arg->ObjectClass() != MATRIX || count >= M) return false;
+    _Matrix *num = (_Matrix *)arg->ComputeNumeric();
+    if (!num || !num->is_numeric() || num->GetHDim() != D || num->GetVDim() != D || !num->theData) return false;
+    _hyhip_dense_copy(num, D * D, dst + (size_t)count * D * D);
+    count++;
+    i++;
+  }
+  return count == M;
+}
+static void _hyhip_mix_collect_pending(_HyHipPart &hp, _TheTree *t, long catID) {
+  if (hp.mcall.pending < 0) return;
+  const long cat = catID < 0 ? 0 : catID, D = t->GetCodeBase(), DD = D * D, M = hp.mix_M, code = hp.mcall.pending;
+  hp.mcall.pending = -1;
+  _CalcNode *nd = (_CalcNode *)t->GetNodeFromFlatIndex(code);
+  if (hp.mix_q[cat].empty()) hp.mix_q[cat].assign(hp.code_of.size() * (size_t)M * DD, 0.);
+  if (!_hyhip_eval_exp_args(nd->GetExplicitFormModel(nd->map_global_to_local_category(catID)), M, D,
+                            hp.mix_q[cat].data() + (size_t)code * M * DD))
+    hp.mcall.broken = true;
+}
+
 // called for every node of ExponentiateMatrices' first loop (tree.cpp copy): true = do not call RecomputeMatrix
 static bool _hyphy_hip_skip_handler(_TheTree *t, long catID, _CalcNode *node, unsigned long nodeID, unsigned long n_nodes) {
   if (_hyhip_defer_depth <= 0) return false;
@@ -531,6 +655,70 @@ static bool _hyphy_hip_skip_handler(_TheTree *t, long catID, _CalcNode *node, un
   if (!php) return false;
   _HyHipPart &hp = *php;
   const long cat = catID < 0 ? 0 : catID;
+  if (nodeID == 0) {
+    hp.mcall = _HyHipPart::MCall();
+    hp.mcall.cat = cat;
+    hp.mcall.active = cat < (long)hp.mix_state.size() && hp.mix_state[cat] == 1 && hp.mixT_state[cat] == 1 &&
+                      (long)n_nodes >= hp.mixT_group.K + 6;
+    // (the analysis needs every branch's components once; the reference queues only the Exp() arguments that changed since a
+    //  formula's last evaluation, so a call that happens to queue all of them may never come: the adapter reads them itself)
+    hp.mcall.learning = !hp.mcall.active && cat < (long)hp.mix_state.size() && hp.mix_state[cat] == 1 && hp.mixT_state[cat] == 0 &&
+                        hp.mix_M > 0 && (long)n_nodes >= 12;
+    _hyhip_force_defer_call = false;
+  }
+  if ((hp.mcall.active || hp.mcall.learning) && hp.mcall.cat == cat) _hyhip_mix_collect_pending(hp, t, catID);  // (the node recomputed just before this one)
+  if (node->HasExplicitFormModel() && hp.mcall.learning && hp.mcall.cat == cat) {
+    auto itl = hp.code_of.find(node);
+    if (itl == hp.code_of.end()) {
+      hp.mcall.broken = true;
+      return false;
+    }
+    hp.mcall.probe.push_back(itl->second);
+    hp.mcall.pending = itl->second;
+    _hyhip_force_defer_call = true;
+    return false;
+  }
+  if (node->HasExplicitFormModel()) {  // mixture template mode: K probes + one verifier go through RecomputeMatrix
+    if (!hp.mcall.active || hp.mcall.cat != cat || hp.mcall.broken) return false;
+    auto itm = hp.code_of.find(node);
+    if (itm == hp.code_of.end() || !_hyhip_mix_conforms(hp, node)) {
+      hp.mcall.broken = true;  // (a branch outside the group: the defer handler recomputes what was skipped so far)
+      return false;
+    }
+    const long code = itm->second, K = hp.mixT_group.K;
+    std::vector<double> &X = hp.mixT_x[cat];
+    if (X.empty()) X.assign(hp.code_of.size() * K, 0.);
+    _hyhip_mix_row(node, K, X.data() + (size_t)code * K);
+    _hyhip_force_defer_call = true;
+    if ((long)hp.mcall.probe.size() < K) {
+      if (_hyhip_mix_independent(X, K, hp.mcall.probe, code)) {
+        hp.mcall.probe.push_back(code);
+        hp.mcall.pending = code;
+      } else {
+        hp.mcall.broken = true;  // (dependent on the probes so far and no basis yet: the ordinary way for this call)
+      }
+      return false;
+    }
+    double dist = 1e300;
+    for (long pc : hp.mcall.probe) {
+      double d = 0.;
+      for (long k = 0; k < K; k++) {
+        const double a = X[(size_t)pc * K + k], b = X[(size_t)code * K + k];
+        d = fmax(d, a == b ? 0. : fabs(a - b) / fmax(fabs(a), fabs(b)));
+      }
+      dist = fmin(dist, d);
+    }
+    if (dist > 0. && hp.mcall.verify < 0) {
+      hp.mcall.verify = code;
+      hp.mcall.verify_dist = dist;
+      hp.mcall.pending = code;
+      return false;
+    }
+    hp.mcall.skipped_dist = fmax(hp.mcall.skipped_dist, dist);
+    hp.mcall.skipped.push_back(code);
+    hp.n_mix_skipped++;
+    return true;
+  }
   if (nodeID == 0) {
     hp.call = _HyHipPart::Call();
     hp.call.cat = cat;
@@ -651,21 +839,28 @@ static bool _hyhip_mixture_weights(_HyHipPart &hp, std::vector<double> &w) {
   }
   return true;
 }
+// (HYPHY_HIP_DEBUG=1 says which test made the mixture hand-over decline a call)
+#define _HYHIP_DECLINE(n)                                                                                  \
+  do {                                                                                                     \
+    if (getenv("HYPHY_HIP_DEBUG")) fprintf(stderr, "[hyphy_hip] defer_mixture: declined at #%d\n", (n)); \
+    return false;                                                                                          \
+  } while (0)
+static void _hyhip_mix_learn(_HyHipPart &hp, _TheTree *t, long catID, const std::vector<long> &codes);
 static bool _hyhip_defer_mixture(_HyHipPart &hp, _TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue,
                                  _SimpleList &parallel, _SimpleList &isExplicitForm) {
   const long D = t->GetCodeBase(), DD = D * D, cat = catID < 0 ? 0 : catID;
-  if (cat >= (long)hp.mix_state.size() || hp.mix_state[cat] < 0 || hp.mix_state[cat] == 2) return false;
+  if (cat >= (long)hp.mix_state.size() || hp.mix_state[cat] < 0 || hp.mix_state[cat] == 2) _HYHIP_DECLINE(1);
   const long M = isExplicitForm.list_data[parallel.get(0)];
-  if (M < 1 || M > 16 || parallel.lLength % M || (hp.mix_M && hp.mix_M != M)) return false;
+  if (M < 1 || M > 16 || parallel.lLength % M || (hp.mix_M && hp.mix_M != M)) _HYHIP_DECLINE(2);
   for (unsigned long g = 0; g < parallel.lLength; g += M) {  // groups of M consecutive queue entries, one node each
     const void *nd = nodesToDo(parallel.get(g));
-    if (hp.code_of.find(nd) == hp.code_of.end()) return false;
+    if (hp.code_of.find(nd) == hp.code_of.end()) _HYHIP_DECLINE(3);
     for (long m = 0; m < M; m++) {
       const long mid = parallel.get(g + m);
       _Matrix *mx = (_Matrix *)matrixQueue(mid);
       if (nodesToDo(mid) != nd || isExplicitForm.list_data[mid] != M || !mx || !mx->is_numeric() || mx->GetHDim() != D ||
           mx->GetVDim() != D || !mx->theData)
-        return false;
+        _HYHIP_DECLINE(4);
     }
   }
   if (hp.mix_state[cat] == 0) {
@@ -673,28 +868,35 @@ static bool _hyhip_defer_mixture(_HyHipPart &hp, _TheTree *t, long catID, _List 
     _CalcNode *first = (_CalcNode *)nodesToDo(parallel.get(0));
     hp.mix_state[cat] = -1;
     if (hp.mix_wf.empty() || hp.mix_M != M) {
-      if (!_hyhip_build_weight_formulas(hp, first->GetExplicitFormModel(first->map_global_to_local_category(catID)), M)) return false;
+      if (!_hyhip_build_weight_formulas(hp, first->GetExplicitFormModel(first->map_global_to_local_category(catID)), M)) _HYHIP_DECLINE(5);
       hp.mix_M = M;
     }
     hp.mix_probe = hp.code_of.at(first);
     hp.mix_probe_q.assign((size_t)M * DD, 0.);
     for (long m = 0; m < M; m++) _hyhip_dense_copy((_Matrix *)matrixQueue(parallel.get(m)), DD, hp.mix_probe_q.data() + (size_t)m * DD);
     hp.mix_state[cat] = 2;
-    return false;
+    _HYHIP_DECLINE(6);
   }
   // enabled: take the whole queue
-  if (!_hyhip_mixture_weights(hp, hp.mix_w[cat])) return false;
+  if (!_hyhip_mixture_weights(hp, hp.mix_w[cat])) _HYHIP_DECLINE(7);
   if (hp.mix_q[cat].empty()) hp.mix_q[cat].assign(hp.code_of.size() * (size_t)M * DD, 0.);
   hp.cat_arg[cat] = catID;
+  auto mark = [&](long code, char how) {  // how: 3 dense component matrices in mix_q, 4 a row of locals in mixT_x
+    hp.q_pending[cat][code] = how;
+    if (!hp.host_stale[cat][code]) hp.n_stale++;
+    hp.host_stale[cat][code] = 3;         // (either way the host's own formula brings the node up to date: _hyphy_hip_flush_part)
+  };
+  auto q_of = [&](long code, long m) -> const double * { return hp.mix_q[cat].data() + ((size_t)code * M + m) * DD; };
+  std::vector<long> codes;
   for (unsigned long g = 0; g < parallel.lLength; g += M) {
     const long code = hp.code_of.at(nodesToDo(parallel.get(g)));
     for (long m = 0; m < M; m++)
       _hyhip_dense_copy((_Matrix *)matrixQueue(parallel.get(g + m)), DD, hp.mix_q[cat].data() + ((size_t)code * M + m) * DD);
-    hp.q_pending[cat][code] = 3;
-    if (!hp.host_stale[cat][code]) hp.n_stale++;
-    hp.host_stale[cat][code] = 3;
+    mark(code, 3);
+    codes.push_back(code);
   }
   _hyhip_deferred += parallel.lLength;
+  if (hp.mixT_state[cat] == 0 && (long)codes.size() >= 12) _hyhip_mix_learn(hp, t, catID, codes);
   return true;
 }
 // first evaluation after the analysis: does sum_m w_m exp(Q_m) reproduce the matrix the host's formula produced?
@@ -717,10 +919,109 @@ static void _hyhip_verify_mixture(_HyHipPart &hp, _TheTree *t, long catID) {
             hp.mix_state[cat] == 1 ? "mixture mode (device exponentials + mixing)" : "host exponentials");
 }
 
+// is every component of the explicit-form model linear in the branches' locals?  `codes`: branches whose M component rate
+// matrices are in mix_q (a call in which every one of them was queued, or the adapter's own learning call)
+static void _hyhip_mix_learn(_HyHipPart &hp, _TheTree *t, long catID, const std::vector<long> &codes) {
+  const long D = t->GetCodeBase(), DD = D * D, cat = catID < 0 ? 0 : catID, M = hp.mix_M;
+  auto q_of = [&](long code, long m) -> const double * { return hp.mix_q[cat].data() + ((size_t)code * M + m) * DD; };
+    // first large call in mixture mode: is every component linear in the branches' locals?  (all component matrices are here)
+    _CalcNode *first = (_CalcNode *)t->GetNodeFromFlatIndex(codes[0]);
+    int verdict = -1;
+    const long K0 = first->iVariables ? (long)first->iVariables->lLength / 2 : 0;
+    if (K0 >= 1 && K0 <= 3 && (hp.mixT_group.K == 0 || hp.mixT_group.K == K0)) {
+      if (hp.mixT_group.K == 0) {
+        hp.mixT_group.K = K0;
+        hp.mixT_group.model = first->GetModelIndex();
+        hp.mixT_group.refs.Clear();
+        for (long k = 0; k < K0; k++) hp.mixT_group.refs << first->iVariables->list_data[2 * k + 1];
+        hp.mixT_group.dep_sig = (first->dVariables && first->dVariables->lLength) ? _hyhip_dep_signature(first) : std::string();
+        hp.mixT_ok.clear();
+      }
+      bool all_conform = hp.mixT_group.dep_sig != "?";
+      for (size_t g = 0; g < codes.size() && all_conform; g++) all_conform = _hyhip_mix_conforms(hp, (_CalcNode *)t->GetNodeFromFlatIndex(codes[g]));
+      if (all_conform) {
+        std::vector<double> &X = hp.mixT_x[cat];
+        X.assign(hp.code_of.size() * K0, 0.);
+        for (size_t g = 0; g < codes.size(); g++)
+          _hyhip_mix_row((_CalcNode *)t->GetNodeFromFlatIndex(codes[g]), K0, X.data() + (size_t)codes[g] * K0);
+        std::vector<long> probe;
+        for (long code : codes)
+          if ((long)probe.size() < K0 && _hyhip_mix_independent(X, K0, probe, code)) probe.push_back(code);
+        std::vector<double> T;
+        if (_hyhip_mix_solve(X, K0, M, DD, probe, q_of, T)) {
+          double worst = 0.;
+          for (long code : codes) worst = fmax(worst, _hyhip_mix_error(K0, M, D, X.data() + (size_t)code * K0, T, code, q_of));
+          verdict = worst < 1e-11 ? 1 : -1;
+          if (getenv("HYPHY_HIP_VERBOSE"))
+            fprintf(stderr, "[hyphy_hip] mixture template analysis, class %ld: %ld components x %ld local parameter(s), %ld branches, worst relative deviation from linearity %.2e -> %s\n",
+                    cat, M, K0, (long)codes.size(), worst, verdict == 1 ? "mixture template mode" : "dense component matrices");
+        } else verdict = 0;  // (dependent probes: try again next time)
+      }
+    }
+    hp.mixT_state[cat] = verdict;
+}
+// end of an ExponentiateMatrices call in mixture template mode: the K probes and the verifier went through RecomputeMatrix (their
+// component matrices were read behind it, _hyhip_mix_collect_pending), every other branch was skipped.  true: every dirty branch
+// is now a row of locals over this call's component templates (nothing left for the host); false: the host goes on normally
+// (the skipped branches have been recomputed by the host's own formula first).
+static bool _hyhip_finish_mixture_call(_HyHipPart &hp, _TheTree *t, long catID) {
+  const long D = t->GetCodeBase(), DD = D * D, cat = catID < 0 ? 0 : catID, M = hp.mix_M, K = hp.mixT_group.K;
+  _hyhip_mix_collect_pending(hp, t, catID);
+  const _HyHipPart::MCall call = hp.mcall;
+  hp.mcall = _HyHipPart::MCall();
+  if (call.learning) {  // the analysis over every branch of this call; the host goes on with its own queue
+    if (!call.broken && call.cat == cat && (long)call.probe.size() >= 12) _hyhip_mix_learn(hp, t, catID, call.probe);
+    return false;
+  }
+  auto q_of = [&](long code, long m) -> const double * { return hp.mix_q[cat].data() + ((size_t)code * M + m) * DD; };
+  bool ok = !call.broken && call.cat == cat && (long)call.probe.size() == K;
+  const bool weak = call.verify >= 0 && call.skipped_dist > 0. && call.verify_dist < 0.01 && call.skipped_dist > 4. * call.verify_dist;
+  std::vector<double> T;
+  bool nonlinear = false;
+  if (ok) {
+    ok = _hyhip_mix_solve(hp.mixT_x[cat], K, M, DD, call.probe, q_of, T);
+    if (ok && call.verify >= 0 && _hyhip_mix_error(K, M, D, hp.mixT_x[cat].data() + (size_t)call.verify * K, T, call.verify, q_of) >= 1e-11)
+      ok = false, nonlinear = true;
+  }
+  if (ok) ok = _hyhip_mixture_weights(hp, hp.mix_w[cat]);
+  if (ok && !weak) {
+    hp.mixT_T[cat].swap(T);
+    hp.cat_arg[cat] = catID;
+    auto mark = [&](long code) {
+      hp.q_pending[cat][code] = 4;
+      if (!hp.host_stale[cat][code]) hp.n_stale++;
+      hp.host_stale[cat][code] = 3;
+    };
+    for (long code : call.probe) mark(code);
+    if (call.verify >= 0) mark(call.verify);
+    for (long code : call.skipped) mark(code);
+    _hyhip_deferred += (long)(call.probe.size() + call.skipped.size() + (call.verify >= 0 ? 1 : 0)) * M;
+    return true;
+  }
+  if (nonlinear) {
+    hp.mixT_state[cat] = -1;
+    ReportWarning("hyphy_hip: the components of the explicit-form model are not linear in the branch parameters; mixture template mode switched off");
+  }
+  for (long code : call.skipped) {  // the skipped branches by the host's own formula (exponentials and recombination on the host)
+    ((_CalcNode *)t->GetNodeFromFlatIndex(code))->RecomputeMatrix(catID, t->categoryCount);
+    hp.q_pending[cat][code] = 0;
+    if (hp.host_stale[cat][code]) {
+      hp.host_stale[cat][code] = 0;
+      hp.n_stale--;
+    }
+  }
+  return false;
+}
+
 // ---- mode B: the host's ExponentiateMatrices hands its queue over instead of exponentiating (tree.cpp copy) ----
 static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue, _SimpleList &parallel,
                                      _SimpleList &isExplicitForm, bool hasExpForm) {
   if (_hyhip_defer_depth <= 0) return false;
+  if (_hyhip_force_defer_call) {  // mixture template mode took decisions in the first loop: it finishes the call, whatever is queued
+    _hyhip_force_defer_call = false;
+    _HyHipPart *mp = _hyhip_part_of_tree(t);
+    return mp ? _hyhip_finish_mixture_call(*mp, t, catID) : false;
+  }
   if (hasExpForm) {
     _HyHipPart *mp = _hyhip_part_of_tree(t);
     return mp ? _hyhip_defer_mixture(*mp, t, catID, nodesToDo, matrixQueue, parallel, isExplicitForm) : false;
@@ -891,12 +1192,13 @@ static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catI
   if (first) n_q = B;  // first evaluation of a rate class: hand over every transition matrix
   hp.qnodes.resize(n_q);
   if (cat < (long)hp.mix_state.size() && hp.mix_state[cat] == 2) _hyhip_verify_mixture(hp, t, catID);
-  long n_pending = 0, n_template = 0, n_mixture = 0;
+  long n_pending = 0, n_template = 0, n_mixture = 0, n_mixT = 0;
   for (long k = 0; k < n_q; k++) {
     hp.qnodes[k] = first ? k : hp.code_of.at(matrices(k));
     n_pending += hp.q_pending[cat][hp.qnodes[k]] != 0;
     n_template += hp.q_pending[cat][hp.qnodes[k]] == 2;
-    n_mixture += hp.q_pending[cat][hp.qnodes[k]] == 3;
+    n_mixture += hp.q_pending[cat][hp.qnodes[k]] == 3 || hp.q_pending[cat][hp.qnodes[k]] == 4;
+    n_mixT += hp.q_pending[cat][hp.qnodes[k]] == 4;
   }
   double ll = 0.;
   int rc = 0;
@@ -905,8 +1207,60 @@ static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catI
     _hyphy_hip_flush_part(hp, t);
     n_pending = n_template = n_mixture = 0;
   }
+  if (n_q > 0 && n_mixture == n_q && n_mixT == n_q && !hp.mixT_T[cat].empty()) {
+    // mixture template mode: M x K templates (this call's), one row of K locals per (branch, component) at the component's columns
+    const long M = hp.mix_M, K = hp.mixT_group.K, KT = M * K;
+    rc = hyphy_hip_update_q_templates(hp.part, KT, hp.mixT_T[cat].data());
+    for (auto &u : hp.tmpl_uploaded) u = 0;   // (the ordinary template mode's upload is gone)
+    hp.pbuf.assign((size_t)n_q * M * KT + (size_t)n_q * M, 0.);
+    double *wq = hp.pbuf.data() + (size_t)n_q * M * KT;
+    std::vector<int64_t> cnt(n_q, M);
+    for (long k = 0; k < n_q; k++)
+      for (long m = 0; m < M; m++) {
+        for (long j = 0; j < K; j++) hp.pbuf[((size_t)k * M + m) * KT + m * K + j] = hp.mixT_x[cat][(size_t)hp.qnodes[k] * K + j];
+        wq[(size_t)k * M + m] = hp.mix_w[cat][m];
+      }
+    if (rc == 0) rc = hyphy_hip_build_q(hp.part, n_q * M, hp.pbuf.data());
+    if (rc == 0)
+      rc = hyphy_hip_evaluate_mixture_built(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(), n_q,
+                                            cnt.data(), wq, t->GetProbs(), &ll, siteRes, (int64_t *)scc);
+    if (rc < 0) {
+      HandleApplicationError(_String("hyphy_hip_evaluate_mixture_built: ") & hyphy_hip_last_error());
+      return rc;
+    }
+    if (rc == 0) {
+      for (long k = 0; k < n_q; k++) hp.q_pending[cat][hp.qnodes[k]] = 0;
+      hp.cat_seen[cat] = 1;
+      hp.n_mixT_evals++;
+      _hyhip_calls++;
+      *result = ll;
+    }
+    return rc;
+  }
   if (n_q > 0 && n_mixture == n_q) {
     const long M = hp.mix_M;
+    if (n_mixT > 0) {  // rows and dense components mixed: the rows become dense component matrices
+      const long K = hp.mixT_group.K;
+      for (long k = 0; k < n_q; k++)
+        if (hp.q_pending[cat][hp.qnodes[k]] == 4) {
+          const long code = hp.qnodes[k];
+          for (long m = 0; m < M; m++) {
+            double *dst = hp.mix_q[cat].data() + ((size_t)code * M + m) * DD;
+            for (long e = 0; e < DD; e++) {
+              double v = 0.;
+              for (long j = 0; j < K; j++) v += hp.mixT_x[cat][(size_t)code * K + j] * hp.mixT_T[cat][((size_t)m * K + j) * DD + e];
+              dst[e] = v;
+            }
+            for (long i = 0; i < D; i++) {
+              double d = 0.;
+              for (long j2 = 0; j2 < D; j2++)
+                if (j2 != i) d -= dst[i * D + j2];
+              dst[i * D + i] = d;
+            }
+          }
+          hp.q_pending[cat][code] = 3;
+        }
+    }
     hp.pbuf.resize((size_t)n_q * M * DD + (size_t)n_q * M);
     double *wq = hp.pbuf.data() + (size_t)n_q * M * DD;
     std::vector<int64_t> cnt(n_q, M);
@@ -1064,7 +1418,7 @@ static int _hyphy_hip_cached(const void *lf, long index, _TheTree *t, long catID
                              long *scc, hyFloat *result) {
   _HyHipPart &hp = _hyhip_lfs[lf][index];
   const long cat = catID < 0 ? 0 : catID, DD = t->GetCodeBase() * t->GetCodeBase();
-  if (hp.q_pending[cat][node] == 3) {  // (an explicit-form mixture: the host's own matrix for this one branch)
+  if (hp.q_pending[cat][node] == 3 || hp.q_pending[cat][node] == 4) {  // (an explicit-form mixture: the host's own matrix for this one branch)
     ((_CalcNode *)t->GetNodeFromFlatIndex(node))->RecomputeMatrix(hp.cat_arg[cat], t->categoryCount);
     hp.q_pending[cat][node] = 0;
     if (hp.host_stale[cat][node]) {
@@ -1247,6 +1601,10 @@ bool (*_hyhip_defer_expm_hook)(_TheTree *, long, _List &, _List &, _SimpleList &
 // template mode: asked for every node of ExponentiateMatrices' first loop; true = the adapter derives this node's rate
 // matrix from the probes of this call, do not run RecomputeMatrix for it
 bool (*_hyhip_skip_recompute_hook)(_TheTree *, long, _CalcNode *, unsigned long, unsigned long) = nullptr;
+// mixture template mode: the adapter took decisions in the first loop (branches skipped, probes chosen) and must see the end of
+// this call even when nothing is queued for the OpenMP loop (weights-only changes of an explicit-form model queue finished
+// matrices, tag -1, on the serial list)
+bool _hyhip_force_defer_call = false;
 #endif
 '''
 TREE_SKIP_OLD = "    if (thisNode->RecomputeMatrix(catID, categoryCount, nil, &matrixQueue,\n                                  &isExplicitForm)) {"
@@ -1259,9 +1617,10 @@ TREE_SKIP_NEW = r'''#ifdef HYPHY_HIP
                                   &isExplicitForm)) {'''
 TREE_HOOK_CALL = r'''
 #ifdef HYPHY_HIP
-  if (_hyhip_defer_expm_hook && serial.lLength == 0UL && parallel.lLength &&
+  if (_hyhip_defer_expm_hook && ((serial.lLength == 0UL && parallel.lLength) || _hyhip_force_defer_call) &&
       _hyhip_defer_expm_hook(this, catID, nodesToDo, matrixQueue, parallel, isExplicitForm, hasExpForm)) {
     parallel.Clear();  // the device exponentiates these; nothing left for the OpenMP loop below ...
+    serial.Clear();    // (mixture template mode: finished matrices of its probe branches — the adapter keeps those branches marked stale)
     if (computedExponentials) {  // ... nor (explicit-form models) for the recombination pass behind it
       DeleteObject(computedExponentials);
       computedExponentials = nil;

@@ -927,6 +927,49 @@ def test_explicit_form_mixture_on_the_device_matches_reference(name):
         assert abs(got - want) <= RTOL * abs(want), (got, want)
 
 
+@pytest.mark.parametrize("name", ["codon_mix2", "codon_mix3"])
+def test_explicit_form_mixture_built_on_the_device_matches_reference(name):
+    """hyphy_hip_build_q + hyphy_hip_evaluate_mixture_built (r04): the same explicit-form likelihood function with every component's
+    rate matrix formed on the device, Q_(b,m) = t_b T_0 + (omega_m t_b) T_1 over two uploaded templates — one coefficient row per
+    (branch, component) crosses PCIe instead of a dense matrix.  Against the reference's log L and per-site log L, against the
+    dense-matrix entry point (same device arithmetic behind the construction: equal to the last bits), and a partial update."""
+    from hyphy_amd import models, tree
+    fx = common.load(name)
+    rev = dict(zip(common.REV_KEYS, (float(x) for x in fx["rev"])))
+    t = np.asarray(fx["t"], dtype=np.float64)
+    nodes = common.all_nodes(fx)
+    omegas = np.asarray(fx["omegas"], dtype=np.float64)
+    M = len(omegas)
+    T = np.zeros((2, 61, 61))
+    rv = dict(rev, AG=1.0)
+    for (i, j, nm, ns, pf) in models.mg94rev_template(fx["pos_freqs"]):
+        T[1 if ns else 0, i, j] = rv[nm] * pf
+    Qc = np.stack([models.mg94rev_Q_batch(t, float(om), rev, fx["pos_freqs"]) for om in omegas], axis=1)   # [B, M, D, D]
+    W = np.tile(np.asarray(fx["weights"], dtype=np.float64), (len(nodes), 1))
+    coeffs = np.empty((len(nodes), M, 2))
+    coeffs[:, :, 0] = t[:, None]
+    coeffs[:, :, 1] = t[:, None] * omegas[None, :]
+    ref = float(fx["logl"])
+    with _mk(fx) as part:
+        part.set_q_templates(T)
+        ll, lik, sc = part.evaluate_mixture_built(nodes, nodes, coeffs, W, fx["root_freqs"], per_site=True)
+        assert abs(ll - ref) <= RTOL * abs(ref), (ll, ref)
+        site = (np.log(lik) - sc * 64 * np.log(2.0))[fx["site_to_pattern"]]
+        assert np.max(np.abs(site - fx["site_logl"]) / np.abs(fx["site_logl"])) < RTOL
+        dense = part.evaluate_mixture(nodes, nodes, Qc, W, fx["root_freqs"])
+        assert abs(ll - dense) <= 1e-13 * abs(dense), (ll, dense)
+        # partial update: one branch gets other coefficients and weights, through both entry points
+        flat = tree.flat_from_parents(fx["flat_parents"], int(fx["L"]))
+        node = 3
+        scale = np.array([0.5, 2.0, 1.5][:M])
+        w2 = np.asarray(fx["weights"], dtype=np.float64)[::-1].copy()
+        upd = flat.path_update_nodes(node)
+        want = part.evaluate_mixture(upd, np.array([node]), (Qc[node] * scale[:, None, None])[None], w2[None], fx["root_freqs"])
+        part.evaluate_mixture(nodes, nodes, Qc, W, fx["root_freqs"])     # back to the start
+        got = part.evaluate_mixture_built(upd, np.array([node]), (coeffs[node] * scale[:, None])[None], w2[None], fx["root_freqs"])
+        assert abs(got - want) <= 1e-13 * abs(want), (got, want)
+
+
 def test_rccl_allreduce_entry_points_single_rank():
     """The C-ABI's own all-reduce (hyphy_hip_comm_* / hyphy_hip_evaluate_allreduce, librccl loaded on first use): with a
     communicator of ONE rank — all this box offers, RCCL refuses two ranks on one device — the all-reduced value is the

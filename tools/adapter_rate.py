@@ -42,7 +42,7 @@ common = dict(names=syn.flat.leaf_names, seqs=syn.seqs, newick=htree.to_newick(s
 
 def emit(tag, host, res, count, t0, extra=None):
     secs = max(res.get("sweep_seconds", 0.0), 1.0)   # (HBL's Time(1) has 1 s resolution)
-    mode = [ln for ln in res.get("stdout", "").split("\n") if "mode:" in ln or "template analysis" in ln or "explicit-form" in ln]
+    mode = [ln for ln in res.get("stdout", "").split("\n") if "mode:" in ln or "template analysis" in ln or "explicit-form" in ln or "template mode" in ln]
     print(json.dumps({"case": tag, "host": host, "evals": count, "sweep_seconds": secs, "evals_per_s": count / secs, "logl": res["logl"],
                       "wall": time.time() - t0, "adapter_says": mode[-2:], **(extra or {})}), flush=True)
 
@@ -100,12 +100,16 @@ if "cat3" in which:
 if "mix3" in which:
     block = hbl.codon_mixture_model_block(tmpl, pi, ["R1", "R2", "R3"], ["W1", "W2", "(1-W1-W2)"])
     g = dict(R1=0.1, R2=1.0, R3=5.0, W1=0.6, W2=0.3, **bench.REV)
-    for host, binary, env, count in (("adapter", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), max(200, n_evals // 4)),
-                                      ("reference 16 threads", None, None, max(4, n_evals // 600))):
-        t0 = time.time()
-        res = hbl.evaluate(model_block=block, globals_=g, upper_bounds=dict(W1=1.0, W2=1.0),
-                           sweep=dict(param="W1", start=0.5, step=0.00001, n=count), threads=(1 if binary else 16), binary=binary, extra_env=env, **common)
-        emit("mix3_64x10k", host, res, count, t0)
+    # three sweeps: a mixture weight (no rate matrix changes: the reference re-mixes cached exponentials), one component's omega
+    # (one component of every branch changes), a nucleotide rate (every component of every branch changes)
+    for param, start, step in (("W1", 0.5, 0.00001), ("R2", 1.0, 0.0001), ("AC", 0.5, 0.0001)):
+        for host, binary, env, count in (("adapter", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals),
+                                          ("adapter, HYPHY_HIP_TEMPLATES=0 (dense components)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always", HYPHY_HIP_TEMPLATES="0"), max(200, n_evals // 4)),
+                                          ("reference 16 threads", None, None, max(4, n_evals // 600))):
+            t0 = time.time()
+            res = hbl.evaluate(model_block=block, globals_=g, upper_bounds=dict(W1=1.0, W2=1.0),
+                               sweep=dict(param=param, start=start, step=step, n=count), threads=(1 if binary else 16), binary=binary, extra_env=env, **common)
+            emit(f"mix3_64x10k sweep of {param}", host, res, count, t0)
 
 if "manylf" in which:
     # N single-codon likelihood functions, 50 evaluations each (FEL's shape: one LF per site)
