@@ -1288,6 +1288,23 @@ def test_busted_fit_of_the_reference_evaluates_on_the_device():
     want = op.site_log_likelihoods(nodes, fx["root_freqs"])
     got = np.log(lik) - sc * 64 * np.log(2.0)
     assert np.max(np.abs(got - want) / np.abs(want)) < RTOL
+    # r04: the same MLEs through the BUILT path — no dense component matrix crosses PCIe: two templates (synonymous and
+    # non-synonymous part of MG94xREV), the row of component k of branch b is (t_b, omega_k t_b) with the test or the background
+    # distribution's omega_k (hyphy_hip_build_q + hyphy_hip_evaluate_mixture_built)
+    from hyphy_amd import models
+    rev = dict(zip(common.REV_KEYS, (float(x) for x in fx["rev"])), AG=1.0)
+    T = np.zeros((2, 61, 61))
+    for (i, j, nm, ns, pf) in models.mg94rev_template(fx["pos_freqs"]):
+        T[1 if ns else 0, i, j] = rev[nm] * pf
+    t = np.asarray(fx["t"], dtype=np.float64)
+    om = np.where(np.asarray(fx["tested"], dtype=bool)[:, None], np.asarray(fx["omega_test"])[None, :], np.asarray(fx["omega_background"])[None, :])
+    coeffs = np.stack([np.repeat(t[:, None], 3, axis=1), om * t[:, None]], axis=2)   # [B, 3, 2]
+    with _mk(fx) as part:
+        part.set_q_templates(T)
+        ll2, lik2, sc2 = part.evaluate_mixture_built(nodes, nodes, coeffs, W, fx["root_freqs"], per_site=True)
+    assert abs(ll2 - ref) <= RTOL * abs(ref), (ll2, ref)
+    got2 = np.log(lik2) - sc2 * 64 * np.log(2.0)
+    assert np.max(np.abs(got2 - want) / np.abs(want)) < RTOL
 
 
 def test_rate_classes_spread_mode_on_the_device_single_rank():
