@@ -134,10 +134,11 @@ def test_meme_driver_bookkeeping():
 
 
 def test_bench_reads_the_measured_instruction_peak_from_the_committed_microbenchmark():
-    """bench.py's `instruction_peak_measured` is read from profiles/r01_ubench_mfma_f64.txt (no literals in the line)."""
+    """bench.py's `instruction_peak_measured` is read from a committed microbenchmark (no literals in the line) — since
+    r04 the VGPR-accumulator run, profiles/r04_ubench_mfma_agpr_vs_vgpr.txt (r01's file measured the AGPR form: half the rate)."""
     import bench
     peak, src = bench.measured_instruction_peak()
-    assert src == "profiles/r01_ubench_mfma_f64.txt" and 45.0 < peak < 55.0
+    assert src == "profiles/r04_ubench_mfma_agpr_vs_vgpr.txt" and 70.0 < peak <= 78.6
     flops, bytes_ = bench.alg_work(61, 9974, 64, 62)
     assert flops == 4642198820 and bytes_ == 599317712      # SURVEY 8d at the headline size (DESIGN 4.1)
 
