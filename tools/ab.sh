@@ -1,7 +1,9 @@
 #!/bin/bash
-# GPU box: one bench line per "label|ENV=.. ENV=..|workload|steps" spec (stdin or $SPECS separated by ';'), condensed.
+# GPU box: A/B runs, one bench line per "label|ENV=.. ENV=..|workload|steps" spec ($SPECS, separated by ';'), condensed; the whole
+# list is repeated $REPS times (interleaved repetitions).  Library builds compete through HYPHY_HIP_LIB=<path> in a spec's ENV.
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/ab; mkdir -p $OUT
+for rep in $(seq 1 ${REPS:-1}); do
 echo "$SPECS" | tr ';' '\n' | while IFS='|' read -r tag envs wl steps; do
   [ -z "$tag" ] && continue
   env HYPHY_HIP_VERBOSE=1 $envs timeout 300 python bench.py --workload $wl --steps ${steps:-200} --warmup 10 --no-cpu-baseline --no-traffic > $OUT/$tag.json 2> $OUT/$tag.err
@@ -18,4 +20,5 @@ try:
 except Exception as e:
     print(f"{tag:44s} FAILED ({e})")
 PY
+done
 done

@@ -1,27 +1,69 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): bench line + rocprofv3 kernel stats + PMC passes for the round.
-# Usage: tools/profile_round.sh rNN
-R=${1:-r01}
+# Runs on the GPU box (via gpurun): the round's evidence.  Usage: tools/profile_round.sh <tag> [parts]   (parts: default "all";
+# any of: line workloads stats pmc nuc adapter phases ubench)
+#   bench_driver_line.json   the driver's exact command (CPU baseline with thread sweep, parity, live PMC traffic, value_cold)
+#   all_workloads.txt        one line per workload with the schedule tuner's report
+#   stats/                   rocprofv3 --kernel-trace --stats, tuner off and the production cut forced (steady-state averages)
+#   pmc_<workload>/          separate --pmc passes, production cut forced: SQ sets (wave cycles, instruction mix, MFMA pipe),
+#                            FETCH_SIZE, WRITE_SIZE
+#   adapter_rate.jsonl       evaluations per second through the real host (tools/adapter_rate.py)
+#   phases_*.txt             where a wave's cycles go (trace build of the wave kernel, tools/timeline_waves.py)
+#   ubench_*.txt             instruction / edge-product / edge+leaf microbenchmarks (tools/ubench)
+R=${1:-r04}; PARTS=${2:-all}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
+has() { [ "$PARTS" = all ] || echo "$PARTS" | grep -qw "$1"; }
 cd $GRAFT_REPO_ROOT
-HYPHY_HIP_ALL_TIMINGS=1 python bench.py --steps 200 --warmup 20 --pipelined --no-cpu-baseline > $OUT/bench_alltimings.json 2>/dev/null
-python bench.py --steps 200 --warmup 20 --pipelined --branch-cache --site-fits 4 --fel > $OUT/bench.json 2> $OUT/bench.err
-cat $OUT/bench.json
+if has line; then timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_line.json 2> $OUT/bench.err; fi
+if has workloads; then
+for wl in mg94_64x10k mg94_32x5k busted3_64x10k mg94_128x100k mg94_64x5000 mg94_64x2500 mg94_64x1250 gtr_32x50k gtr_32x1m hky_8x1k; do
+  steps=200; [ $wl = mg94_128x100k ] && steps=30
+  HYPHY_HIP_VERBOSE=1 timeout 300 python bench.py --workload $wl --steps $steps --warmup 10 --no-cpu-baseline --no-traffic > $OUT/wl_$wl.json 2> $OUT/wl_$wl.err
+  grep "schedule tuner" $OUT/wl_$wl.err | tail -1
+  python - $wl $OUT/wl_$wl.json <<'PY'
+import json, sys
+tag, path = sys.argv[1], sys.argv[2]
+try:
+    j = json.loads([l for l in open(path) if l.startswith("{")][-1]); r = j["roofline"]
+    fr = r["frac"] if r.get("frac") is not None else float("nan")
+    extra = f"  VALU {r['valu_tflops']:.2f} TFLOP/s" if r.get("valu_tflops") is not None else ""
+    print(f"{tag:18s} {j['value']:9.1f} evals/s  step {j['ms_per_step']*1e3:8.1f} us  {r['kernel']} {r['kernel_ms']*1e3:8.1f} us  {r['achieved']:8.2f} {r['unit']}  frac {fr:.3f}{extra}  expm {r['expm_ms']}  reduce {r['reduce_ms']}")
+except Exception as e:
+    print(f"{tag:18s} FAILED ({e})")
+PY
+done > $OUT/all_workloads.txt 2>&1
+fi
 cd /tmp && export TMPDIR=/tmp
-HYPHY_HIP_ALL_TIMINGS=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --branch-cache --site-fits 4 > $OUT/stats.log 2>&1
-# counters: own runs, kernel-trace only (guide: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2 -> separate passes)
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
-           "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
-           "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
-  timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --site-fits 2 > /dev/null 2>&1
-done
+if has stats; then
+  HYPHY_HIP_CHAIN_M=12 HYPHY_HIP_TIMING_EVERY=1000000 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > $OUT/stats.log 2>&1
+fi
+pmc() { wl=$1; shift
+  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+             "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \
+             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INST_LEVEL_VMEM" \
+             "FETCH_SIZE" "WRITE_SIZE"; do
+    env "$@" timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$wl -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 20 --warmup 6 --no-cpu-baseline --no-traffic > /dev/null 2>&1
+  done
+}
+if has pmc; then
+  pmc mg94_64x10k HYPHY_HIP_CHAIN_M=12
+  pmc mg94_128x100k HYPHY_HIP_CHAIN_M=40
+fi
+if has nuc; then
+  pmc gtr_32x1m X=1
+  pmc gtr_32x50k X=1
+fi
 cd $GRAFT_REPO_ROOT
-./tools/ubench_mfma_f64 > $OUT/ubench_mfma_f64.txt 2>&1
-bash tools/sweep_small_shards.sh > $OUT/kernel_choice_by_shard_size.txt 2>&1
-bash tools/bench_all_workloads.sh > $OUT/all_workloads.txt 2>&1
-# the real host through the adapter: mode B (device exponentials), then mode A
-(HYPHY_HIP_DEVICE_EXPM=always timeout 200 python tests/adapter_rate.py 12000 1,16; HYPHY_HIP_DEVICE_EXPM=0 timeout 200 python tests/adapter_rate.py 4000 1,16) 2>/dev/null | grep '"host"' > $OUT/adapter_rate.jsonl
-# randomised stress runs, seeds other than the test-suite's
-(HYPHY_HIP_POISON=1 timeout 300 python tests/stress_codon.py 80 5000 | tail -1; HYPHY_HIP_POISON=1 timeout 300 python tests/stress_generic.py 120 7000 | tail -1) > $OUT/stress.txt 2>&1
-find $OUT -name "*.csv" | head -30
+if has adapter; then timeout 1500 python tools/adapter_rate.py headline,class2,cat3,mix3,manylf 10000 2000 2>/dev/null > $OUT/adapter_rate.jsonl; fi
+if has phases; then
+  for spec in "mg94_64x10k 12 624" "mg94_128x100k 40 6250" "mg94_64x2500 8 157"; do
+    set -- $spec
+    HYPHY_HIP_CHAIN_M=$2 HYPHY_HIP_TIMELINE=$OUT/tl_$1.txt timeout 300 python bench.py --workload $1 --steps 3 --warmup 3 --no-cpu-baseline --no-traffic > /dev/null 2>&1
+    (echo "# $1, chain cut m = $2, trace build of prune_wave_kernel (HYPHY_HIP_TIMELINE; every stamp is an s_memtime + lgkmcnt(0): ~25 % slower than production)"; python tools/timeline_waves.py $OUT/tl_$1.txt $3) > $OUT/phases_$1.txt
+    rm -f $OUT/tl_$1.txt
+  done
+fi
+if has ubench; then
+  (cd tools/ubench && OLD_ONLY=1 ./mfma4_skew > $OUT/ubench_agpr_vs_vgpr.txt 2>&1; ./mfma4_skew > $OUT/ubench_edge_product.txt 2>&1; ./overlap_probe > $OUT/ubench_edge_plus_leaf.txt 2>&1)
+fi
+find $OUT -name "*.csv" | wc -l
