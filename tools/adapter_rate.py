@@ -9,7 +9,7 @@ by oracle/hbl.py, next to the unmodified reference —
   mix3      the same alignment under the reference's EXPLICIT-FORM 3-component branch-site mixture
             ("Exp(Q1)*W1+Exp(Q2)*W2+Exp(Q3)*(1-W1-W2)"): LFCompute sweep of W1 with device exponentials forced (mode B, mixture mode);
   manylf    N single-codon likelihood functions on the 64-taxon tree (what FEL does per site): create, 50 LFCompute calls with R
-            swept, destroy — through the device, through the device with the adapter's size policy (default), and on the CPU.
+            swept, destroy — through the device (with and without the schedule tuner's cache), with host exponentials, and on the CPU.
 One JSON line per measurement.  Usage (GPU box): python tools/adapter_rate.py [headline,class2,cat3,mix3,manylf] [n_evals] [n_lfs]"""
 import json
 import os
@@ -44,7 +44,9 @@ def emit(tag, host, res, count, t0, extra=None):
     secs = max(res.get("sweep_seconds", 0.0), 1.0)   # (HBL's Time(1) has 1 s resolution)
     mode = [ln for ln in res.get("stdout", "").split("\n") if "mode:" in ln or "template analysis" in ln or "explicit-form" in ln or "template mode" in ln]
     print(json.dumps({"case": tag, "host": host, "evals": count, "sweep_seconds": secs, "evals_per_s": count / secs, "logl": res["logl"],
-                      "wall": time.time() - t0, "adapter_says": mode[-2:], **(extra or {})}), flush=True)
+                      "wall": time.time() - t0, "adapter_says": mode[-2:], **(extra or {}),
+                      **({"tuner_says": [ln[:400] for ln in res.get("stdout", "").split("\n") if "schedule tuner" in ln][:3]} if os.environ.get("ADAPTER_RATE_TUNER") else {})}),
+          flush=True)
 
 
 if "headline" in which:
@@ -91,7 +93,10 @@ if "class2" in which:
 if "cat3" in which:
     block = hbl.codon_model_block(tmpl, pi, omega="R*cc")
     cat = dict(name="cc", weights=[0.7, 0.25, 0.05], values=[0.1 / 0.3, 1.0 / 0.3, 5.0 / 0.3])
-    for host, binary, env, count in (("adapter", HIP_BIN, ENV, n_evals), ("reference 16 threads", None, None, max(6, n_evals // 200))):
+    # (LFCompute outside Optimize: device exponentials have to be asked for, as in every other case of this script)
+    for host, binary, env, count in (("adapter", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals),
+                                      ("adapter, HYPHY_HIP_DEVICE_EXPM unset (mode A outside Optimize: host exponentials)", HIP_BIN, ENV, max(100, n_evals // 20)),
+                                      ("reference 16 threads", None, None, max(6, n_evals // 200))):
         t0 = time.time()
         res = hbl.evaluate(model_block=block, globals_=dict(R=0.3, **bench.REV), category=cat,
                            sweep=dict(param="R", start=0.3, step=0.0001, n=count), threads=(1 if binary else 16), binary=binary, extra_env=env, **common)
@@ -137,8 +142,9 @@ if "manylf" in which:
     L.append(f'fprintf ("{outp}", CLEAR_FILE, "LOGL ", Format (tot_, 30, 17), "\\n", "SWEEP_SECONDS ", Format (t1_-t0_, 20, 6), "\\n");')
     script = "\n".join(L) + "\n"
     n_ref = max(4, n_lfs // 40)   # (the host spends ~10 ms per evaluation on the 125 exponentials of a one-codon LF)
-    for host, binary, env, n_here in (("adapter, every LF on the device", HIP_BIN, dict(ENV, HYPHY_HIP_MIN_PATTERNS="0", HYPHY_HIP_VERBOSE="0"), n_lfs),
-                                      ("adapter, schedule tuner cache off", HIP_BIN, dict(ENV, HYPHY_HIP_TUNE_CACHE="0", HYPHY_HIP_VERBOSE="0"), n_lfs),
+    for host, binary, env, n_here in (("adapter, every LF on the device", HIP_BIN, dict(ENV, HYPHY_HIP_MIN_PATTERNS="0", HYPHY_HIP_VERBOSE="0", HYPHY_HIP_DEVICE_EXPM="always"), n_lfs),
+                                      ("adapter, schedule tuner cache off", HIP_BIN, dict(ENV, HYPHY_HIP_MIN_PATTERNS="0", HYPHY_HIP_TUNE_CACHE="0", HYPHY_HIP_VERBOSE="0", HYPHY_HIP_DEVICE_EXPM="always"), n_lfs),
+                                      ("adapter, HYPHY_HIP_DEVICE_EXPM unset (host exponentials outside Optimize)", HIP_BIN, dict(ENV, HYPHY_HIP_VERBOSE="0"), max(4, n_lfs // 10)),
                                       ("reference 1 thread", None, None, n_ref)):
         t0 = time.time()
         try:

@@ -54,7 +54,7 @@ if has nuc; then
   pmc gtr_32x50k X=1
 fi
 cd $GRAFT_REPO_ROOT
-if has adapter; then timeout 1500 python tools/adapter_rate.py headline,class2,cat3,mix3,manylf 10000 2000 2>/dev/null > $OUT/adapter_rate.jsonl; fi
+if has adapter; then timeout 1500 python tools/adapter_rate.py headline,class2,cat3,mix3,manylf 10000 400 2>/dev/null > $OUT/adapter_rate.jsonl; fi
 if has phases; then
   for spec in "mg94_64x10k 12 624" "mg94_128x100k 40 6250" "mg94_64x2500 8 157"; do
     set -- $spec
