@@ -465,10 +465,14 @@ __device__ __forceinline__ void mm64(const double *__restrict__ Lm, const double
   for (int c = 0; c < NTW; c++) d[c] = e[c] = (f64x4){0., 0., 0., 0.};
 #pragma unroll 4
   for (int kk = 0; kk < 16; kk += 2) {
-    const double a0 = Lm[(16 * rb + sl) * LD + 4 * kk + g], a1 = Lm[(16 * rb + sl) * LD + 4 * kk + 4 + g];
+    // k-slot g of MFMA step kk carries k = 16 g + kk (any bijection does): with the row stride of 65 doubles the 32 lanes of a
+    // ds_read_b64 lane group (sl = 0..15, g = 0, 1 / 2, 3) then fall on 32 different bank pairs for the A operand (sl + 16 g)
+    // AND for the B operand (16 g 65 + sl = 16 g + sl mod 32).  k = 4 kk + g (r03) put both on sl + g: two-way conflicts on
+    // every operand read, SQ_LDS_BANK_CONFLICT 0.86 cycles per LDS instruction of the launch.
+    const double a0 = Lm[(16 * rb + sl) * LD + 16 * g + kk], a1 = Lm[(16 * rb + sl) * LD + 16 * g + kk + 1];
 #pragma unroll
     for (int c = 0; c < NTW; c++) {
-      const double b0 = Rm[(4 * kk + g) * LD + 16 * (ct0 + c) + sl], b1 = Rm[(4 * kk + 4 + g) * LD + 16 * (ct0 + c) + sl];
+      const double b0 = Rm[(16 * g + kk) * LD + 16 * (ct0 + c) + sl], b1 = Rm[(16 * g + kk + 1) * LD + 16 * (ct0 + c) + sl];
       d[c] = mfma(a0, b0, d[c]);
       e[c] = mfma(a1, b1, e[c]);
     }
