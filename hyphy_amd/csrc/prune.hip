@@ -16,6 +16,7 @@
 //  * Rescaling is stateless per evaluation: integer exponents per (node, pattern) are carried up
 //    the tree; observable contract of SURVEY A.5 (l_s, c_s with L_s = l_s 2^(-64 c_s)).
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include "expm4.h"
@@ -2147,6 +2148,14 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const double *__restrict
   }
 }
 
+// The same combine by ONE wave (r04): combine_partials — what the fused launches' last arriver runs — in a launch of its own.
+// All partials of a 512-entry block are in flight together (the 256-thread kernel above walks them in dependent round trips
+// and then an 8-step LDS tree with barriers); same record, same flags, a different (fixed) order of summation.
+__global__ __launch_bounds__(64) void wave_reduce_kernel(double *wg_sum, long long *wg_cnt, int *wg_flag, int n, double *out,
+                                                         double *out_cnt, const int *status, double seq) {
+  combine_partials(wg_sum, wg_cnt, wg_flag, n, out, out_cnt, status, seq, (int)threadIdx.x);
+}
+
 // Category mixing on the device: PopulateConditionalProbabilities weighted-sum mode
 // (likefunc2.cpp:820-853): buf[s] = sum_c w_c L_c[s] 2^(-64 (c_c[s] - min_c c_c[s])).
 __global__ void mix_categories_kernel(const double *__restrict__ site_lik, const int32_t *__restrict__ site_cnt,
@@ -2421,8 +2430,12 @@ void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const d
 
 void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *wg_flag, int n, double *out_logl,
                       double *out_cnt, const int *status, hipStream_t stream, double seq) {
-  hipLaunchKernelGGL(wg_reduce_kernel, dim3(1), dim3(256), 0, stream, wg_sum, wg_cnt, wg_flag, n, out_logl, out_cnt,
-                     status, seq);
+  static const bool block_form = getenv("HYPHY_HIP_REDUCE") && !strcmp(getenv("HYPHY_HIP_REDUCE"), "block");
+  if (block_form)
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3(1), dim3(256), 0, stream, wg_sum, wg_cnt, wg_flag, n, out_logl, out_cnt, status, seq);
+  else
+    hipLaunchKernelGGL(wave_reduce_kernel, dim3(1), dim3(64), 0, stream, const_cast<double *>(wg_sum), const_cast<long long *>(wg_cnt),
+                       const_cast<int *>(wg_flag), n, out_logl, out_cnt, status, seq);
 }
 
 int prune_mfma_grid(const PruneArgs &a) { return a.ntiles / a.T; }

@@ -16,7 +16,7 @@ try:
     for l in open(err):
         m = re.search(r"-> (\S+)", l)
         if "schedule tuner" in l and m: sched = m.group(1)
-    print(f"{tag:44s} step {j['ms_per_step']*1e3:8.1f} us  {r['kernel']:18s} {r['kernel_ms']*1e3:8.1f} us  frac {r['frac']:.3f}  expm {1e3*(r.get('expm_ms') or 0):5.1f} reduce {1e3*(r.get('reduce_ms') or 0):4.1f}  {sched}")
+    print(f"{tag:44s} step {j['ms_per_step']*1e3:8.1f} us  {r['kernel']:18s} {r['kernel_ms']*1e3:8.1f} us  frac {(r['frac'] or 0):.3f}  expm {1e3*(r.get('expm_ms') or 0):5.1f} reduce {1e3*(r.get('reduce_ms') or 0):4.1f}  {sched}")
 except Exception as e:
     print(f"{tag:44s} FAILED ({e})")
 PY
