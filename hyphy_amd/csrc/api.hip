@@ -28,10 +28,10 @@ void free_shard(Shard &s) {
                  s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.mix_q, s.mix_p, s.mix_w, s.mix_off, s.ar_buf, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops};
   for (void *d : dev)
-    if (d) hipFree(d);
+    if (d) pool_free(d);  // (the stream was synchronised above)
   void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn};
   for (void *h : host)
-    if (h) hipHostFree(h);
+    if (h) pool_host_free(h);
   for (auto &e : s.ev)
     if (e) hipEventDestroy(e);
   for (auto &e : s.ev_ar)
@@ -41,7 +41,7 @@ void free_shard(Shard &s) {
   for (auto &e : s.coeff_ev)
     if (e) hipEventDestroy(e);
   if (s.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s.comm);
-  if (s.own_stream) hipStreamDestroy(s.own_stream);
+  if (s.own_stream) pool_stream_put(s.own_stream);
   s = Shard();
 }
 
@@ -167,7 +167,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
   }
   if (p->chain && !s.deposits) {  // edge products of non-last arrivers: one tile per (class, node, tile), like `partials`
     const size_t bytes = (size_t)p->C * s.partial_stride * sizeof(double);
-    HIPCHK(hipMalloc((void **)&s.deposits, bytes));
+    HIPCHK(pool_malloc((void **)&s.deposits, bytes));
     if (getenv("HYPHY_HIP_POISON")) {
       HIPCHK(hipMemset(s.deposits, 0xff, bytes));
       HIPCHK(hipDeviceSynchronize());
@@ -214,15 +214,15 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       if (s.mix_cap < n_tot || s.mix_nq_cap < (size_t)n_q) {
         HIPCHK(hipStreamSynchronize(s.stream));
         for (void *d : {(void *)s.mix_q, (void *)s.mix_p, (void *)s.mix_w, (void *)s.mix_off})
-          if (d) hipFree(d);
+          if (d) pool_free_sync(d);
         s.mix_q = s.mix_p = s.mix_w = nullptr;
         s.mix_off = nullptr;
         s.mix_cap = std::max(n_tot, (size_t)(2 * B));
         s.mix_nq_cap = (size_t)B;
-        HIPCHK(hipMalloc((void **)&s.mix_q, s.mix_cap * DD * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&s.mix_p, s.mix_cap * DD * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&s.mix_w, s.mix_cap * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&s.mix_off, (s.mix_nq_cap + 1) * sizeof(int)));
+        HIPCHK(pool_malloc((void **)&s.mix_q, s.mix_cap * DD * sizeof(double)));
+        HIPCHK(pool_malloc((void **)&s.mix_p, s.mix_cap * DD * sizeof(double)));
+        HIPCHK(pool_malloc((void **)&s.mix_w, s.mix_cap * sizeof(double)));
+        HIPCHK(pool_malloc((void **)&s.mix_off, (s.mix_nq_cap + 1) * sizeof(int)));
       }
       std::vector<int> off((size_t)n_q + 1, 0);
       for (int64_t k = 0; k < n_q; k++) off[k + 1] = off[k] + (int)mix->count[k];
@@ -405,7 +405,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     const size_t tl_waves = (size_t)s.ntiles * std::max(1, n_cat_batch) * std::max<size_t>(1, p->programs.size());
     const size_t tl_n = tl_wave ? tl_waves * 24 : (size_t)kTraceWG * p->NW * std::max(1, n_ops) * 4;
     if (tl_path && n_ops > 0 && s.T == 1) {
-      HIPCHK(hipMalloc((void **)&pa.timeline, tl_n * sizeof(long long)));
+      HIPCHK(pool_malloc((void **)&pa.timeline, tl_n * sizeof(long long)));
       HIPCHK(hipMemsetAsync(pa.timeline, 0, tl_n * sizeof(long long), s.stream));
     }
     n_wg = prune_mfma_grid(pa);
@@ -444,7 +444,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       std::vector<long long> h(tl_n);
       HIPCHK(hipStreamSynchronize(s.stream));
       HIPCHK(hipMemcpy(h.data(), pa.timeline, tl_n * sizeof(long long), hipMemcpyDeviceToHost));
-      hipFree(pa.timeline);
+      pool_free_sync(pa.timeline);
       if (tl_wave) {
         if (FILE *f = fopen(tl_path, "w")) {
           fprintf(f, "# wave t_start t_prologue t_program t_end levels how hw_id xcc_id   (100 MHz ticks; grid = %s)  then shader cycles: "
@@ -677,7 +677,7 @@ int hyphy_hip_device_count(void) {
 void hyphy_hip_destroy(hyphy_hip_partition *p) {
   if (!p) return;
   for (Shard &s : p->shards) free_shard(s);
-  if (p->h_qstage) hipHostFree(p->h_qstage);
+  if (p->h_qstage) { hipDeviceSynchronize(); pool_host_free(p->h_qstage); }
   delete p;
 }
 
@@ -823,7 +823,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     const bool poison = getenv("HYPHY_HIP_POISON") != nullptr;
 #define A_(ptr, n)                                                                                           \
   {                                                                                                          \
-    if (hipMalloc((void **)&(ptr), (n)) != hipSuccess) {                                                     \
+    if (pool_malloc((void **)&(ptr), (n)) != hipSuccess) {                                                     \
       hyphy_hip_destroy(p);                                                                                  \
       return fail("hipMalloc failed (" #ptr ")");                                                            \
     }                                                                                                        \
@@ -832,7 +832,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       hipDeviceSynchronize();                                                                                \
     }                                                                                                        \
   }
-    hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking);
+    pool_stream_get(&s.own_stream);
     s.stream = s.own_stream;
     for (auto &e : s.ev) hipEventCreate(&e);
     s.ring.assign(2 * kTimingRing, nullptr);
@@ -890,12 +890,12 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     hipMemset(s.wg_flag + (size_t)C * s.wg_cap, 0, 4 * sizeof(int));  // (the last word: arrival counter of the 4-state kernel's fused combine)
 #undef A_
     s.h_small_cap = (size_t)std::max<int64_t>(std::max<int64_t>(DP, C), 64);
-    if (hipHostMalloc((void **)&s.h_ops, ops_capacity(p) * sizeof(int4)) != hipSuccess ||
-        hipHostMalloc((void **)&s.h_prog, (size_t)(I + 2) * sizeof(int4)) != hipSuccess ||
-        hipHostMalloc((void **)&s.h_jn, (size_t)(I + 2) * sizeof(int4)) != hipSuccess ||
-        hipHostMalloc((void **)&s.h_out, 4 * sizeof(double)) != hipSuccess ||
-        hipHostMalloc((void **)&s.h_slots, (size_t)C * B * sizeof(int32_t)) != hipSuccess ||
-        hipHostMalloc((void **)&s.h_small, s.h_small_cap * sizeof(double)) != hipSuccess) {
+    if (pool_host_malloc((void **)&s.h_ops, ops_capacity(p) * sizeof(int4)) != hipSuccess ||
+        pool_host_malloc((void **)&s.h_prog, (size_t)(I + 2) * sizeof(int4)) != hipSuccess ||
+        pool_host_malloc((void **)&s.h_jn, (size_t)(I + 2) * sizeof(int4)) != hipSuccess ||
+        pool_host_malloc((void **)&s.h_out, 4 * sizeof(double)) != hipSuccess ||
+        pool_host_malloc((void **)&s.h_slots, (size_t)C * B * sizeof(int32_t)) != hipSuccess ||
+        pool_host_malloc((void **)&s.h_small, s.h_small_cap * sizeof(double)) != hipSuccess) {
       hyphy_hip_destroy(p);
       return fail("hipHostMalloc failed");
     }
@@ -1139,11 +1139,11 @@ int hyphy_hip_evaluate_async(hyphy_hip_partition *p, int64_t cat, const int64_t 
     if (!q_dense) return fail("null matrix list");
     if (p->h_qstage_cap < n) {
       if (hyphy_hip_synchronize(p)) return -1;
-      if (p->h_qstage) hipHostFree(p->h_qstage);
+      if (p->h_qstage) { hipDeviceSynchronize(); pool_host_free(p->h_qstage); }
       p->h_qstage = nullptr;
       p->h_qstage_cap = 0;
       const size_t cap = std::max(n, (size_t)p->B * p->D * p->D);
-      HIPCHK(hipHostMalloc((void **)&p->h_qstage, cap * sizeof(double)));
+      HIPCHK(pool_host_malloc((void **)&p->h_qstage, cap * sizeof(double)));
       p->h_qstage_cap = cap;
     }
     // (the previous asynchronous evaluation was collected or synchronised above: the staging buffer is free)
@@ -1304,7 +1304,7 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
               inode_cache[(n * S + caller_pattern(p, s.s0 + k)) * 4 + j] = tmp[((size_t)n * 4 + j) * s.S_pad + k];
       } else {
         double *dtmp = nullptr;
-        HIPCHK(hipMalloc((void **)&dtmp, (size_t)I * s.S * D * sizeof(double)));
+        HIPCHK(pool_malloc((void **)&dtmp, (size_t)I * s.S * D * sizeof(double)));
         launch_unpack_partials_mfma(s.partials + (size_t)cat * s.partial_stride, (int)I, s.ntiles, p->NW, (int)D,
                                     (int)s.S, dtmp, s.stream);
         hipError_t e;
@@ -1322,7 +1322,7 @@ int hyphy_hip_download_partials(hyphy_hip_partition *p, int64_t cat, double *ino
               memcpy(inode_cache + ((size_t)n * S + p->perm[s.s0 + k]) * D, tmp.data() + (size_t)k * D, (size_t)D * sizeof(double));
           }
         }
-        hipFree(dtmp);
+        pool_free_sync(dtmp);
         if (e != hipSuccess) return fail(std::string("download_partials: ") + hipGetErrorString(e));
       }
     }
@@ -1580,9 +1580,9 @@ int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_
   double *dq = nullptr, *dp = nullptr;
   int32_t *st = nullptr;
   const size_t bytes = (size_t)n * D * D * sizeof(double);
-  HIPCHK(hipMalloc((void **)&dq, bytes));
-  HIPCHK(hipMalloc((void **)&dp, bytes));
-  HIPCHK(hipMalloc((void **)&st, sizeof(int32_t)));
+  HIPCHK(pool_malloc((void **)&dq, bytes));
+  HIPCHK(pool_malloc((void **)&dp, bytes));
+  HIPCHK(pool_malloc((void **)&st, sizeof(int32_t)));
   HIPCHK(hipMemset(st, 0, sizeof(int32_t)));
   HIPCHK(hipMemcpy(dq, q_dense, bytes, hipMemcpyHostToDevice));
   ExpmArgs ea;
@@ -1593,7 +1593,7 @@ int hyphy_hip_expm_batch(int64_t D, int64_t n, const double *q_dense, double *p_
   int32_t hst = 0;
   hipError_t e1 = hipMemcpy(p_out, dp, bytes, hipMemcpyDeviceToHost);
   hipError_t e2 = hipMemcpy(&hst, st, sizeof(int32_t), hipMemcpyDeviceToHost);
-  hipFree(dq); hipFree(dp); hipFree(st);
+  pool_free_sync(dq); pool_free_sync(dp); pool_free_sync(st);
   if (e1 != hipSuccess || e2 != hipSuccess) return fail("expm_batch: device copy failed");
   if (hst) return fail("Failed to compute a valid transition matrix; this is usually caused by ill-conditioned rate "
                        "matrices (e.g. very large rate values)");
@@ -1616,15 +1616,15 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
     HIPCHK(hipStreamSynchronize(s.stream));
-    if (s.templates) hipFree(s.templates);
-    if (s.coeffs) hipFree(s.coeffs);
+    if (s.templates) pool_free_sync(s.templates);
+    if (s.coeffs) pool_free_sync(s.coeffs);
     s.templates = s.coeffs = nullptr;
-    HIPCHK(hipMalloc((void **)&s.templates, (size_t)K * D * D * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&s.templates, (size_t)K * D * D * sizeof(double)));
     // rows: one per (class, branch), or — mixtures built on the device — one per (branch, component), up to kMixRows components
     const size_t coeff_rows_cap = (size_t)std::max<int64_t>(p->C, kMixRows) * p->B;
-    HIPCHK(hipMalloc((void **)&s.coeffs, coeff_rows_cap * K * sizeof(double)));
-    if (s.h_coeffs) hipHostFree(s.h_coeffs);
-    HIPCHK(hipHostMalloc((void **)&s.h_coeffs, (size_t)4 * coeff_rows_cap * K * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&s.coeffs, coeff_rows_cap * K * sizeof(double)));
+    if (s.h_coeffs) { hipDeviceSynchronize(); pool_host_free(s.h_coeffs); }
+    HIPCHK(pool_host_malloc((void **)&s.h_coeffs, (size_t)4 * coeff_rows_cap * K * sizeof(double)));
     if (hipHostGetDevicePointer((void **)&s.d_hcoeffs, s.h_coeffs, 0) != hipSuccess) s.d_hcoeffs = nullptr;
     s.coeffs_cur = nullptr;
     s.coeff_rows = 0;
@@ -1635,10 +1635,10 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
       if (!s.coeff_ev[k]) HIPCHK(hipEventCreateWithFlags(&s.coeff_ev[k], hipEventDisableTiming));
     }
     HIPCHK(hipMemcpy(s.templates, templates, (size_t)K * D * D * sizeof(double), hipMemcpyHostToDevice));
-    if (s.templates_pad) hipFree(s.templates_pad);
+    if (s.templates_pad) pool_free_sync(s.templates_pad);
     s.templates_pad = nullptr;
     if (p->DP == 64) {
-      HIPCHK(hipMalloc((void **)&s.templates_pad, (size_t)K * 64 * 64 * sizeof(double)));
+      HIPCHK(pool_malloc((void **)&s.templates_pad, (size_t)K * 64 * 64 * sizeof(double)));
       const std::vector<double> pad = padded_templates(templates, K, D);
       HIPCHK(hipMemcpy(s.templates_pad, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
     }
@@ -1838,11 +1838,11 @@ static int site_fits_common(hyphy_hip_partition *p, int64_t n_sets, int64_t n_gr
     HIPCHK(hipSetDevice(s.device));
     HIPCHK(hipStreamSynchronize(s.stream));
     if (!s.fit_Timg) {
-      HIPCHK(hipMalloc((void **)&s.fit_Timg, (size_t)4 * DP * DP * sizeof(double)));
-      HIPCHK(hipMalloc((void **)&s.fit_bcoef, (size_t)B * 4 * sizeof(double)));
-      HIPCHK(hipMalloc((void **)&s.fit_bgroup, (size_t)B * sizeof(int)));
-      HIPCHK(hipMalloc((void **)&s.fit_pi, (size_t)DP * sizeof(double)));
-      HIPCHK(hipMalloc((void **)&s.fit_ops, ops_capacity(p) * sizeof(int4)));
+      HIPCHK(pool_malloc((void **)&s.fit_Timg, (size_t)4 * DP * DP * sizeof(double)));
+      HIPCHK(pool_malloc((void **)&s.fit_bcoef, (size_t)B * 4 * sizeof(double)));
+      HIPCHK(pool_malloc((void **)&s.fit_bgroup, (size_t)B * sizeof(int)));
+      HIPCHK(pool_malloc((void **)&s.fit_pi, (size_t)DP * sizeof(double)));
+      HIPCHK(pool_malloc((void **)&s.fit_ops, ops_capacity(p) * sizeof(int4)));
     }
     if (!s.fit_static_current) {
       if (p->fit_ops_host.size() > ops_capacity(p)) return fail("internal: site-fit schedule overflow");
@@ -1852,20 +1852,20 @@ static int site_fits_common(hyphy_hip_partition *p, int64_t n_sets, int64_t n_gr
     }
     const size_t need = (size_t)n_sets * std::max<size_t>(GK, 1);  // (doubles per pattern)
     if (s.fit_sets_cap < need) {
-      if (s.fit_smult) hipFree(s.fit_smult);
-      if (s.fit_out) hipFree(s.fit_out);
+      if (s.fit_smult) pool_free_sync(s.fit_smult);
+      if (s.fit_out) pool_free_sync(s.fit_out);
       s.fit_smult = s.fit_out = nullptr;
       s.fit_sets_cap = 0;
-      if (s.fit_smix) hipFree(s.fit_smix);
+      if (s.fit_smix) pool_free_sync(s.fit_smix);
       s.fit_smix = nullptr;
-      HIPCHK(hipMalloc((void **)&s.fit_smult, need * s.S_pad * sizeof(double)));
-      HIPCHK(hipMalloc((void **)&s.fit_out, need * s.S_pad * sizeof(double)));
-      HIPCHK(hipMalloc((void **)&s.fit_smix, need * s.S_pad * sizeof(double)));
+      HIPCHK(pool_malloc((void **)&s.fit_smult, need * s.S_pad * sizeof(double)));
+      HIPCHK(pool_malloc((void **)&s.fit_out, need * s.S_pad * sizeof(double)));
+      HIPCHK(pool_malloc((void **)&s.fit_smix, need * s.S_pad * sizeof(double)));
       s.fit_sets_cap = need;
     }
     if (p->fit_spills && s.fit_scratch_sets < (size_t)n_sets) {
-      if (s.fit_scratch) hipFree(s.fit_scratch);
-      if (s.fit_scratch_cnt) hipFree(s.fit_scratch_cnt);
+      if (s.fit_scratch) pool_free_sync(s.fit_scratch);
+      if (s.fit_scratch_cnt) pool_free_sync(s.fit_scratch_cnt);
       s.fit_scratch = nullptr;
       s.fit_scratch_cnt = nullptr;
       s.fit_scratch_sets = 0;
@@ -1876,8 +1876,8 @@ static int site_fits_common(hyphy_hip_partition *p, int64_t n_sets, int64_t n_gr
         g_last_error = "site fits: scratch for spilled nodes does not fit; use fewer parameter sets per call";
         return 1;
       }
-      HIPCHK(hipMalloc((void **)&s.fit_scratch, bytes));
-      HIPCHK(hipMalloc((void **)&s.fit_scratch_cnt, (size_t)n_sets * I * s.S_pad * sizeof(int32_t)));
+      HIPCHK(pool_malloc((void **)&s.fit_scratch, bytes));
+      HIPCHK(pool_malloc((void **)&s.fit_scratch_cnt, (size_t)n_sets * I * s.S_pad * sizeof(int32_t)));
       s.fit_scratch_sets = (size_t)n_sets;
     }
     // site multipliers of this shard's pattern range, padded with zeros (padding sites: exp(0) = I, weightless)

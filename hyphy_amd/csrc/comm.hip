@@ -102,7 +102,7 @@ int hyphy_hip_comm_init_rank(hyphy_hip_partition *p, const void *unique_id, int 
   RcclUniqueId id;
   memcpy(id.internal, unique_id, sizeof id.internal);
   RCCLCHK(g_rccl_init_rank(&s.comm, n_ranks, id, rank));
-  if (!s.ar_buf) HIPCHK(hipMalloc((void **)&s.ar_buf, 2 * sizeof(double)));
+  if (!s.ar_buf) HIPCHK(pool_malloc((void **)&s.ar_buf, 2 * sizeof(double)));
   return 0;
 }
 
@@ -211,7 +211,7 @@ int hyphy_hip_comm_init_all(hyphy_hip_partition *p) {
     HIPCHK(hipSetDevice(s.device));
     if (s.comm) g_rccl.CommDestroy(s.comm);
     s.comm = comms[k];
-    if (!s.ar_buf) HIPCHK(hipMalloc((void **)&s.ar_buf, 2 * sizeof(double)));
+    if (!s.ar_buf) HIPCHK(pool_malloc((void **)&s.ar_buf, 2 * sizeof(double)));
   }
   return 0;
 }

@@ -24,6 +24,20 @@ namespace hyhip {
 extern thread_local std::string g_last_error;
 int fail(const std::string &msg);
 
+// Recycling allocator (pool.hip): analyses that create one likelihood function after another on the same tree (FEL: one per
+// site) allocate the same ~45 device / pinned-host blocks and a stream over and over; hipMalloc / hipHostMalloc / hipFree /
+// stream creation cost that life cycle more than its 50 evaluations.  Freed blocks go to a free list keyed by (device, size)
+// and are handed out again on an exact size match.  pool_free does NOT synchronise (hipFree does, implicitly): callers that
+// free while work may be in flight use pool_free_sync.  HYPHY_HIP_POOL_MB (default 1024; 0: off) caps the cached bytes per
+// kind; blocks above 64 MiB are never cached.
+hipError_t pool_malloc(void **p, size_t bytes);
+void pool_free(void *p);
+void pool_free_sync(void *p);
+hipError_t pool_host_malloc(void **p, size_t bytes);
+void pool_host_free(void *p);
+hipError_t pool_stream_get(hipStream_t *s);   // a non-blocking stream of the current device
+void pool_stream_put(hipStream_t s);          // (idle: the caller has synchronised it)
+
 // ---- RCCL, loaded on first use (librccl.so is part of ROCm; a host that never all-reduces does not need it) -------------
 struct Rccl {
   void *lib = nullptr;

@@ -24,7 +24,7 @@ int upload_schedule(hyphy_hip_partition *p, Shard &s) {
     HIPCHK(hipMemcpyAsync(s.jn, s.h_jn, p->jn_host.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
     if (!s.deposits) {
       const size_t bytes = (size_t)p->C * s.partial_stride * sizeof(double);
-      HIPCHK(hipMalloc((void **)&s.deposits, bytes));
+      HIPCHK(pool_malloc((void **)&s.deposits, bytes));
       if (getenv("HYPHY_HIP_POISON")) {
         HIPCHK(hipMemset(s.deposits, 0xff, bytes));
         HIPCHK(hipDeviceSynchronize());

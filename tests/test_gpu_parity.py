@@ -1438,3 +1438,43 @@ def test_ordinary_per_site_evaluation_reproduces_the_reference_fubar_grid():
             assert fin.sum() >= 40, (g, fin.sum())
             assert np.max(np.abs(got[fin] - want[g][fin]) / np.abs(want[g][fin])) < 1e-9, g
             assert abs(ll - got.sum()) <= 1e-10 * abs(ll)
+
+
+def test_recycled_allocations_carry_nothing_over():
+    """The library recycles the device / pinned blocks and the stream of a destroyed partition for the next one of the same
+    shape (pool.hip: what FEL's one-likelihood-function-per-site life cycle needs).  Partitions of ONE shape and DIFFERENT data
+    created and destroyed back to back — log-L and per-site values of each against the oracle, with a partial update in
+    between, so that persisted nodes, arrival counters or the result record of a predecessor would show."""
+    from hyphy_amd import data, models
+    from oracle import oracle
+    pf = np.array([[0.3, 0.2, 0.25, 0.25], [0.2, 0.3, 0.3, 0.2], [0.25, 0.25, 0.2, 0.3]])
+    rev = dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4)
+    pi = models.f3x4_codon_freqs(pf)
+    hip = _hip()
+    seen = set()
+    for rep in range(6):
+        syn = data.evolve(12, 40, 3, seed=100 + rep % 3, p_change=0.1 + 0.1 * (rep % 3))   # three alignments, each twice
+        pd = data.from_states(syn.states, 61, compress_patterns=False)                       # (the same S every time)
+        flat = syn.flat
+        B = flat.n_branches
+        ts = np.random.default_rng(rep).uniform(0.01, 0.6, size=B)
+        Q = models.mg94rev_Q_batch(ts, 0.5 + 0.1 * rep, rev, pf)
+        nodes = np.arange(B, dtype=np.int64)
+        op = oracle.OraclePartition(61, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq)
+        op.set_P(nodes, oracle.expm(Q, True))
+        ref = op.compute_block(nodes, pi)
+        ref_site = op.site_log_likelihoods(nodes, pi)
+        with hip.HipPartition(61, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq, 1) as part:
+            ll, lik, sc = part.evaluate(nodes, nodes, Q, pi, per_site=True)
+            assert abs(ll - ref) <= RTOL * abs(ref), (rep, ll, ref)
+            got_site = np.log(lik) - sc * 64 * np.log(2.0)
+            assert np.max(np.abs(got_site - ref_site) / np.abs(ref_site)) < RTOL
+            node = int(rep % B)
+            Qn = models.mg94rev_Q_batch(ts[node:node + 1] * 1.7, 0.5 + 0.1 * rep, rev, pf)
+            un = flat.path_update_nodes(node)
+            ll2 = part.evaluate(un, [node], Qn, pi)
+            op.set_P([node], oracle.expm(Qn, True))
+            ref2 = op.compute_block(un, pi)
+            assert abs(ll2 - ref2) <= RTOL * abs(ref2), (rep, ll2, ref2)
+        seen.add(round(ll, 6))
+    assert len(seen) >= 3

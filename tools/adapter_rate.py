@@ -137,6 +137,7 @@ if "manylf" in which:
     L.append("  for (k_ = 0; k_ < 50; k_ += 1) { R = 0.3 + 0.001*k_; LFCompute (slf_, r_); }")
     L.append("  LFCompute (slf_, LF_DONE_COMPUTE);")
     L.append("  tot_ += r_;")
+    L.append('  if (s_ % 200 == 199) { fprintf (stdout, "PROGRESS ", s_ + 1, " likelihood functions after ", Time (1) - t0_, " s\\n"); }')
     L.append("}")
     L.append("t1_ = Time (1);")
     L.append(f'fprintf ("{outp}", CLEAR_FILE, "LOGL ", Format (tot_, 30, 17), "\\n", "SWEEP_SECONDS ", Format (t1_-t0_, 20, 6), "\\n");')
@@ -146,11 +147,14 @@ if "manylf" in which:
                                       ("adapter, schedule tuner cache off", HIP_BIN, dict(ENV, HYPHY_HIP_MIN_PATTERNS="0", HYPHY_HIP_TUNE_CACHE="0", HYPHY_HIP_VERBOSE="0", HYPHY_HIP_DEVICE_EXPM="always"), n_lfs),
                                       ("adapter, HYPHY_HIP_DEVICE_EXPM unset (host exponentials outside Optimize)", HIP_BIN, dict(ENV, HYPHY_HIP_VERBOSE="0"), max(4, n_lfs // 10)),
                                       ("reference 1 thread", None, None, n_ref)):
+        if os.environ.get("ADAPTER_RATE_ROWS") == "first" and not host.startswith("adapter, every"):
+            continue
         t0 = time.time()
         try:
             stdout = hbl.run_script(script.replace("N_LFS_", str(n_here)), tmp, cpus=1, timeout=1800.0, binary=binary, extra_env=env)
             res = hbl.parse_output(outp)
             res["stdout"] = stdout
-            emit("manylf_64taxa_1codon_x50", host, res, 50 * n_here, t0, extra={"likelihood_functions": n_here})
+            prog = [ln.replace("PROGRESS ", "") for ln in stdout.split("\n") if ln.startswith("PROGRESS")]
+            emit("manylf_64taxa_1codon_x50", host, res, 50 * n_here, t0, extra={"likelihood_functions": n_here, "progress": prog})
         except Exception as e:  # (report and go on: the other hosts still run)
             print(json.dumps({"case": "manylf", "host": host, "error": str(e)[-600:]}), flush=True)
