@@ -920,15 +920,8 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
   // Leaf column gathers in flight (r04).  A gather is 2 NW 16-byte loads per lane from the transposed image of the leaf's
   // matrix; its latency (1.1 k cycles alone, up to 4 k when every wave of the CU gathers) used to be exposed once per leaf.
   // r04: the two gathers of a leaf pair are in flight together (two waves per SIMD only: the 168-register builds spill).
-  // Also built and measured in r04, and NOT kept (GPF): the gather of the first leaf behind an internal edge of the same parent
-  // requested inside that edge's product, after the product's last A-operand request (so that nothing of the operand stream
-  // queues behind it in the in-order return path — r02 lost 11 % with the gather ahead of the stream), and multiplied in right
-  // behind the product.  Correct (parity suite green), but its 32 registers do not fit: held across the interpreter's loop the
-  // kernel spilled 26-34 registers and went from 116 to 154 us at the headline size, kept local to the schedule step (live from
-  // the product's last quarter only) the allocator still spilled 10-47 and the launch took 122-125 us against 115 without it
-  // (profiles/r04_wave_kernel_steps.txt).
-  constexpr bool GPF = false;
-  bool leaf0_done = false;
+  // (Built, measured and removed in r04: the first leaf's gather requested inside the preceding edge product of the same parent —
+  //  into registers of its own, or into the running product where that is still all ones; DESIGN §4.1, profiles/r04_wave_kernel_steps.txt.)
   auto gather_issue = [&](f64x2 (&dst)[2 * NW], int lf, int c) {
     const double *bl = a.PTg + (size_t)lf * DP * DP;  // uniform; [code][w][g][r]
 #pragma unroll
@@ -946,9 +939,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
   int polled = 0;  // (lane 0) arrival counter sampled near the end of an edge product, see the trunk loop
   [[maybe_unused]] f64x2 Apre[NW];   // APF: first A chunk of branch `apre_branch`, requested under the previous product
   [[maybe_unused]] int apre_branch = -1;
-  auto edge_product = [&](int branch, auto bsrc, const double *pre, const int *poll = nullptr, int next_branch = -1, int glf = -1,
-                          int gcode = 0) {
-    [[maybe_unused]] f64x2 gath[2 * NW];
+  auto edge_product = [&](int branch, auto bsrc, const double *pre, const int *poll = nullptr, int next_branch = -1) {
     HYPHY_TR(12)
     const double *pf = a.Pfrag + (size_t)((HYPHY_ABL & 1) ? (branch & abl_mask) : branch) * NW * TILE;  // uniform
     const __amdgpu_buffer_rsrc_t pfr = agent_rsrc(pf);
@@ -983,7 +974,6 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
         for (int w = 0; w < NW; w++) Apre[w] = ld16(pn, (unsigned)((w * TILE + lane * 2) * 8));
       }
       if (poll && k2 == NKK / 2 - 2 && lane == 0) polled = __hip_atomic_load(poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (GPF && glf >= 0 && k2 == (NKK / 2 >= 2 ? NKK / 2 - 2 : 0)) gather_issue(gath, glf, gcode);  // (the last A chunk has just been requested)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int w = 0; w < NW; w++) D[w] = mfma(Ac[w][0], bc[0], D[w]);
@@ -1001,10 +991,6 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
     }
 #pragma unroll
     for (int w = 0; w < NW; w++) acc[w] *= D[w];
-    if (GPF && glf >= 0) {
-      gather_apply(gath);
-      leaf0_done = true;
-    }
     if (HYPHY_ABL & 16) abl_after_edge = true;
     if (APF) apre_branch = next_branch;
     if constexpr (TRACE) {
@@ -1031,27 +1017,16 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
       if (oi + 1 < n_ops) nb = (nk == OPK_INTERNAL || nk == OPK_INTERNAL_GLOBAL) ? nxt.z : -1;
       else nb = last_next;
     }
-    // the gather that can ride inside this entry's edge product: first leaf of the NEXT entry, when that is a leaf group of
-    // the same parent without ambiguity codes
-    int glf = -1, gcode = 0;
-    if (GPF && !(HYPHY_ABL & (4 | 16)) && kind != OPK_LEAF && kind != OPK_DEP && oi + 1 < n_ops && (nxt.x & 3) == OPK_LEAF &&
-        !(nxt.x & OPF_AMBIG) && ((nxt.x >> 8) & 0x3f) > 0 && nxt.y == op.y) {
-      glf = nxt.z & 0xffff;
-      const int c = leaf_code(glf);
-      gcode = c < 0 ? 0 : c;
-    }
     if (kind == OPK_LEAF) {
       const int nl = (op.x >> 8) & 0x3f;
       if (nl == 0) {
         // (padding entry of a program)
       } else if (!(op.x & OPF_AMBIG) && !(HYPHY_ABL & (4 | 16))) {
-        // no ambiguity codes in this leaf group: column gathers only.  The first leaf's columns may be in flight already
-        // (requested inside the preceding edge product); a second leaf's are requested before the first's are consumed.
+        // no ambiguity codes in this leaf group: column gathers only.  A second leaf's columns are requested before the
+        // first's are consumed.
         const int lf0 = op.z & 0xffff, lf1 = (op.z >> 16) & 0xffff;
         f64x2 g0[2 * NW];
-        const bool done0 = GPF && leaf0_done;  // (wave-uniform: the first leaf went in behind the preceding edge product)
-        leaf0_done = false;
-        if (!done0) {
+        {
           const int c0 = leaf_code(lf0);
           gather_issue(g0, lf0, c0 < 0 ? 0 : c0);
         }
@@ -1061,10 +1036,10 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
             const int c1 = leaf_code(lf1);
             gather_issue(g1, lf1, c1 < 0 ? 0 : c1);
           }
-          if (!done0) gather_apply(g0);
+          gather_apply(g0);
           if (nl > 1) gather_apply(g1);
         } else {
-          if (!done0) gather_apply(g0);
+          gather_apply(g0);
           if (nl > 1) {
             const int c1 = leaf_code(lf1);
             gather_issue(g0, lf1, c1 < 0 ? 0 : c1);
@@ -1103,7 +1078,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
         edge_product(op.z, [&](int k2) -> f64x2 {
           if constexpr (LB) return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2);
           else return (f64x2){bch[k2 >> 1][(k2 & 1) * 2], bch[k2 >> 1][(k2 & 1) * 2 + 1]};
-        }, nullptr, nullptr, nb, glf, gcode);
+        }, nullptr, nullptr, nb);
         cnt += bcnt;
       } else {
         const double *src = park + (slot - 2) * TILE;
@@ -1112,7 +1087,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
         for (int q = 1; q < NP; q++) ccnt = (slot - 2 == q) ? pcnt[q] : ccnt;
         edge_product(op.z, [&](int k2) -> f64x2 {
           return *reinterpret_cast<const f64x2 *>(src + (k2 * 64 + lane) * 2);
-        }, nullptr, nullptr, nb, glf, gcode);
+        }, nullptr, nullptr, nb);
         cnt += ccnt;
       }
     } else if (kind == OPK_DEP) {
@@ -1163,9 +1138,9 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
 #pragma unroll
         for (int k2 = 0; k2 < NKK / 2; k2++) *reinterpret_cast<f64x2 *>(stage + (k2 * 64 + lane) * 2) = gq[k2];
         edge_product(op.z, [&](int k2) -> f64x2 { return *reinterpret_cast<const f64x2 *>(stage + (k2 * 64 + lane) * 2); },
-                     nullptr, nullptr, nb, glf, gcode);
+                     nullptr, nullptr, nb);
       } else {
-        edge_product(op.z, [&](int k2) -> f64x2 { return gq[k2]; }, nullptr, nullptr, nb, glf, gcode);
+        edge_product(op.z, [&](int k2) -> f64x2 { return gq[k2]; }, nullptr, nullptr, nb);
       }
       cnt += ccnt;
     }
