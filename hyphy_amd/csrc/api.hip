@@ -29,7 +29,7 @@ void free_shard(Shard &s) {
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops};
   for (void *d : dev)
     if (d) pool_free(d);  // (the stream was synchronised above)
-  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn};
+  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn, s.h_tstage};
   for (void *h : host)
     if (h) pool_host_free(h);
   for (auto &e : s.ev)
@@ -39,6 +39,8 @@ void free_shard(Shard &s) {
   for (auto &e : s.ring)
     if (e) hipEventDestroy(e);
   for (auto &e : s.coeff_ev)
+    if (e) hipEventDestroy(e);
+  for (auto &e : s.tstage_ev)
     if (e) hipEventDestroy(e);
   if (s.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s.comm);
   if (s.own_stream) pool_stream_put(s.own_stream);
@@ -1642,6 +1644,15 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
       const std::vector<double> pad = padded_templates(templates, K, D);
       HIPCHK(hipMemcpy(s.templates_pad, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    // pinned ring for hyphy_hip_update_q_templates (two slots: the copy of one update may still be queued when the next arrives)
+    if (s.h_tstage) { hipDeviceSynchronize(); pool_host_free(s.h_tstage); }
+    s.h_tstage = nullptr;
+    s.tstage_slot = (size_t)K * D * D + (p->DP == 64 ? (size_t)K * 64 * 64 : 0);
+    HIPCHK(pool_host_malloc((void **)&s.h_tstage, 2 * s.tstage_slot * sizeof(double)));
+    for (int k = 0; k < 2; k++) {
+      s.tstage_busy[k] = false;
+      if (!s.tstage_ev[k]) HIPCHK(hipEventCreateWithFlags(&s.tstage_ev[k], hipEventDisableTiming));
+    }
   }
   p->K = K;
   p->templates_host.assign(templates, templates + (size_t)K * D * D);
@@ -1661,15 +1672,30 @@ int hyphy_hip_update_q_templates(hyphy_hip_partition *p, int64_t K, const double
   p->templates_host.assign(templates, templates + n);
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
-    // (staged through the pinned coefficient ring's allocation would race with queued kernels; a small synchronous
-    //  wait on the stream keeps it simple: the previous evaluation has been collected by the time a host adapter gets here)
-    HIPCHK(hipStreamSynchronize(s.stream));
-    HIPCHK(hipMemcpyAsync(s.templates, p->templates_host.data(), n * sizeof(double), hipMemcpyHostToDevice, s.stream));
-    if (s.templates_pad) {
-      const std::vector<double> pad = padded_templates(templates, K, D);
-      HIPCHK(hipMemcpyAsync(s.templates_pad, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice, s.stream));
-      HIPCHK(hipStreamSynchronize(s.stream));  // (pageable source that goes out of scope)
+    // r04: through a pinned ring, in-stream, no wait on the host — the copies run behind whatever is queued on the stream and
+    // ahead of the exponential launch that reads them (r03 copied from pageable memory and synchronised the stream twice:
+    // ~40 us of every evaluation of a host whose templates follow its global parameters).  A slot is reused
+    // two updates later; its event says when its copy has run.
+    const int slot = (int)(s.tstage_turn++ & 1);
+    if (s.tstage_busy[slot]) {
+      HIPCHK(hipEventSynchronize(s.tstage_ev[slot]));
+      s.tstage_busy[slot] = false;
     }
+    double *st = s.h_tstage + (size_t)slot * s.tstage_slot;
+    memcpy(st, templates, n * sizeof(double));
+    HIPCHK(hipMemcpyAsync(s.templates, st, n * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    if (s.templates_pad) {  // [K][64*64]: zero padding, zero diagonals (padded_templates)
+      double *pad = st + n;
+      memset(pad, 0, (size_t)K * 64 * 64 * sizeof(double));
+      for (int64_t k = 0; k < K; k++)
+        for (int64_t r = 0; r < D; r++) {
+          memcpy(pad + ((size_t)k * 64 + r) * 64, templates + ((size_t)k * D + r) * D, (size_t)D * sizeof(double));
+          pad[((size_t)k * 64 + r) * 64 + r] = 0.;
+        }
+      HIPCHK(hipMemcpyAsync(s.templates_pad, pad, (size_t)K * 64 * 64 * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    }
+    HIPCHK(hipEventRecord(s.tstage_ev[slot], s.stream));
+    s.tstage_busy[slot] = true;
     s.fit_static_current = false;
   }
   return 0;

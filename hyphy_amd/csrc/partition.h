@@ -156,6 +156,11 @@ struct Shard {
   // (hyphy_hip_evaluate_device) the host may run ahead of the device: an event recorded behind the consuming launch
   // guards the slot, and hyphy_hip_build_q waits for it before rewriting the slot.
   hipEvent_t coeff_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double *h_tstage = nullptr;     // pinned ring of 2: [K D D unpadded | K 64 64 padded] template images on their way to the device (update_q_templates)
+  size_t tstage_slot = 0;         // doubles per ring slot
+  hipEvent_t tstage_ev[2] = {nullptr, nullptr};
+  bool tstage_busy[2] = {false, false};
+  unsigned tstage_turn = 0;
   bool coeff_busy[4] = {false, false, false, false};
   int coeff_slot = -1;                 // ring slot of the staged coefficients
   int64_t coeff_rows = 0;              // rows staged by the last hyphy_hip_build_q (0: nothing staged)
