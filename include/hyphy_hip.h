@@ -68,7 +68,9 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
                      const int64_t *flat_parents, const int64_t *leaf_codes, const double *ambig,
                      int64_t n_ambig, const int64_t *pattern_freq, int device_first, int device_count);
 
-/* Replaces DeleteCaches (likefunc.cpp:10556-10600) for the partition. NULL is a no-op. */
+/* Replaces DeleteCaches (likefunc.cpp:10556-10600) for the partition. NULL is a no-op.  The partition's device and pinned host
+ * blocks and its stream are kept for the next hyphy_hip_create of the same shape in this process (analyses that build one
+ * likelihood function per site: FEL); HYPHY_HIP_POOL_MB caps what is kept (MiB per kind, default 1024, 0: nothing). */
 void hyphy_hip_destroy(hyphy_hip_partition *p);
 
 /*
@@ -249,7 +251,9 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
 int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs /* host [n*K] */);
 /* New VALUES for the K templates (K unchanged: no reallocation): for hosts whose templates depend on the global
  * parameters of the current evaluation — the HyPhy adapter derives M_k(globals) from K probe branches per
- * ExponentiateMatrices call and sends Q_b = sum_k x_bk M_k as K coefficients per branch. */
+ * ExponentiateMatrices call and sends Q_b = sum_k x_bk M_k as K coefficients per branch.
+ * The caller's array is copied before the call returns (pinned staging ring); the upload itself is queued on the partition's
+ * stream ahead of the next exponential launch, the host does not wait for it. */
 int hyphy_hip_update_q_templates(hyphy_hip_partition *p, int64_t K, const double *templates /* [K*D*D] */);
 double *hyphy_hip_q_buffer(hyphy_hip_partition *p); /* device pointer, capacity (L+I-1)*C*D*D doubles */
 
