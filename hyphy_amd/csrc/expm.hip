@@ -468,7 +468,8 @@ __device__ __forceinline__ void mm64(const double *__restrict__ Lm, const double
     // k-slot g of MFMA step kk carries k = 16 g + kk (any bijection does): with the row stride of 65 doubles the 32 lanes of a
     // ds_read_b64 lane group (sl = 0..15, g = 0, 1 / 2, 3) then fall on 32 different bank pairs for the A operand (sl + 16 g)
     // AND for the B operand (16 g 65 + sl = 16 g + sl mod 32).  k = 4 kk + g (r03) put both on sl + g: two-way conflicts on
-    // every operand read, SQ_LDS_BANK_CONFLICT 0.86 cycles per LDS instruction of the launch.
+    // every operand read (SQ_LDS_BANK_CONFLICT of the headline launch: 382 620 -> 254 620; the rest are the C-layout tile stores /
+    // loads and the image passes, profiles/r04_pmc_final_build_lds.json).
     const double a0 = Lm[(16 * rb + sl) * LD + 16 * g + kk], a1 = Lm[(16 * rb + sl) * LD + 16 * g + kk + 1];
 #pragma unroll
     for (int c = 0; c < NTW; c++) {
