@@ -29,7 +29,7 @@ void free_shard(Shard &s) {
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops};
   for (void *d : dev)
     if (d) pool_free(d);  // (the stream was synchronised above)
-  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn, s.h_tstage};
+  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn, s.h_tstage, s.h_site};
   for (void *h : host)
     if (h) pool_host_free(h);
   for (auto &e : s.ev)
@@ -616,23 +616,21 @@ int gather_sites(hyphy_hip_partition *p, int cat, double *site_lik_out, int64_t 
     HIPCHK(hipSetDevice(s.device));
     const double *lik = mixed ? s.mixed_lik : s.site_lik + (size_t)cat * s.S_pad;
     const int32_t *cn = mixed ? s.mixed_cnt : s.site_cnt + (size_t)cat * s.S_pad;
-    if (site_lik_out) {
-      if (p->perm.empty()) {
-        HIPCHK(hipMemcpyAsync(site_lik_out + s.s0, lik, s.S * sizeof(double), hipMemcpyDeviceToHost, s.stream));
-      } else {  // the device keeps its patterns sorted: scatter back into the caller's order
-        std::vector<double> tmp(s.S);
-        HIPCHK(hipMemcpyAsync(tmp.data(), lik, s.S * sizeof(double), hipMemcpyDeviceToHost, s.stream));
-        HIPCHK(hipStreamSynchronize(s.stream));
-        for (int64_t k = 0; k < s.S; k++) site_lik_out[p->perm[s.s0 + k]] = tmp[k];
-      }
-    }
-    if (site_scaler_out) {
-      std::vector<int32_t> tmp(s.S);
-      HIPCHK(hipMemcpyAsync(tmp.data(), cn, s.S * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
-      HIPCHK(hipStreamSynchronize(s.stream));
-      for (int64_t k = 0; k < s.S; k++) site_scaler_out[caller_pattern(p, s.s0 + k)] = tmp[k];
-    }
+    // both arrays through ONE pinned staging block and one wait (r04; was: two pageable temporaries, a wait behind each copy —
+    // a host that mixes rate classes itself asks for these once per class and evaluation)
+    if (!s.h_site) HIPCHK(pool_host_malloc((void **)&s.h_site, (size_t)s.S_pad * (sizeof(double) + sizeof(int32_t))));
+    double *hl = s.h_site;
+    int32_t *hc = reinterpret_cast<int32_t *>(s.h_site + s.S_pad);
+    if (site_lik_out) HIPCHK(hipMemcpyAsync(hl, lik, s.S * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    if (site_scaler_out) HIPCHK(hipMemcpyAsync(hc, cn, s.S * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
     HIPCHK(hipStreamSynchronize(s.stream));
+    if (site_lik_out) {
+      if (p->perm.empty()) memcpy(site_lik_out + s.s0, hl, s.S * sizeof(double));
+      else  // the device keeps its patterns sorted: scatter back into the caller's order
+        for (int64_t k = 0; k < s.S; k++) site_lik_out[p->perm[s.s0 + k]] = hl[k];
+    }
+    if (site_scaler_out)
+      for (int64_t k = 0; k < s.S; k++) site_scaler_out[caller_pattern(p, s.s0 + k)] = hc[k];
   }
   return 0;
 }

@@ -156,6 +156,7 @@ struct Shard {
   // (hyphy_hip_evaluate_device) the host may run ahead of the device: an event recorded behind the consuming launch
   // guards the slot, and hyphy_hip_build_q waits for it before rewriting the slot.
   hipEvent_t coeff_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double *h_site = nullptr;       // pinned staging of per-pattern results on their way to the caller (gather_sites): [S_pad] doubles + [S_pad] int32
   double *h_tstage = nullptr;     // pinned ring of 2: [K D D unpadded | K 64 64 padded] template images on their way to the device (update_q_templates)
   size_t tstage_slot = 0;         // doubles per ring slot
   hipEvent_t tstage_ev[2] = {nullptr, nullptr};

@@ -97,6 +97,8 @@ if "cat3" in which:
     for host, binary, env, count in (("adapter", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals),
                                       ("adapter, HYPHY_HIP_DEVICE_EXPM unset (mode A outside Optimize: host exponentials)", HIP_BIN, ENV, max(100, n_evals // 20)),
                                       ("reference 16 threads", None, None, max(6, n_evals // 200))):
+        if os.environ.get("ADAPTER_RATE_ROWS") == "first" and host != "adapter":
+            continue
         t0 = time.time()
         res = hbl.evaluate(model_block=block, globals_=dict(R=0.3, **bench.REV), category=cat,
                            sweep=dict(param="R", start=0.3, step=0.0001, n=count), threads=(1 if binary else 16), binary=binary, extra_env=env, **common)
