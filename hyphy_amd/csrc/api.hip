@@ -26,10 +26,11 @@ void free_shard(Shard &s) {
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
                  s.weights, s.templates, s.templates_pad, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.pi_ones, s.codes_tile,
                  s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.mix_q, s.mix_p, s.mix_w, s.mix_off, s.ar_buf, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
-                 s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops};
+                 s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops, s.rep_tab, s.rep_cnt, s.rep_map, s.rep_desc, s.rep_items, s.rep_sync,
+                 s.rep_codes_tile, s.rep_leaf};
   for (void *d : dev)
     if (d) pool_free(d);  // (the stream was synchronised above)
-  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn, s.h_tstage, s.h_site};
+  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn, s.h_tstage, s.h_site, s.h_rep_items};
   for (void *h : host)
     if (h) pool_host_free(h);
   for (auto &e : s.ev)
@@ -76,7 +77,7 @@ void refresh_twins(hyphy_hip_partition *p, Shard &s) {
   if (p->rr_path.empty() || p->nuc) return;
   const size_t DD = (size_t)p->DP * p->DP;
   for (size_t j = 0; j + 1 < p->rr_path.size(); j++)
-    launch_transpose_frag(s.Pfrag + (size_t)(p->L + p->rr_path[j + 1]) * DD, s.Pfrag + (size_t)(twin_slot0(p) + (int)j) * DD,
+    launch_transpose_frag(s.Pfrag + (size_t)p->vw().slot[p->vw().L + p->rr_path[j + 1]] * DD, s.Pfrag + (size_t)(twin_slot0(p) + (int)j) * DD,
                           j == 0 ? s.pi : nullptr, p->NW, s.stream);
   s.twins_dirty = false;
 }
@@ -95,16 +96,26 @@ PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
   pa.T = s.T;
   pa.S_pad = s.S_pad;
   pa.ntiles = s.ntiles;
-  pa.root_inode = (int)p->I - 1;
+  const hyphy_hip_partition::View &v = p->vw();  // (node indices and leaf numbers are the view's; class strides the partition's)
+  pa.root_inode = v.I - 1;
   pa.root_slot = p->root_slot;
-  pa.L = (int)p->L;
+  pa.L = v.L;
   pa.variant = p->variant;
   pa.n_slots = p->n_slots;
-  pa.codes_in_lds = ((size_t)p->L * s.T * 32 + (size_t)(p->L + p->I) * 16 <= 24576) ? 1 : 0;
+  pa.codes_in_lds = ((size_t)v.L * s.T * 32 + (size_t)(v.L + v.I) * 16 <= 24576) ? 1 : 0;
   pa.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
   pa.PTg = s.PTg + (size_t)cat * B * DP * DP;
   pa.codes = s.codes;
   pa.codes_tile = s.codes_tile;
+  if (p->mode == 1) {  // the trunk of a class-compressed partition: generalised leaves (repeats.hip)
+    pa.codes_tile = s.rep_codes_tile;
+    pa.codes = nullptr;  // (row-major leaf table: the kernels of this mode read the tile-major one)
+    pa.leaf_tab = s.rep_leaf;
+    pa.gtab = s.rep_tab + (size_t)cat * s.rep_rows * DP;
+    pa.gcnt = s.rep_cnt + (size_t)cat * s.rep_rows;
+    pa.cs_gtab = (size_t)s.rep_rows * DP;
+    pa.cs_gcnt = (size_t)s.rep_rows;
+  }
   pa.pin = s.pin;
   pa.pin_leaf = (p->pin_node >= 0 && p->pin_node < p->L) ? (int)p->pin_node : -1;
   pa.pin_inode = p->pin_node >= p->L ? (int)(p->pin_node - p->L) : -1;
@@ -307,7 +318,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     if (!p->rr_path.empty() && !p->nuc && n_cat_batch <= 1) {  // keep the transposed twins in step with the matrices they mirror
       const size_t k = p->rr_path.size() - 1;
       ea.n_twin = (int)k;
-      for (size_t j = 0; j < k; j++) ea.twin_src[j] = (int)(p->L + p->rr_path[j + 1]);
+      for (size_t j = 0; j < k; j++) ea.twin_src[j] = p->vw().slot[p->vw().L + p->rr_path[j + 1]];
       ea.twin_dst0 = twin_slot0(p);
       ea.twin_pi = s.pi;
       size_t covered = 0;
@@ -344,6 +355,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
   }
   if (p->all_timings) HIPCHK(hipEventRecord(s.ev[1], s.stream));  // (before the ring's stamp: the exponentials' interval ends here)
   if (stamp) HIPCHK(hipEventRecord(s.ring[ring_slot], s.stream));
+  if (p->mode == 1 && rep_launch(p, s, cat)) return -1;  // lower phase: the class tables this pass recomputes
   int n_ops = 0;  // longest program
   for (const auto &pr : p->programs) n_ops = std::max(n_ops, pr.n);
   double *site_lik = s.site_lik + (size_t)cat * s.S_pad;
@@ -505,22 +517,28 @@ bool same_update(const hyphy_hip_partition *p, const int64_t *u, int64_t n, bool
 }
 
 int prepare_schedule(hyphy_hip_partition *p, int cat, const int64_t *update_nodes, int64_t n_update, bool *changed,
-                     bool force_persist = false) {
+                     bool force_persist, const int64_t *q_nodes, int64_t n_q, int n_classes) {
   bool full = !p->initialized[cat];
   if (!full && n_update >= p->B) full = true;
   const bool requested_full = full;
   bool persist_all = true;
-  if (!full && !p->resident[cat]) full = true;  // a partial update needs current persisted copies: promote to a persisting full pass
+  const std::vector<char> &res = p->mode == 1 ? p->rep_resident : p->resident;  // (each view keeps its own copies)
+  if (!full && !res[cat]) full = true;  // a partial update needs current persisted copies: promote to a persisting full pass
   else if (full && p->initialized[cat] && p->cache_policy == 1 && p->last_full[cat] && !force_persist)
     persist_all = false;
   p->sched_full = full;
   p->sched_persist = persist_all;
   p->last_full[cat] = requested_full ? 1 : 0;
+  std::vector<int64_t> view_update;
+  if (p->mode == 1) {  // class tables to recompute (item queues on the device), and the trunk's own update list
+    if (rep_prepare_pass(p, update_nodes, n_update, q_nodes, n_q, full, cat, n_classes, view_update)) return -1;
+  }
   if (same_update(p, update_nodes, n_update, full) && p->cached_persist == persist_all) {
     *changed = false;
     return 0;
   }
-  build_schedule(p, update_nodes, n_update, full);
+  if (p->mode == 1) build_schedule(p, view_update.data(), (int64_t)view_update.size(), full);
+  else build_schedule(p, update_nodes, n_update, full);
   if (p->ops_host.size() > ops_capacity(p)) return fail("internal: schedule overflow");
   p->cached_update.assign(update_nodes, update_nodes + (full ? 0 : n_update));
   p->cached_full = full;
@@ -747,6 +765,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
   if (const char *e = getenv("HYPHY_HIP_TILES")) tiles_override = atoi(e);
   if (!p->nuc && !(getenv("HYPHY_HIP_SORT_PATTERNS") && atoi(getenv("HYPHY_HIP_SORT_PATTERNS")) == 0))
     sort_patterns(p, leaf_codes, L, S);
+  init_plain_view(p);
   if (!p->nuc && C == 1) reroot_path(p);
   auto src_pattern = [&](int64_t j) -> int64_t { return p->perm.empty() ? j : p->perm[j]; };
 
@@ -759,6 +778,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     s0 += s.S;
     p->shards.push_back(s);
   }
+  std::vector<std::vector<int16_t>> shard_codes;  // per shard: the leaf table in device pattern order (class computation below)
   for (Shard &s : p->shards) {
     if (hipSetDevice(s.device) != hipSuccess) { hyphy_hip_destroy(p); return fail("hipSetDevice failed"); }
     hipDeviceProp_t prop;
@@ -907,7 +927,8 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     hipMemsetAsync(s.site_lik, 0, (size_t)C * s.S_pad * sizeof(double), s.stream);
     hipMemsetAsync(s.site_cnt, 0, (size_t)C * s.S_pad * sizeof(int32_t), s.stream);
     // leaf table: int64 pattern-indexed -> packed int16 [L][S_pad]; padding patterns use state 0, weight 0
-    std::vector<int16_t> codes((size_t)L * s.S_pad, 0);
+    shard_codes.push_back(std::vector<int16_t>((size_t)L * s.S_pad, 0));
+    std::vector<int16_t> &codes = shard_codes.back();
     for (int64_t l = 0; l < L; l++)
       for (int64_t k = 0; k < s.S; k++) codes[(size_t)l * s.S_pad + k] = (int16_t)leaf_codes[l * S + src_pattern(s.s0 + k)];
     std::vector<double> fr(s.S_pad, 0.0);
@@ -930,7 +951,42 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       return fail("device initialisation failed");
     }
   }
+  // subtree repeats: classes, compressed set, trunk view and tables (repeats.hip); leaves rep_on false when it would not pay
+  if (rep_setup(p, shard_codes)) {
+    hyphy_hip_destroy(p);
+    return -1;
+  }
   *out = p;
+  return 0;
+}
+
+/* Subtree repeats (repeats.hip) are used wherever they pay; `on` = 0 turns them off for this partition (the pruning kernels
+ * then walk every node at every pattern), 1 back on.  Same results either way (HYPHY_HIP_REPEATS=0 does the same for
+ * every partition created afterwards). */
+int hyphy_hip_set_repeats(hyphy_hip_partition *p, int on) {
+  if (!p) return fail("partition == NULL");
+  if (finish_pending_async(p)) return -1;
+  p->rep_enabled = on != 0;
+  return 0;
+}
+
+/* What the class compression does on this partition's first shard: out[0] available, [1] class tables, [2] table rows (classes
+ * padded to tiles of 16: the edge products of the lower phase), [3] / [4] internal nodes / leaves of the trunk, [5] edge
+ * products one full pass executes with repeats on, [6] ... with repeats off (every internal edge at every pattern), [7] in use. */
+int hyphy_hip_repeat_stats(const hyphy_hip_partition *p, int64_t out[8]) {
+  if (!p || !out) return fail("null argument");
+  for (int k = 0; k < 8; k++) out[k] = 0;
+  const Shard &s = p->shards[0];
+  out[6] = (p->I - 1) * (int64_t)s.S_pad;
+  out[5] = out[6];
+  if (!p->rep_on) return 0;
+  out[0] = 1;
+  out[1] = (int64_t)p->rep_nodes.size();
+  out[2] = s.rep_rows;
+  out[3] = p->views[1].I;
+  out[4] = p->views[1].L;
+  out[5] = s.rep_rows + (int64_t)(p->views[1].I - 1) * s.S_pad;
+  out[7] = p->rep_enabled ? 1 : 0;
   return 0;
 }
 
@@ -981,20 +1037,23 @@ int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes
       seen[q_nodes[k]] = 1;
     }
   }
+  // the view this evaluation runs under: the class-compressed one wherever it exists, except with pinned states and for the
+  // internal passes that restore the per-pattern copies of every node (branch cache, downloads)
+  switch_mode(p, (p->rep_on && p->rep_enabled && p->pin_node < 0 && !force_persist) ? 1 : 0);
   bool changed = false;
   const int64_t bc = batch ? p->C : 1;
   if (bc != p->batch_classes) {
     p->batch_classes = bc;
     p->cached_valid = 0;  // fragment sizing depends on how many classes share the launch
   }
-  if (prepare_schedule(p, (int)cat, update_nodes, n_update, &changed, force_persist)) return -1;
+  if (prepare_schedule(p, (int)cat, update_nodes, n_update, &changed, force_persist, q_nodes, n_q, batch ? (int)p->C : 1)) return -1;
   {
     const bool tune_on = p->tuned_for != p->batch_classes && !(getenv("HYPHY_HIP_TUNE") && atoi(getenv("HYPHY_HIP_TUNE")) == 0) && !getenv("HYPHY_HIP_CHAIN_M") &&
                                 !getenv("HYPHY_HIP_CUT") && !getenv("HYPHY_HIP_FRAGMENT");
     if (tune_on && !p->nuc && (p->variant >= 1 || (!p->kernel_forced && p->shards[0].ntiles >= 32)) && p->shards[0].T == 1 && p->sched_full && !p->sched_persist &&
         p->tuned_for != p->batch_classes && p->initialized[cat]) {
       if (tune_schedule(p, (int)cat, batch ? (int)p->C : 1)) return -1;
-      build_schedule(p, update_nodes, n_update, true);  // the chosen cut
+      build_schedule(p, nullptr, 0, true);  // the chosen cut (a full pass: no update list)
       if (p->ops_host.size() > ops_capacity(p)) return fail("internal: schedule overflow");
       changed = true;
     }
@@ -1018,14 +1077,17 @@ int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes
       p->initialized[cat] = 0;
       return -1;
     }
+  std::vector<char> &res_here = p->mode == 1 ? p->rep_resident : p->resident, &res_other = p->mode == 1 ? p->resident : p->rep_resident;
   if (batch)
     for (int64_t c = 0; c < p->C; c++) {
       p->initialized[c] = 1;
-      if (p->sched_full) p->resident[c] = p->sched_persist ? 1 : 0;
+      if (p->sched_full) res_here[c] = p->sched_persist ? 1 : 0;
+      if (!res_other.empty()) res_other[c] = 0;  // (the other view's copies are stale now)
       p->last_full[c] = p->last_full[0];
     }
   p->initialized[cat] = 1;
-  if (p->sched_full) p->resident[cat] = p->sched_persist ? 1 : 0;
+  if (p->sched_full) res_here[cat] = p->sched_persist ? 1 : 0;
+  if (!res_other.empty()) res_other[cat] = 0;
   return 0;  // (coefficients staged by hyphy_hip_build_q stay valid — and pending — until the next hyphy_hip_build_q)
 }
 
@@ -1402,6 +1464,7 @@ int hyphy_hip_branch_cache_build(hyphy_hip_partition *p, int64_t cat, int64_t no
   if (node < 0 || node >= p->B) return fail("branch cache: node out of range (the root has no branch)");
   if (!p->initialized[cat]) return fail("branch cache: evaluate the partition first (conditionals must be resident)");
   if (ensure_resident(p, cat)) return -1;
+  switch_mode(p, 0);  // (the outside vector is built over the partition's own tree)
   const int L = (int)p->L, I = (int)p->I, C = (int)p->C;
   const int64_t B = p->B;
   const int DP = p->DP;
@@ -1512,6 +1575,8 @@ int hyphy_hip_branch_cache_evaluate(hyphy_hip_partition *p, int64_t cat, int64_t
     return fail("branch cache: no cache resident for this branch (call hyphy_hip_branch_cache_build after an evaluation)");
   if (!q_dense) return fail("null matrix pointer");
   if (finish_pending_async(p)) return -1;
+  p->rep_stale_branch = node;  // (this branch's matrix image is rewritten below: its class table is stale)
+  std::fill(p->rep_resident.begin(), p->rep_resident.end(), 0);
   const int L = (int)p->L, I = (int)p->I, C = (int)p->C;
   const int64_t B = p->B, D = p->D;
   const int DP = p->DP;
@@ -1761,6 +1826,7 @@ static int site_fits_common(hyphy_hip_partition *p, int64_t n_sets, int64_t n_gr
   if (!branch_group || !branch_coeffs || !site_mult || !root_freqs || !site_logl_out || (n_mix > 1 && !site_weights))
     return fail("site fits: null argument");
   if (finish_pending_async(p)) return -1;
+  switch_mode(p, 0);  // (the per-site kernel walks the partition's own tree)
   const int64_t D = p->D, B = p->B, K = p->K, S = p->S;
   const int L = (int)p->L, I = (int)p->I, DP = p->DP, NW = p->NW;
   const int NKK = 4 * NW, TILE = NKK * 64;

@@ -131,6 +131,11 @@ struct PruneArgs {
   double red_seq;
   int *red_done;             // arrivals of finalised roots (zero between launches)
   int red_n;                 // roots the launch finalises = entries of wg_sum
+  // subtree repeats (repeats.hip; prune_wave_kernel<REP>): the schedule's leaves are those of the trunk view
+  const int2 *leaf_tab = nullptr;   // [L] (first row of the leaf's class table or -1: ordinary leaf, first exponent row / matrix slot)
+  const double *gtab = nullptr;     // [rows][DP] class tables, column-gather layout
+  const int32_t *gcnt = nullptr;    // [rows] their 2^64 exponents
+  size_t cs_gtab = 0, cs_gcnt = 0;  // class strides
 };
 constexpr int kTraceWG = 8;
 constexpr int kNucParkSlots = 4;  // LDS parking slots of the 4-state kernel (nodes whose parent is not the next entry)

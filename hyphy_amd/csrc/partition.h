@@ -93,6 +93,13 @@ struct Trace {
 
 constexpr int kTimingRing = 1024;
 
+// Subtree repeats: one class table per compressed internal node / leaf with ambiguity codes, per shard
+struct RepTable {
+  int U = 0, rows = 0;       // classes of this shard, padded to a multiple of 16
+  int64_t row0 = 0;          // first row in the shard's table buffer
+  std::vector<int64_t> map0; // per child: offset of its index map in rep_map
+};
+
 struct Shard {
   int device = 0;
   hipStream_t stream = nullptr;      // stream in use
@@ -186,6 +193,21 @@ struct Shard {
   int4 *fit_ops = nullptr;
   size_t fit_sets_cap = 0, fit_scratch_sets = 0;
   bool fit_static_current = false;  // template images + schedule on the device match the host copies
+  // subtree repeats (repeats.hip): class tables of the compressed nodes of this shard
+  std::vector<RepTable> rep_tabs;    // per descriptor (hyphy_hip_partition::rep_nodes order): classes of this shard
+  int64_t rep_rows = 0;              // table rows (classes, padded to whole tiles of 16) over all descriptors
+  double *rep_tab = nullptr;         // [C][rep_rows][DP]   E_n[u] = P_n x (conditionals of class u below n), column-gather layout
+  int32_t *rep_cnt = nullptr;        // [C][rep_rows]       their 2^64 exponents
+  int32_t *rep_map = nullptr;        // per (descriptor, child): [rows of the descriptor] class of the child / leaf code
+  int4 *rep_desc = nullptr;          // descriptor headers and child entries (repeats.hip: RepDesc)
+  int4 *rep_items = nullptr;         // work items of the current pass, eight queues
+  int *rep_sync = nullptr;           // queue heads, exit counter, per (class, descriptor) finished tiles (zero between launches)
+  int4 *h_rep_items = nullptr;       // pinned staging of the item queues
+  size_t rep_items_cap = 0;          // items per queue the buffers hold
+  int16_t *rep_codes_tile = nullptr; // [tile][view leaves][16] leaf table of the trunk: state codes / class ids of generalised leaves
+  int2 *rep_leaf = nullptr;          // [view leaves] (table row0 or -1: ordinary leaf, exponent row0 / matrix slot)
+  int rep_qcap = 0;                  // items per queue of the pass the device queues hold
+  int rep_waves = 0;                 // waves its launch runs
 };
 
 }  // namespace hyhip
@@ -197,6 +219,47 @@ struct hyphy_hip_partition {
   bool nuc_leaf_pairs = false;               // 4 states: leaf entries carry up to two leaves (prune_nuc2_kernel; prune_nuc_kernel takes one)
   std::vector<int64_t> parents;              // [L+I]
   std::vector<std::vector<int>> children;    // per internal node, ascending node codes
+  // The tree the schedule compiler and the pruning kernels walk.  views[0]: the partition's own tree.  views[1] (subtree
+  // repeats, repeats.hip): the TRUNK — the internal nodes whose subtrees are not class-compressed — over generalised
+  // leaves (ordinary leaves below trunk nodes, compressed subtree roots, leaves with ambiguity codes).  Internal
+  // indices / leaf numbers are the view's own; `slot` maps a view node back to its transition-matrix slot (= node code
+  // of the partition's tree).
+  struct View {
+    int L = 0, I = 0;
+    std::vector<int64_t> parents;            // [L+I] view-internal index of the parent
+    std::vector<std::vector<int>> children;  // per view-internal node: view node codes, ascending
+    std::vector<char> leaf_has_ambig;        // [L]
+    std::vector<int> slot;                   // [L+I] matrix slot (node code in the partition's tree)
+  };
+  View views[2];
+  int mode = 0;                              // view in use (switch_mode)
+  const View &vw() const { return views[mode]; }
+  struct ModeState {                         // what the tuner / re-rooting decided, per view
+    int variant = 0, wave_variant = 0, n_slots = 0, chain_m_forced = 0;
+    bool rr_use = false, kernel_forced = false;
+    int64_t tuned_for = 0;
+    std::string tune_report;
+    std::vector<int> rr_path;
+    std::vector<std::vector<int>> rr_cands;
+  };
+  ModeState saved_mode[2];
+  // subtree repeats
+  bool rep_on = false;                       // views[1] exists
+  bool rep_enabled = true;                   // ... and ordinary evaluations use it (hyphy_hip_set_repeats)
+  struct RepNode {                           // one class table (descriptor): a compressed internal node or a leaf with ambiguity codes
+    int node = 0;                            // node code in the partition's tree
+    int level = 0;                           // 0: no table among its children
+    std::vector<int> kids;                   // internal nodes: children (node codes)
+    std::vector<int> kid_desc;               // ... descriptor of the child's table, -1: ordinary leaf (gathered by state code)
+  };
+  std::vector<RepNode> rep_nodes;            // children before parents
+  std::vector<int> rep_desc_of;              // [L+I] descriptor of a node's table, -1: none
+  std::vector<char> rep_resident;            // per class: tables and trunk copies are current (mode 1 counterpart of `resident`)
+  std::vector<int> rep_cached_dirty;         // descriptors the item queues on the device were built for
+  int rep_cached_classes = 0;
+  bool rep_cached_valid = false;
+  int64_t rep_stale_branch = -1;             // a branch whose matrix image was rewritten outside an evaluation (branch cache)
+  double rep_kernel_ms = 0.;
   std::vector<hyhip::Shard> shards;
   std::vector<char> initialized;             // per class: a full evaluation has populated the caches
   std::vector<char> leaf_has_ambig;          // per leaf: any ambiguity code in its row of the leaf table
@@ -282,6 +345,7 @@ struct MixSpec {
 };
 
 // schedule.hip
+void init_plain_view(hyphy_hip_partition *p);
 int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *offset_out, int *n_out, bool handoff = false,
                  bool is_root_program = true);
 void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, bool full);
@@ -303,6 +367,13 @@ int collect_status(hyphy_hip_partition *p);
 int publish_and_collect(hyphy_hip_partition *p, const double *d_value, double *value_out);  // (single-shard partitions)
 void record_timings(hyphy_hip_partition *p);
 double combine(const std::vector<double> &parts);
+// repeats.hip
+struct RepArgs;
+int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &codes);
+void switch_mode(hyphy_hip_partition *p, int mode);
+int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, const int64_t *q_nodes, int64_t n_q, bool full,
+                     int cat0, int n_classes, std::vector<int64_t> &view_update);
+int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0);
 // comm.hip
 int combine_shards(hyphy_hip_partition *p, double *logl_out);
 

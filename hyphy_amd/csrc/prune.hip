@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "devutil.h"
 #include "expm4.h"
 
 #ifndef HYPHY_OCC
@@ -29,10 +30,6 @@ namespace hyhip {
 
 namespace {
 
-__device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
-
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
 // counter (vmcnt(0)), i.e. it would stall every node on the operand prefetch issued for the next
 // schedule entry and on the fire-and-forget persist stores; nothing exchanged between the waves of
@@ -41,68 +38,6 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-}
-
-// Decide the power-of-2^64 rescale for a site whose conditional vector sums to `tot`
-// (__ll_loop_handle_scaling tree_evaluator.cpp:410-525, _computeBoostScaler /
-// _computeReductionScaler tree.cpp:160-202).  Returns the exponent change m (true value =
-// stored * 2^(-64 m)) and the multiplier in `sc`.
-__device__ __forceinline__ int rescale_decision(double tot, double &sc) {
-  int m = 0;
-  sc = 1.0;
-  if (tot < kScalerThreshold && tot > 0.0) {
-    do {
-      tot *= kScalerUp;
-      sc *= kScalerUp;
-      m++;
-    } while (tot < kScalerThreshold && m < 15);
-  } else if (tot > kScalerUp && tot < HUGE_VAL) {
-    do {
-      tot *= kScalerThreshold;
-      sc *= kScalerThreshold;
-      m--;
-    } while (tot > kScalerUp && m > -15);
-  }
-  return m;
-}
-
-// 16-byte access at (wave-uniform base) + (32-bit per-lane byte offset): lets the compiler keep the
-// base in SGPRs and a single VGPR offset instead of a 64-bit per-lane pointer per stream.
-__device__ __forceinline__ f64x2 ld16(const double *ubase, unsigned byte_off) {
-  return *reinterpret_cast<const f64x2 *>(reinterpret_cast<const char *>(ubase) + byte_off);
-}
-__device__ __forceinline__ void st16(double *ubase, unsigned byte_off, f64x2 v) {
-  *reinterpret_cast<f64x2 *>(reinterpret_cast<char *>(ubase) + byte_off) = v;
-}
-
-// The same at AGENT scope (sc1: write-through store / L1-bypassing load) for data handed between
-// workgroups inside a launch — valid under any workgroup -> XCD placement (microarch guide, inter-
-// workgroup visibility).  Raw buffer instructions carry the cache-policy bits and are tracked by the
-// compiler's s_waitcnt insertion (inline asm would not be).
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t agent_rsrc(const double *ubase) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(ubase), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ f64x2 ld16_agent(const double *ubase, unsigned byte_off) {
-  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(agent_rsrc(ubase), byte_off, 0, 16);
-  f64x2 r;
-  __builtin_memcpy(&r, &v, 16);
-  return r;
-}
-// The A-operand stream of the wave kernel: buffer loads (plain cache policy) so that the address is (4 SGPRs of resource) +
-// (ONE per-lane VGPR offset, lane * 16) + (a scalar / immediate offset per chunk).  With global_load the compiler materialised a
-// 64-bit per-lane address per row block and advanced it with v_add_co / v_addc per chunk: ~10 VGPRs and ~8 VALU instructions
-// (plus their s_nop hazards) per k-step that the matrix pipe's shadow had to absorb.
-__device__ __forceinline__ f64x2 ld16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, unsigned uniform_off) {
-  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, uniform_off, 0);
-  f64x2 r;
-  __builtin_memcpy(&r, &v, 16);
-  return r;
-}
-__device__ __forceinline__ void st16_agent(double *ubase, unsigned byte_off, f64x2 x) {
-  u32x4_t v;
-  __builtin_memcpy(&v, &x, 16);
-  __builtin_amdgcn_raw_buffer_store_b128(v, agent_rsrc(ubase), byte_off, 0, 16);
 }
 
 // A root-finalising wave's share of the log-likelihood sum (all 64 lanes active, values wave-uniform): entry `idx` of the
@@ -774,19 +709,6 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
                          &slot_cnt[a.root_slot][w][0][0], tile0, w, lane);
 }
 
-// sum over the four 16-lane rows of a wave (every lane ends up with the same value, same order): x[i] + x[i ^ 16], then
-// + x[i ^ 32], on gfx950's row / half swaps (v_permlane16_swap, v_permlane32_swap: pure VALU, no LDS round trip as a
-// ds_bpermute shuffle has; bit-identical to the shuffle form, a + b == b + a)
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double row_sum4(double x) {
-  unsigned lo = __double2loint(x), hi = __double2hiint(x);
-  u32x2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-  lo = __double2loint(x), hi = __double2hiint(x);
-  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Wave-per-tile variant (T = 1): ONE wave owns a 16-pattern tile and all DP parent rows, so there is
 // no cross-wave exchange at all — no barrier, no LDS round trip for the common child -> parent hand
@@ -840,7 +762,10 @@ __device__ __forceinline__ double row_sum4(double x) {
 // PRE: a sibling's deposit is streamed into registers under the wave's own product (32 registers).
 // APF: the first A-operand chunk of the NEXT edge product is requested during the last k-step of the current one (the
 //      schedule names it), so that an edge does not start with an exposed L2 round trip.
-template <int NW, int NP, bool CLDS, bool TRACE = false, bool LB = false, int OCC = HYPHY_OCC3, bool PRE = true, bool APF = false, bool FUSE = false>
+// REP: the tree is the TRUNK of a class-compressed partition (repeats.hip): a leaf of the schedule may be a generalised leaf —
+//      its columns are rows of a class table (gathered by class id instead of state code) and carry a 2^64 exponent.
+template <int NW, int NP, bool CLDS, bool TRACE = false, bool LB = false, int OCC = HYPHY_OCC3, bool PRE = true, bool APF = false, bool FUSE = false,
+          bool REP = false>
 __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restrict__ ops, const int4 *__restrict__ prog,
                                                                              const int4 *__restrict__ jn, PruneArgs a) {
   if (a.chain && (int)blockIdx.x >= a.ntiles) return;  // (tile dimension padded to a multiple of 8: launch_prune_T)
@@ -871,6 +796,10 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
     a.wg_sum += cat * a.cs_wg;
     a.wg_cnt += cat * a.cs_wg;
     a.wg_flag += cat * a.cs_wg;
+    if constexpr (REP) {
+      a.gtab += cat * a.cs_gtab;
+      a.gcnt += cat * a.cs_gcnt;
+    }
   }
   constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
   // LDS of a wave: NP parked nodes (scaled, fragment layout) + the tile's leaf codes; LB builds also keep the node finalised last
@@ -924,6 +853,11 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
   //  into registers of its own, or into the running product where that is still all ones; DESIGN §4.1, profiles/r04_wave_kernel_steps.txt.)
   auto gather_issue = [&](f64x2 (&dst)[2 * NW], int lf, int c) {
     const double *bl = a.PTg + (size_t)lf * DP * DP;  // uniform; [code][w][g][r]
+    if constexpr (REP) {
+      const int2 lt = a.leaf_tab[lf];  // (first row of the leaf's class table or -1, first exponent row / matrix slot)
+      bl = lt.x >= 0 ? a.gtab + (size_t)lt.x * DP : a.PTg + (size_t)lt.y * DP * DP;
+      if (lt.x >= 0) cnt += a.gcnt[lt.y + c];
+    }
 #pragma unroll
     for (int w = 0; w < NW; w++) {
       const unsigned off = (unsigned)((c * NW + w) * 16 + g * 4) * 8u;
@@ -1059,7 +993,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
           abl_after_edge = false;
         } else {  // ambiguity codes in this tile: full product with the resolution vector
           const double *av = a.ambig + (size_t)(c < 0 ? -c - 1 : 0) * DP;
-          edge_product(lf, [&](int k2) -> f64x2 {
+          edge_product(REP ? a.leaf_tab[lf].y : lf, [&](int k2) -> f64x2 {
             f64x2 b;
             b[0] = (c >= 0) ? ((8 * k2 + g == c) ? 1.0 : 0.0) : av[8 * k2 + g];
             b[1] = (c >= 0) ? ((8 * k2 + 4 + g == c) ? 1.0 : 0.0) : av[8 * k2 + 4 + g];
@@ -2192,6 +2126,12 @@ void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
   if (a.variant == 1 && a.T == 1) {  // wave-per-tile kernel: one wave per workgroup
     const dim3 block1(64);
     const size_t lds1 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
+    if (a.leaf_tab) {  // the trunk of a class-compressed partition (production instantiations only)
+      if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<NW, 0, CLDS, false, false, HYPHY_OCC3, true, false, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      else if (a.n_slots == 3) hipLaunchKernelGGL((prune_wave_kernel<NW, 1, CLDS, false, false, HYPHY_OCC3, true, false, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      else hipLaunchKernelGGL((prune_wave_kernel<NW, 2, CLDS, false, false, HYPHY_OCC3, true, false, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      return;
+    }
     if (a.timeline && NW == 4 && CLDS) {  // tracing build (HYPHY_HIP_TIMELINE)
       if (a.n_slots <= 3) hipLaunchKernelGGL((prune_wave_kernel<4, 1, true, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
       else hipLaunchKernelGGL((prune_wave_kernel<4, 2, true, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);

@@ -1,0 +1,829 @@
+// Subtree repeats on the device — the counterpart of the reference's `tcc` traversal masks (src/core/tree.cpp:2801-2858
+// marks, per internal node and site position, a subtree whose leaf states equal the previous site's;
+// src/core/likefunc.cpp:10854 passes the mask on every ComputeBlock; src/core/tree_evaluator.cpp:57-76 skips the node and
+// :240-256 copies the previous site's child vector; OptimalOrder, likefunc.cpp:11463+, orders sites to lengthen the runs).
+//
+// The reference's form is a run-length one (it helps a serial walk over sorted sites).  The device form is per-node
+// pattern-CLASS compression: two patterns are in the same class of internal node n when the leaves below n carry the
+// same states.  Classes are static per partition shard (they depend on the alignment and the topology only):
+//   host, once per partition   class ids bottom-up (class of n at pattern s = id of the tuple of its children's classes),
+//                              U_n = number of classes of n; the COMPRESSED nodes are the maximal subtrees with U_n <=
+//                              theta * patterns, every other internal node is a TRUNK node;
+//   lower phase, per evaluation  class_table_kernel: for every compressed node n and class u
+//                                    E_n[u] = P_n x prod_c E_c[class_c(u)]
+//                              — one [D x D] x [D x 16 classes] MFMA product per tile of 16 classes, children read by
+//                              class index from THEIR tables (a leaf child: the column of P_leaf of its state; a leaf with
+//                              ambiguity codes: a table of its own over its distinct codes), result stored edge-applied in
+//                              the column-gather layout of the leaf matrices ([class][w][g][r]) with its 2^64 exponent;
+//   trunk phase                the pruning kernels (prune.hip) over the trunk, in which a compressed subtree root is a
+//                              GENERALISED LEAF: a 64-vector gather by class id + an exponent.
+// Work per evaluation: sum of U_n over the compressed nodes + (trunk edges) x patterns edge products instead of
+// (internal edges) x patterns: 0.26 of them on the headline alignment at theta = 0.5 (tools/repeat_stats.py).
+//
+// Scheduling inside the lower phase.  A node's tiles need rows of its children's tables from anywhere in them, so the
+// dependency is node -> node.  Work items (node, tile) sit in 32 queues in level order (children before parents; every
+// level padded to a multiple of 32 items, so that all queues cross a level at the same index).  A wave takes tickets with
+// one returning atomic on the head of its XCD's queue (another queue when that one is empty), checks the item's child tables
+// against per-node counters of finished tiles, and — instead of waiting while tickets of LOWER levels are still unsold —
+// takes and runs those first (a small stack of held tickets, lowest level on top).  A wave therefore only sleeps when every
+// item below its ticket's level has a holder, and the holder of the lowest unfinished level never sleeps: no dispatch order,
+// residency or workgroup -> XCD placement is assumed (MI355X_MICROARCH.md, "placement-independent protocols only").
+// Hand-off of table rows between waves of the launch: 16-byte sc1 (write-through) stores -> asm "s_waitcnt vmcnt(0)" ->
+// relaxed agent-scope RMW on the node's counter; consumer: relaxed agent-scope load that proves the count -> sc1 loads (the
+// same contract as the chain joins of prune.hip).
+#include <unordered_map>
+
+#include "devutil.h"
+#include "partition.h"
+
+namespace hyhip {
+
+// Device descriptors (int4 words in Shard::rep_desc).  Descriptor d: header words 2 d, 2 d + 1; its child entries at
+// h1.x .. h1.x + nk - 1.
+//   h0 = (first table row, classes U, transition-matrix slot of the node's branch, nk | kind << 16)
+//   h1 = (first child entry, offset of the code list in rep_map (kind 1), tiles, 0)
+//   child entry = (first row of the child's table or -1: ordinary leaf, matrix slot of an ordinary leaf,
+//                  offset of the index map in rep_map, descriptor of the child's table | its tiles << 16, or -1)
+// kind 0: compressed internal node, kind 1: leaf with ambiguity codes (table over its distinct codes).
+// Work item = (descriptor or -1: padding, tile, rate class, first index of the item's level in every queue).
+constexpr int kRepQueues = 32;                       // (one word saturates at ~88 returning atomics per microsecond: 2 048 waves start at once)
+// Every word the waves of the launch meet at — queue heads, exit counter, per (class, descriptor) finished tiles — sits 4 352 bytes
+// from the next: device-scope atomics execute at the memory side, one channel serves ~88 of them per microsecond, and 64-byte
+// spacing put all 32 heads and every counter on one channel (measured: 17 us per ticket with 2 048 waves, the CU's memory queue
+// backed up behind them and the A-operand stream of the products with it).
+constexpr int kRepHeadStride = 1088;                 // ints between the words
+constexpr int kRepSyncExit = kRepQueues * kRepHeadStride;
+constexpr int kRepSyncDone = kRepSyncExit + kRepHeadStride;  // per (class, descriptor) finished tiles from here, same spacing
+constexpr int kRepStack = 24;                        // held tickets per wave (tree heights beyond that fall back to waiting)
+
+struct RepArgs {
+  const int4 *desc;
+  const int4 *items;          // [8][qcap]
+  int qcap;                   // items per queue (the same in every queue: levels are padded to multiples of kRepQueues)
+  const int *live;            // [n_desc] 1: the table is recomputed by this pass (a child table that is not counts as finished)
+  int n_desc;
+  int *sync;
+  double *tab;                // [classes][rows][DP]
+  int32_t *cnt;               // [classes][rows]
+  const int32_t *map;
+  long long rows;             // table rows per class
+  const double *Pfrag;        // class 0
+  const double *PTg;
+  size_t cs_P;
+  const double *ambig;
+  int n_waves;                // grid size (the last wave to leave resets `sync`)
+  int sync_words;             // words of `sync` in use (kRepHeadStride ints apart)
+  long long *dbg;             // diagnostic (HYPHY_HIP_REP_TIMELINE): per wave [wall start, wall end, items, failed polls, shader cycles in
+                              // tickets, waiting, gathers, product, publish, + first-item wall stamps] (16 words), or nullptr
+};
+
+namespace {
+
+#define REP_TR(b)                          \
+  if constexpr (TRACE) {                   \
+    const long long n_ = clock64();        \
+    tr[b] += n_ - tr_last, tr_last = n_;   \
+  }
+template <int NW, bool TRACE = false>
+__global__ __launch_bounds__(64, 2) void class_table_kernel(RepArgs a) {
+  [[maybe_unused]] long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] long long tr_last = 0;
+  if constexpr (TRACE) {
+    tr[0] = wall_clock64();
+    tr_last = clock64();
+  }
+  constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
+  __shared__ int4 held[kRepStack];
+  // a finished tile on its way out: [16 classes][DP + 2] (rows padded to keep the 16-byte writes of the 16 class lanes on
+  // different banks) + the 16 exponents
+  __shared__ __align__(16) double stage[16 * (DP + 2)];
+  __shared__ __align__(16) int stage_cnt[16];
+  const int lane = threadIdx.x, g = lane >> 4, sl = lane & 15;
+  // this wave's queue: four per XCD (HW_REG_XCC_ID), so that a ticket is an L2 atomic next door
+  const int own = (((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7) << 2) | ((blockIdx.x >> 3) & 3)) & (kRepQueues - 1);
+  auto uni = [](int4 v) -> int4 {  // (items are wave-uniform: keep them in SGPRs wherever they come from)
+    return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z),
+                     __builtin_amdgcn_readfirstlane(v.w));
+  };
+  int sp = 0, polls = 0;
+  unsigned exhausted = 0;
+  const f64x4 ones = (f64x4){1., 1., 1., 1.}, zeros = (f64x4){0., 0., 0., 0.};
+
+  // one ticket from queue q: the item, or x = -2 when the queue is sold out
+  auto ticket = [&](int q) -> int4 {
+    int k = 0;
+    if (lane == 0) k = __hip_atomic_fetch_add(a.sync + q * kRepHeadStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    k = __builtin_amdgcn_readfirstlane(k);
+    if (k >= a.qcap) return make_int4(-2, 0, 0, 0);
+    return uni(a.items[(size_t)q * a.qcap + k]);
+  };
+  auto pull = [&]() -> int4 {
+    for (int t = 0; t < kRepQueues; t++) {
+      const int q = (own + t) & (kRepQueues - 1);
+      if ((exhausted >> q) & 1u) continue;
+      const int4 it = ticket(q);
+      if (it.x != -2) return it;
+      exhausted |= 1u << q;
+    }
+    return make_int4(-2, 0, 0, 0);
+  };
+  // held tickets, lowest level (item.w) on top
+  auto push = [&](const int4 &it) {
+    int pos = sp;
+    while (pos > 0 && held[pos - 1].w < it.w) {
+      held[pos] = held[pos - 1];
+      pos--;
+    }
+    held[pos] = it;
+    sp++;
+  };
+
+  int4 cur = pull();
+  REP_TR(4)
+  while (cur.x != -2) {
+    if (cur.x < 0) {  // padding item of a level
+      cur = sp > 0 ? uni(held[--sp]) : pull();
+      continue;
+    }
+    const int4 h0 = a.desc[2 * cur.x], h1 = a.desc[2 * cur.x + 1];
+    const int nk = h0.w & 0xffff, kind = h0.w >> 16;
+    const int cat = cur.z;
+    int *done = a.sync + kRepSyncDone + (size_t)cat * a.n_desc * kRepHeadStride;
+    // ---- are the child tables complete? ----
+    if (nk > 0) {
+      bool ready;
+      {
+        int ok = 1;
+        for (int j0 = 0; j0 < nk; j0 += 64) {
+          if (j0 + lane < nk) {
+            const int dep = a.desc[h1.x + j0 + lane].w;
+            if (dep >= 0 && a.live[dep & 0xffff])
+              ok &= __hip_atomic_load(done + (size_t)(dep & 0xffff) * kRepHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (dep >> 16);
+          }
+        }
+        ready = __all(ok);
+      }
+      asm volatile("" ::: "memory");
+      if (!ready) {
+        // unsold tickets below this item's level?  take one (never wait for work nobody holds).  The heads are looked at on the
+        // first failed poll and every eighth after it: a sleeping wave costs the memory system one counter line per child and
+        // poll — a thousand waiting waves sweeping 32 head lines each as well took the launch from tens to hundreds of
+        // microseconds.
+        unsigned long long m = 0ull;
+        if ((polls++ & 7) == 0) {
+          int h = 0x7fffffff;
+          if (lane < kRepQueues) h = __hip_atomic_load(a.sync + lane * kRepHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          m = __ballot(lane < kRepQueues && h < cur.w && h < a.qcap);
+        }
+        if (m != 0ull && sp < kRepStack - 1) {
+          polls = 0;
+          const int4 it = ticket(__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(m)));
+          if (it.x != -2) {
+            if (it.x < 0) {
+              // (padding)
+            } else if (it.w < cur.w) {
+              push(cur);
+              cur = it;
+            } else {
+              push(it);  // (another wave was faster: a ticket of this level or above — keep it for later)
+            }
+          }
+        } else {
+          __builtin_amdgcn_s_sleep(16);
+        }
+        if constexpr (TRACE) tr[3]++;
+        REP_TR(5)
+        continue;
+      }
+      polls = 0;
+    }
+    REP_TR(5)
+    // ---- one tile of 16 classes ----
+    const int u0 = cur.y * 16;
+    const long long row = (long long)cat * a.rows + h0.x + u0;
+    const double *Pf = a.Pfrag + (size_t)cat * a.cs_P + (size_t)h0.z * NW * TILE;
+    f64x4 acc[NW];
+    int cnt = 0;
+    int code = 0;  // kind 1: this lane's code
+#pragma unroll
+    for (int w = 0; w < NW; w++) acc[w] = ones;
+    if (kind == 0) {
+      for (int j = 0; j < nk; j++) {
+        const int4 ke = a.desc[h1.x + j];  // uniform
+        const int idx = a.map[ke.z + u0 + sl];
+        const double *src = ke.x >= 0 ? a.tab + ((size_t)cat * a.rows + ke.x) * DP
+                                      : a.PTg + (size_t)cat * a.cs_P + (size_t)ke.y * DP * DP;  // uniform
+        f64x2 v[2 * NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          const unsigned off = (unsigned)((idx * NW + w) * 16 + g * 4) * 8u;
+          v[2 * w] = ld16_agent(src, off), v[2 * w + 1] = ld16_agent(src, off + 16u);
+        }
+        if (ke.x >= 0) cnt += __hip_atomic_load(a.cnt + (size_t)cat * a.rows + ke.x + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int w = 0; w < NW; w++) acc[w] *= (f64x4){v[2 * w][0], v[2 * w][1], v[2 * w + 1][0], v[2 * w + 1][1]};
+      }
+      // the node's conditionals of these classes: per-class 2^64 rescale (tested at every compressed node)
+      double s = 0.;
+#pragma unroll
+      for (int w = 0; w < NW; w++) s += (acc[w][0] + acc[w][1]) + (acc[w][2] + acc[w][3]);
+      const double tot = row_sum4(s);
+      double sc = 1.0;
+      int m = 0;
+      if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) m = rescale_decision(tot, sc);  // rare
+      cnt += m;
+#pragma unroll
+      for (int w = 0; w < NW; w++) acc[w] *= sc;
+    } else {
+      code = a.map[h1.y + u0 + sl];
+    }
+    if constexpr (TRACE) asm volatile("" ::"v"(acc[0][0]), "v"(code));
+    REP_TR(6)
+    // ---- E = P_n x T: the edge towards the parent, A-operand image of P_n streamed from L2 ----
+    f64x4 D[NW];
+    {
+      const double *av = a.ambig + (size_t)(code < 0 ? -code - 1 : 0) * DP;
+      auto bsrc = [&](int k2) -> f64x2 {
+        if (kind == 0) return (f64x2){acc[k2 >> 1][(k2 & 1) * 2], acc[k2 >> 1][(k2 & 1) * 2 + 1]};
+        f64x2 b;
+        b[0] = (code >= 0) ? ((8 * k2 + g == code) ? 1.0 : 0.0) : av[8 * k2 + g];
+        b[1] = (code >= 0) ? ((8 * k2 + 4 + g == code) ? 1.0 : 0.0) : av[8 * k2 + 4 + g];
+        return b;
+      };
+      const __amdgpu_buffer_rsrc_t pfr = agent_rsrc(Pf);
+      const unsigned lane16 = (unsigned)lane * 16u;
+#pragma unroll
+      for (int w = 0; w < NW; w++) D[w] = zeros;
+      f64x2 Ac[NW], An[NW], bc, bn;
+#pragma unroll
+      for (int w = 0; w < NW; w++) Ac[w] = ld16_buf(pfr, lane16, (unsigned)(w * TILE * 8));
+      bc = bsrc(0);
+#pragma unroll
+      for (int k2 = 0; k2 < NKK / 2; k2++) {
+        if (k2 + 1 < NKK / 2) {
+#pragma unroll
+          for (int w = 0; w < NW; w++) An[w] = ld16_buf(pfr, lane16, (unsigned)((w * TILE + (k2 + 1) * 128) * 8));
+          bn = bsrc(k2 + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int w = 0; w < NW; w++) D[w] = mfma(Ac[w][0], bc[0], D[w]);
+#pragma unroll
+        for (int w = 0; w < NW; w++) D[w] = mfma(Ac[w][1], bc[1], D[w]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int w = 0; w < NW; w++) Ac[w] = An[w];
+        bc = bn;
+      }
+    }
+    // ---- publish the rows ([class][w][g][r] = E[16 w + 4 r + g][class]) and their exponents, then the tile ----
+    if constexpr (TRACE) asm volatile("" ::"v"(D[0][0]));
+    REP_TR(7)
+    // Through LDS: a lane holds 4 doubles of each of NW row blocks of ONE class; written from the registers, a store
+    // instruction scatters 64 half-sectors over 16 lines, and write-through (sc1) stores go to the fabric as they are
+    // (measured: 330 us for the launch).  Transposed through the wave's LDS tile, every store instruction writes 1 KiB of
+    // consecutive bytes.
+    {
+      double *out = a.tab + (size_t)row * DP;  // uniform
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        *reinterpret_cast<f64x2 *>(stage + sl * (DP + 2) + w * 16 + g * 4) = (f64x2){D[w][0], D[w][1]};
+        *reinterpret_cast<f64x2 *>(stage + sl * (DP + 2) + w * 16 + g * 4 + 2) = (f64x2){D[w][2], D[w][3]};
+      }
+      if (g == 0) stage_cnt[sl] = cnt;
+      __syncthreads();  // (one wave per workgroup: orders the LDS round trip)
+#pragma unroll
+      for (int i = 0; i < 2 * NW; i++) {
+        const int e = i * 128 + lane * 2, r = e / DP, c = e % DP;
+        st16_agent(out, (unsigned)e * 8u, *reinterpret_cast<const f64x2 *>(stage + r * (DP + 2) + c));
+      }
+      if (lane < 4) {
+        const int4 cv = *reinterpret_cast<const int4 *>(stage_cnt + 4 * lane);
+        u32x4_t v;
+        __builtin_memcpy(&v, &cv, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, agent_rsrc(reinterpret_cast<const double *>(a.cnt + row)), (unsigned)lane * 16u, 0, 16);
+      }
+      __syncthreads();  // (the tile is free for the next item)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(done + (size_t)cur.x * kRepHeadStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    REP_TR(8)
+    if constexpr (TRACE) tr[2]++;
+    cur = sp > 0 ? uni(held[--sp]) : pull();
+    REP_TR(4)
+  }
+  if constexpr (TRACE) {
+    if (a.dbg && lane == 0) {
+      tr[1] = wall_clock64();
+      for (int i = 0; i < 16; i++) a.dbg[(size_t)blockIdx.x * 16 + i] = tr[i];
+    }
+  }
+  // the last wave to leave resets the queue heads and the counters for the next launch (nobody touches them after its exit
+  // ticket; every wave has drained its own stores above)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(a.sync + kRepSyncExit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old + 1 == a.n_waves)
+    for (int i = lane; i < a.sync_words; i += 64) __hip_atomic_store(a.sync + (size_t)i * kRepHeadStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace
+
+void launch_class_tables(const RepArgs &a, int NW, hipStream_t stream) {
+  const dim3 grid(a.n_waves), block(64);
+  if (a.dbg && NW == 4) {
+    hipLaunchKernelGGL((class_table_kernel<4, true>), grid, block, 0, stream, a);
+    return;
+  }
+  switch (NW) {
+    case 1: hipLaunchKernelGGL((class_table_kernel<1>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((class_table_kernel<2>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((class_table_kernel<3>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((class_table_kernel<4>), grid, block, 0, stream, a); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Host side: classes, compressed set, the trunk view, tables and maps (once per partition); item queues per pass.
+// ------------------------------------------------------------------------------------------------------------------
+
+namespace {
+
+// class ids of the pairs (a[s], b[s]) in order of first occurrence
+int pair_classes(const std::vector<int> &a, const std::vector<int> &b, std::vector<int> &out) {
+  std::unordered_map<uint64_t, int> seen;
+  seen.reserve(a.size() / 2 + 16);
+  out.resize(a.size());
+  int n = 0;
+  for (size_t s = 0; s < a.size(); s++) {
+    const uint64_t key = ((uint64_t)(uint32_t)a[s] << 32) | (uint32_t)b[s];
+    auto it = seen.find(key);
+    if (it == seen.end()) it = seen.emplace(key, n++).first;
+    out[s] = it->second;
+  }
+  return n;
+}
+
+// ... of a single column
+int column_classes(const std::vector<int> &a, std::vector<int> &out) {
+  std::unordered_map<int, int> seen;
+  out.resize(a.size());
+  int n = 0;
+  for (size_t s = 0; s < a.size(); s++) {
+    auto it = seen.find(a[s]);
+    if (it == seen.end()) it = seen.emplace(a[s], n++).first;
+    out[s] = it->second;
+  }
+  return n;
+}
+
+}  // namespace
+
+// Decide the compressed set, build views[1] and every shard's tables.  `codes[k]`: shard k's leaf table [L][S_pad] in device
+// pattern order (padding patterns included: they are patterns like any other).  Leaves p->rep_on false when compression
+// would not pay (or cannot be used) — nothing else changes then.
+int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &codes) {
+  p->rep_on = false;
+  const char *env = getenv("HYPHY_HIP_REPEATS");
+  if (env && atoi(env) == 0) return 0;
+  if (p->nuc || p->shards.empty()) return 0;
+  for (const Shard &s : p->shards)
+    if (s.T != 1) return 0;
+  if (p->variant != 1 && !(env && atoi(env) == 2)) return 0;  // (tiny shards: the workgroup-per-tile kernel keeps the whole tree)
+  const int L = (int)p->L, I = (int)p->I, DP = p->DP;
+  if (I < 2) return 0;
+  double theta = 0.5;
+  if (const char *e = getenv("HYPHY_HIP_REP_THETA")) theta = atof(e);
+  const size_t nsh = p->shards.size();
+  // ---- classes per shard ----
+  std::vector<std::vector<std::vector<int>>> cls(nsh);  // [shard][internal node][pattern]
+  std::vector<std::vector<int>> U(nsh, std::vector<int>(I, 0));
+  for (size_t k = 0; k < nsh; k++) {
+    const Shard &s = p->shards[k];
+    const size_t SP = (size_t)s.S_pad;
+    cls[k].resize(I);
+    std::vector<int> col(SP), tmp;
+    for (int n = 0; n < I; n++) {
+      std::vector<int> run;
+      bool first = true;
+      for (int c : p->children[n]) {
+        const std::vector<int> *cc;
+        if (c < L) {
+          for (size_t j = 0; j < SP; j++) col[j] = (int)codes[k][(size_t)c * SP + j];
+          cc = &col;
+        } else {
+          cc = &cls[k][c - L];
+        }
+        if (first) {
+          run = *cc;
+          first = false;
+        } else {
+          pair_classes(run, *cc, tmp);
+          run.swap(tmp);
+        }
+      }
+      U[k][n] = column_classes(run, cls[k][n]);
+    }
+  }
+  // ---- compressed set: the same on every shard (one schedule serves them all) ----
+  std::vector<char> comp(I, 0);
+  for (int n = 0; n < I - 1; n++) {
+    bool ok = true;
+    for (size_t k = 0; k < nsh; k++)
+      if ((double)U[k][n] > theta * p->shards[k].S_pad || U[k][n] > 32000) ok = false;
+    for (int c : p->children[n])
+      if (c >= L && !comp[c - L]) ok = false;
+    comp[n] = ok ? 1 : 0;
+  }
+  {  // worth it?  compare the edge products of the two forms on the first shard
+    double full = 0., rep = 0.;
+    for (int n = 0; n < I - 1; n++) {
+      full += p->shards[0].S_pad;
+      rep += comp[n] ? (U[0][n] + 15) / 16 * 16 : p->shards[0].S_pad;
+    }
+    const double need = getenv("HYPHY_HIP_REP_MIN_GAIN") ? atof(getenv("HYPHY_HIP_REP_MIN_GAIN")) : 0.15;
+    if (!(env && atoi(env) == 2) && (rep > (1.0 - need) * full || p->shards[0].ntiles < 8)) return 0;
+  }
+  // ---- descriptors: leaves with ambiguity codes first (level 0), compressed nodes children before parents ----
+  p->rep_nodes.clear();
+  p->rep_desc_of.assign((size_t)L + I, -1);
+  for (int l = 0; l < L; l++)
+    if (p->leaf_has_ambig[l]) {
+      hyphy_hip_partition::RepNode rn;
+      rn.node = l;
+      rn.level = 0;
+      p->rep_desc_of[l] = (int)p->rep_nodes.size();
+      p->rep_nodes.push_back(rn);
+    }
+  for (int n = 0; n < I; n++)
+    if (comp[n]) {
+      hyphy_hip_partition::RepNode rn;
+      rn.node = L + n;
+      rn.level = 0;
+      for (int c : p->children[n]) {
+        rn.kids.push_back(c);
+        const int d = p->rep_desc_of[c];
+        rn.kid_desc.push_back(d);
+        if (d >= 0) rn.level = std::max(rn.level, p->rep_nodes[d].level + 1);
+      }
+      p->rep_desc_of[L + n] = (int)p->rep_nodes.size();
+      p->rep_nodes.push_back(rn);
+    }
+  const int ND = (int)p->rep_nodes.size();
+  if (ND == 0 || ND > 65535) return 0;
+  // ---- the trunk view ----
+  hyphy_hip_partition::View &v = p->views[1];
+  v = hyphy_hip_partition::View();
+  std::vector<int> vint(I, -1);  // view-internal index of a trunk node
+  for (int n = 0; n < I; n++)
+    if (!comp[n]) vint[n] = v.I++;
+  std::vector<int> leaf_nodes;  // node code (partition's tree) of every view leaf
+  std::vector<int> vleaf((size_t)L + I, -1);
+  for (int n = 0; n < I; n++)
+    if (!comp[n])
+      for (int c : p->children[n])
+        if (c < L || comp[c - L]) {
+          vleaf[c] = (int)leaf_nodes.size();
+          leaf_nodes.push_back(c);
+        }
+  v.L = (int)leaf_nodes.size();
+  if (v.L > 65535 || v.L < 1) return 0;
+  v.parents.assign((size_t)v.L + v.I, -1);
+  v.children.assign(v.I, std::vector<int>());
+  v.slot.assign((size_t)v.L + v.I, 0);
+  v.leaf_has_ambig.assign(v.L, 0);  // (ambiguity codes live in class tables: no leaf of the view takes the resolution-vector path)
+  for (int n = 0; n < I; n++) {
+    if (comp[n]) continue;
+    v.slot[v.L + vint[n]] = L + n;
+    const int64_t par = p->parents[L + n];
+    v.parents[v.L + vint[n]] = par < 0 ? -1 : vint[par];
+    for (int c : p->children[n]) {
+      if (c < L || comp[c - L]) {
+        v.children[vint[n]].push_back(vleaf[c]);
+        v.parents[vleaf[c]] = vint[n];
+        v.slot[vleaf[c]] = c;
+      } else {
+        v.children[vint[n]].push_back(v.L + vint[c - L]);
+      }
+    }
+    std::sort(v.children[vint[n]].begin(), v.children[vint[n]].end());
+  }
+  // ---- per shard: table rows, index maps, descriptors, the trunk's leaf table ----
+  for (size_t k = 0; k < nsh; k++) {
+    Shard &s = p->shards[k];
+    if (hipSetDevice(s.device) != hipSuccess) return fail("hipSetDevice failed");
+    const size_t SP = (size_t)s.S_pad;
+    s.rep_tabs.assign(ND, RepTable());
+    std::vector<std::vector<int>> leaf_cls(L);  // classes of the leaves that own a table
+    std::vector<int32_t> maps;
+    int64_t rows = 0;
+    std::vector<std::vector<int>> first_pat(ND);  // representative pattern of every class
+    for (int d = 0; d < ND; d++) {
+      const hyphy_hip_partition::RepNode &rn = p->rep_nodes[d];
+      RepTable &t = s.rep_tabs[d];
+      const std::vector<int> *cl;
+      std::vector<int> col(SP);
+      if (rn.node < L) {
+        for (size_t j = 0; j < SP; j++) col[j] = (int)codes[k][(size_t)rn.node * SP + j];
+        t.U = column_classes(col, leaf_cls[rn.node]);
+        cl = &leaf_cls[rn.node];
+      } else {
+        t.U = U[k][rn.node - L];
+        cl = &cls[k][rn.node - L];
+      }
+      t.rows = (t.U + 15) / 16 * 16;
+      t.row0 = rows;
+      rows += t.rows;
+      first_pat[d].assign(t.rows, -1);
+      for (size_t j = 0; j < SP; j++)
+        if (first_pat[d][(*cl)[j]] < 0) first_pat[d][(*cl)[j]] = (int)j;
+      for (int u = t.U; u < t.rows; u++) first_pat[d][u] = first_pat[d][0];  // padding rows repeat class 0
+      if (rn.node < L) {  // the code of every class
+        t.map0.push_back((int64_t)maps.size());
+        for (int u = 0; u < t.rows; u++) maps.push_back((int32_t)codes[k][(size_t)rn.node * SP + first_pat[d][u]]);
+      } else {
+        for (size_t j = 0; j < rn.kids.size(); j++) {
+          t.map0.push_back((int64_t)maps.size());
+          const int c = rn.kids[j], cd = rn.kid_desc[j];
+          for (int u = 0; u < t.rows; u++) {
+            const int pat = first_pat[d][u];
+            int32_t idx;
+            if (cd < 0) idx = (int32_t)codes[k][(size_t)c * SP + pat];        // ordinary leaf: its state
+            else if (c < L) idx = (int32_t)leaf_cls[c][pat];                  // leaf with a table: class of its code
+            else idx = (int32_t)cls[k][c - L][pat];                           // compressed child: its class
+            maps.push_back(idx);
+          }
+        }
+      }
+    }
+    s.rep_rows = rows;
+    if (maps.size() > 0x7fffffffull || rows > 0x7fffffffll) return 0;
+    std::vector<int4> desc((size_t)2 * ND);
+    for (int d = 0; d < ND; d++) {
+      const hyphy_hip_partition::RepNode &rn = p->rep_nodes[d];
+      const RepTable &t = s.rep_tabs[d];
+      const int kind = rn.node < L ? 1 : 0;
+      desc[2 * d] = make_int4((int)t.row0, t.U, rn.node, (int)rn.kids.size() | (kind << 16));
+      desc[2 * d + 1] = make_int4((int)desc.size(), kind ? (int)t.map0[0] : 0, t.rows / 16, rn.level);
+      for (size_t j = 0; j < rn.kids.size(); j++) {
+        const int cd = rn.kid_desc[j];
+        desc.push_back(make_int4(cd >= 0 ? (int)s.rep_tabs[cd].row0 : -1, rn.kids[j], (int)t.map0[j],
+                                 cd >= 0 ? (cd | ((s.rep_tabs[cd].rows / 16) << 16)) : -1));
+      }
+    }
+    // the trunk's leaf table, tile-major, and where each view leaf gathers from
+    std::vector<int16_t> ct((size_t)v.L * SP, 0);
+    std::vector<int2> lt(v.L);
+    for (int vl = 0; vl < v.L; vl++) {
+      const int c = leaf_nodes[vl], d = p->rep_desc_of[c];
+      lt[vl] = d >= 0 ? make_int2((int)s.rep_tabs[d].row0, (int)s.rep_tabs[d].row0) : make_int2(-1, c);
+      for (size_t j = 0; j < SP; j++) {
+        int val;
+        if (d < 0) val = (int)codes[k][(size_t)c * SP + j];
+        else if (c < L) val = leaf_cls[c][j];
+        else val = cls[k][c - L][j];
+        ct[((j >> 4) * (size_t)v.L + vl) * 16 + (j & 15)] = (int16_t)val;
+      }
+    }
+    const size_t sync_words = ((size_t)kRepQueues + 1 + (size_t)p->C * ND) * kRepHeadStride;
+#define R_(ptr, bytes)                                                                  \
+  if (pool_malloc((void **)&(ptr), (bytes)) != hipSuccess) return fail("hipMalloc failed (" #ptr ")");
+    R_(s.rep_tab, (size_t)p->C * rows * DP * sizeof(double));
+    R_(s.rep_cnt, (size_t)p->C * rows * sizeof(int32_t));
+    R_(s.rep_map, std::max<size_t>(1, maps.size()) * sizeof(int32_t));
+    R_(s.rep_desc, desc.size() * sizeof(int4));
+    R_(s.rep_sync, sync_words * sizeof(int));
+    R_(s.rep_codes_tile, ct.size() * sizeof(int16_t));
+    R_(s.rep_leaf, lt.size() * sizeof(int2));
+#undef R_
+    if (getenv("HYPHY_HIP_POISON")) {
+      hipMemset(s.rep_tab, 0xff, (size_t)p->C * rows * DP * sizeof(double));
+      hipMemset(s.rep_cnt, 0xff, (size_t)p->C * rows * sizeof(int32_t));
+    }
+    hipMemset(s.rep_sync, 0, sync_words * sizeof(int));
+    hipMemcpy(s.rep_map, maps.data(), maps.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    hipMemcpy(s.rep_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice);
+    hipMemcpy(s.rep_codes_tile, ct.data(), ct.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+    hipMemcpy(s.rep_leaf, lt.data(), lt.size() * sizeof(int2), hipMemcpyHostToDevice);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail("repeats: device initialisation failed");
+  }
+  p->rep_resident.assign(p->C, 0);
+  p->rep_cached_valid = false;
+  // what the trunk's schedules start from (the tuner refines them): the wave-per-tile kernel, no re-rooting
+  hyphy_hip_partition::ModeState &ms = p->saved_mode[1];
+  ms.variant = 1;
+  ms.wave_variant = 0;
+  ms.n_slots = p->n_slots_wave;
+  ms.chain_m_forced = 0;
+  ms.rr_use = false;
+  ms.kernel_forced = true;
+  ms.tuned_for = 0;
+  p->rep_on = true;
+  if (getenv("HYPHY_HIP_VERBOSE")) {
+    long long lower = 0;
+    for (const RepTable &t : p->shards[0].rep_tabs) lower += t.rows;
+    fprintf(stderr, "[hyphy_hip] subtree repeats: theta %.2f, %d class tables (%lld rows on shard 0), trunk of %d internal nodes over %d leaves; "
+                    "edge products per pass %lld + %lld (every pattern at every node: %lld)\n",
+            theta, ND, lower, v.I, v.L, lower, (long long)(v.I - 1) * p->shards[0].S_pad, (long long)(I - 1) * p->shards[0].S_pad);
+  }
+  return 0;
+}
+
+// The view in use: saves what the tuner decided for the view that is left and restores the other's.
+void switch_mode(hyphy_hip_partition *p, int mode) {
+  if (p->mode == mode) return;
+  hyphy_hip_partition::ModeState &out = p->saved_mode[p->mode];
+  out.variant = p->variant;
+  out.wave_variant = p->wave_variant;
+  out.n_slots = p->n_slots;
+  out.chain_m_forced = p->chain_m_forced;
+  out.rr_use = p->rr_use;
+  out.kernel_forced = p->kernel_forced;
+  out.tuned_for = p->tuned_for;
+  out.tune_report = p->tune_report;
+  out.rr_path = p->rr_path;
+  out.rr_cands = p->rr_cands;
+  const hyphy_hip_partition::ModeState &in = p->saved_mode[mode];
+  p->variant = in.variant;
+  p->wave_variant = in.wave_variant;
+  p->n_slots = in.n_slots;
+  p->chain_m_forced = in.chain_m_forced;
+  p->rr_use = in.rr_use;
+  p->kernel_forced = in.kernel_forced;
+  p->tuned_for = in.tuned_for;
+  p->tune_report = in.tune_report;
+  p->rr_path = in.rr_path;
+  p->rr_cands = in.rr_cands;
+  p->mode = mode;
+  p->cached_valid = 0;
+  p->rr_active = false;
+  std::fill(p->last_full.begin(), p->last_full.end(), 0);  // (the first full pass under a view stores every node it keeps)
+}
+
+// Translate the caller's update list (node codes of the partition's tree) for a pass under views[1]: the descriptors whose
+// tables must be recomputed (children before parents) and the update list of the trunk (view node codes).  A table E_n =
+// P_n x (conditionals below n) is stale when n's conditionals are (n is the parent of a listed node, or an ancestor of one)
+// or when its own branch's matrix changed (n among q_nodes).
+void rep_translate_update(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, const int64_t *q_nodes, int64_t n_q,
+                          bool full, std::vector<int> &dirty_desc, std::vector<int64_t> &view_update) {
+  const int L = (int)p->L, I = (int)p->I;
+  const int ND = (int)p->rep_nodes.size();
+  dirty_desc.clear();
+  view_update.clear();
+  if (full) {
+    for (int d = 0; d < ND; d++) dirty_desc.push_back(d);
+    return;
+  }
+  std::vector<char> touched(I, 0), qd((size_t)L + I, 0);
+  for (int64_t k = 0; k < n_update; k++) {
+    const int64_t n = update_nodes[k];
+    if (n < 0 || n >= L + I) continue;
+    int64_t par = p->parents[n];
+    while (par >= 0 && !touched[par]) {
+      touched[par] = 1;
+      par = p->parents[L + par];
+    }
+  }
+  for (int64_t k = 0; k < n_q; k++)
+    if (q_nodes[k] >= 0 && q_nodes[k] < L + I) qd[q_nodes[k]] = 1;
+  if (p->rep_stale_branch >= 0 && p->rep_stale_branch < L + I) qd[p->rep_stale_branch] = 1;
+  const hyphy_hip_partition::View &v = p->views[1];
+  for (int d = 0; d < ND; d++) {
+    const int n = p->rep_nodes[d].node;
+    if (qd[n] || (n >= L && touched[n - L])) dirty_desc.push_back(d);
+  }
+  // the trunk: list the view nodes whose parents must be recomputed — a trunk node that is touched lists itself through any of
+  // its view children; simplest exact form: every view node whose parent (a trunk node) is touched in the partition's tree
+  for (int n = 0; n < v.L + v.I; n++) {
+    const int64_t par = v.parents[n];
+    if (par < 0) continue;
+    const int pn = v.slot[v.L + par] - L;  // the parent's internal index in the partition's tree
+    if (touched[pn]) view_update.push_back(n);
+  }
+}
+
+// Item queues of a pass over the descriptors `dirty` (children before parents) for `n_classes` rate classes starting at `cat0`:
+// eight queues in level order, every level padded to a multiple of eight items.  Returns items per queue.
+int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vector<int> &dirty, int cat0, int n_classes,
+                    std::vector<int4> &queues /* [kRepQueues][qcap] */) {
+  int max_level = 0;
+  for (int d : dirty) max_level = std::max(max_level, p->rep_nodes[d].level);
+  // (a partial pass keeps the levels of the full one; child tables outside `dirty` count as finished: RepArgs::live)
+  std::vector<std::vector<int4>> by_level(max_level + 1);
+  for (int c = 0; c < n_classes; c++)
+    for (int d : dirty) {
+      const int lev = p->rep_nodes[d].level;
+      for (int t = 0; t < s.rep_tabs[d].rows / 16; t++) by_level[lev].push_back(make_int4(d, t, cat0 + c, 0));
+    }
+  std::vector<int4> all;
+  for (int lev = 0; lev <= max_level; lev++) {
+    const int bound = (int)all.size() / kRepQueues;  // first index of this level in every queue
+    for (int4 it : by_level[lev]) {
+      it.w = bound;
+      all.push_back(it);
+    }
+    while (all.size() % kRepQueues) all.push_back(make_int4(-1, 0, 0, bound));
+  }
+  const int per_q = (int)all.size() / kRepQueues;
+  queues.assign((size_t)kRepQueues * std::max(1, per_q), make_int4(-1, 0, 0, 0));
+  for (size_t i = 0; i < all.size(); i++) queues[(i % kRepQueues) * (size_t)std::max(1, per_q) + i / kRepQueues] = all[i];
+  return per_q;
+}
+
+// Everything a pass under views[1] needs on the device besides the trunk's schedule: the item queues of the tables that are
+// stale (uploaded when they differ from the ones the device holds) — and the trunk's update list for the schedule compiler.
+int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, const int64_t *q_nodes, int64_t n_q, bool full,
+                     int cat0, int n_classes, std::vector<int64_t> &view_update) {
+  std::vector<int> dirty;
+  rep_translate_update(p, update_nodes, n_update, q_nodes, n_q, full, dirty, view_update);
+  p->rep_stale_branch = -1;
+  const bool same = p->rep_cached_valid && p->rep_cached_dirty == dirty && p->rep_cached_classes == n_classes * 65536 + cat0;
+  if (same) return 0;
+  const int ND = (int)p->rep_nodes.size();
+  for (Shard &s : p->shards) {
+    HIPCHK(hipSetDevice(s.device));
+    std::vector<int4> queues;
+    const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues);
+    const size_t words = (size_t)kRepQueues * std::max(1, per_q) + (size_t)(ND + 3) / 4;  // queues, then the live flags
+    if (words > s.rep_items_cap) {
+      HIPCHK(hipStreamSynchronize(s.stream));
+      if (s.rep_items) pool_free_sync(s.rep_items);
+      if (s.h_rep_items) pool_host_free(s.h_rep_items);
+      s.rep_items = nullptr;
+      s.h_rep_items = nullptr;
+      // (sized for a full pass of every class: partial passes never need more)
+      size_t cap = words;
+      {
+        size_t all = 0;
+        for (const RepTable &t : s.rep_tabs) all += (size_t)t.rows / 16;
+        cap = std::max(cap, (all * (size_t)p->C + (size_t)kRepQueues * (ND + 2)) + (size_t)(ND + 3) / 4 + kRepQueues);
+      }
+      HIPCHK(pool_malloc((void **)&s.rep_items, cap * sizeof(int4)));
+      HIPCHK(pool_host_malloc((void **)&s.h_rep_items, cap * sizeof(int4)));
+      s.rep_items_cap = cap;
+    }
+    HIPCHK(hipStreamSynchronize(s.stream));  // (staging buffer reuse)
+    if (per_q > 0) memcpy(s.h_rep_items, queues.data(), (size_t)kRepQueues * per_q * sizeof(int4));
+    int *live = reinterpret_cast<int *>(s.h_rep_items + (size_t)kRepQueues * std::max(1, per_q));
+    for (int d = 0; d < ND; d++) live[d] = 0;
+    for (int d : dirty) live[d] = getenv("HYPHY_HIP_REP_NODEPS") ? 0 : 1;  // (diagnostic: nobody waits, results invalid)
+    HIPCHK(hipMemcpyAsync(s.rep_items, s.h_rep_items, words * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+    s.rep_qcap = per_q;
+    s.rep_waves = std::min(per_q * kRepQueues, s.cus * 8);
+    if (const char *e = getenv("HYPHY_HIP_REP_WAVES")) s.rep_waves = std::max(1, std::min(per_q * kRepQueues, atoi(e)));
+  }
+  p->rep_cached_dirty = dirty;
+  p->rep_cached_classes = n_classes * 65536 + cat0;
+  p->rep_cached_valid = true;
+  return 0;
+}
+
+// The lower phase of a pass: one launch over the item queues prepared by rep_prepare_pass (behind the exponentials, ahead of
+// the trunk's pruning launch, on the shard's stream).
+int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
+  if (s.rep_qcap <= 0) return 0;
+  (void)cat0;  // (the items name their rate class)
+  RepArgs a;
+  a.desc = s.rep_desc;
+  a.items = s.rep_items;
+  a.qcap = s.rep_qcap;
+  a.live = reinterpret_cast<const int *>(s.rep_items + (size_t)kRepQueues * s.rep_qcap);
+  a.n_desc = (int)p->rep_nodes.size();
+  a.sync = s.rep_sync;
+  a.tab = s.rep_tab;
+  a.cnt = s.rep_cnt;
+  a.map = s.rep_map;
+  a.rows = s.rep_rows;
+  a.Pfrag = s.Pfrag;
+  a.PTg = s.PTg;
+  a.cs_P = (size_t)p->B * p->DP * p->DP;
+  a.ambig = s.ambig;
+  a.n_waves = s.rep_waves;
+  a.sync_words = kRepQueues + 1 + (int)p->C * a.n_desc;
+  a.dbg = nullptr;
+  const char *tl = getenv("HYPHY_HIP_REP_TIMELINE");
+  if (tl && p->NW == 4) {  // diagnostic: synchronous, one file per launch (the last launch survives)
+    const size_t n = (size_t)a.n_waves * 16;
+    HIPCHK(pool_malloc((void **)&a.dbg, n * sizeof(long long)));
+    HIPCHK(hipMemsetAsync(a.dbg, 0, n * sizeof(long long), s.stream));
+    launch_class_tables(a, p->NW, s.stream);
+    std::vector<long long> h(n);
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipMemcpy(h.data(), a.dbg, n * sizeof(long long), hipMemcpyDeviceToHost));
+    pool_free_sync(a.dbg);
+    if (FILE *f = fopen(tl, "w")) {
+      fprintf(f, "# wave wall_start wall_end(100MHz) items failed_polls cycles: tickets waiting gathers product publish\n");
+      for (int w = 0; w < a.n_waves; w++) {
+        const long long *r = &h[(size_t)w * 16];
+        fprintf(f, "%d %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", w, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+      }
+      fclose(f);
+    }
+    return 0;
+  }
+  launch_class_tables(a, p->NW, s.stream);
+  return 0;
+}
+
+}  // namespace hyhip

@@ -6,6 +6,17 @@
 
 namespace hyhip {
 
+// views[0] = the partition's own tree (matrix slot of a node = its node code)
+void init_plain_view(hyphy_hip_partition *p) {
+  hyphy_hip_partition::View &v = p->views[0];
+  v.L = (int)p->L;
+  v.I = (int)p->I;
+  v.parents = p->parents;
+  v.children = p->children;
+  v.leaf_has_ambig = p->leaf_has_ambig;
+  v.slot.resize((size_t)(p->L + p->I));
+  for (size_t n = 0; n < v.slot.size(); n++) v.slot[n] = (int)n;
+}
 
 // Build the post-order schedule for the nodes the host marked dirty.  update_nodes comes from
 // DetermineNodesForUpdate (tree.cpp:3117-3331): dirty nodes, their ancestors and the direct
@@ -19,7 +30,8 @@ namespace hyhip {
 // fetches entries two ahead).  Returns the LDS slot its last node was finalised into.
 int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *offset_out, int *n_out, bool handoff,
                  bool is_root_program) {
-  const int L = (int)p->L, I = (int)p->I;
+  const hyphy_hip_partition::View &v = p->vw();
+  const int L = v.L, I = v.I;
   const int T = p->shards.empty() ? 1 : p->shards[0].T;
   const int G = p->nuc ? (p->nuc_leaf_pairs ? 2 : 1) : (T <= 2 ? 2 : 1);  // leaves per leaf-group entry (prune.hip)
   // A finished node whose parent is the next node of the program is read by that parent straight from
@@ -39,16 +51,16 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
     const int par = nodes[ti];
     std::vector<int> ch_filtered;
     if (par == p->emit_skip_par) {  // (re-rooted schedules: the given root no longer has the first node of rr_path below it)
-      for (int c : p->children[par])
+      for (int c : v.children[par])
         if (c != p->emit_skip_child) ch_filtered.push_back(c);
     }
-    const std::vector<int> &ch = par == p->emit_skip_par ? ch_filtered : p->children[par];
+    const std::vector<int> &ch = par == p->emit_skip_par ? ch_filtered : v.children[par];
     std::vector<int4> entries;
     std::vector<int> release_after;
     auto internal_entry = [&](int c) {
       int4 op;
       op.y = par;
-      op.z = c;
+      op.z = v.slot[c];
       op.w = c - L;
       // (4-state kernel: only parking slots are LDS; the node finalised last is still in registers)
       const int sl = p->nuc ? (slot_of[c - L] >= 2 ? slot_of[c - L] : -1) : slot_of[c - L];
@@ -81,8 +93,8 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
     // (its tiles may need a full matrix product instead of the column gather)
     for (size_t k = 0; k < leaves.size();) {
       int nl = 1;
-      const bool amb0 = p->leaf_has_ambig[leaves[k]];
-      if (!amb0 && G > 1 && k + 1 < leaves.size() && !p->leaf_has_ambig[leaves[k + 1]]) nl = 2;
+      const bool amb0 = v.leaf_has_ambig[leaves[k]];
+      if (!amb0 && G > 1 && k + 1 < leaves.size() && !v.leaf_has_ambig[leaves[k + 1]]) nl = 2;
       const unsigned l0 = (unsigned)leaves[k], l1 = nl > 1 ? (unsigned)leaves[k + 1] : l0;
       int4 op;
       op.x = OPK_LEAF | (amb0 ? OPF_AMBIG : 0) | (nl << 8) | (0xff << 24);
@@ -96,7 +108,7 @@ int emit_program(hyphy_hip_partition *p, const std::vector<int> &nodes, int *off
       if (c >= L && c != first_internal) internal_entry(c);
     // destination slot of the finished node
     int dst = fin & 1;
-    const bool next_consumes = ti + 1 < nodes.size() && p->parents[L + par] == nodes[ti + 1];
+    const bool next_consumes = ti + 1 < nodes.size() && v.parents[L + par] == nodes[ti + 1];
     {
       if (!next_consumes && ti + 1 < nodes.size()) {
         dst = -1;
@@ -154,7 +166,8 @@ namespace {
 // 16-pattern tile walking the whole tree, 10k codons give only 624 workgroups for 768 resident
 // slots (and 78 per GPU when sharded 8 ways): cutting the tree multiplies the workgroup count.
 void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, bool full) {
-  const int L = (int)p->L, I = (int)p->I;
+  const hyphy_hip_partition::View &v = p->vw();  // (update_nodes: node codes of the view)
+  const int L = v.L, I = v.I;
   std::vector<char> touched(I, 0);
   if (full) {
     std::fill(touched.begin(), touched.end(), 1);
@@ -162,10 +175,10 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
     for (int64_t k = 0; k < n_update; k++) {
       int64_t n = update_nodes[k];
       if (n < 0 || n >= L + I) continue;
-      int64_t par = p->parents[n];
+      int64_t par = v.parents[n];
       while (par >= 0 && !touched[par]) {
         touched[par] = 1;
-        par = p->parents[L + par];
+        par = v.parents[L + par];
       }
     }
   }
@@ -209,7 +222,7 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
     const bool rr = !p->rr_path.empty() && (rr_env == 1 || (rr_env != 0 && p->rr_use)) && lazy_full && p->pin_node < 0 &&
                     p->batch_classes <= 1 && p->C == 1;
     std::vector<int> rpar(I, -1), on_path(I, -1), order;
-    for (int n = 0; n < I - 1; n++) rpar[n] = (int)p->parents[L + n];
+    for (int n = 0; n < I - 1; n++) rpar[n] = (int)v.parents[L + n];
     int root_idx = I - 1;
     if (rr) {
       const std::vector<int> &a = p->rr_path;
@@ -264,7 +277,7 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
     // behind the branch cache's, at B + I + 2 + k — below 2^15, at most 255 internal children per node.  A tree beyond that
     // (upwards of ~10 000 taxa, or a star of > 255 subtrees) is walked by the cuts that need no join table.
     {
-      bool ok = I <= 65535 && (long)p->B + I + 2 + kMaxTwin < 32768;
+      bool ok = I <= 65535 && (long)p->B + p->I + 2 + kMaxTwin < 32768;
       for (int n = 0; n < I && ok; n++)
         if (ich[n].size() > 255) ok = false;
       if (!ok) m = I;
@@ -318,22 +331,22 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
         if (ich[n].size() == 2) sum = ich[n][0] + ich[n][1];  // (read by a wave that finds its ONE sibling already arrived)
         // x: parent | image slot of the edge above n << 16: the node's own branch L + n, or — reversed edges of a re-rooted
         // schedule — the transposed twin of the branch of the NEXT node on the path (expm.hip; slot behind the branch cache's)
-        const int slot = (rr && on_path[n] >= 0) ? (int)(p->B + (I + 2) + on_path[n]) : L + n;
+        const int slot = (rr && on_path[n] >= 0) ? (int)(p->B + (p->I + 2) + on_path[n]) : v.slot[L + n];
         int4 j = make_int4(rpar[n] < 0 ? -1 : (rpar[n] | (slot << 16)), (int)ich[n].size() | (sum << 8), 0, 0);
         if (!in_source[n]) {  // trunk node: its leaf groups, one OPK_DEP entry per internal child, finalisation flags
           j.z = (int)p->ops_host.size();
           std::vector<int> leaves;
-          for (int c : p->children[n])
+          for (int c : v.children[n])
             if (c < L) leaves.push_back(c);
           for (size_t k = 0; k < leaves.size();) {
             int nl = 1;
-            const bool amb0 = p->leaf_has_ambig[leaves[k]];
-            if (!amb0 && k + 1 < leaves.size() && !p->leaf_has_ambig[leaves[k + 1]]) nl = 2;
+            const bool amb0 = v.leaf_has_ambig[leaves[k]];
+            if (!amb0 && k + 1 < leaves.size() && !v.leaf_has_ambig[leaves[k + 1]]) nl = 2;
             const unsigned l0 = (unsigned)leaves[k], l1 = nl > 1 ? (unsigned)leaves[k + 1] : l0;
             p->ops_host.push_back(make_int4(OPK_LEAF | (amb0 ? OPF_AMBIG : 0) | (nl << 8) | (0xff << 24), n, (int)(l0 | (l1 << 16)), 0));
             k += nl;
           }
-          for (int c : ich[n]) p->ops_host.push_back(make_int4(OPK_DEP | (0xff << 24), n, L + c, c));
+          for (int c : ich[n]) p->ops_host.push_back(make_int4(OPK_DEP | (0xff << 24), n, v.slot[L + c], c));
           p->ops_host.back().x |= OPF_LAST | (lazy ? OPF_NOPERSIST : 0);
           j.w = (int)p->ops_host.size() - j.z;
         }
@@ -371,7 +384,7 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
     for (int n = 0; n < I; n++) {  // post-order: children before parents
       if (done[n]) { size[n] = 0; continue; }
       int sz = 1;
-      for (int c : p->children[n])
+      for (int c : v.children[n])
         if (c >= L) sz += size[c - L];
       size[n] = sz;
     }
@@ -388,7 +401,7 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
       std::vector<int> frag_root(I, -1);
       for (int n = I - 1; n >= 0; n--) {  // parents before children
         if (done[n]) continue;
-        const int par = (int)p->parents[L + n];
+        const int par = (int)v.parents[L + n];
         if (par >= 0 && !done[par] && frag_root[par] >= 0) frag_root[n] = frag_root[par];
         else if (size[n] <= max_frag) frag_root[n] = n;
       }
@@ -435,7 +448,7 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
         const int4 &op = p->ops_host[p->programs[k].off + e];
         if (op.x & OPF_LAST) froot = op.y;
       }
-      const int par_node = froot >= 0 ? (int)p->parents[L + froot] : -1;
+      const int par_node = froot >= 0 ? (int)v.parents[L + froot] : -1;
       if (par_node >= 0) {
         p->programs[k].parent = prog_of[par_node];
         p->programs[p->programs[k].parent].need++;
@@ -456,13 +469,16 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
 void thin_rescale_tests(hyphy_hip_partition *p) {
   static const bool on = !(getenv("HYPHY_HIP_SCALE_THIN") && atoi(getenv("HYPHY_HIP_SCALE_THIN")) == 0);
   if (!on) return;
-  const int L = (int)p->L, I = (int)p->I;
+  const hyphy_hip_partition::View &v = p->vw();
+  const int L = v.L, I = v.I;
   std::vector<char> tested(I, 1);
   for (int n = 0; n < I; n++) {  // children before parents
     bool kids_tested = true;
-    for (int c : p->children[n])
+    for (int c : v.children[n])
       if (c >= L && !tested[c - L]) kids_tested = false;
-    tested[n] = (n == I - 1 || !kids_tested || p->children[n].size() > 4 || n == p->pin_node - L) ? 1 : 0;
+    // (mode 1: the class-table kernel tests every compressed node, so a generalised leaf counts like a tested child;
+    //  pinned states only exist in mode 0)
+    tested[n] = (n == I - 1 || !kids_tested || v.children[n].size() > 4 || (p->mode == 0 && n == p->pin_node - L)) ? 1 : 0;
   }
   if (p->rr_active)  // (re-rooted schedule: the nodes whose children differ from the given topology — and the new root — always test)
     for (int n : p->rr_path) tested[n] = 1;
@@ -487,13 +503,14 @@ void build_schedule(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t
 // The internal node that minimises the tree's height (edges to the farthest leaf) when the tree is hung from it, and the path
 // to it from the given root (rr_path, see hyphy_hip_partition).  Topology only; ties keep the given root.
 void reroot_path(hyphy_hip_partition *p) {
-  const int L = (int)p->L, I = (int)p->I, N = L + I;
+  const hyphy_hip_partition::View &vw = p->vw();
+  const int L = vw.L, I = vw.I, N = L + I;
   p->rr_path.clear();
   p->rr_cands.clear();
   if (I < 4) return;
   std::vector<std::vector<int>> adj(N);
   for (int n = 0; n < N - 1; n++) {
-    const int par = L + (int)p->parents[n];
+    const int par = L + (int)vw.parents[n];
     adj[n].push_back(par);
     adj[par].push_back(n);
   }
@@ -531,7 +548,7 @@ void reroot_path(hyphy_hip_partition *p) {
   p->rr_cands.clear();
   for (int best : mids) {
     std::vector<int> up;  // best -> ... -> root
-    for (int n = best; n != root; n = L + (int)p->parents[n]) up.push_back(n - L);
+    for (int n = best; n != root; n = L + (int)vw.parents[n]) up.push_back(n - L);
     up.push_back(I - 1);
     if ((int)up.size() - 1 > kMaxTwin) continue;
     p->rr_cands.push_back(std::vector<int>(up.rbegin(), up.rend()));
@@ -581,6 +598,10 @@ int64_t hyphy_hip_plan_reroot(int64_t L, int64_t I, const int64_t *flat_parents,
   tmp.parents.assign(flat_parents, flat_parents + L + I);
   for (int64_t n = 0; n < L + I - 1; n++)
     if (flat_parents[n] < 0 || flat_parents[n] >= I) return -1;
+  tmp.children.assign(I, std::vector<int>());
+  for (int64_t n = 0; n < L + I - 1; n++) tmp.children[flat_parents[n]].push_back((int)n);
+  tmp.leaf_has_ambig.assign(L, 0);
+  init_plain_view(&tmp);
   reroot_path(&tmp);
   if (candidate < 0 || candidate >= (int64_t)tmp.rr_cands.size()) return 0;
   const std::vector<int> &path = tmp.rr_cands[(size_t)candidate];
@@ -613,6 +634,7 @@ int hyphy_hip_plan_schedule(int64_t L, int64_t I, const int64_t *flat_parents, i
     tmp.children[par].push_back((int)n);
   }
   tmp.leaf_has_ambig.assign(L, 0);
+  init_plain_view(&tmp);
   tmp.shards.resize(1);
   tmp.shards[0].T = 1;
   tmp.shards[0].ntiles = (int)ntiles;

@@ -62,7 +62,7 @@ void launch_prune_current(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
 // (HYPHY_HIP_CHAIN_M / HYPHY_HIP_CUT / HYPHY_HIP_FRAGMENT) disables it.
 int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   p->tuned_for = p->batch_classes;
-  const int I = (int)p->I;
+  const int I = p->vw().I;  // (the tree the schedules are cut from: the trunk when the partition is class-compressed)
   Shard &s = p->shards[0];
   const int T0 = s.T;
   // a candidate: kernel (0 row-split workgroups / 1 wave per tile / 2 row-split workgroups on a chain schedule), cut
@@ -124,18 +124,20 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   // anything: analyses that create one likelihood function after another on the same tree (FEL: one per site) tune once.
   // (HYPHY_HIP_TUNE_CACHE=0: every partition measures for itself.)
   struct Key {
-    int64_t D, L, I, ntiles, classes, forced;
+    int64_t D, L, I, ntiles, classes, forced, mode;
     uint64_t topo;
     bool operator<(const Key &o) const {
-      return std::tie(D, L, I, ntiles, classes, forced, topo) < std::tie(o.D, o.L, o.I, o.ntiles, o.classes, o.forced, o.topo);
+      return std::tie(D, L, I, ntiles, classes, forced, mode, topo) < std::tie(o.D, o.L, o.I, o.ntiles, o.classes, o.forced, o.mode, o.topo);
     }
   };
   static std::map<Key, Cand> cache;
   static std::mutex cache_mutex;
   static const bool cache_on = !(getenv("HYPHY_HIP_TUNE_CACHE") && atoi(getenv("HYPHY_HIP_TUNE_CACHE")) == 0);
   uint64_t topo = 1469598103934665603ull;  // FNV-1a over the parent vector
-  for (int64_t v : p->parents) topo = (topo ^ (uint64_t)v) * 1099511628211ull;
-  const Key key{p->D, p->L, p->I, s.ntiles, n_cat_batch, p->kernel_forced ? p->variant : -1, topo};
+  for (int64_t v : p->vw().parents) topo = (topo ^ (uint64_t)v) * 1099511628211ull;
+  if (p->mode == 1)  // (the trunk depends on the alignment: leaves that are class tables gather differently from plain ones)
+    for (int sl : p->vw().slot) topo = (topo ^ (uint64_t)sl) * 1099511628211ull;
+  const Key key{p->D, p->vw().L, p->vw().I, s.ntiles, n_cat_batch, p->kernel_forced ? p->variant : -1, p->mode, topo};
   if (cache_on) {
     std::lock_guard<std::mutex> lock(cache_mutex);
     auto hit = cache.find(key);
@@ -150,8 +152,8 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   const int forced = p->kernel_forced ? p->variant : -1;  // HYPHY_HIP_KERNEL / T > 1: only that kernel's cuts compete
   if (forced < 0 || forced == 1) {
     stage1.push_back({1, -1, 0, -1});
-    for (int m : {3, 5, 8, 12, 16, 24, 40, 64})
-      if (m < I) stage1.push_back({1, m, 0, -1});
+    for (int m : {1, 2, 3, 5, 8, 12, 16, 24, 40, 64})
+      if (m < I && (m >= 3 || p->mode == 1)) stage1.push_back({1, m, 0, -1});  // (a trunk is a handful of nodes: small sources matter there)
   }
   const bool small = T0 == 1 && s.ntiles < 2 * s.cus;   // below two tiles per CU
   const bool medium = T0 == 1 && s.ntiles < 4 * s.cus;
@@ -176,7 +178,7 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   // slot, no register prefetch of deposits) on its three fastest cuts — it wins where waves are plentiful ----
   const double stage1_ms = best_ms;
   int wave_wv = 0;  // instantiation the wave kernel's candidates of the third stage use
-  if (best.kernel == 1 && best.m > 0 && p->NW == 4 && !getenv("HYPHY_HIP_WAVE_VARIANT") && !getenv("HYPHY_HIP_SLOTS"))
+  if (best.kernel == 1 && best.m > 0 && p->NW == 4 && p->mode == 0 && !getenv("HYPHY_HIP_WAVE_VARIANT") && !getenv("HYPHY_HIP_SLOTS"))
     for (size_t k = 0; k < ranked[1].size() && k < 3; k++) {
       const Cand c{1, ranked[1][k].second, 2, -1};
       const double t = time_it(c);

@@ -24,7 +24,7 @@ EXPORTS = [
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
     "hyphy_hip_set_pinned_states", "hyphy_hip_site_fits_evaluate", "hyphy_hip_site_fits_evaluate_mixture", "hyphy_hip_site_fits_kernel_ms",
-    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_last_error",
+    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_set_repeats", "hyphy_hip_repeat_stats", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
 
@@ -134,6 +134,10 @@ def load():
     lib.hyphy_hip_branch_cache_evaluate.argtypes = [vp, C.c_int64, C.c_int64, dp, C.c_int, dp, dp, lp]
     lib.hyphy_hip_prune_kernel_name.restype = C.c_char_p
     lib.hyphy_hip_prune_kernel_name.argtypes = [vp]
+    lib.hyphy_hip_set_repeats.restype = C.c_int
+    lib.hyphy_hip_set_repeats.argtypes = [vp, C.c_int]
+    lib.hyphy_hip_repeat_stats.restype = C.c_int
+    lib.hyphy_hip_repeat_stats.argtypes = [vp, lp]
     lib.hyphy_hip_last_error.restype = C.c_char_p
     lib.hyphy_hip_version.restype = C.c_char_p
     _lib = lib
@@ -580,6 +584,16 @@ class HipPartition:
 
     def schedule_info(self) -> str:
         return self._lib.hyphy_hip_schedule_info(self._h).decode()
+
+    def set_repeats(self, on: bool):
+        """Subtree repeats (class-compressed lower phase) on / off for this partition; same results either way."""
+        _check(self._lib.hyphy_hip_set_repeats(self._h, 1 if on else 0))
+
+    def repeat_stats(self) -> dict:
+        out = np.zeros(8, dtype=np.int64)
+        _check(self._lib.hyphy_hip_repeat_stats(self._h, _l(out)))
+        keys = ("available", "tables", "table_rows", "trunk_internal", "trunk_leaves", "edge_products_on", "edge_products_off", "in_use")
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def set_all_timings(self, on: bool):
         """Also stamp the expm and reduction kernels of the evaluations that follow (``last_timings()[0]``, ``[2]``)."""

@@ -398,6 +398,21 @@ int hyphy_hip_plan_schedule(int64_t L, int64_t I, const int64_t *flat_parents, i
 
 const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p);
 
+/* Subtree repeats — the device form of the reference's `tcc` traversal masks (src/core/tree.cpp:2801-2858 populates them,
+ * src/core/likefunc.cpp:10854 passes them on every ComputeBlock, src/core/tree_evaluator.cpp:57-76, 240-256 skip a subtree
+ * whose leaf states repeat the previous site's).  At hyphy_hip_create the library groups, per internal node, the patterns
+ * whose leaves below the node carry the same states into CLASSES; subtrees with few classes are evaluated once per class
+ * (class tables, one MFMA product per 16 classes) and enter the rest of the tree as generalised leaves.  Results are the same
+ * with and without; partial updates, rate classes, shards and mixtures all run on the compressed form, pinned states and the
+ * branch cache on the plain one.
+ *   hyphy_hip_set_repeats   on = 0: this partition walks every node at every pattern; 1: back on (default where it pays;
+ *                           HYPHY_HIP_REPEATS=0 in the environment turns it off for every partition created afterwards).
+ *   hyphy_hip_repeat_stats  first shard: out[0] compression available, [1] class tables, [2] table rows (classes padded to
+ *                           tiles of 16 = edge products of the lower phase), [3] / [4] internal nodes / leaves of the trunk,
+ *                           [5] edge products of one full pass with repeats on, [6] ... off, [7] in use. */
+int hyphy_hip_set_repeats(hyphy_hip_partition *p, int on);
+int hyphy_hip_repeat_stats(const hyphy_hip_partition *p, int64_t out[8]);
+
 const char *hyphy_hip_last_error(void);
 const char *hyphy_hip_version(void);
 
