@@ -115,6 +115,9 @@ PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
     pa.gcnt = s.rep_cnt + (size_t)cat * s.rep_rows;
     pa.cs_gtab = (size_t)s.rep_rows * DP;
     pa.cs_gcnt = (size_t)s.rep_rows;
+    pa.rep_sync = s.rep_sync;
+    pa.rep_sync_words = (int)rep_sync_words(p);
+    pa.rep_sync_stride = rep_sync_stride();
   }
   pa.pin = s.pin;
   pa.pin_leaf = (p->pin_node >= 0 && p->pin_node < p->L) ? (int)p->pin_node : -1;
@@ -454,6 +457,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       pa.red_out = pa.do_root ? red_out : nullptr;
       launch_prune_mfma(pa, s.stream);
     }
+    if (p->mode == 1 && n_ops > 0) s.rep_sync_dirty = false;  // (the trunk's launch has reset the lower phase's counters)
     if (pa.timeline) {  // tracing only: synchronous dump of the per-entry s_memtime stamps
       std::vector<long long> h(tl_n);
       HIPCHK(hipStreamSynchronize(s.stream));
@@ -967,6 +971,7 @@ int hyphy_hip_set_repeats(hyphy_hip_partition *p, int on) {
   if (!p) return fail("partition == NULL");
   if (finish_pending_async(p)) return -1;
   p->rep_enabled = on != 0;
+  p->rep_decided = true;  // (the caller's choice stands: no measurement overrides it)
   return 0;
 }
 
@@ -985,7 +990,9 @@ int hyphy_hip_repeat_stats(const hyphy_hip_partition *p, int64_t out[8]) {
   out[2] = s.rep_rows;
   out[3] = p->views[1].I;
   out[4] = p->views[1].L;
-  out[5] = s.rep_rows + (int64_t)(p->views[1].I - 1) * s.S_pad;
+  out[5] = (int64_t)(p->views[1].I - 1) * s.S_pad;
+  for (size_t d = 0; d < p->rep_nodes.size(); d++)  // (a path of k nodes is walked once per 16 classes of its top node)
+    out[5] += (int64_t)s.rep_tabs[d].rows * (int64_t)std::max<size_t>(1, p->rep_nodes[d].path.size());
   out[7] = p->rep_enabled ? 1 : 0;
   return 0;
 }
@@ -1053,6 +1060,8 @@ int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes
     if (tune_on && !p->nuc && (p->variant >= 1 || (!p->kernel_forced && p->shards[0].ntiles >= 32)) && p->shards[0].T == 1 && p->sched_full && !p->sched_persist &&
         p->tuned_for != p->batch_classes && p->initialized[cat]) {
       if (tune_schedule(p, (int)cat, batch ? (int)p->C : 1)) return -1;
+      // class-compressed or plain?  settled once per partition by timing both (repeats.hip), unless the caller or the environment chose
+      if (p->mode == 1 && !p->rep_decided && !getenv("HYPHY_HIP_REPEATS") && rep_decide(p, (int)cat, batch ? (int)p->C : 1)) return -1;
       build_schedule(p, nullptr, 0, true);  // the chosen cut (a full pass: no update list)
       if (p->ops_host.size() > ops_capacity(p)) return fail("internal: schedule overflow");
       changed = true;

@@ -208,6 +208,7 @@ struct Shard {
   int2 *rep_leaf = nullptr;          // [view leaves] (table row0 or -1: ordinary leaf, exponent row0 / matrix slot)
   int rep_qcap = 0;                  // items per queue of the pass the device queues hold
   int rep_waves = 0;                 // waves its launch runs
+  bool rep_sync_dirty = false;       // a lower-phase launch has run and no trunk launch has reset rep_sync behind it yet
 };
 
 }  // namespace hyhip
@@ -246,11 +247,12 @@ struct hyphy_hip_partition {
   // subtree repeats
   bool rep_on = false;                       // views[1] exists
   bool rep_enabled = true;                   // ... and ordinary evaluations use it (hyphy_hip_set_repeats)
-  struct RepNode {                           // one class table (descriptor): a compressed internal node or a leaf with ambiguity codes
-    int node = 0;                            // node code in the partition's tree
-    int level = 0;                           // 0: no table among its children
-    std::vector<int> kids;                   // internal nodes: children (node codes)
-    std::vector<int> kid_desc;               // ... descriptor of the child's table, -1: ordinary leaf (gathered by state code)
+  struct RepNode {                           // one class table (descriptor): a path of compressed internal nodes or a leaf with ambiguity codes
+    int node = 0;                            // node code (partition's tree) of the node whose classes the table has: the path's top / the leaf
+    int level = 0;                           // 0: no table among its inputs
+    std::vector<int> path;                   // compressed nodes walked by one wave, bottom first (empty: a leaf's table)
+    std::vector<std::vector<int>> kids;      // per path node: its children off the path (node codes)
+    std::vector<std::vector<int>> kid_desc;  // ... descriptor of the child's table, -1: ordinary leaf (gathered by state code)
   };
   std::vector<RepNode> rep_nodes;            // children before parents
   std::vector<int> rep_desc_of;              // [L+I] descriptor of a node's table, -1: none
@@ -308,6 +310,9 @@ struct hyphy_hip_partition {
   int chain_m_forced = 0;                    // cut chosen by the schedule tuner: > 0 source size limit m, -1 level-peeled fragments, 0 heuristic
   int64_t tuned_for = 0;                     // batch_classes the tuner ran for (0: not yet)
   std::string tune_report;                   // what the tuner measured (hyphy_hip_schedule_info)
+  double tuned_ms = 0.;                      // duration of the pruning pass under the schedule it chose
+  bool rep_decided = false;                  // subtree repeats on / off has been settled by measurement (or by the caller)
+  std::string rep_report;                    // ... and what was measured
   std::vector<int4> jn_host;                 // ... its per-node join table
   struct Level { int first, count; };
   std::vector<Prog> programs;                // (offset, padded entry count) into ops_host
@@ -374,6 +379,9 @@ void switch_mode(hyphy_hip_partition *p, int mode);
 int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, const int64_t *q_nodes, int64_t n_q, bool full,
                      int cat0, int n_classes, std::vector<int64_t> &view_update);
 int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0);
+int rep_decide(hyphy_hip_partition *p, int cat, int n_classes);
+size_t rep_sync_words(const hyphy_hip_partition *p);
+int rep_sync_stride();
 // comm.hip
 int combine_shards(hyphy_hip_partition *p, double *logl_out);
 

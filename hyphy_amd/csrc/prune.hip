@@ -799,6 +799,10 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
     if constexpr (REP) {
       a.gtab += cat * a.cs_gtab;
       a.gcnt += cat * a.cs_gcnt;
+      // the lower phase's queue heads and counters (repeats.hip), zero again for its next launch: this launch runs strictly
+      // between two of them on the stream, which spares that kernel an exit count of all its waves on one word
+      if (a.rep_sync && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int i = threadIdx.x; i < a.rep_sync_words; i += 64) a.rep_sync[(size_t)i * a.rep_sync_stride] = 0;
     }
   }
   constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;

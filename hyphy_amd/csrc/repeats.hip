@@ -20,14 +20,14 @@
 // Work per evaluation: sum of U_n over the compressed nodes + (trunk edges) x patterns edge products instead of
 // (internal edges) x patterns: 0.26 of them on the headline alignment at theta = 0.5 (tools/repeat_stats.py).
 //
-// Scheduling inside the lower phase.  A node's tiles need rows of its children's tables from anywhere in them, so the
-// dependency is node -> node.  Work items (node, tile) sit in 32 queues in level order (children before parents; every
-// level padded to a multiple of 32 items, so that all queues cross a level at the same index).  A wave takes tickets with
-// one returning atomic on the head of its XCD's queue (another queue when that one is empty), checks the item's child tables
-// against per-node counters of finished tiles, and — instead of waiting while tickets of LOWER levels are still unsold —
-// takes and runs those first (a small stack of held tickets, lowest level on top).  A wave therefore only sleeps when every
-// item below its ticket's level has a holder, and the holder of the lowest unfinished level never sleeps: no dispatch order,
-// residency or workgroup -> XCD placement is assumed (MI355X_MICROARCH.md, "placement-independent protocols only").
+// Scheduling inside the lower phase.  A tile needs rows of its input tables from anywhere in them, so the dependency is
+// table -> table.  The work items (table, tile) form one sequence in which every table precedes its readers, dealt round-robin
+// over 32 queues.  A wave takes tickets with one returning atomic on the head of its XCD's queue (another queue when that one is
+// empty) and, before it works on an item, makes sure that the tickets of all the item's inputs are SOLD (every queue head beyond
+// the item's bound) — unsold earlier tickets it takes and runs first (a small stack of held tickets, earliest on top).  Inside an
+// item it then waits, where the walk reaches them, on per-table counters of finished tiles.  A wave therefore only sleeps on
+// work that has a holder, and the holder of the earliest unfinished item never sleeps: no dispatch order, residency or workgroup
+// -> XCD placement is assumed (MI355X_MICROARCH.md, "placement-independent protocols only").
 // Hand-off of table rows between waves of the launch: 16-byte sc1 (write-through) stores -> asm "s_waitcnt vmcnt(0)" ->
 // relaxed agent-scope RMW on the node's counter; consumer: relaxed agent-scope load that proves the count -> sc1 loads (the
 // same contract as the chain joins of prune.hip).
@@ -38,14 +38,26 @@
 
 namespace hyhip {
 
-// Device descriptors (int4 words in Shard::rep_desc).  Descriptor d: header words 2 d, 2 d + 1; its child entries at
-// h1.x .. h1.x + nk - 1.
-//   h0 = (first table row, classes U, transition-matrix slot of the node's branch, nk | kind << 16)
-//   h1 = (first child entry, offset of the code list in rep_map (kind 1), tiles, 0)
-//   child entry = (first row of the child's table or -1: ordinary leaf, matrix slot of an ordinary leaf,
-//                  offset of the index map in rep_map, descriptor of the child's table | its tiles << 16, or -1)
-// kind 0: compressed internal node, kind 1: leaf with ambiguity codes (table over its distinct codes).
-// Work item = (descriptor or -1: padding, tile, rate class, first index of the item's level in every queue).
+// Paths.  A table per compressed node means a memory hand-off per tree level (publish -> drain -> counter -> poll -> gather:
+// ~6 us of fabric round trips), and the lower phase is bound by exactly that chain, not by its arithmetic (the headline's
+// 5 000 tiles are 5 us of the chip's matrix pipes).  A descriptor is therefore a PATH: a compressed node together with the
+// chain of heaviest compressed children below it (while the child keeps >= rho of the parent's classes); one wave takes 16
+// classes of the path's TOP node and walks the path bottom-up in registers — the edge product of one node is the next node's
+// first factor, as in the pruning kernels — and only the top's rows are stored.  Children off the path are tops of their own
+// paths (tables).  A path of k nodes costs k products per 16 top classes instead of one per 16 classes of each node (8 900
+// against 5 075 tile products at the headline with rho = 0), and turns k hand-offs into one (launch 190 -> ~25 us).
+//
+// Device descriptors (int4 words in Shard::rep_desc).  Descriptor d: header words 2 d, 2 d + 1.
+//   h0 = (first table row, classes U of the top node, path nodes | kind << 16, first node entry)
+//   h1 = (kind 1: offset of the code list in rep_map, tiles, level, kind 1: matrix slot of the leaf's branch / kind 0: inputs of the path)
+//   node entry  = (matrix slot of the node's branch, inputs, first input entry, 0), bottom of the path first; the path's input
+//                 entries follow its node entries, in path order
+//   input entry = (first row of the input's table or -1: ordinary leaf, matrix slot of an ordinary leaf,
+//                  offset of the index map in rep_map (class of the TOP node -> row of the input / state of the leaf),
+//                  descriptor of the input's table | its tiles << 16, or -1)
+// kind 0: a path of compressed internal nodes, kind 1: leaf with ambiguity codes (table over its distinct codes).
+// Work item = (descriptor or -1: padding, tile | rate class << 20, position in the launch's item sequence, queue index every head must
+// have passed before all inputs of the item are sold).
 constexpr int kRepQueues = 32;                       // (one word saturates at ~88 returning atomics per microsecond: 2 048 waves start at once)
 // Every word the waves of the launch meet at — queue heads, exit counter, per (class, descriptor) finished tiles — sits 4 352 bytes
 // from the next: device-scope atomics execute at the memory side, one channel serves ~88 of them per microsecond, and 64-byte
@@ -55,6 +67,8 @@ constexpr int kRepHeadStride = 1088;                 // ints between the words
 constexpr int kRepSyncExit = kRepQueues * kRepHeadStride;
 constexpr int kRepSyncDone = kRepSyncExit + kRepHeadStride;  // per (class, descriptor) finished tiles from here, same spacing
 constexpr int kRepStack = 24;                        // held tickets per wave (tree heights beyond that fall back to waiting)
+constexpr int kRepMaxInputs = 64;                    // inputs of a path whose class indices are staged in LDS (longer paths: cut by the host)
+constexpr int kRepAStages = 3;                       // A-operand chunks in flight ahead of the MFMAs of an edge product
 
 struct RepArgs {
   const int4 *desc;
@@ -71,8 +85,7 @@ struct RepArgs {
   const double *PTg;
   size_t cs_P;
   const double *ambig;
-  int n_waves;                // grid size (the last wave to leave resets `sync`)
-  int sync_words;             // words of `sync` in use (kRepHeadStride ints apart)
+  int n_waves;                // grid size
   long long *dbg;             // diagnostic (HYPHY_HIP_REP_TIMELINE): per wave [wall start, wall end, items, failed polls, shader cycles in
                               // tickets, waiting, gathers, product, publish, + first-item wall stamps] (16 words), or nullptr
 };
@@ -84,8 +97,12 @@ namespace {
     const long long n_ = clock64();        \
     tr[b] += n_ - tr_last, tr_last = n_;   \
   }
+// (descriptors, items and live flags are __restrict__ kernel arguments of their own: read-only for the launch, they then come
+//  through scalar loads; as members of the argument struct every descriptor word was a vector load + vmcnt(0) + readfirstlane —
+//  four to five L2 round trips in series per path node)
 template <int NW, bool TRACE = false>
-__global__ __launch_bounds__(64, 2) void class_table_kernel(RepArgs a) {
+__global__ __launch_bounds__(64, 2) void class_table_kernel(const int4 *__restrict__ desc, const int4 *__restrict__ items,
+                                                            const int *__restrict__ live, RepArgs a) {
   [[maybe_unused]] long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   [[maybe_unused]] long long tr_last = 0;
   if constexpr (TRACE) {
@@ -98,39 +115,59 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(RepArgs a) {
   // different banks) + the 16 exponents
   __shared__ __align__(16) double stage[16 * (DP + 2)];
   __shared__ __align__(16) int stage_cnt[16];
+  __shared__ int sidx[kRepMaxInputs * 16];  // the class indices of a path's inputs, fetched at the item's start
   const int lane = threadIdx.x, g = lane >> 4, sl = lane & 15;
-  // this wave's queue: four per XCD (HW_REG_XCC_ID), so that a ticket is an L2 atomic next door
+  // this wave's queue: four per XCD (HW_REG_XCC_ID)
   const int own = (((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7) << 2) | ((blockIdx.x >> 3) & 3)) & (kRepQueues - 1);
   auto uni = [](int4 v) -> int4 {  // (items are wave-uniform: keep them in SGPRs wherever they come from)
     return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z),
                      __builtin_amdgcn_readfirstlane(v.w));
   };
-  int sp = 0, polls = 0;
-  unsigned exhausted = 0;
+  int sp = 0;
+  int sold_below = 0;  // every queue's head has been seen at or beyond this index: all tickets below it have holders
+  bool own_empty = false;
   const f64x4 ones = (f64x4){1., 1., 1., 1.}, zeros = (f64x4){0., 0., 0., 0.};
 
   // one ticket from queue q: the item, or x = -2 when the queue is sold out
   auto ticket = [&](int q) -> int4 {
     int k = 0;
-    if (lane == 0) k = __hip_atomic_fetch_add(a.sync + q * kRepHeadStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) k = __hip_atomic_fetch_add(a.sync + (size_t)q * kRepHeadStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     k = __builtin_amdgcn_readfirstlane(k);
     if (k >= a.qcap) return make_int4(-2, 0, 0, 0);
-    return uni(a.items[(size_t)q * a.qcap + k]);
+    return uni(items[(size_t)q * a.qcap + k]);
   };
+  // the heads of all queues in one load: queues with tickets below index `bound` left (bit mask), and the lowest head
+  auto heads = [&](int bound, int &hmin) -> unsigned {
+    int h = 0x7fffffff;
+    if (lane < kRepQueues) h = __hip_atomic_load(a.sync + (size_t)lane * kRepHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned m = (unsigned)__ballot(lane < kRepQueues && h < bound && h < a.qcap);
+    int mn = h;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off));  // (lanes 0..31 hold the heads)
+    hmin = __builtin_amdgcn_readfirstlane(mn);
+    return m;
+  };
+  // next item: this wave's own queue, then whichever queue still has tickets (one look at all heads instead of 31 more atomics:
+  // every wave of the launch comes through here when the queues run dry)
   auto pull = [&]() -> int4 {
-    for (int t = 0; t < kRepQueues; t++) {
-      const int q = (own + t) & (kRepQueues - 1);
-      if ((exhausted >> q) & 1u) continue;
-      const int4 it = ticket(q);
+    if (!own_empty) {
+      const int4 it = ticket(own);
       if (it.x != -2) return it;
-      exhausted |= 1u << q;
+      own_empty = true;
     }
-    return make_int4(-2, 0, 0, 0);
+    for (;;) {
+      int hmin;
+      const unsigned m = heads(0x7fffffff, hmin);
+      if (m == 0u) return make_int4(-2, 0, 0, 0);
+      const unsigned rot = (m >> own) | (own ? m << (kRepQueues - own) : 0u);  // start looking behind the own queue
+      const int4 it = ticket((own + __builtin_ctz(rot)) & (kRepQueues - 1));
+      if (it.x != -2) return it;
+    }
   };
-  // held tickets, lowest level (item.w) on top
+  // held tickets, the earliest of the sequence (item.z) on top
   auto push = [&](const int4 &it) {
     int pos = sp;
-    while (pos > 0 && held[pos - 1].w < it.w) {
+    while (pos > 0 && held[pos - 1].z < it.z) {
       held[pos] = held[pos - 1];
       pos--;
     }
@@ -141,129 +178,66 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(RepArgs a) {
   int4 cur = pull();
   REP_TR(4)
   while (cur.x != -2) {
-    if (cur.x < 0) {  // padding item of a level
+    if (cur.x < 0) {  // padding behind the last item
       cur = sp > 0 ? uni(held[--sp]) : pull();
       continue;
     }
-    const int4 h0 = a.desc[2 * cur.x], h1 = a.desc[2 * cur.x + 1];
-    const int nk = h0.w & 0xffff, kind = h0.w >> 16;
-    const int cat = cur.z;
-    int *done = a.sync + kRepSyncDone + (size_t)cat * a.n_desc * kRepHeadStride;
-    // ---- are the child tables complete? ----
-    if (nk > 0) {
-      bool ready;
-      {
-        int ok = 1;
-        for (int j0 = 0; j0 < nk; j0 += 64) {
-          if (j0 + lane < nk) {
-            const int dep = a.desc[h1.x + j0 + lane].w;
-            if (dep >= 0 && a.live[dep & 0xffff])
-              ok &= __hip_atomic_load(done + (size_t)(dep & 0xffff) * kRepHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (dep >> 16);
+    // Never wait for work nobody holds: an item is only worked on once the tickets of all its inputs are sold (every head beyond
+    // the item's bound; the heads only grow, so what was seen once stays true) — unsold earlier tickets are taken and run first.
+    if (cur.w > sold_below) {
+      int hmin;
+      const unsigned m = heads(cur.w, hmin);
+      sold_below = max(sold_below, hmin);
+      if (m != 0u && sp < kRepStack - 1) {
+        const int4 it = ticket(__builtin_ctz(m));
+        if (it.x >= 0) {
+          if (it.z < cur.z) {
+            push(cur);
+            cur = it;
+          } else {
+            push(it);  // (another wave was faster: a later ticket than this one — keep it for afterwards)
           }
         }
-        ready = __all(ok);
-      }
-      asm volatile("" ::: "memory");
-      if (!ready) {
-        // unsold tickets below this item's level?  take one (never wait for work nobody holds).  The heads are looked at on the
-        // first failed poll and every eighth after it: a sleeping wave costs the memory system one counter line per child and
-        // poll — a thousand waiting waves sweeping 32 head lines each as well took the launch from tens to hundreds of
-        // microseconds.
-        unsigned long long m = 0ull;
-        if ((polls++ & 7) == 0) {
-          int h = 0x7fffffff;
-          if (lane < kRepQueues) h = __hip_atomic_load(a.sync + lane * kRepHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          m = __ballot(lane < kRepQueues && h < cur.w && h < a.qcap);
-        }
-        if (m != 0ull && sp < kRepStack - 1) {
-          polls = 0;
-          const int4 it = ticket(__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(m)));
-          if (it.x != -2) {
-            if (it.x < 0) {
-              // (padding)
-            } else if (it.w < cur.w) {
-              push(cur);
-              cur = it;
-            } else {
-              push(it);  // (another wave was faster: a ticket of this level or above — keep it for later)
-            }
-          }
-        } else {
-          __builtin_amdgcn_s_sleep(16);
-        }
-        if constexpr (TRACE) tr[3]++;
         REP_TR(5)
         continue;
       }
-      polls = 0;
     }
     REP_TR(5)
-    // ---- one tile of 16 classes ----
-    const int u0 = cur.y * 16;
+    const int4 h0 = desc[2 * cur.x], h1 = desc[2 * cur.x + 1];
+    const int n_nodes = h0.z & 0xffff, kind = h0.z >> 16;
+    const int cat = cur.y >> 20;
+    int *done = a.sync + kRepSyncDone + (size_t)cat * a.n_desc * kRepHeadStride;
+    // ---- one tile of 16 classes of the path's top node ----
+    const int u0 = (cur.y & 0xfffff) * 16;
     const long long row = (long long)cat * a.rows + h0.x + u0;
-    const double *Pf = a.Pfrag + (size_t)cat * a.cs_P + (size_t)h0.z * NW * TILE;
-    f64x4 acc[NW];
+    f64x4 acc[NW];  // conditionals of the node being assembled; behind its edge product: the next node's first factor
     int cnt = 0;
-    int code = 0;  // kind 1: this lane's code
-#pragma unroll
-    for (int w = 0; w < NW; w++) acc[w] = ones;
-    if (kind == 0) {
-      for (int j = 0; j < nk; j++) {
-        const int4 ke = a.desc[h1.x + j];  // uniform
-        const int idx = a.map[ke.z + u0 + sl];
-        const double *src = ke.x >= 0 ? a.tab + ((size_t)cat * a.rows + ke.x) * DP
-                                      : a.PTg + (size_t)cat * a.cs_P + (size_t)ke.y * DP * DP;  // uniform
-        f64x2 v[2 * NW];
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-          const unsigned off = (unsigned)((idx * NW + w) * 16 + g * 4) * 8u;
-          v[2 * w] = ld16_agent(src, off), v[2 * w + 1] = ld16_agent(src, off + 16u);
-        }
-        if (ke.x >= 0) cnt += __hip_atomic_load(a.cnt + (size_t)cat * a.rows + ke.x + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int w = 0; w < NW; w++) acc[w] *= (f64x4){v[2 * w][0], v[2 * w][1], v[2 * w + 1][0], v[2 * w + 1][1]};
-      }
-      // the node's conditionals of these classes: per-class 2^64 rescale (tested at every compressed node)
-      double s = 0.;
-#pragma unroll
-      for (int w = 0; w < NW; w++) s += (acc[w][0] + acc[w][1]) + (acc[w][2] + acc[w][3]);
-      const double tot = row_sum4(s);
-      double sc = 1.0;
-      int m = 0;
-      if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) m = rescale_decision(tot, sc);  // rare
-      cnt += m;
-#pragma unroll
-      for (int w = 0; w < NW; w++) acc[w] *= sc;
-    } else {
-      code = a.map[h1.y + u0 + sl];
-    }
-    if constexpr (TRACE) asm volatile("" ::"v"(acc[0][0]), "v"(code));
-    REP_TR(6)
-    // ---- E = P_n x T: the edge towards the parent, A-operand image of P_n streamed from L2 ----
-    f64x4 D[NW];
-    {
-      const double *av = a.ambig + (size_t)(code < 0 ? -code - 1 : 0) * DP;
-      auto bsrc = [&](int k2) -> f64x2 {
-        if (kind == 0) return (f64x2){acc[k2 >> 1][(k2 & 1) * 2], acc[k2 >> 1][(k2 & 1) * 2 + 1]};
-        f64x2 b;
-        b[0] = (code >= 0) ? ((8 * k2 + g == code) ? 1.0 : 0.0) : av[8 * k2 + g];
-        b[1] = (code >= 0) ? ((8 * k2 + 4 + g == code) ? 1.0 : 0.0) : av[8 * k2 + 4 + g];
-        return b;
-      };
+    // E = P x T for the branch in matrix slot `slot`: the A-operand image streamed from L2, T from `bsrc`
+    // (kRepAStages chunks of the image in flight: a wave of this launch is mostly alone on its SIMD — 2 000 items on 1 024 SIMDs —
+    //  and with one chunk ahead every k-step waited a full L2 round trip: 8 300 cycles per product against 2 048 of MFMA issue)
+    auto product = [&](int slot, auto bsrc) {
+      const double *Pf = a.Pfrag + (size_t)cat * a.cs_P + (size_t)slot * NW * TILE;  // uniform
       const __amdgpu_buffer_rsrc_t pfr = agent_rsrc(Pf);
       const unsigned lane16 = (unsigned)lane * 16u;
+      constexpr int NS = NKK / 2, PF = kRepAStages < NS ? kRepAStages : NS;
+      f64x4 D[NW];
 #pragma unroll
       for (int w = 0; w < NW; w++) D[w] = zeros;
-      f64x2 Ac[NW], An[NW], bc, bn;
+      f64x2 A[PF][NW];
 #pragma unroll
-      for (int w = 0; w < NW; w++) Ac[w] = ld16_buf(pfr, lane16, (unsigned)(w * TILE * 8));
-      bc = bsrc(0);
+      for (int st = 0; st < PF; st++)
 #pragma unroll
-      for (int k2 = 0; k2 < NKK / 2; k2++) {
-        if (k2 + 1 < NKK / 2) {
+        for (int w = 0; w < NW; w++) A[st][w] = ld16_buf(pfr, lane16, (unsigned)((w * TILE + st * 128) * 8));
 #pragma unroll
-          for (int w = 0; w < NW; w++) An[w] = ld16_buf(pfr, lane16, (unsigned)((w * TILE + (k2 + 1) * 128) * 8));
-          bn = bsrc(k2 + 1);
+      for (int k2 = 0; k2 < NS; k2++) {
+        const f64x2 bc = bsrc(k2);
+        f64x2 Ac[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) Ac[w] = A[k2 % PF][w];
+        asm volatile("" ::"v"(Ac[0]));  // (the chunk has arrived: its registers are free for the one PF steps ahead)
+        if (k2 + PF < NS) {
+#pragma unroll
+          for (int w = 0; w < NW; w++) A[k2 % PF][w] = ld16_buf(pfr, lane16, (unsigned)((w * TILE + (k2 + PF) * 128) * 8));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -271,24 +245,135 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(RepArgs a) {
 #pragma unroll
         for (int w = 0; w < NW; w++) D[w] = mfma(Ac[w][1], bc[1], D[w]);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int w = 0; w < NW; w++) Ac[w] = An[w];
-        bc = bn;
       }
+#pragma unroll
+      for (int w = 0; w < NW; w++) acc[w] = D[w];
+    };
+    if (kind == 0) {
+      // walk the path bottom-up: the edge product of node k is node k + 1's first factor, straight from the registers (the MFMA's
+      // C/D image is its B-operand image, common.h); everything else a node needs comes by class index from tables below the path
+      // class indices of every input of the path (class of the top node -> row of the input's table / state of the leaf): one pass at
+      // the start, four inputs per load instruction, parked in LDS
+      const int in0 = h0.w + n_nodes, n_in = h1.w;  // (the input entries of a path follow its node entries)
+      for (int e0 = 0; e0 < n_in; e0 += 4) {
+        const int e = e0 + g;
+        if (e < n_in) sidx[e * 16 + sl] = a.map[desc[in0 + e].z + u0 + sl];
+      }
+      __syncthreads();
+      // is the table behind input entry `ie` complete?  (one look; `block`: sleep until it is)
+      auto table_ready = [&](const int4 &ie, bool block) -> bool {
+        if (ie.w < 0 || !live[ie.w & 0xffff]) return true;
+        const int *ctr = done + (size_t)(ie.w & 0xffff) * kRepHeadStride;
+        for (;;) {
+          int v = 0;
+          if (lane == 0) v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__builtin_amdgcn_readfirstlane(v) >= (ie.w >> 16)) break;
+          if (!block) return false;
+          __builtin_amdgcn_s_sleep(8);
+          if constexpr (TRACE) tr[3]++;
+        }
+        asm volatile("" ::: "memory");
+        return true;
+      };
+      auto gather = [&](const int4 &ie, int e, f64x2 (&v)[2 * NW], int &ec) {
+        const int idx = sidx[e * 16 + sl];
+        const double *src = ie.x >= 0 ? a.tab + ((size_t)cat * a.rows + ie.x) * DP
+                                      : a.PTg + (size_t)cat * a.cs_P + (size_t)ie.y * DP * DP;  // uniform
+        ec = 0;
+        if (ie.x >= 0) {  // rows written by another wave of this launch (write-through): L1-bypassing loads
+#pragma unroll
+          for (int w = 0; w < NW; w++) {
+            const unsigned off = (unsigned)((idx * NW + w) * 16 + g * 4) * 8u;
+            v[2 * w] = ld16_agent(src, off), v[2 * w + 1] = ld16_agent(src, off + 16u);
+          }
+          ec = __hip_atomic_load(a.cnt + (size_t)cat * a.rows + ie.x + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {  // columns of a leaf's matrix (written by the exponential kernel): plain loads, L1 / L2 hits
+#pragma unroll
+          for (int w = 0; w < NW; w++) {
+            const unsigned off = (unsigned)((idx * NW + w) * 16 + g * 4) * 8u;
+            v[2 * w] = ld16(src, off), v[2 * w + 1] = ld16(src, off + 16u);
+          }
+        }
+      };
+      f64x2 pv[2 * NW];  // the first input of the NEXT node, requested before this node's edge product
+      int pcnt = 0;
+      bool pf = false;
+      int e_node = 0;    // first input (path-wide numbering) of the current node
+      for (int k = 0; k < n_nodes; k++) {
+        const int4 ne = desc[h0.w + k];  // (matrix slot of the node's branch, inputs, first input entry)
+        if (k == 0) {
+#pragma unroll
+          for (int w = 0; w < NW; w++) acc[w] = ones;
+        }
+        for (int j = 0; j < ne.y; j++) {
+          if (j == 0 && pf) {
+#pragma unroll
+            for (int w = 0; w < NW; w++) acc[w] *= (f64x4){pv[2 * w][0], pv[2 * w][1], pv[2 * w + 1][0], pv[2 * w + 1][1]};
+            cnt += pcnt;
+            continue;
+          }
+          const int4 ie = desc[ne.z + j];  // uniform
+          if (!table_ready(ie, true)) {}
+          REP_TR(5)
+          f64x2 v[2 * NW];
+          int ec;
+          gather(ie, e_node + j, v, ec);
+#pragma unroll
+          for (int w = 0; w < NW; w++) acc[w] *= (f64x4){v[2 * w][0], v[2 * w][1], v[2 * w + 1][0], v[2 * w + 1][1]};
+          cnt += ec;
+        }
+        e_node += ne.y;
+        // the node's conditionals of these classes: per-class 2^64 rescale (tested at every compressed node)
+        double s = 0.;
+#pragma unroll
+        for (int w = 0; w < NW; w++) s += (acc[w][0] + acc[w][1]) + (acc[w][2] + acc[w][3]);
+        const double tot = row_sum4(s);
+        double sc = 1.0;
+        int m = 0;
+        if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) m = rescale_decision(tot, sc);  // rare
+        cnt += m;
+#pragma unroll
+        for (int w = 0; w < NW; w++) acc[w] *= sc;
+        if constexpr (TRACE) asm volatile("" ::"v"(acc[0][0]));
+        REP_TR(6)
+        pf = false;
+        if (k + 1 < n_nodes) {  // the next node's first input rides under this node's product (if its table is complete already)
+          const int4 ne2 = desc[h0.w + k + 1];
+          if (ne2.y > 0) {
+            const int4 ie2 = desc[ne2.z];
+            if (table_ready(ie2, false)) {
+              gather(ie2, e_node, pv, pcnt);
+              pf = true;
+            }
+          }
+        }
+        product(ne.x, [&](int k2) -> f64x2 { return (f64x2){acc[k2 >> 1][(k2 & 1) * 2], acc[k2 >> 1][(k2 & 1) * 2 + 1]}; });
+        if constexpr (TRACE) asm volatile("" ::"v"(acc[0][0]));
+        REP_TR(7)
+      }
+    } else {
+      // a leaf with ambiguity codes: E[u] = P_leaf x (resolution vector of the u-th distinct code)
+      const int code = a.map[h1.x + u0 + sl];
+      const double *av = a.ambig + (size_t)(code < 0 ? -code - 1 : 0) * DP;
+      product(h1.w, [&](int k2) -> f64x2 {
+        f64x2 b;
+        b[0] = (code >= 0) ? ((8 * k2 + g == code) ? 1.0 : 0.0) : av[8 * k2 + g];
+        b[1] = (code >= 0) ? ((8 * k2 + 4 + g == code) ? 1.0 : 0.0) : av[8 * k2 + 4 + g];
+        return b;
+      });
+      if constexpr (TRACE) asm volatile("" ::"v"(acc[0][0]));
+      REP_TR(7)
     }
     // ---- publish the rows ([class][w][g][r] = E[16 w + 4 r + g][class]) and their exponents, then the tile ----
-    if constexpr (TRACE) asm volatile("" ::"v"(D[0][0]));
-    REP_TR(7)
     // Through LDS: a lane holds 4 doubles of each of NW row blocks of ONE class; written from the registers, a store
-    // instruction scatters 64 half-sectors over 16 lines, and write-through (sc1) stores go to the fabric as they are
-    // (measured: 330 us for the launch).  Transposed through the wave's LDS tile, every store instruction writes 1 KiB of
-    // consecutive bytes.
+    // instruction scatters 64 half-sectors over 16 lines.  Transposed through the wave's LDS tile, every store instruction
+    // writes 1 KiB of consecutive bytes (write-through stores go to the fabric as they are).
     {
       double *out = a.tab + (size_t)row * DP;  // uniform
 #pragma unroll
       for (int w = 0; w < NW; w++) {
-        *reinterpret_cast<f64x2 *>(stage + sl * (DP + 2) + w * 16 + g * 4) = (f64x2){D[w][0], D[w][1]};
-        *reinterpret_cast<f64x2 *>(stage + sl * (DP + 2) + w * 16 + g * 4 + 2) = (f64x2){D[w][2], D[w][3]};
+        *reinterpret_cast<f64x2 *>(stage + sl * (DP + 2) + w * 16 + g * 4) = (f64x2){acc[w][0], acc[w][1]};
+        *reinterpret_cast<f64x2 *>(stage + sl * (DP + 2) + w * 16 + g * 4 + 2) = (f64x2){acc[w][2], acc[w][3]};
       }
       if (g == 0) stage_cnt[sl] = cnt;
       __syncthreads();  // (one wave per workgroup: orders the LDS round trip)
@@ -318,14 +403,7 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(RepArgs a) {
       for (int i = 0; i < 16; i++) a.dbg[(size_t)blockIdx.x * 16 + i] = tr[i];
     }
   }
-  // the last wave to leave resets the queue heads and the counters for the next launch (nobody touches them after its exit
-  // ticket; every wave has drained its own stores above)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  int old = 0;
-  if (lane == 0) old = __hip_atomic_fetch_add(a.sync + kRepSyncExit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  old = __builtin_amdgcn_readfirstlane(old);
-  if (old + 1 == a.n_waves)
-    for (int i = lane; i < a.sync_words; i += 64) __hip_atomic_store(a.sync + (size_t)i * kRepHeadStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (queue heads and counters are reset by the launch that follows on the stream: the trunk's pruning kernel, prune.hip)
 }
 
 }  // namespace
@@ -333,14 +411,14 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(RepArgs a) {
 void launch_class_tables(const RepArgs &a, int NW, hipStream_t stream) {
   const dim3 grid(a.n_waves), block(64);
   if (a.dbg && NW == 4) {
-    hipLaunchKernelGGL((class_table_kernel<4, true>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((class_table_kernel<4, true>), grid, block, 0, stream, a.desc, a.items, a.live, a);
     return;
   }
   switch (NW) {
-    case 1: hipLaunchKernelGGL((class_table_kernel<1>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((class_table_kernel<2>), grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((class_table_kernel<3>), grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL((class_table_kernel<4>), grid, block, 0, stream, a); break;
+    case 1: hipLaunchKernelGGL((class_table_kernel<1>), grid, block, 0, stream, a.desc, a.items, a.live, a); break;
+    case 2: hipLaunchKernelGGL((class_table_kernel<2>), grid, block, 0, stream, a.desc, a.items, a.live, a); break;
+    case 3: hipLaunchKernelGGL((class_table_kernel<3>), grid, block, 0, stream, a.desc, a.items, a.live, a); break;
+    default: hipLaunchKernelGGL((class_table_kernel<4>), grid, block, 0, stream, a.desc, a.items, a.live, a); break;
   }
 }
 
@@ -388,12 +466,19 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
   const char *env = getenv("HYPHY_HIP_REPEATS");
   if (env && atoi(env) == 0) return 0;
   if (p->nuc || p->shards.empty()) return 0;
+  if (!env)  // (the diagnostic switches that force a kernel, an instantiation or a cut are about the per-pattern kernels)
+    for (const char *sw : {"HYPHY_HIP_KERNEL", "HYPHY_HIP_WAVE_VARIANT", "HYPHY_HIP_CUT", "HYPHY_HIP_CHAIN_M", "HYPHY_HIP_FRAGMENT",
+                           "HYPHY_HIP_SLOTS", "HYPHY_HIP_REROOT", "HYPHY_HIP_TILES", "HYPHY_HIP_TIMELINE", "HYPHY_HIP_ABLATE"})
+      if (getenv(sw)) return 0;
   for (const Shard &s : p->shards)
     if (s.T != 1) return 0;
   if (p->variant != 1 && !(env && atoi(env) == 2)) return 0;  // (tiny shards: the workgroup-per-tile kernel keeps the whole tree)
   const int L = (int)p->L, I = (int)p->I, DP = p->DP;
   if (I < 2) return 0;
-  double theta = 0.5;
+  // theta: the share of the patterns below which a node's classes are worth a table.  0.3-0.4 is the flat optimum of the headline
+  // alignment (0.2: 100 us of pruning launches, 0.3: 89, 0.4: 89, 0.5: 101, 0.7: 106): above it the walks of the lower phase get long
+  // and few, below it the trunk keeps nodes that repeat heavily
+  double theta = 0.35;
   if (const char *e = getenv("HYPHY_HIP_REP_THETA")) theta = atof(e);
   const size_t nsh = p->shards.size();
   // ---- classes per shard ----
@@ -434,6 +519,7 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
       if ((double)U[k][n] > theta * p->shards[k].S_pad || U[k][n] > 32000) ok = false;
     for (int c : p->children[n])
       if (c >= L && !comp[c - L]) ok = false;
+    if ((int)p->children[n].size() > kRepMaxInputs - 8) ok = false;  // (a star: its children's indices would not fit the wave's LDS list)
     comp[n] = ok ? 1 : 0;
   }
   {  // worth it?  compare the edge products of the two forms on the first shard
@@ -445,7 +531,35 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
     const double need = getenv("HYPHY_HIP_REP_MIN_GAIN") ? atof(getenv("HYPHY_HIP_REP_MIN_GAIN")) : 0.15;
     if (!(env && atoi(env) == 2) && (rep > (1.0 - need) * full || p->shards[0].ntiles < 8)) return 0;
   }
-  // ---- descriptors: leaves with ambiguity codes first (level 0), compressed nodes children before parents ----
+  // ---- descriptors: leaves with ambiguity codes first (level 0), then the paths, inputs before the paths that read them ----
+  double rho = 0.6;
+  {
+    long tiles = 0;
+    for (int n = 0; n < I; n++)
+      if (comp[n]) tiles += (U[0][n] + 15) / 16;
+    if (tiles < 2L * p->shards[0].cus * 8) rho = 0.;  // (a launch that does not fill the chip twice is bound by its dependency chain)
+    if (const char *e = getenv("HYPHY_HIP_REP_RHO")) rho = atof(e);
+  }
+  std::vector<int> heavy(I, -1);     // the compressed child a node's path continues into
+  std::vector<char> continued(I, 0); // the node is inside its parent's path (no table of its own)
+  std::vector<int> path_inputs(I, 0), path_len(I, 0);
+  for (int n = 0; n < I; n++) {
+    if (!comp[n]) continue;
+    int best = -1;
+    for (int c : p->children[n])
+      if (c >= L && (best < 0 || U[0][c - L] > U[0][best])) best = c - L;
+    // (a path's inputs are staged in LDS by index: long caterpillars / wide multifurcations are cut into several paths)
+    const int own_inputs = (int)p->children[n].size();
+    path_inputs[n] = own_inputs;
+    path_len[n] = 1;
+    if (best >= 0 && (double)U[0][best] >= rho * (double)U[0][n] && path_inputs[best] + own_inputs - 1 <= kRepMaxInputs - 8 &&
+        path_len[best] < 32 && own_inputs <= kRepMaxInputs / 2) {
+      heavy[n] = best;
+      continued[best] = 1;
+      path_inputs[n] = path_inputs[best] + own_inputs - 1;
+      path_len[n] = path_len[best] + 1;
+    }
+  }
   p->rep_nodes.clear();
   p->rep_desc_of.assign((size_t)L + I, -1);
   for (int l = 0; l < L; l++)
@@ -457,15 +571,24 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
       p->rep_nodes.push_back(rn);
     }
   for (int n = 0; n < I; n++)
-    if (comp[n]) {
+    if (comp[n] && !continued[n]) {  // a path's top (ascending: every input's top comes first)
       hyphy_hip_partition::RepNode rn;
       rn.node = L + n;
       rn.level = 0;
-      for (int c : p->children[n]) {
-        rn.kids.push_back(c);
-        const int d = p->rep_desc_of[c];
-        rn.kid_desc.push_back(d);
-        if (d >= 0) rn.level = std::max(rn.level, p->rep_nodes[d].level + 1);
+      std::vector<int> down;
+      for (int x = n; x >= 0; x = heavy[x]) down.push_back(x);
+      for (size_t k = down.size(); k-- > 0;) {
+        const int x = down[k];
+        rn.path.push_back(L + x);
+        rn.kids.push_back(std::vector<int>());
+        rn.kid_desc.push_back(std::vector<int>());
+        for (int c : p->children[x]) {
+          if (c >= L && c - L == heavy[x]) continue;  // (the node below on the path: comes through the registers)
+          rn.kids.back().push_back(c);
+          const int d = p->rep_desc_of[c];
+          rn.kid_desc.back().push_back(d);
+          if (d >= 0) rn.level = std::max(rn.level, p->rep_nodes[d].level + 1);
+        }
       }
       p->rep_desc_of[L + n] = (int)p->rep_nodes.size();
       p->rep_nodes.push_back(rn);
@@ -543,18 +666,19 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
         t.map0.push_back((int64_t)maps.size());
         for (int u = 0; u < t.rows; u++) maps.push_back((int32_t)codes[k][(size_t)rn.node * SP + first_pat[d][u]]);
       } else {
-        for (size_t j = 0; j < rn.kids.size(); j++) {
-          t.map0.push_back((int64_t)maps.size());
-          const int c = rn.kids[j], cd = rn.kid_desc[j];
-          for (int u = 0; u < t.rows; u++) {
-            const int pat = first_pat[d][u];
-            int32_t idx;
-            if (cd < 0) idx = (int32_t)codes[k][(size_t)c * SP + pat];        // ordinary leaf: its state
-            else if (c < L) idx = (int32_t)leaf_cls[c][pat];                  // leaf with a table: class of its code
-            else idx = (int32_t)cls[k][c - L][pat];                           // compressed child: its class
-            maps.push_back(idx);
+        for (size_t x = 0; x < rn.path.size(); x++)
+          for (size_t j = 0; j < rn.kids[x].size(); j++) {
+            t.map0.push_back((int64_t)maps.size());
+            const int c = rn.kids[x][j], cd = rn.kid_desc[x][j];
+            for (int u = 0; u < t.rows; u++) {
+              const int pat = first_pat[d][u];  // (a class of the top node fixes the class of everything below it)
+              int32_t idx;
+              if (cd < 0) idx = (int32_t)codes[k][(size_t)c * SP + pat];        // ordinary leaf: its state
+              else if (c < L) idx = (int32_t)leaf_cls[c][pat];                  // leaf with a table: class of its code
+              else idx = (int32_t)cls[k][c - L][pat];                           // compressed child: its class
+              maps.push_back(idx);
+            }
           }
-        }
       }
     }
     s.rep_rows = rows;
@@ -564,12 +688,20 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
       const hyphy_hip_partition::RepNode &rn = p->rep_nodes[d];
       const RepTable &t = s.rep_tabs[d];
       const int kind = rn.node < L ? 1 : 0;
-      desc[2 * d] = make_int4((int)t.row0, t.U, rn.node, (int)rn.kids.size() | (kind << 16));
-      desc[2 * d + 1] = make_int4((int)desc.size(), kind ? (int)t.map0[0] : 0, t.rows / 16, rn.level);
-      for (size_t j = 0; j < rn.kids.size(); j++) {
-        const int cd = rn.kid_desc[j];
-        desc.push_back(make_int4(cd >= 0 ? (int)s.rep_tabs[cd].row0 : -1, rn.kids[j], (int)t.map0[j],
-                                 cd >= 0 ? (cd | ((s.rep_tabs[cd].rows / 16) << 16)) : -1));
+      const int node0 = (int)desc.size();
+      desc[2 * d] = make_int4((int)t.row0, t.U, (int)rn.path.size() | (kind << 16), node0);
+      int n_in = 0;
+      for (const std::vector<int> &kk : rn.kids) n_in += (int)kk.size();
+      desc[2 * d + 1] = make_int4(kind ? (int)t.map0[0] : 0, t.rows / 16, rn.level, kind ? rn.node : n_in);
+      desc.resize(desc.size() + rn.path.size());
+      size_t mi = 0;
+      for (size_t x = 0; x < rn.path.size(); x++) {
+        desc[node0 + x] = make_int4(rn.path[x], (int)rn.kids[x].size(), (int)desc.size(), 0);
+        for (size_t j = 0; j < rn.kids[x].size(); j++, mi++) {
+          const int cd = rn.kid_desc[x][j];
+          desc.push_back(make_int4(cd >= 0 ? (int)s.rep_tabs[cd].row0 : -1, rn.kids[x][j], (int)t.map0[mi],
+                                   cd >= 0 ? (cd | ((s.rep_tabs[cd].rows / 16) << 16)) : -1));
+        }
       }
     }
     // the trunk's leaf table, tile-major, and where each view leaf gathers from
@@ -586,7 +718,7 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
         ct[((j >> 4) * (size_t)v.L + vl) * 16 + (j & 15)] = (int16_t)val;
       }
     }
-    const size_t sync_words = ((size_t)kRepQueues + 1 + (size_t)p->C * ND) * kRepHeadStride;
+    const size_t sync_words = ((size_t)kRepQueues + 1 + (size_t)p->C * ND) * kRepHeadStride;  // (= rep_sync_words(p) words)
 #define R_(ptr, bytes)                                                                  \
   if (pool_malloc((void **)&(ptr), (bytes)) != hipSuccess) return fail("hipMalloc failed (" #ptr ")");
     R_(s.rep_tab, (size_t)p->C * rows * DP * sizeof(double));
@@ -621,11 +753,14 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
   ms.tuned_for = 0;
   p->rep_on = true;
   if (getenv("HYPHY_HIP_VERBOSE")) {
-    long long lower = 0;
-    for (const RepTable &t : p->shards[0].rep_tabs) lower += t.rows;
-    fprintf(stderr, "[hyphy_hip] subtree repeats: theta %.2f, %d class tables (%lld rows on shard 0), trunk of %d internal nodes over %d leaves; "
+    long long rows = 0, lower = 0;
+    for (int d = 0; d < ND; d++) {
+      rows += p->shards[0].rep_tabs[d].rows;
+      lower += (long long)p->shards[0].rep_tabs[d].rows * std::max<size_t>(1, p->rep_nodes[d].path.size());
+    }
+    fprintf(stderr, "[hyphy_hip] subtree repeats: theta %.2f, rho %.2f, %d class tables (%lld rows on shard 0), trunk of %d internal nodes over %d leaves; "
                     "edge products per pass %lld + %lld (every pattern at every node: %lld)\n",
-            theta, ND, lower, v.I, v.L, lower, (long long)(v.I - 1) * p->shards[0].S_pad, (long long)(I - 1) * p->shards[0].S_pad);
+            theta, rho, ND, rows, v.I, v.L, lower, (long long)(v.I - 1) * p->shards[0].S_pad, (long long)(I - 1) * p->shards[0].S_pad);
   }
   return 0;
 }
@@ -690,8 +825,10 @@ void rep_translate_update(hyphy_hip_partition *p, const int64_t *update_nodes, i
   if (p->rep_stale_branch >= 0 && p->rep_stale_branch < L + I) qd[p->rep_stale_branch] = 1;
   const hyphy_hip_partition::View &v = p->views[1];
   for (int d = 0; d < ND; d++) {
-    const int n = p->rep_nodes[d].node;
-    if (qd[n] || (n >= L && touched[n - L])) dirty_desc.push_back(d);
+    const hyphy_hip_partition::RepNode &rn = p->rep_nodes[d];
+    bool dirty = rn.node < L && qd[rn.node];
+    for (int n : rn.path) dirty = dirty || qd[n] || touched[n - L];
+    if (dirty) dirty_desc.push_back(d);
   }
   // the trunk: list the view nodes whose parents must be recomputed — a trunk node that is touched lists itself through any of
   // its view children; simplest exact form: every view node whose parent (a trunk node) is touched in the partition's tree
@@ -703,28 +840,40 @@ void rep_translate_update(hyphy_hip_partition *p, const int64_t *update_nodes, i
   }
 }
 
-// Item queues of a pass over the descriptors `dirty` (children before parents) for `n_classes` rate classes starting at `cat0`:
-// eight queues in level order, every level padded to a multiple of eight items.  Returns items per queue.
+// Item queues of a pass over the descriptors `dirty` for `n_classes` rate classes starting at `cat0`.  The items form ONE sequence,
+// dealt round-robin over the queues (item at position g: queue g % 32, index g / 32), in an order in which every table comes before
+// the paths that read it — by descending PRIORITY = products of the path + the longest chain of paths that wait for it: the side
+// tables of the long paths first, then the long paths (they are what the launch waits for at its end), short independent ones last
+// to fill the gaps.  An item's `bound` = the queue index every head must have passed for all its inputs to be sold.
+// Returns items per queue.
 int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vector<int> &dirty, int cat0, int n_classes,
                     std::vector<int4> &queues /* [kRepQueues][qcap] */) {
-  int max_level = 0;
-  for (int d : dirty) max_level = std::max(max_level, p->rep_nodes[d].level);
-  // (a partial pass keeps the levels of the full one; child tables outside `dirty` count as finished: RepArgs::live)
-  std::vector<std::vector<int4>> by_level(max_level + 1);
-  for (int c = 0; c < n_classes; c++)
-    for (int d : dirty) {
-      const int lev = p->rep_nodes[d].level;
-      for (int t = 0; t < s.rep_tabs[d].rows / 16; t++) by_level[lev].push_back(make_int4(d, t, cat0 + c, 0));
-    }
-  std::vector<int4> all;
-  for (int lev = 0; lev <= max_level; lev++) {
-    const int bound = (int)all.size() / kRepQueues;  // first index of this level in every queue
-    for (int4 it : by_level[lev]) {
-      it.w = bound;
-      all.push_back(it);
-    }
-    while (all.size() % kRepQueues) all.push_back(make_int4(-1, 0, 0, bound));
+  const int ND = (int)p->rep_nodes.size();
+  std::vector<char> live(ND, 0);
+  for (int d : dirty) live[d] = 1;
+  std::vector<long> prio(ND, 0);
+  for (int d = ND - 1; d >= 0; d--) {  // (descriptors are stored inputs first: consumers have larger numbers)
+    if (!live[d]) continue;
+    prio[d] += (long)std::max<size_t>(1, p->rep_nodes[d].path.size());
+    for (const std::vector<int> &kk : p->rep_nodes[d].kid_desc)
+      for (int dd : kk)
+        if (dd >= 0 && live[dd]) prio[dd] = std::max(prio[dd], prio[d]);  // (so far: the longest chain above dd; its own length is added when its turn comes)
   }
+  std::vector<int> order(dirty);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return prio[x] > prio[y]; });
+  std::vector<int4> all;
+  std::vector<long> pos0((size_t)ND * n_classes, -1);
+  for (int d : order)
+    for (int c = 0; c < n_classes; c++) {
+      long last_dep = -1;
+      for (const std::vector<int> &kk : p->rep_nodes[d].kid_desc)
+        for (int dd : kk)
+          if (dd >= 0 && live[dd]) last_dep = std::max(last_dep, pos0[(size_t)dd * n_classes + c] + s.rep_tabs[dd].rows / 16 - 1);
+      const int bound = last_dep < 0 ? 0 : (int)(last_dep / kRepQueues) + 1;
+      pos0[(size_t)d * n_classes + c] = (long)all.size();
+      for (int t = 0; t < s.rep_tabs[d].rows / 16; t++) all.push_back(make_int4(d, t | ((cat0 + c) << 20), (int)all.size(), bound));
+    }
+  while (all.size() % kRepQueues) all.push_back(make_int4(-1, 0, (int)all.size(), 0));
   const int per_q = (int)all.size() / kRepQueues;
   queues.assign((size_t)kRepQueues * std::max(1, per_q), make_int4(-1, 0, 0, 0));
   for (size_t i = 0; i < all.size(); i++) queues[(i % kRepQueues) * (size_t)std::max(1, per_q) + i / kRepQueues] = all[i];
@@ -770,7 +919,9 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
     for (int d : dirty) live[d] = getenv("HYPHY_HIP_REP_NODEPS") ? 0 : 1;  // (diagnostic: nobody waits, results invalid)
     HIPCHK(hipMemcpyAsync(s.rep_items, s.h_rep_items, words * sizeof(int4), hipMemcpyHostToDevice, s.stream));
     s.rep_qcap = per_q;
-    s.rep_waves = std::min(per_q * kRepQueues, s.cus * 8);
+    // one wave per SIMD while the items fit two rounds of that (a walk is bound by the SIMD's matrix pipe: two walks on one SIMD take
+    // twice as long each, and the launch ends with its longest walk), two per SIMD beyond
+    s.rep_waves = per_q * kRepQueues <= 8 * s.cus ? std::min(per_q * kRepQueues, s.cus * 4) : s.cus * 8;
     if (const char *e = getenv("HYPHY_HIP_REP_WAVES")) s.rep_waves = std::max(1, std::min(per_q * kRepQueues, atoi(e)));
   }
   p->rep_cached_dirty = dirty;
@@ -778,6 +929,9 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
   p->rep_cached_valid = true;
   return 0;
 }
+
+size_t rep_sync_words(const hyphy_hip_partition *p) { return (size_t)kRepQueues + 1 + (size_t)p->C * p->rep_nodes.size(); }
+int rep_sync_stride() { return kRepHeadStride; }
 
 // The lower phase of a pass: one launch over the item queues prepared by rep_prepare_pass (behind the exponentials, ahead of
 // the trunk's pruning launch, on the shard's stream).
@@ -800,8 +954,11 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
   a.cs_P = (size_t)p->B * p->DP * p->DP;
   a.ambig = s.ambig;
   a.n_waves = s.rep_waves;
-  a.sync_words = kRepQueues + 1 + (int)p->C * a.n_desc;
   a.dbg = nullptr;
+  // queue heads and counters are zero between launches: the trunk's pruning launch that follows resets them (PruneArgs::rep_sync);
+  // should a launch not have been followed by one (a failed evaluation), they are cleared here
+  if (s.rep_sync_dirty) HIPCHK(hipMemsetAsync(s.rep_sync, 0, rep_sync_words(p) * kRepHeadStride * sizeof(int), s.stream));
+  s.rep_sync_dirty = true;
   const char *tl = getenv("HYPHY_HIP_REP_TIMELINE");
   if (tl && p->NW == 4) {  // diagnostic: synchronous, one file per launch (the last launch survives)
     const size_t n = (size_t)a.n_waves * 16;
@@ -823,6 +980,50 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
     return 0;
   }
   launch_class_tables(a, p->NW, s.stream);
+  return 0;
+}
+
+// Settle, by measurement, whether this partition's evaluations run class-compressed.  Called on the first steady-state full pass
+// under views[1], behind the schedule tuner (which has just timed the trunk's pruning pass under its best cut): the lower phase is
+// timed on the resident matrices (its items are on the device), then the plain form is tuned and timed the same way, and the faster
+// of the two stays.  Compression costs a second launch and a chain of table hand-offs; on small shards (a rank's share of an
+// alignment at 4 or 8 GPUs) that outweighs the edge products it saves.  What was decided for the same tree, shard and class
+// batch earlier in this process is taken over without timing anything.
+int rep_decide(hyphy_hip_partition *p, int cat, int n_classes) {
+  p->rep_decided = true;
+  Shard &s = p->shards[0];
+  HIPCHK(hipSetDevice(s.device));
+  const double trunk_ms = p->tuned_ms;
+  float a_ms = 0.f, b_ms = 0.f;
+  if (rep_launch(p, s, cat)) return -1;  // warm-up
+  HIPCHK(hipEventRecord(s.ev[0], s.stream));
+  if (rep_launch(p, s, cat)) return -1;
+  HIPCHK(hipEventRecord(s.ev[1], s.stream));
+  if (rep_launch(p, s, cat)) return -1;
+  HIPCHK(hipEventRecord(s.ev[2], s.stream));
+  HIPCHK(hipStreamSynchronize(s.stream));
+  if (hipEventElapsedTime(&a_ms, s.ev[0], s.ev[1]) != hipSuccess || hipEventElapsedTime(&b_ms, s.ev[1], s.ev[2]) != hipSuccess) return 0;
+  const double lower_ms = std::min(a_ms, b_ms);
+  // the plain form under its own best schedule
+  switch_mode(p, 0);
+  p->cached_valid = 0;
+  if (p->tuned_for != p->batch_classes) {
+    if (tune_schedule(p, cat, n_classes)) return -1;
+  } else {
+    p->tuned_ms = 0.;  // (tuned earlier without a recorded time: keep compression on)
+  }
+  const double plain_ms = p->tuned_ms;
+  const double on_ms = trunk_ms + lower_ms;
+  char b[160];
+  snprintf(b, sizeof b, "repeats: lower phase %.1fus + trunk %.1fus against %.1fus without -> %s", 1e3 * lower_ms, 1e3 * trunk_ms, 1e3 * plain_ms,
+           (plain_ms > 0. && plain_ms <= on_ms) ? "off" : "on");
+  p->rep_report = b;
+  if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %s\n", b);
+  if (plain_ms > 0. && plain_ms <= on_ms) {
+    p->rep_enabled = false;  // (stays under views[0]; the caller rebuilds the schedule)
+  } else {
+    switch_mode(p, 1);
+  }
   return 0;
 }
 

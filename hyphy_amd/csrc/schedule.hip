@@ -693,6 +693,7 @@ const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p) {
   snprintf(buf, sizeof buf, " [current: %s%s, %zu program(s)]", p->chain ? "chain" : "levels", p->rr_active ? ", re-rooted" : "",
            p->programs.size());
   out = p->tune_report + buf;
+  if (!p->rep_report.empty()) out += " {" + p->rep_report + "}";
   return out.c_str();
 }
 

@@ -130,7 +130,8 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
       return std::tie(D, L, I, ntiles, classes, forced, mode, topo) < std::tie(o.D, o.L, o.I, o.ntiles, o.classes, o.forced, o.mode, o.topo);
     }
   };
-  static std::map<Key, Cand> cache;
+  struct Choice { Cand cand; double ms; };
+  static std::map<Key, Choice> cache;
   static std::mutex cache_mutex;
   static const bool cache_on = !(getenv("HYPHY_HIP_TUNE_CACHE") && atoi(getenv("HYPHY_HIP_TUNE_CACHE")) == 0);
   uint64_t topo = 1469598103934665603ull;  // FNV-1a over the parent vector
@@ -141,8 +142,9 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   if (cache_on) {
     std::lock_guard<std::mutex> lock(cache_mutex);
     auto hit = cache.find(key);
-    if (hit != cache.end() && apply(hit->second)) {
-      p->tune_report = "(same tree, shard size and class batch as an earlier partition of this process) -> " + label(hit->second);
+    if (hit != cache.end() && apply(hit->second.cand)) {
+      p->tuned_ms = hit->second.ms;
+      p->tune_report = "(same tree, shard size and class batch as an earlier partition of this process) -> " + label(hit->second.cand);
       if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] schedule tuner (%d classes per launch): %s\n", n_cat_batch, p->tune_report.c_str());
       return 0;
     }
@@ -214,8 +216,9 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   apply(best);  // (leaves kernel, slot budget, instantiation, cut and re-rooting path set; the caller rebuilds the schedule)
   if (cache_on) {
     std::lock_guard<std::mutex> lock(cache_mutex);
-    cache[key] = best;
+    cache[key] = Choice{best, best_ms};
   }
+  p->tuned_ms = best_ms;
   p->tune_report += " -> " + label(best);
   if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] schedule tuner (%d classes per launch): %s\n", n_cat_batch, p->tune_report.c_str());
   return 0;
