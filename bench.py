@@ -220,7 +220,7 @@ def cpu_baseline(wl, syn, omega0, t_branch, n_threads, steps, budget_s=20.0):
     return cb, ref
 
 
-def measure_traffic(workload, kernel):
+def measure_traffic(workload, kernels):
     """HBM traffic of the dominant kernel, measured by re-running THIS script under rocprofv3 with the L2's memory-side
     counters — two passes (FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md, PMC section), counter
     collection only (no trace domains besides the kernel trace).  Returns per-launch bytes with the guide's gfx950
@@ -242,14 +242,17 @@ def measure_traffic(workload, kernel):
             subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable,
                             os.path.abspath(__file__), "--workload", workload, "--steps", "12", "--warmup", "6", "--no-cpu-baseline",
                             "--no-traffic"], cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
-            rows = []
-            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                        rows.append(float(r["Counter_Value"]))
-            if len(rows) < 4:
-                return None
-            vals[counter] = float(np.median(rows[2:]))   # (the first passes persist every node / tune the schedule)
+            total = 0.0
+            for kernel in kernels:   # (a class-compressed pass is two launches: lower phase + trunk; their traffic adds up)
+                rows = []
+                for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                            rows.append(float(r["Counter_Value"]))
+                if len(rows) < 4:
+                    return None
+                total += float(np.median(rows[len(rows) // 2:]))   # (the first passes persist every node / tune the schedule)
+            vals[counter] = total
         except Exception:
             return None
         finally:
@@ -690,10 +693,23 @@ def main():
         bytes_ *= n_classes
         prune_ms = max(t_prune / args.steps, 1e-9)
         bound = "mfma" if D > 4 else "hbm"
+        # subtree repeats (repeats.hip): a class-compressed pass EXECUTES fewer edge products than the algorithmic count (every internal
+        # edge at every pattern).  `achieved` / `frac` are on the executed flops — what the matrix pipes did; the algorithmic flops
+        # over the same time are `effective_tflops` (what the caller got; may exceed what any pipe could do without the reuse).
+        rs = part.repeat_stats()
+        rep_on = bool(rs["available"] and rs["in_use"])
+        exec_flops = flops
+        if rep_on and D > 4:
+            exec_flops = n_classes * (rs["edge_products_on"] * (2 * D * D + 2 * D) + S_rank * (L * D + 2 * D))
         if bound == "mfma":
-            ach = flops / (prune_ms * 1e-3) / 1e12
+            ach = exec_flops / (prune_ms * 1e-3) / 1e12
             roof = dict(bound="mfma", achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=ach / FP64_MFMA_PEAK_TFLOPS, traffic=None)
+            roof["executed_flops_per_step"] = exec_flops
+            roof["repeat_ratio"] = rs["edge_products_on"] / max(1, rs["edge_products_off"]) if rep_on else 1.0
+            roof["effective_tflops"] = flops / (prune_ms * 1e-3) / 1e12
+            roof["subtree_repeats"] = dict(rs, note="first shard; edge products per full pass with / without class compression (tables padded to "
+                                                    "tiles of 16 classes, a path of k nodes walked once per 16 classes of its top node)")
         else:
             # 4 states.  SURVEY 8d's algorithmic bytes assume every internal conditional vector goes through HBM once each
             # way; the kernel keeps them on chip (registers / LDS parking, lazy persistence), so that model is not what the
@@ -711,6 +727,10 @@ def main():
                 roof["note"] = ("algorithmic bytes / time exceeds the HBM peak: the modelled traffic (every conditional vector through "
                                 "HBM) does not exist — see traffic_rate_gbs (PMC) and valu_tflops")
         roof["kernel"] = part.prune_kernel_name()
+        kernels = [roof["kernel"]]
+        if rep_on and D > 4:   # two launches per pass: the class tables (lower phase), then the trunk through the pruning kernel
+            kernels = ["class_table_kernel", roof["kernel"]]
+            roof["kernel"] = "class_table_kernel + " + roof["kernel"]
         if bound == "mfma":
             # measured ceiling of the instruction the kernel issues (tools/ubench/mfma4_skew.hip): v_mfma_f64_16x16x4_f64 with VGPR
             # accumulators sustains 73-78 TFLOP/s chip-wide from one operand pair and 66-72 with the kernel's own operand stream
@@ -724,7 +744,7 @@ def main():
         # kernel (levels of subtree fragments).  achieved = (algorithmic work of the pass / launches) / (mean
         # launch duration) = work of the pass / time of the pass; rocprofv3's per-launch average x launches
         # per step must agree with kernel_ms_per_step.
-        nl = part.prune_launches()
+        nl = part.prune_launches() + (1 if rep_on and D > 4 else 0)
         roof["launches_per_step"] = nl
         roof["kernel_ms_per_launch"] = prune_ms / nl
         roof["kernel_ms"] = prune_ms
@@ -738,7 +758,7 @@ def main():
         # HBM traffic per launch: measured now (two rocprofv3 counter passes of this same script), else the value of the
         # round's committed profile of the same workload and kernel, else null
         if N == 1 and not args.no_traffic and not args.no_cpu_baseline:
-            tr_ = measure_traffic(args.workload, roof["kernel"])
+            tr_ = measure_traffic(args.workload, kernels)
             if tr_:
                 roof["traffic"] = tr_["bytes_per_launch"]
                 roof["traffic_detail"] = tr_
