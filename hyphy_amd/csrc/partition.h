@@ -208,6 +208,7 @@ struct Shard {
   int2 *rep_leaf = nullptr;          // [view leaves] (table row0 or -1: ordinary leaf, exponent row0 / matrix slot)
   int rep_qcap = 0;                  // items per queue of the pass the device queues hold
   int rep_waves = 0;                 // waves its launch runs
+  int rep_static = 0;                // > 0: its items do not depend on one another and are dealt by position (RepArgs::n_static)
   bool rep_sync_dirty = false;       // a lower-phase launch has run and no trunk launch has reset rep_sync behind it yet
 };
 
@@ -250,7 +251,8 @@ struct hyphy_hip_partition {
   struct RepNode {                           // one class table (descriptor): a path of compressed internal nodes or a leaf with ambiguity codes
     int node = 0;                            // node code (partition's tree) of the node whose classes the table has: the path's top / the leaf
     int level = 0;                           // 0: no table among its inputs
-    std::vector<int> path;                   // compressed nodes walked by one wave, bottom first (empty: a leaf's table)
+    std::vector<int> path;                   // compressed nodes walked by one wave, in walking order (empty: a leaf's table)
+    std::vector<int> flags;                  // per walked node: 1 first node of a side chain walked inline, 2 its last node
     std::vector<std::vector<int>> kids;      // per path node: its children off the path (node codes)
     std::vector<std::vector<int>> kid_desc;  // ... descriptor of the child's table, -1: ordinary leaf (gathered by state code)
   };

@@ -49,9 +49,12 @@ namespace hyhip {
 //
 // Device descriptors (int4 words in Shard::rep_desc).  Descriptor d: header words 2 d, 2 d + 1.
 //   h0 = (first table row, classes U of the top node, path nodes | kind << 16, first node entry)
-//   h1 = (kind 1: offset of the code list in rep_map, tiles, level, kind 1: matrix slot of the leaf's branch / kind 0: inputs of the path)
-//   node entry  = (matrix slot of the node's branch, inputs, first input entry, 0), bottom of the path first; the path's input
-//                 entries follow its node entries, in path order
+//   h1 = (offset in rep_map of the code list (kind 1) / of the first input's index map (kind 0; the others follow, `rows` entries each),
+//         tiles, level, kind 1: matrix slot of the leaf's branch / kind 0: inputs of the path)
+//   node entry  = (matrix slot of the node's branch, inputs, first input entry, flags), in the order of the walk (bottom of the path
+//                 first; a side chain walked inline sits in front of the path node it hangs off).  flags 1: first node of an inline
+//                 chain (park the running product, start from ones), 2: its last node (multiply the parked product back in behind
+//                 the edge product).  The path's input entries follow its node entries, in the same order
 //   input entry = (first row of the input's table or -1: ordinary leaf, matrix slot of an ordinary leaf,
 //                  offset of the index map in rep_map (class of the TOP node -> row of the input / state of the leaf),
 //                  descriptor of the input's table | its tiles << 16, or -1)
@@ -86,6 +89,8 @@ struct RepArgs {
   size_t cs_P;
   const double *ambig;
   int n_waves;                // grid size
+  int n_static;               // > 0: no item of this pass reads a table of this pass — the items (this many) are dealt to the waves by
+                              // position (wave b: items b, b + n_waves, ..), nobody takes tickets, counts tiles or drains its stores
   long long *dbg;             // diagnostic (HYPHY_HIP_REP_TIMELINE): per wave [wall start, wall end, items, failed polls, shader cycles in
                               // tickets, waiting, gathers, product, publish, + first-item wall stamps] (16 words), or nullptr
 };
@@ -175,11 +180,24 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(const int4 *__restri
     sp++;
   };
 
-  int4 cur = pull();
+  int spos = blockIdx.x, round = 0;  // (n_static: this wave's next item)
+  auto next_item = [&]() -> int4 {
+    if (a.n_static > 0) {
+      if (spos >= a.n_static) return make_int4(-2, 0, 0, 0);
+      const int4 it = items[(size_t)(spos % kRepQueues) * a.qcap + spos / kRepQueues];
+      // (the items are in descending order of cost: back and forth over the waves, so that the wave with the longest first item
+      //  gets the shortest second one)
+      round++;
+      spos = round * a.n_waves + ((round & 1) ? a.n_waves - 1 - (int)blockIdx.x : (int)blockIdx.x);
+      return it;
+    }
+    return sp > 0 ? uni(held[--sp]) : pull();
+  };
+  int4 cur = next_item();
   REP_TR(4)
   while (cur.x != -2) {
     if (cur.x < 0) {  // padding behind the last item
-      cur = sp > 0 ? uni(held[--sp]) : pull();
+      cur = next_item();
       continue;
     }
     // Never wait for work nobody holds: an item is only worked on once the tickets of all its inputs are sold (every head beyond
@@ -254,10 +272,11 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(const int4 *__restri
       // C/D image is its B-operand image, common.h); everything else a node needs comes by class index from tables below the path
       // class indices of every input of the path (class of the top node -> row of the input's table / state of the leaf): one pass at
       // the start, four inputs per load instruction, parked in LDS
-      const int in0 = h0.w + n_nodes, n_in = h1.w;  // (the input entries of a path follow its node entries)
+      // (a descriptor's index maps lie one behind the other, `rows` entries each, in input order)
+      const int n_in = h1.w, map0 = h1.x, rows = h1.y * 16;
       for (int e0 = 0; e0 < n_in; e0 += 4) {
         const int e = e0 + g;
-        if (e < n_in) sidx[e * 16 + sl] = a.map[desc[in0 + e].z + u0 + sl];
+        if (e < n_in) sidx[e * 16 + sl] = a.map[map0 + e * rows + u0 + sl];
       }
       __syncthreads();
       // is the table behind input entry `ie` complete?  (one look; `block`: sleep until it is)
@@ -296,12 +315,23 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(const int4 *__restri
         }
       };
       f64x2 pv[2 * NW];  // the first input of the NEXT node, requested before this node's edge product
-      int pcnt = 0;
+      int pcnt = 0, park_cnt = 0;
       bool pf = false;
       int e_node = 0;    // first input (path-wide numbering) of the current node
       for (int k = 0; k < n_nodes; k++) {
         const int4 ne = desc[h0.w + k];  // (matrix slot of the node's branch, inputs, first input entry)
         if (k == 0) {
+#pragma unroll
+          for (int w = 0; w < NW; w++) acc[w] = ones;
+        }
+        if (ne.w & 1) {  // an inline side chain starts: the running product (ones in front of the walk's first node) waits in the wave's LDS tile
+#pragma unroll
+          for (int w = 0; w < NW; w++) {
+            *reinterpret_cast<f64x2 *>(stage + ((2 * w) * 64 + lane) * 2) = (f64x2){acc[w][0], acc[w][1]};
+            *reinterpret_cast<f64x2 *>(stage + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){acc[w][2], acc[w][3]};
+          }
+          park_cnt = cnt;
+          cnt = 0;
 #pragma unroll
           for (int w = 0; w < NW; w++) acc[w] = ones;
         }
@@ -348,6 +378,15 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(const int4 *__restri
           }
         }
         product(ne.x, [&](int k2) -> f64x2 { return (f64x2){acc[k2 >> 1][(k2 & 1) * 2], acc[k2 >> 1][(k2 & 1) * 2 + 1]}; });
+        if (ne.w & 2) {  // the chain's edge product joins the product it was walked for
+#pragma unroll
+          for (int w = 0; w < NW; w++) {
+            const f64x2 p0 = *reinterpret_cast<const f64x2 *>(stage + ((2 * w) * 64 + lane) * 2);
+            const f64x2 p1 = *reinterpret_cast<const f64x2 *>(stage + ((2 * w + 1) * 64 + lane) * 2);
+            acc[w] *= (f64x4){p0[0], p0[1], p1[0], p1[1]};
+          }
+          cnt += park_cnt;
+        }
         if constexpr (TRACE) asm volatile("" ::"v"(acc[0][0]));
         REP_TR(7)
       }
@@ -389,12 +428,14 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(const int4 *__restri
         __builtin_amdgcn_raw_buffer_store_b128(v, agent_rsrc(reinterpret_cast<const double *>(a.cnt + row)), (unsigned)lane * 16u, 0, 16);
       }
       __syncthreads();  // (the tile is free for the next item)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(done + (size_t)cur.x * kRepHeadStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.n_static == 0) {  // (somebody in this launch may be waiting for the table)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(done + (size_t)cur.x * kRepHeadStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     REP_TR(8)
     if constexpr (TRACE) tr[2]++;
-    cur = sp > 0 ? uni(held[--sp]) : pull();
+    cur = next_item();
     REP_TR(4)
   }
   if constexpr (TRACE) {
@@ -532,14 +573,12 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
     if (!(env && atoi(env) == 2) && (rep > (1.0 - need) * full || p->shards[0].ntiles < 8)) return 0;
   }
   // ---- descriptors: leaves with ambiguity codes first (level 0), then the paths, inputs before the paths that read them ----
-  double rho = 0.6;
-  {
-    long tiles = 0;
-    for (int n = 0; n < I; n++)
-      if (comp[n]) tiles += (U[0][n] + 15) / 16;
-    if (tiles < 2L * p->shards[0].cus * 8) rho = 0.;  // (a launch that does not fill the chip twice is bound by its dependency chain)
-    if (const char *e = getenv("HYPHY_HIP_REP_RHO")) rho = atof(e);
-  }
+  // rho: a path goes on into the heaviest compressed child while that child keeps at least rho of the node's classes.  0: paths
+  // run to the bottom of the subtree (no table hand-offs on the way up: the lower phase is bound by exactly those, not by its
+  // arithmetic — headline: 82 us of pruning launches against 131 with rho = 0.6, 128 x 100 k: 726 against 785 although the paths
+  // execute 3.4 x the products of the tables); larger values trade products for hand-offs (HYPHY_HIP_REP_RHO)
+  double rho = 0.;
+  if (const char *e = getenv("HYPHY_HIP_REP_RHO")) rho = atof(e);
   std::vector<int> heavy(I, -1);     // the compressed child a node's path continues into
   std::vector<char> continued(I, 0); // the node is inside its parent's path (no table of its own)
   std::vector<int> path_inputs(I, 0), path_len(I, 0);
@@ -570,25 +609,75 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
       p->rep_desc_of[l] = (int)p->rep_nodes.size();
       p->rep_nodes.push_back(rn);
     }
+  // Side chains walked inline (latency mode, rho = 0).  A side path whose nodes read leaves only — a cherry, a short caterpillar —
+  // hanging off another path is not worth a table of its own: its table would be one more hand-off in the dependency chain of the
+  // path that reads it (publish, drain, counter, poll, gather: ~8 us with the item's fixed costs) to save a few products.  Such a
+  // chain is walked INSIDE the item of the path it hangs off: the running product is parked in the wave's LDS tile, the chain
+  // is walked from ones, and its edge product is multiplied back in (one parking slot: inlined chains do not nest).
+  const bool inline_chains = getenv("HYPHY_HIP_REP_INLINE") ? atoi(getenv("HYPHY_HIP_REP_INLINE")) != 0 : rho == 0.;
+  auto chain_of = [&](int top) {
+    std::vector<int> down;
+    for (int x = top; x >= 0; x = heavy[x]) down.push_back(x);
+    return std::vector<int>(down.rbegin(), down.rend());  // bottom first
+  };
+  std::vector<char> leafy(I, 0);  // a path top whose whole path reads ordinary leaves / leaf tables only
   for (int n = 0; n < I; n++)
-    if (comp[n] && !continued[n]) {  // a path's top (ascending: every input's top comes first)
+    if (comp[n] && !continued[n]) {
+      bool ok = true;
+      for (int x : chain_of(n))
+        for (int c : p->children[x])
+          if (c >= L && c - L != heavy[x]) ok = false;
+      leafy[n] = ok ? 1 : 0;
+    }
+  // (first which chains go inline — the path they hang off decides, within what its LDS index list holds —, then the descriptors)
+  std::vector<char> absorbed(I, 0);
+  std::vector<std::vector<int>> inline_at(I);  // per path node: the side tops walked inline in front of it
+  if (inline_chains)
+    for (int n = 0; n < I; n++)
+      if (comp[n] && !continued[n]) {
+        int n_inputs = 0, n_entries = 0;
+        for (int x : chain_of(n)) n_inputs += (int)p->children[x].size() - (heavy[x] >= 0 ? 1 : 0), n_entries++;
+        for (int x : chain_of(n))
+          for (int c : p->children[x]) {
+            if (c < L || c - L == heavy[x] || !comp[c - L] || !leafy[c - L]) continue;
+            const std::vector<int> side = chain_of(c - L);
+            int side_inputs = 0;
+            for (int y : side) side_inputs += (int)p->children[y].size();
+            if (n_inputs + side_inputs > kRepMaxInputs - 8 || n_entries + (int)side.size() > 40) continue;
+            n_inputs += side_inputs - 1;  // (the chain's table would have been one input)
+            n_entries += (int)side.size();
+            absorbed[c - L] = 1;
+            inline_at[x].push_back(c - L);
+          }
+      }
+  for (int n = 0; n < I; n++)
+    if (comp[n] && !continued[n] && !absorbed[n]) {  // a path's top (ascending: every input's top comes first)
       hyphy_hip_partition::RepNode rn;
       rn.node = L + n;
       rn.level = 0;
-      std::vector<int> down;
-      for (int x = n; x >= 0; x = heavy[x]) down.push_back(x);
-      for (size_t k = down.size(); k-- > 0;) {
-        const int x = down[k];
+      auto add_node = [&](int x, int skip_child, int flags) {
         rn.path.push_back(L + x);
+        rn.flags.push_back(flags);
         rn.kids.push_back(std::vector<int>());
         rn.kid_desc.push_back(std::vector<int>());
         for (int c : p->children[x]) {
-          if (c >= L && c - L == heavy[x]) continue;  // (the node below on the path: comes through the registers)
+          if (c == skip_child) continue;  // (comes through the registers / was walked inline just before)
+          if (c >= L && absorbed[c - L]) continue;
           rn.kids.back().push_back(c);
           const int d = p->rep_desc_of[c];
           rn.kid_desc.back().push_back(d);
           if (d >= 0) rn.level = std::max(rn.level, p->rep_nodes[d].level + 1);
         }
+      };
+      const std::vector<int> main_path = chain_of(n);
+      for (size_t k = 0; k < main_path.size(); k++) {
+        const int x = main_path[k];
+        for (int c : inline_at[x]) {
+          const std::vector<int> side = chain_of(c);
+          for (size_t j = 0; j < side.size(); j++)
+            add_node(side[j], j > 0 ? L + side[j - 1] : -1, (j == 0 ? 1 : 0) | (j + 1 == side.size() ? 2 : 0));
+        }
+        add_node(x, k > 0 ? L + main_path[k - 1] : -1, 0);
       }
       p->rep_desc_of[L + n] = (int)p->rep_nodes.size();
       p->rep_nodes.push_back(rn);
@@ -692,11 +781,11 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
       desc[2 * d] = make_int4((int)t.row0, t.U, (int)rn.path.size() | (kind << 16), node0);
       int n_in = 0;
       for (const std::vector<int> &kk : rn.kids) n_in += (int)kk.size();
-      desc[2 * d + 1] = make_int4(kind ? (int)t.map0[0] : 0, t.rows / 16, rn.level, kind ? rn.node : n_in);
+      desc[2 * d + 1] = make_int4(t.map0.empty() ? 0 : (int)t.map0[0], t.rows / 16, rn.level, kind ? rn.node : n_in);
       desc.resize(desc.size() + rn.path.size());
       size_t mi = 0;
       for (size_t x = 0; x < rn.path.size(); x++) {
-        desc[node0 + x] = make_int4(rn.path[x], (int)rn.kids[x].size(), (int)desc.size(), 0);
+        desc[node0 + x] = make_int4(rn.path[x], (int)rn.kids[x].size(), (int)desc.size(), rn.flags[x]);
         for (size_t j = 0; j < rn.kids[x].size(); j++, mi++) {
           const int cd = rn.kid_desc[x][j];
           desc.push_back(make_int4(cd >= 0 ? (int)s.rep_tabs[cd].row0 : -1, rn.kids[x][j], (int)t.map0[mi],
@@ -847,7 +936,7 @@ void rep_translate_update(hyphy_hip_partition *p, const int64_t *update_nodes, i
 // to fill the gaps.  An item's `bound` = the queue index every head must have passed for all its inputs to be sold.
 // Returns items per queue.
 int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vector<int> &dirty, int cat0, int n_classes,
-                    std::vector<int4> &queues /* [kRepQueues][qcap] */) {
+                    std::vector<int4> &queues /* [kRepQueues][qcap] */, int *n_static = nullptr) {
   const int ND = (int)p->rep_nodes.size();
   std::vector<char> live(ND, 0);
   for (int d : dirty) live[d] = 1;
@@ -873,6 +962,11 @@ int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vec
       pos0[(size_t)d * n_classes + c] = (long)all.size();
       for (int t = 0; t < s.rep_tabs[d].rows / 16; t++) all.push_back(make_int4(d, t | ((cat0 + c) << 20), (int)all.size(), bound));
     }
+  if (n_static) {  // no item waits for another one of this pass?
+    *n_static = (int)all.size();
+    for (const int4 &it : all)
+      if (it.w > 0) *n_static = 0;
+  }
   while (all.size() % kRepQueues) all.push_back(make_int4(-1, 0, (int)all.size(), 0));
   const int per_q = (int)all.size() / kRepQueues;
   queues.assign((size_t)kRepQueues * std::max(1, per_q), make_int4(-1, 0, 0, 0));
@@ -893,7 +987,9 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
     std::vector<int4> queues;
-    const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues);
+    int n_static = 0;
+    const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues, &n_static);
+    s.rep_static = getenv("HYPHY_HIP_REP_STATIC") && atoi(getenv("HYPHY_HIP_REP_STATIC")) == 0 ? 0 : n_static;
     const size_t words = (size_t)kRepQueues * std::max(1, per_q) + (size_t)(ND + 3) / 4;  // queues, then the live flags
     if (words > s.rep_items_cap) {
       HIPCHK(hipStreamSynchronize(s.stream));
@@ -954,6 +1050,7 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
   a.cs_P = (size_t)p->B * p->DP * p->DP;
   a.ambig = s.ambig;
   a.n_waves = s.rep_waves;
+  a.n_static = s.rep_static;
   a.dbg = nullptr;
   // queue heads and counters are zero between launches: the trunk's pruning launch that follows resets them (PruneArgs::rep_sync);
   // should a launch not have been followed by one (a failed evaluation), they are cleared here

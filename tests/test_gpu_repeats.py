@@ -30,12 +30,14 @@ def _site(lik, sc):
     return np.log(lik) - sc * LOG_SCALER
 
 
-@pytest.mark.parametrize("rho", ["0", "0.6", "2"])
+@pytest.mark.parametrize("rho,inline", [("0", "1"), ("0", "0"), ("0.6", "0"), ("0.6", "1"), ("2", "0"), ("2", "1")])
 @pytest.mark.parametrize("name", ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "ref_smallcodon"])
-def test_compressed_equals_plain_and_reference(name, rho, monkeypatch):
+def test_compressed_equals_plain_and_reference(name, rho, inline, monkeypatch):
     """Full passes (first: every node stored; then steady state), per-pattern values and 2^64 exponents: compressed against plain
-    against the reference.  rho = 2: one table per node; 0.6: paths while the child keeps 60 % of the classes; 0: longest paths."""
+    against the reference.  rho = 2: one table per node; 0.6: paths while the child keeps 60 % of the classes; 0: longest paths.
+    inline: leaf-only side chains walked inside the item of the path they hang off (the default with rho = 0) or as tables."""
     monkeypatch.setenv("HYPHY_HIP_REPEATS", "2")
+    monkeypatch.setenv("HYPHY_HIP_REP_INLINE", inline)
     monkeypatch.setenv("HYPHY_HIP_REP_RHO", rho)
     monkeypatch.setenv("HYPHY_HIP_REP_THETA", "0.9")
     monkeypatch.setenv("HYPHY_HIP_POISON", "1")
