@@ -3,13 +3,14 @@
 # any of: line workloads stats pmc nuc adapter phases ubench)
 #   bench_driver_line.json   the driver's exact command (CPU baseline with thread sweep, parity, live PMC traffic, value_cold)
 #   all_workloads.txt        one line per workload with the schedule tuner's report
-#   stats/                   rocprofv3 --kernel-trace --stats, tuner off and the production cut forced (steady-state averages)
+#   stats/                   rocprofv3 --kernel-trace --stats, tuner off: subtree repeats on and the trunk's production cut forced
+#                            (steady-state averages)
 #   pmc_<workload>/          separate --pmc passes, production cut forced: SQ sets (wave cycles, instruction mix, MFMA pipe),
 #                            FETCH_SIZE, WRITE_SIZE
 #   adapter_rate.jsonl       evaluations per second through the real host (tools/adapter_rate.py)
 #   phases_*.txt             where a wave's cycles go (trace build of the wave kernel, tools/timeline_waves.py)
 #   ubench_*.txt             instruction / edge-product / edge+leaf microbenchmarks (tools/ubench)
-R=${1:-r04}; PARTS=${2:-all}
+R=${1:-r05}; PARTS=${2:-all}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
 has() { [ "$PARTS" = all ] || echo "$PARTS" | grep -qw "$1"; }
@@ -35,7 +36,7 @@ done > $OUT/all_workloads.txt 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp
 if has stats; then
-  HYPHY_HIP_CHAIN_M=12 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > $OUT/stats.log 2>&1
+  HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=12 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > $OUT/stats.log 2>&1
 fi
 pmc() { wl=$1; shift
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
@@ -46,8 +47,8 @@ pmc() { wl=$1; shift
   done
 }
 if has pmc; then
-  pmc mg94_64x10k HYPHY_HIP_CHAIN_M=12
-  pmc mg94_128x100k HYPHY_HIP_CHAIN_M=40
+  pmc mg94_64x10k HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=12
+  pmc mg94_128x100k HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=16
 fi
 if has nuc; then
   pmc gtr_32x1m X=1

@@ -50,6 +50,11 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         b = last_json(wj)
         kern, ms = b["roofline"]["kernel"], b["roofline"]["kernel_ms_per_launch"]
         pm = means_all[wl].get(kern, {})
+        if " + " in kern:   # a class-compressed pass: lower phase + trunk, two launches whose traffic adds up
+            parts = [means_all[wl].get(k.strip(), {}) for k in kern.split("+")]
+            if all("FETCH_SIZE" in q and "WRITE_SIZE" in q for q in parts):
+                pm = {c: sum(q[c] for q in parts) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+            ms = b["roofline"]["kernel_ms"]
         if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
             bytes_ = (2 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
             traffic[wl] = {"kernel": kern, "FETCH_SIZE_KB": pm["FETCH_SIZE"], "WRITE_SIZE_KB": pm["WRITE_SIZE"],
@@ -99,6 +104,18 @@ for wl in ("mg94_64x10k", "mg94_128x100k"):
                   "mfma_pipe_busy_fraction (counter: 64 cycles per v_mfma_f64_16x16x4_f64)": pm["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles),
                   "mfma_instruction": "v_mfma_f64_16x16x4_f64 only (VGPR accumulators; tools/ubench/mfma4_skew.hip: 66-72 TFLOP/s with the kernel's operand stream)",
                   "LDS_bank_conflict_cycles": pm.get("SQ_LDS_BANK_CONFLICT")})
+        pc = means_all.get(wl, {}).get("class_table_kernel", {})
+        if "SQ_INSTS_MFMA" in pc:   # subtree repeats: the lower phase is a launch of its own
+            uc = wave_cycle_table(pc)
+            cyc = pc["GRBM_GUI_ACTIVE"] / 8.0
+            uc.update({"SQ_INSTS_MFMA": pc["SQ_INSTS_MFMA"], "SQ_VALU_MFMA_BUSY_CYCLES": pc.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+                       "mfma_pipe_busy_fraction (counter: 64 cycles per v_mfma_f64_16x16x4_f64)": pc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cyc) if cyc else None})
+            u = {"prune_wave_kernel (trunk)": u, "class_table_kernel (lower phase)": uc,
+                 "SQ_INSTS_MFMA_per_evaluation": pm.get("SQ_INSTS_MFMA", 0.0) + pc["SQ_INSTS_MFMA"],
+                 "SQ_INSTS_MFMA_per_evaluation_without_repeats (r04, every internal edge at every pattern)": 2436096 if wl == "mg94_64x10k" else None,
+                 "mfma_pipe_busy_fraction (counter: 64 cycles per v_mfma_f64_16x16x4_f64)":
+                     (pm["SQ_VALU_MFMA_BUSY_CYCLES"] + pc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)) / (1024 * (cycles + cyc)),
+                 "mean_resident_waves_per_simd": u["mean_resident_waves_per_simd"]}
         util[wl] = u
         print(wl, "MFMA pipe busy", round(u["mfma_pipe_busy_fraction (counter: 64 cycles per v_mfma_f64_16x16x4_f64)"], 3),
               "resident waves/SIMD", round(u["mean_resident_waves_per_simd"] or 0, 2))
