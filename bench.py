@@ -51,6 +51,10 @@ WORKLOADS = {
     # configs[2]: BUSTED-style, 3 omega classes (weights .7/.25/.05, omega .1/1/5 scaled by the swept factor),
     # classes batched into one expm launch + one pruning launch, mixed on the device
     "busted3_64x10k": dict(taxa=64, sites=10000, unit=3, seed=3, classes=3),
+    # configs[2] in the form BUSTED really runs: explicit-form branch-site mixture, P_b = sum_m w_m exp(Q_b(omega_m)), M = 3 components
+    # (weights .6/.3/.1, omegas .1/1/5 x the swept factor); 375 component matrices built and exponentiated on the device per step,
+    # mixed into 125 transition matrices, ONE pruning pass (hyphy_hip_build_q + hyphy_hip_evaluate_mixture_built)
+    "mix3_64x10k": dict(taxa=64, sites=10000, unit=3, seed=3, mixture=3),
     "gtr_32x50k": dict(taxa=32, sites=50000, unit=1, seed=5, p_change=0.25),   # one partition of configs[4]
     "gtr_32x1m": dict(taxa=32, sites=1000000, unit=1, seed=6, p_change=0.25),  # same shape, large enough to leave the L2/MALL
 }
@@ -217,6 +221,51 @@ def cpu_baseline(wl, syn, omega0, t_branch, n_threads, steps, budget_s=20.0):
                      f"hyphy 2.5.100 built by oracle/Makefile.ref, NUMBER_THREADS={n_threads} (best of this run's thread sweep: cpu_baseline.thread_sweep)",
               seconds=best["seconds"],
               one_thread=dict(value=out[1]["value"], unit="evals/s", cores=1, evals=out[1]["evals"], seconds=out[1]["seconds"]))
+    return cb, ref
+
+
+MIX_OMEGAS = (0.1, 1.0, 5.0)
+MIX_WEIGHTS = (0.6, 0.3, 0.1)
+
+
+def cpu_baseline_mixture(wl, syn, t_branch, steps, n_threads=16, budget_s=20.0):
+    """The reference on the explicit-form mixture workload (BS_REL.bf:48; tree.cpp:3047-3090): LFCompute with the second component's
+    omega swept exactly as the GPU loop sweeps it, timed as the difference of two runs of different length, NUMBER_THREADS fixed at 16
+    (the best count of the headline workload's sweep; no sweep of its own: one evaluation costs 3 x the headline's exponentials)."""
+    from oracle import hbl
+    from hyphy_amd import tree as htree
+    if not hbl.have_reference():
+        return None, None
+    tmpl = models.mg94rev_template(POS_FREQS)
+    pi = models.f3x4_codon_freqs(POS_FREQS)
+    M = wl["mixture"]
+    g = dict(REV)
+    for m in range(M):
+        g[f"R{m + 1}"] = MIX_OMEGAS[m]
+    for m in range(M - 1):
+        g[f"W{m + 1}"] = MIX_WEIGHTS[m]
+    wexpr = [f"W{m}" for m in range(1, M)] + ["(1" + "".join(f"-W{m}" for m in range(1, M)) + ")"]
+    block = hbl.codon_mixture_model_block(tmpl, pi, [f"R{m}" for m in range(1, M + 1)], wexpr)
+    bt = {n: t_branch for n in syn.flat.branch_names()}
+    n_long = int(max(12, budget_s * 14.0))
+    n_short = max(2, n_long // 10)
+    secs, ref = {}, {}
+    for n in (n_short, n_long):
+        rec = min(steps, n) if n == n_long else 0
+        t0 = time.perf_counter()
+        res = hbl.evaluate(names=syn.flat.leaf_names, seqs=syn.seqs, newick=htree.to_newick(syn.tree), unit=3, model_block=block,
+                           model_name="MGM", globals_=g, branch_t=bt, upper_bounds={f"W{m}": 1.0 for m in range(1, M)},
+                           sweep=dict(param="R2", start=MIX_OMEGAS[1], step=0.001, n=n, record=rec), threads=n_threads, per_site=False,
+                           timeout=1800.0)
+        secs[n] = time.perf_counter() - t0
+        ref["logl"] = res["logl"]
+        if rec:
+            ref["sweep_values"] = res.get("sweep_values")
+    dt = max(secs[n_long] - secs[n_short], 1e-3)
+    cb = dict(value=(n_long - n_short) / dt, unit="evals/s", cores=n_threads, kind="reference",
+              sample=f"{n_long - n_short} LFCompute calls of the explicit-form {M}-component mixture with R2 swept in {dt:.1f} s (difference of two "
+                     f"runs of the same script with different loop lengths) on the same alignment/tree, reference hyphy built by "
+                     f"oracle/Makefile.ref, NUMBER_THREADS={n_threads}", seconds=dt)
     return cb, ref
 
 
@@ -451,6 +500,7 @@ def main():
     omega0 = 0.3
 
     n_classes = wl.get("classes", 1)
+    n_mix = wl.get("mixture", 0)
     part = hip.HipPartition(D, flat.flat_parents, L, codes, None, freq, C_cat=n_classes,
                             device_first=(local if multi else 0), device_count=(N if single else 1))
     part.set_q_templates(T)
@@ -497,7 +547,15 @@ def main():
     class_omega = np.array([0.1, 1.0, 5.0][:n_classes]) / 0.3 if n_classes > 1 else np.array([1.0])
     class_w = np.array([0.7, 0.25, 0.05])
     ar_step = None
-    if n_classes > 1:
+    if n_mix:
+        # explicit-form mixture: one coefficient row per (branch, component); the second component's omega is what the loop sweeps
+        mix_coeffs = np.empty((B, n_mix, 2))
+        mix_coeffs[:, :, 0] = tb[:, None]
+        mix_coeffs[:, :, 1] = tb[:, None] * np.array(MIX_OMEGAS[:n_mix])[None, :]
+        mix_w = np.ascontiguousarray(np.tile(np.array(MIX_WEIGHTS[:n_mix]), (B, 1)))
+        mix_step = part.prepare_mixture_built_step(nodes, nodes, mix_w, pi, mix_coeffs)
+        sync_step = enqueue = fetch = None
+    elif n_classes > 1:
         cat_step = part.prepare_built_categories_step(nodes, nodes, class_w, pi, coeffs)
     else:
         enqueue = part.prepare_device_step(nodes, nodes, pi, d_logl.data_ptr(), coeffs)
@@ -506,6 +564,14 @@ def main():
         ar_step = part.prepare_built_allreduce_step(nodes, nodes, pi, coeffs) if collective == "cabi" else None
 
     def step(k, sync=True, force_torch=False):
+        if n_mix:
+            np.multiply(tb, MIX_OMEGAS[1] + 0.001 * k, out=mix_coeffs[:, 1, 1])   # R2 = 1.0 + 0.001 k on every branch
+            v = mix_step()
+            if multi:   # (a rank's partial log-L over its patterns)
+                d_logl[0] = v
+                hdist.allreduce_logl(d_logl[:1])
+                v = float(d_logl[0].item())
+            return v
         omega = omega0 + 0.001 * k
         if n_classes > 1:
             coeffs[:, 1] = np.repeat(class_omega * omega, B) * coeffs[:, 0]
@@ -607,7 +673,7 @@ def main():
     pt = part.prune_timings(min(max(1, args.steps // TIMING_EVERY), 1024))
     t_prune = float(pt.sum()) * (args.steps / max(1, len(pt)))
     t_exp = t_red = None
-    if n_classes == 1:
+    if n_classes == 1 and not n_mix:
         # expm (incl. the fused rate-matrix build) and reduction kernels: event-timed on a few extra steps AFTER the
         # timed region (two more event records per step would perturb it)
         part.set_all_timings(True)
@@ -644,7 +710,7 @@ def main():
                 collective_ab[name + "_ms_per_step"] = 1e3 * max_over_ranks(dist, ctl, time.perf_counter() - ta) / 8
 
     branch_cache = None
-    if args.branch_cache and n_classes == 1 and N == 1 and D > 4 and collective == "none":
+    if args.branch_cache and n_classes == 1 and not n_mix and N == 1 and D > 4 and collective == "none":
         # one-branch line search (the optimiser's inner loop): all parameters fixed, ONE branch
         # length varies; each evaluation = 1 expm + 1 [D x D] x [D x S] contraction + reduction
         node = L + I // 2                                  # an internal branch in the middle of the tree
@@ -674,11 +740,11 @@ def main():
                         "rel_err_vs_full": abs(same - full) / abs(full), "logl_last": lastb}
 
     site_fits = None
-    if args.site_fits > 0 and n_classes == 1 and N == 1 and D > 4:
+    if args.site_fits > 0 and n_classes == 1 and not n_mix and N == 1 and D > 4:
         site_fits = time_site_fits(part, args, wl, pd_all, flat, T, pi, tb)
 
     pipelined = None
-    if args.pipelined and n_classes == 1:
+    if args.pipelined and n_classes == 1 and not n_mix:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for k in range(args.steps):
@@ -793,7 +859,9 @@ def main():
                        **({"collective_note": collective_note} if collective_note else {}),
                        **({"DIAGNOSTIC": "HYPHY_BENCH_SHARE_DEVICE: all ranks ran on ONE device over gloo — the N > 1 code path was walked, the rate means nothing"} if share else {}),
                        "patterns_rank0": int(S_rank),
-                       "step": "device Q build + expm of all branches + full pruning pass + reduction" +
+                       **({"mixture_components": n_mix, "mixture_weights": list(MIX_WEIGHTS[:n_mix]), "mixture_omegas": list(MIX_OMEGAS[:n_mix])} if n_mix else {}),
+                       "step": ("device build + expm of every component of every branch + mixing into the branches' matrices + full pruning pass + reduction" if n_mix else
+                                "device Q build + expm of all branches + full pruning pass + reduction") +
                                (" + RCCL all-reduce" if (multi or collective == "cabi") else "") + ", log-L returned to host every step"},
             "logl_first": ll0, "logl_last": last,
             "roofline": roof,
@@ -807,7 +875,23 @@ def main():
             out.update(top_m)
         if pipelined:
             out["value_pipelined_no_host_sync"] = pipelined
-        if not args.no_cpu_baseline and N == 1 and n_classes == 1:
+        if not args.no_cpu_baseline and N == 1 and n_mix:
+            try:
+                cb, ref = cpu_baseline_mixture(wl, syn, t_branch, args.steps)
+            except Exception as e:
+                sys.stderr.write(f"[bench] reference baseline unavailable: {e}\n")
+                cb = ref = None
+            if cb is not None:
+                out["cpu_baseline"] = cb
+                par = {"logl_gpu": ll0, "logl_cpu": ref["logl"], "rel_err": abs(ll0 - ref["logl"]) / abs(ref["logl"]), "tolerance": 1e-6}
+                sv = ref.get("sweep_values")
+                if sv is not None and len(sv):
+                    n = min(len(sv), args.steps)
+                    rel = np.abs(np.array(timed_values[:n]) - sv[:n]) / np.abs(sv[:n])
+                    par["timed_points_checked"] = int(n)
+                    par["timed_points_max_rel_err"] = float(rel.max())
+                out["parity"] = par
+        elif not args.no_cpu_baseline and N == 1 and n_classes == 1:
             cb = ref = sweep = None
             try:
                 from oracle import hbl

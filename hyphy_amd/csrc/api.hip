@@ -83,6 +83,35 @@ void refresh_twins(hyphy_hip_partition *p, Shard &s) {
 }
 
 // Everything in a PruneArgs that does not depend on the schedule being launched.
+// Edge products of the non-last arrivers of a chain schedule: one tile per (class, internal node of the view, tile).  Sized for the
+// tree the schedules are cut from — the trunk when the partition runs class-compressed (16 of 62 internal nodes at the headline
+// workload, 20 of 127 at 128 x 100 k: 1.0 GB instead of 6.5) — and grown when a larger view needs it.
+int ensure_deposits(hyphy_hip_partition *p, Shard &s) {
+  const size_t node_stride = (size_t)s.ntiles * 16 * p->DP;
+  const size_t class_stride = (size_t)p->vw().I * node_stride;
+  const size_t need = (size_t)p->C * class_stride;
+  if (s.deposits && s.deposits_cap >= need) {
+    s.deposits_class_stride = class_stride;
+    return 0;
+  }
+  if (s.deposits) {
+    HIPCHK(hipStreamSynchronize(s.stream));
+    pool_free_sync(s.deposits);
+    s.dev_bytes -= s.deposits_cap * sizeof(double);
+    s.deposits = nullptr;
+    s.deposits_cap = 0;
+  }
+  HIPCHK(pool_malloc((void **)&s.deposits, need * sizeof(double)));
+  s.deposits_cap = need;
+  s.deposits_class_stride = class_stride;
+  s.dev_bytes += need * sizeof(double);
+  if (getenv("HYPHY_HIP_POISON")) {
+    HIPCHK(hipMemset(s.deposits, 0xff, need * sizeof(double)));
+    HIPCHK(hipDeviceSynchronize());
+  }
+  return 0;
+}
+
 PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch) {
   const int64_t B = p->B;
   const int DP = p->DP;
@@ -181,14 +210,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       HIPCHK(hipMemcpyAsync(s.jn, s.h_jn, p->jn_host.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
     }
   }
-  if (p->chain && !s.deposits) {  // edge products of non-last arrivers: one tile per (class, node, tile), like `partials`
-    const size_t bytes = (size_t)p->C * s.partial_stride * sizeof(double);
-    HIPCHK(pool_malloc((void **)&s.deposits, bytes));
-    if (getenv("HYPHY_HIP_POISON")) {
-      HIPCHK(hipMemset(s.deposits, 0xff, bytes));
-      HIPCHK(hipDeviceSynchronize());
-    }
-  }
+  if (p->chain && ensure_deposits(p, s)) return -1;
   // root frequencies, zero padded (uploaded only when they change)
   if (pi_changed) {
     std::vector<double> pi(p->nuc ? 4 : DP, 0.0);
@@ -432,6 +454,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     pa.chain = p->chain ? 1 : 0;
     pa.jn = s.jn;
     pa.deposits = s.deposits;
+    pa.cs_deposits = s.deposits_class_stride;
     // Fused final combine: the launch that finalises the roots also sums the per-tile partial sums and publishes the record —
     // the last root-finalising wave does what wg_reduce_kernel would do in a launch of its own (prune.hip: publish_partial).
     // Saves 1.5-3 us per evaluation of a small shard (below two tiles per CU; 64 x 1 250: 69.1 -> 67.7 us, 32 x 5 000: 79.8 ->
@@ -851,6 +874,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
       hyphy_hip_destroy(p);                                                                                  \
       return fail("hipMalloc failed (" #ptr ")");                                                            \
     }                                                                                                        \
+    s.dev_bytes += (size_t)(n);                                                                              \
     if (poison && !getenv("HYPHY_HIP_NOPOISON_" #ptr)) {                                                     \
       hipMemset((ptr), 0xff, (n));                                                                           \
       hipDeviceSynchronize();                                                                                \

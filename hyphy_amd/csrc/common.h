@@ -93,6 +93,7 @@ struct PruneArgs {
   const int4 *jn;            // [I] per internal node: (parent internal index or -1, arrivals needed | sum of internal child
                              //     indices << 8, offset of the node's trunk entries in ops, number of entries)
   double *deposits;          // [I][ntiles][NKK*64] edge product of (node -> parent), written by non-last arrivers
+  size_t cs_deposits = 0;    //     class stride (I = internal nodes of the view the schedule was cut from)
                              //     (exponents: hand_cnt; arrival counters: frag_ctr indexed by node)
   int n_slots;               // LDS slots the schedule was compiled for (2 exchange + parking)
   const double *Pfrag;       // [B][NW][NKK*64]      A-operand images of the transition matrices

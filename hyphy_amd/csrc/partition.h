@@ -134,7 +134,9 @@ struct Shard {
   size_t mix_cap = 0, mix_nq_cap = 0;
   int4 *jn = nullptr;         // chain schedules: per internal node (parent, arrivals needed | child sum << 8, trunk entries offset, count)
   int4 *h_jn = nullptr;
-  double *deposits = nullptr; // chain schedules: [C][I][ntiles][TILE] edge products of non-last arrivers (allocated on first use)
+  double *deposits = nullptr; // chain schedules: [C][view's I][ntiles][TILE] edge products of non-last arrivers (allocated on first use: ensure_deposits)
+  size_t deposits_cap = 0, deposits_class_stride = 0;  // doubles
+  size_t dev_bytes = 0;       // device memory this shard holds
   int *frag_ctr = nullptr;    // [classes][programs][tiles] arrivals of child fragments (wave-per-tile kernel)
   int32_t *hand_cnt = nullptr;  // [classes][I][tiles][32] 2^64-exponents of fragment roots (own 128-byte line each)
   double *pi = nullptr;       // [DP]
@@ -365,6 +367,7 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch);
 // api.hip
 void refresh_twins(hyphy_hip_partition *p, Shard &s);
 PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch);
+int ensure_deposits(hyphy_hip_partition *p, Shard &s);
 int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update, const int64_t *q_nodes,
                 int64_t n_q, const double *q, bool q_on_device, int q_is_probability, const double *root_freqs,
                 double *d_logl_out, bool reduce, bool floor_log, bool batch = false, bool force_persist = false,

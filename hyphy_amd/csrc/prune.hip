@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
     if (CHAIN) {
       a.frag_ctr += cat * (size_t)a.n_prog_total * a.ntiles;
       a.hand_cnt += cat * (size_t)(a.root_inode + 1) * a.ntiles * 32;
-      a.deposits += cat * a.cs_partials;
+      a.deposits += cat * a.cs_deposits;
     }
     a.Pfrag += cat * a.cs_P;
     a.PTg += cat * a.cs_P;
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
     a.Pfrag += cat * a.cs_P;
     a.PTg += cat * a.cs_P;
     a.partials += cat * a.cs_partials;
-    a.deposits += cat * a.cs_partials;
+    a.deposits += cat * a.cs_deposits;
     a.counts += cat * a.cs_counts;
     a.site_lik += cat * a.cs_site;
     a.site_cnt += cat * a.cs_site;

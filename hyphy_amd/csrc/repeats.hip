@@ -809,7 +809,8 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
     }
     const size_t sync_words = ((size_t)kRepQueues + 1 + (size_t)p->C * ND) * kRepHeadStride;  // (= rep_sync_words(p) words)
 #define R_(ptr, bytes)                                                                  \
-  if (pool_malloc((void **)&(ptr), (bytes)) != hipSuccess) return fail("hipMalloc failed (" #ptr ")");
+  if (pool_malloc((void **)&(ptr), (bytes)) != hipSuccess) return fail("hipMalloc failed (" #ptr ")"); \
+  s.dev_bytes += (size_t)(bytes);
     R_(s.rep_tab, (size_t)p->C * rows * DP * sizeof(double));
     R_(s.rep_cnt, (size_t)p->C * rows * sizeof(int32_t));
     R_(s.rep_map, std::max<size_t>(1, maps.size()) * sizeof(int32_t));
@@ -1120,6 +1121,15 @@ int rep_decide(hyphy_hip_partition *p, int cat, int n_classes) {
     p->rep_enabled = false;  // (stays under views[0]; the caller rebuilds the schedule)
   } else {
     switch_mode(p, 1);
+    for (Shard &sh : p->shards)  // (the plain form's tuning sized the chain deposits for every internal node: back to the trunk's)
+      if (sh.deposits) {
+        HIPCHK(hipSetDevice(sh.device));
+        HIPCHK(hipStreamSynchronize(sh.stream));
+        pool_free_sync(sh.deposits);
+        sh.dev_bytes -= sh.deposits_cap * sizeof(double);
+        sh.deposits = nullptr;
+        sh.deposits_cap = 0;
+      }
   }
   return 0;
 }

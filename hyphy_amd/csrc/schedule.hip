@@ -208,7 +208,7 @@ void build_schedule_impl(hyphy_hip_partition *p, const int64_t *update_nodes, in
   // edge product towards the parent and arrives there, the last arriver finalises the parent and goes on (prune.hip).
   // The critical path of a tile is then the height of the tree (not the size of its largest fragment), and the grid is
   // dispatched source-major with the sources sorted by their distance to the root, so that every tile's critical path
-  // starts first and the short chains that join near the root fill the end of the launch (tools/flow_sim.py).
+  // starts first and the short chains that join near the root fill the end of the launch.
   // (HYPHY_HIP_CUT=levels or an explicit HYPHY_HIP_FRAGMENT keep the level-peeled fragments; HYPHY_HIP_CHAIN_M sets m)
   const bool want_levels = (getenv("HYPHY_HIP_CUT") && !strcmp(getenv("HYPHY_HIP_CUT"), "levels")) ||
                            (getenv("HYPHY_HIP_FRAGMENT") && !getenv("HYPHY_HIP_CHAIN_M")) ||
@@ -694,6 +694,10 @@ const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p) {
            p->programs.size());
   out = p->tune_report + buf;
   if (!p->rep_report.empty()) out += " {" + p->rep_report + "}";
+  if (!p->shards.empty()) {
+    snprintf(buf, sizeof buf, " [device memory, first shard: %.1f MB]", p->shards[0].dev_bytes / 1e6);
+    out += buf;
+  }
   return out.c_str();
 }
 

@@ -22,14 +22,7 @@ int upload_schedule(hyphy_hip_partition *p, Shard &s) {
   if (p->chain) {
     memcpy(s.h_jn, p->jn_host.data(), p->jn_host.size() * sizeof(int4));
     HIPCHK(hipMemcpyAsync(s.jn, s.h_jn, p->jn_host.size() * sizeof(int4), hipMemcpyHostToDevice, s.stream));
-    if (!s.deposits) {
-      const size_t bytes = (size_t)p->C * s.partial_stride * sizeof(double);
-      HIPCHK(pool_malloc((void **)&s.deposits, bytes));
-      if (getenv("HYPHY_HIP_POISON")) {
-        HIPCHK(hipMemset(s.deposits, 0xff, bytes));
-        HIPCHK(hipDeviceSynchronize());
-      }
-    }
+    if (ensure_deposits(p, s)) return -1;
   }
   return 0;
 }
@@ -45,6 +38,7 @@ void launch_prune_current(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
   pa.chain = p->chain ? 1 : 0;
   pa.jn = s.jn;
   pa.deposits = s.deposits;
+  pa.cs_deposits = s.deposits_class_stride;
   if (const char *ab = getenv("HYPHY_HIP_ABLATE")) pa.ablate = atoi(ab);
   for (size_t lv = 0; lv < p->levels.size(); lv++) {
     pa.prog = s.prog + p->levels[lv].first;

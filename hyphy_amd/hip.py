@@ -317,6 +317,31 @@ class HipPartition:
                                                           C.byref(out), _d(sl), _l(sc)))
         return (out.value, sl, sc) if per_site else out.value
 
+    def prepare_mixture_built_step(self, update_nodes, q_nodes, weights, root_freqs, coeffs: np.ndarray, cat: int = -1):
+        """Zero-argument callable: ``build_q`` of one coefficient row per (branch, component) + ``evaluate_mixture_built`` -> log-L.
+        ``coeffs`` [n_q, M, K] and ``weights`` [n_q, M] are read at call time."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        assert coeffs.flags.c_contiguous and coeffs.dtype == np.float64 and coeffs.ndim == 3 and coeffs.shape[0] == len(qn)
+        assert weights.flags.c_contiguous and weights.dtype == np.float64 and weights.shape == coeffs.shape[:2]
+        cnt = np.full(len(qn), coeffs.shape[1], dtype=np.int64)
+        keep = (un, qn, rf, coeffs, weights, cnt)
+        lib, h = self._lib, self._h
+        pun, pqn, prf, pco, pw, pcnt = _l(un), _l(qn), _d(rf), _d(coeffs), _d(weights), _l(cnt)
+        nun, nqn, nrows = len(un), len(qn), coeffs.shape[0] * coeffs.shape[1]
+        out = C.c_double(0.0)
+        pout = C.byref(out)
+
+        def step(_keep=keep):
+            rc = lib.hyphy_hip_build_q(h, nrows, pco)
+            if rc == 0:
+                rc = lib.hyphy_hip_evaluate_mixture_built(h, cat, pun, nun, pqn, nqn, pcnt, pw, prf, pout, None, None)
+            if rc:
+                _check(rc)
+            return out.value
+        return step
+
     def evaluate_async(self, update_nodes, q_nodes, q_dense, root_freqs, cat: int = -1, q_is_probability: bool = False):
         """Enqueue an evaluation and return at once (``collect`` waits for it): lets the partitions of one
         likelihood function overlap on different devices / streams."""

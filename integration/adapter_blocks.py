@@ -8,6 +8,7 @@ HELPERS = r'''
 #ifdef HYPHY_HIP
 // ===== MI355X likelihood core: host adapter (see INTEGRATION.md) =====================================
 #include "hyphy_hip.h"
+#include <algorithm>
 #include <map>
 #include <unordered_map>
 #include <cstdlib>
@@ -1017,10 +1018,59 @@ static bool _hyhip_finish_mixture_call(_HyHipPart &hp, _TheTree *t, long catID) 
 static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue, _SimpleList &parallel,
                                      _SimpleList &isExplicitForm, bool hasExpForm) {
   if (_hyhip_defer_depth <= 0) return false;
-  if (_hyhip_force_defer_call) {  // mixture template mode took decisions in the first loop: it finishes the call, whatever is queued
+  if (_hyhip_force_defer_call) {  // mixture template mode took decisions in the first loop: it finishes the call
     _hyhip_force_defer_call = false;
     _HyHipPart *mp = _hyhip_part_of_tree(t);
-    return mp ? _hyhip_finish_mixture_call(*mp, t, catID) : false;
+    if (!mp) return false;
+    _HyHipPart &fp = *mp;
+    const long fcat = catID < 0 ? 0 : catID;
+    // A "true" from here makes the host drop its queues.  That is only right when every queued node is one the mixture analysis of
+    // THIS call handled (its probes and verifier; the skipped branches never entered the queue): a queue that also holds other
+    // recomputed branches — not of the explicit-form group, or left over by the ordinary template mode — is finished by the host
+    // (the call counts as broken: the skipped branches are recomputed by the host's own formula and nothing is dropped).
+    {
+      const _HyHipPart::MCall &mc = fp.mcall;
+      bool foreign = false;
+      for (unsigned long id = 0; id < nodesToDo.lLength && !foreign; id++) {
+        auto c = fp.code_of.find(nodesToDo(id));
+        if (c == fp.code_of.end()) {
+          foreign = true;
+          break;
+        }
+        const long code = c->second;
+        foreign = !(std::find(mc.probe.begin(), mc.probe.end(), code) != mc.probe.end() || code == mc.verify ||
+                    std::find(mc.skipped.begin(), mc.skipped.end(), code) != mc.skipped.end());
+      }
+      if (foreign) fp.mcall.broken = true;
+    }
+    if (fp.call.active) {
+      // the ordinary template mode skipped branches in the same call and will not be finalised for it (this branch returns before
+      // that code): take them the normal way — dense, exponentiated on the device — and close the call
+      const long D = t->GetCodeBase(), DD = D * D;
+      if (fcat < (long)fp.qstash.size() && fp.call.cat == fcat) {
+        if (fp.qstash[fcat].empty()) fp.qstash[fcat].assign((size_t)(fp.code_of.size()) * DD, 0.);
+        for (long code : fp.call.skipped) {
+          _List lq;
+          _SimpleList lt;
+          _CalcNode *nd = (_CalcNode *)t->GetNodeFromFlatIndex(code);
+          nd->RecomputeMatrix(catID, t->categoryCount, nil, &lq, &lt);
+          if (lq.lLength != 1) {
+            fp.mcall.broken = true;
+            continue;
+          }
+          _hyhip_dense_copy((_Matrix *)lq(0), DD, fp.qstash[fcat].data() + (size_t)code * DD);
+          fp.q_pending[fcat][code] = 1;
+          if (!fp.host_stale[fcat][code]) fp.n_stale++;
+          fp.host_stale[fcat][code] = 1;
+        }
+        fp.cat_arg[fcat] = catID;
+      } else {
+        fp.mcall.broken = true;
+      }
+      fp.call = _HyHipPart::Call();
+      fp.mcall.broken = true;  // (a mixed call: the host keeps its queue)
+    }
+    return _hyhip_finish_mixture_call(fp, t, catID);
   }
   if (hasExpForm) {
     _HyHipPart *mp = _hyhip_part_of_tree(t);

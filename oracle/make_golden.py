@@ -646,6 +646,34 @@ def fullsize_codon(name, taxa, codons, seed, classes=None, threads=8):
     print(f"{name}: logL = {res['logl']!r}  sites stored {len(idx)}")
 
 
+def fullsize_mix3(name="full_mix3_64x10k", taxa=64, codons=10000, seed=3, omegas=(0.1, 1.0, 5.0), weights=(0.6, 0.3, 0.1), threads=16):
+    """configs[2] in the form BUSTED really runs (BS_REL.bf:48, tree.cpp:3047-3090): every branch's transition matrix is the
+    explicit-form mixture sum_m w_m Exp(Q_b(omega_m)) over three omega classes — bench.py's headline alignment, branch lengths 0.05,
+    the weights / omegas of tools/adapter_rate.py's `mix3` rows.  Scalar log L + 2 000 sampled per-site values."""
+    syn = data.evolve(taxa, codons, 3, seed=seed, p_change=0.04)
+    flat = syn.flat
+    bt = {n: 0.05 for n in flat.branch_names()}
+    tmpl = models.mg94rev_template(POS_FREQS)
+    pi = models.f3x4_codon_freqs(POS_FREQS)
+    M = len(omegas)
+    g = dict(REV)
+    for m, om in enumerate(omegas, start=1):
+        g[f"R{m}"] = om
+    for m, w in enumerate(weights[:-1], start=1):
+        g[f"W{m}"] = w
+    wexpr = [f"W{m}" for m in range(1, M)] + ["(1" + "".join(f"-W{m}" for m in range(1, M)) + ")"]
+    block = hbl.codon_mixture_model_block(tmpl, pi, [f"R{m}" for m in range(1, M + 1)], wexpr)
+    res = hbl.evaluate(names=flat.leaf_names, seqs=syn.seqs, newick=tree.to_newick(syn.tree), unit=3, model_block=block,
+                       model_name="MGM", globals_=g, branch_t=bt, upper_bounds={f"W{m}": 1.0 for m in range(1, M)}, threads=threads,
+                       timeout=3600.0)
+    idx = np.sort(np.random.default_rng(seed).choice(codons, size=2000, replace=False))
+    fx = dict(kind="codon_mixture_full", taxa=taxa, sites=codons, seed=seed, p_change=0.04, states_crc=_crc(syn.states.astype(np.int16)),
+              t=0.05, omegas=np.array(omegas), weights=np.array(weights), rev=np.array([REV[k] for k in ("AC", "AT", "CG", "CT", "GT")]),
+              pos_freqs=POS_FREQS, logl=res["logl"], site_index=idx, site_logl=res["site_logl"][idx])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(f"{name}: logL = {res['logl']!r}  sites stored {len(idx)}")
+
+
 def fullsize_nuc(name="full_hky_8x1k", taxa=8, sites=1000, seed=1, kappa=0.35, threads=1):
     """configs[0]: HKY85 (transversions kappa x transitions, the parameterisation of the reference's IntermediateNuc.bf), 8 taxa x
     1 000 sites — bench.py's `hky_8x1k` alignment at its stated size: scalar and per-site log L of the reference, and its log L at
@@ -744,6 +772,7 @@ def fullsize_cases():
     fullsize_codon("full_mg94_128x100k", 128, 100000, seed=4)      # configs[3] (all 100 000 codons on one device in the test)
     fullsize_partitions()                                          # configs[4]
     fullsize_nuc()                                                 # configs[0]
+    fullsize_mix3()                                                # configs[2] as an explicit-form branch-site mixture
 
 
 def main():
@@ -780,6 +809,12 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize_hky":
         fullsize_nuc()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize_mix3":
+        if not hbl.have_reference():
+            raise SystemExit("oracle/_ref/hyphy missing: run `make -f oracle/Makefile.ref -j8` first")
+        os.makedirs(OUT, exist_ok=True)
+        fullsize_mix3()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
         if not hbl.have_reference():

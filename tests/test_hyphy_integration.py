@@ -356,6 +356,36 @@ def test_hbl_explicit_form_mixture_through_device():
     assert np.max(np.abs(gpu["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10
 
 
+def test_hbl_explicit_form_mixture_at_stated_size_through_device():
+    """configs[2] as BUSTED runs it, through the real host: 64 taxa x 10 000 codons, three omega classes in the reference's explicit
+    form — LFCompute and a short sweep of a component's omega (the adapter's mixture template mode: the component rate matrices reach
+    the device as coefficient rows), against the committed value of the unmodified reference (tests/golden/full_mix3_64x10k.npz)."""
+    _need_binaries()
+    from hyphy_amd import data, models, tree
+    from oracle import hbl, make_golden as mg
+    fx = common.load("full_mix3_64x10k")
+    syn = data.evolve(int(fx["taxa"]), int(fx["sites"]), 3, seed=int(fx["seed"]), p_change=float(fx["p_change"]))
+    om, w = fx["omegas"], fx["weights"]
+    block = hbl.codon_mixture_model_block(models.mg94rev_template(mg.POS_FREQS), models.f3x4_codon_freqs(mg.POS_FREQS),
+                                          ["R1", "R2", "R3"], ["W1", "W2", "(1-W1-W2)"])
+    case = dict(names=syn.flat.leaf_names, seqs=syn.seqs, newick=tree.to_newick(syn.tree), unit=3, model_block=block, model_name="MGM",
+                globals_=dict(R1=float(om[0]), R2=float(om[1]), R3=float(om[2]), W1=float(w[0]), W2=float(w[1]), **mg.REV),
+                branch_t={n: float(fx["t"]) for n in syn.flat.branch_names()}, upper_bounds=dict(W1=1.0, W2=1.0))
+    res = hbl.evaluate(binary=HIP_BIN, extra_env=dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), threads=1, **case)
+    assert _device_calls(res["stdout"]) > 0
+    ref = float(fx["logl"])
+    assert abs(res["logl"] - ref) <= 1e-10 * abs(ref), (res["logl"], ref)
+    got = res["site_logl"][fx["site_index"]]
+    assert np.max(np.abs(got - fx["site_logl"]) / np.abs(fx["site_logl"])) < 1e-10
+    # a sweep that dirties one component of every branch (mixture template mode after the adapter's learning calls), every point against
+    # the unmodified binary run beside it
+    sweep = dict(param="R2", start=float(om[1]), step=0.01, n=12, record=12)
+    gpu = hbl.evaluate(sweep=sweep, per_site=False, binary=HIP_BIN, extra_env=dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), threads=1, **case)
+    cpu = hbl.evaluate(sweep=sweep, per_site=False, threads=16, **case)
+    assert np.max(np.abs(gpu["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10, (gpu["sweep_values"], cpu["sweep_values"])
+    assert "mixture template mode" in gpu["stdout"], gpu["stdout"][-1500:]
+
+
 def test_hbl_spmd_site_shard_one_rank_through_device():
     """SPMD site sharding of the adapter (one host process per GPU, every process runs the same batch file,
     HYPHY_HIP_WORLD / HYPHY_HIP_RANK): with a world of ONE — what a single-GPU box can run — the partition goes
