@@ -497,6 +497,53 @@ int column_classes(const std::vector<int> &a, std::vector<int> &out) {
   return n;
 }
 
+// class of every (internal node, pattern) bottom-up — the id of the tuple of the children's classes (a leaf: its code, ambiguity codes
+// included) in order of first occurrence — and the number of classes per node
+void count_classes(const std::vector<std::vector<int>> &children, int L, int I, const std::vector<int16_t> &codes, size_t SP,
+                   std::vector<std::vector<int>> &cls, std::vector<int> &U) {
+  cls.assign(I, std::vector<int>());
+  U.assign(I, 0);
+  std::vector<int> col(SP), tmp;
+  for (int n = 0; n < I; n++) {
+    std::vector<int> run;
+    bool first = true;
+    for (int c : children[n]) {
+      const std::vector<int> *cc;
+      if (c < L) {
+        for (size_t j = 0; j < SP; j++) col[j] = (int)codes[(size_t)c * SP + j];
+        cc = &col;
+      } else {
+        cc = &cls[c - L];
+      }
+      if (first) {
+        run = *cc;
+        first = false;
+      } else {
+        pair_classes(run, *cc, tmp);
+        run.swap(tmp);
+      }
+    }
+    U[n] = column_classes(run, cls[n]);
+  }
+}
+
+// the compressed set: internal nodes (never the root) with at most theta x patterns classes on every shard, all of whose internal
+// children are compressed too
+std::vector<char> compressed_set(const std::vector<std::vector<int>> &children, int L, int I, const std::vector<std::vector<int>> &U,
+                                 const std::vector<int> &S_pad, double theta) {
+  std::vector<char> comp(I, 0);
+  for (int n = 0; n < I - 1; n++) {
+    bool ok = true;
+    for (size_t k = 0; k < U.size(); k++)
+      if ((double)U[k][n] > theta * S_pad[k] || U[k][n] > 32000) ok = false;
+    for (int c : children[n])
+      if (c >= L && !comp[c - L]) ok = false;
+    if ((int)children[n].size() > kRepMaxInputs - 8) ok = false;  // (a star: its children's indices would not fit the wave's LDS list)
+    comp[n] = ok ? 1 : 0;
+  }
+  return comp;
+}
+
 }  // namespace
 
 // Decide the compressed set, build views[1] and every shard's tables.  `codes[k]`: shard k's leaf table [L][S_pad] in device
@@ -525,44 +572,11 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
   // ---- classes per shard ----
   std::vector<std::vector<std::vector<int>>> cls(nsh);  // [shard][internal node][pattern]
   std::vector<std::vector<int>> U(nsh, std::vector<int>(I, 0));
-  for (size_t k = 0; k < nsh; k++) {
-    const Shard &s = p->shards[k];
-    const size_t SP = (size_t)s.S_pad;
-    cls[k].resize(I);
-    std::vector<int> col(SP), tmp;
-    for (int n = 0; n < I; n++) {
-      std::vector<int> run;
-      bool first = true;
-      for (int c : p->children[n]) {
-        const std::vector<int> *cc;
-        if (c < L) {
-          for (size_t j = 0; j < SP; j++) col[j] = (int)codes[k][(size_t)c * SP + j];
-          cc = &col;
-        } else {
-          cc = &cls[k][c - L];
-        }
-        if (first) {
-          run = *cc;
-          first = false;
-        } else {
-          pair_classes(run, *cc, tmp);
-          run.swap(tmp);
-        }
-      }
-      U[k][n] = column_classes(run, cls[k][n]);
-    }
-  }
+  for (size_t k = 0; k < nsh; k++) count_classes(p->children, L, I, codes[k], (size_t)p->shards[k].S_pad, cls[k], U[k]);
   // ---- compressed set: the same on every shard (one schedule serves them all) ----
-  std::vector<char> comp(I, 0);
-  for (int n = 0; n < I - 1; n++) {
-    bool ok = true;
-    for (size_t k = 0; k < nsh; k++)
-      if ((double)U[k][n] > theta * p->shards[k].S_pad || U[k][n] > 32000) ok = false;
-    for (int c : p->children[n])
-      if (c >= L && !comp[c - L]) ok = false;
-    if ((int)p->children[n].size() > kRepMaxInputs - 8) ok = false;  // (a star: its children's indices would not fit the wave's LDS list)
-    comp[n] = ok ? 1 : 0;
-  }
+  std::vector<int> spads;
+  for (const Shard &s : p->shards) spads.push_back(s.S_pad);
+  const std::vector<char> comp = compressed_set(p->children, L, I, U, spads, theta);
   {  // worth it?  compare the edge products of the two forms on the first shard
     double full = 0., rep = 0.;
     for (int n = 0; n < I - 1; n++) {
@@ -1135,3 +1149,40 @@ int rep_decide(hyphy_hip_partition *p, int cat, int n_classes) {
 }
 
 }  // namespace hyhip
+
+using namespace hyhip;
+
+extern "C" {
+
+/* Host-only (no device needed): what hyphy_hip_create decides about subtree repeats from the topology and the leaf table alone.
+ * classes_out[I]: classes of every internal node over the S patterns as given (no padding, one shard); compressed_out[I]: 1 where
+ * the node's subtree is evaluated per class (theta <= 0: the library's default).  Returns the edge products a full pass executes
+ * with one table per compressed node (sum of their classes + S per trunk edge), < 0 on bad arguments. */
+int64_t hyphy_hip_plan_repeats(int64_t L, int64_t I, const int64_t *flat_parents, int64_t S, const int64_t *leaf_codes, double theta,
+                               int64_t *classes_out, int64_t *compressed_out) {
+  if (L < 2 || I < 1 || S < 1 || !flat_parents || !leaf_codes) return -1;
+  std::vector<std::vector<int>> children((size_t)I);
+  for (int64_t n = 0; n < L + I - 1; n++) {
+    const int64_t par = flat_parents[n];
+    if (par < 0 || par >= I || (n >= L && par <= n - L)) return -1;
+    children[(size_t)par].push_back((int)n);
+  }
+  std::vector<int16_t> codes((size_t)L * S);
+  for (int64_t k = 0; k < L * S; k++) {
+    if (leaf_codes[k] > 32767 || leaf_codes[k] < -32768) return -1;
+    codes[(size_t)k] = (int16_t)leaf_codes[k];
+  }
+  std::vector<std::vector<int>> cls;
+  std::vector<std::vector<int>> U(1);
+  count_classes(children, (int)L, (int)I, codes, (size_t)S, cls, U[0]);
+  const std::vector<char> comp = compressed_set(children, (int)L, (int)I, U, std::vector<int>(1, (int)S), theta > 0. ? theta : 0.35);
+  int64_t work = 0;
+  for (int64_t n = 0; n < I; n++) {
+    if (classes_out) classes_out[n] = U[0][(size_t)n];
+    if (compressed_out) compressed_out[n] = comp[(size_t)n];
+    if (n < I - 1) work += comp[(size_t)n] ? U[0][(size_t)n] : S;
+  }
+  return work;
+}
+
+}  // extern "C"

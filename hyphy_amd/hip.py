@@ -24,7 +24,7 @@ EXPORTS = [
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
     "hyphy_hip_set_pinned_states", "hyphy_hip_site_fits_evaluate", "hyphy_hip_site_fits_evaluate_mixture", "hyphy_hip_site_fits_kernel_ms",
-    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_set_repeats", "hyphy_hip_repeat_stats", "hyphy_hip_last_error",
+    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_set_repeats", "hyphy_hip_repeat_stats", "hyphy_hip_plan_repeats", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
 
@@ -136,6 +136,8 @@ def load():
     lib.hyphy_hip_prune_kernel_name.argtypes = [vp]
     lib.hyphy_hip_set_repeats.restype = C.c_int
     lib.hyphy_hip_set_repeats.argtypes = [vp, C.c_int]
+    lib.hyphy_hip_plan_repeats.restype = C.c_int64
+    lib.hyphy_hip_plan_repeats.argtypes = [C.c_int64, C.c_int64, lp, C.c_int64, lp, C.c_double, lp, lp]
     lib.hyphy_hip_repeat_stats.restype = C.c_int
     lib.hyphy_hip_repeat_stats.argtypes = [vp, lp]
     lib.hyphy_hip_last_error.restype = C.c_char_p
@@ -189,6 +191,20 @@ def plan_schedule(flat_parents, L: int, kernel: int = 1, chain_m: int = 0, ntile
         raise HipError("plan_schedule: bad arguments")
     keys = ("chain", "programs", "entries", "max_slot", "max_need", "decode_errors", "rerooted", "trunk_nodes")
     return dict(zip(keys, (int(v) for v in info)))
+
+
+def plan_repeats(flat_parents, L: int, leaf_codes, theta: float = 0.0):
+    """Host-only: (classes per internal node, compressed flags, edge products of a full pass with one table per compressed node)."""
+    lib = load()
+    fp = np.ascontiguousarray(flat_parents, dtype=np.int64)
+    lc = np.ascontiguousarray(leaf_codes, dtype=np.int64)
+    I = len(fp) - L
+    cl = np.zeros(I, dtype=np.int64)
+    cp = np.zeros(I, dtype=np.int64)
+    work = lib.hyphy_hip_plan_repeats(L, I, _l(fp), lc.shape[1], _l(lc), float(theta), _l(cl), _l(cp))
+    if work < 0:
+        raise HipError("plan_repeats: bad arguments")
+    return cl, cp.astype(bool), int(work)
 
 
 def device_count() -> int:

@@ -411,6 +411,11 @@ const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p);
  *                           tiles of 16 = edge products of the lower phase), [3] / [4] internal nodes / leaves of the trunk,
  *                           [5] edge products of one full pass with repeats on, [6] ... off, [7] in use. */
 int hyphy_hip_set_repeats(hyphy_hip_partition *p, int on);
+/*   hyphy_hip_plan_repeats  host-only (no device): classes of every internal node over the S patterns as given (classes_out[I]), the
+ *                           compressed set for `theta` (compressed_out[I]; theta <= 0: the default 0.35); returns the edge products
+ *                           of a full pass with one table per compressed node, < 0 on bad arguments. */
+int64_t hyphy_hip_plan_repeats(int64_t L, int64_t I, const int64_t *flat_parents, int64_t S, const int64_t *leaf_codes, double theta,
+                               int64_t *classes_out, int64_t *compressed_out);
 int hyphy_hip_repeat_stats(const hyphy_hip_partition *p, int64_t out[8]);
 
 const char *hyphy_hip_last_error(void);

@@ -142,3 +142,46 @@ def test_trees_beyond_the_packed_join_table_get_no_chain_schedule():
     fp2[L2 + 200] = -1
     star2 = hip.plan_schedule(fp2, L2, kernel=1, chain_m=1, ntiles=16)
     assert star2["chain"] == 1 and star2["max_need"] == 200 and star2["decode_errors"] == 0
+
+
+def test_subtree_repeat_classes_and_compressed_set():
+    """Subtree repeats (repeats.hip; the reference's tcc masks, src/core/tree.cpp:2801-2858): the classes hyphy_hip_create counts per
+    internal node are the distinct leaf sub-patterns below it, the compressed set is closed downwards and never contains the root, and
+    the reference's run-length form (a site whose subtree leaves equal the PREVIOUS site's is skipped) can never skip more than the
+    class form does."""
+    from hyphy_amd import data
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        taxa = int(rng.integers(6, 40))
+        syn = data.evolve(taxa, 400, 3, seed=100 + trial, p_change=0.06)
+        pd = data.from_states(syn.states, 61, compress_patterns=True)
+        flat = syn.flat
+        L, I = flat.L, flat.I
+        codes = np.asarray(pd.leaf_codes)
+        if trial % 2:   # ambiguity codes are characters like any other
+            mask = rng.random(codes.shape) < 0.04
+            codes = codes.copy()
+            codes[mask] = -1 - rng.integers(0, 3, size=int(mask.sum()))
+        S = codes.shape[1]
+        theta = [0.2, 0.35, 0.6][trial % 3]
+        classes, comp, work = hip.plan_repeats(flat.flat_parents, L, codes, theta)
+        # independent count: leaves below every internal node, distinct columns of the leaf table restricted to them
+        parents = np.asarray(flat.flat_parents)
+        below = [set() for _ in range(I)]
+        for n in range(L + I - 1):
+            below[parents[n]] |= ({n} if n < L else below[n - L])
+        for n in range(I):
+            rows = sorted(below[n])
+            want = len({tuple(codes[rows, s]) for s in range(S)})
+            assert classes[n] == want, (trial, n, classes[n], want)
+        assert not comp[I - 1]
+        for n in range(I - 1):
+            kids_ok = all(comp[c - L] for c in range(L, L + I - 1) if parents[c] == n)
+            assert comp[n] == (classes[n] <= theta * S and classes[n] <= 32000 and kids_ok), (trial, n)
+        assert work == sum(int(classes[n]) if comp[n] else S for n in range(I - 1))
+        # the reference's masks: node n is skipped at site position s > 0 when its leaves equal those of position s - 1; at best
+        # (sites sorted so that equal sub-patterns are neighbours) that leaves one evaluation per class
+        for n in range(I - 1):
+            rows = sorted(below[n])
+            runs = 1 + sum(1 for s in range(1, S) if tuple(codes[rows, s]) != tuple(codes[rows, s - 1]))
+            assert runs >= classes[n]

@@ -49,15 +49,35 @@ def emit(tag, host, res, count, t0, extra=None):
           flush=True)
 
 
+def measure(tag, host, run, n_pilot, target_s=10.0, min_evals=0, extra=None):
+    """evaluations per second as the DIFFERENCE of the wall clock of two runs of the same script with different sweep lengths
+    (process start, data reading, likelihood-function set-up and the adapter's learning calls cancel): a pilot of `n_pilot`
+    evaluations sizes the long run for >= target_s seconds and >= min_evals evaluations of difference.  (r04 divided by HBL's Time(1),
+    whole seconds: most rows were one or two ticks.)"""
+    t0 = time.time()
+    res0 = run(n_pilot)
+    w0 = time.time() - t0
+    secs0 = max(res0.get("sweep_seconds", 0.0), 1.0)
+    n_long = n_pilot + int(max(min_evals, (n_pilot / secs0) * target_s))
+    t1 = time.time()
+    res = run(n_long)
+    w1 = time.time() - t1
+    dt = max(w1 - w0, 1e-3)
+    mode = [ln for ln in res.get("stdout", "").split("\n") if "mode:" in ln or "template analysis" in ln or "explicit-form" in ln or "template mode" in ln]
+    print(json.dumps({"case": tag, "host": host, "evals": n_long - n_pilot, "seconds": dt, "evals_per_s": (n_long - n_pilot) / dt,
+                      "method": f"wall clock of two runs, {n_pilot} and {n_long} evaluations: ({n_long} - {n_pilot}) / ({w1:.2f} s - {w0:.2f} s)",
+                      "hbl_timer_seconds_long_run": res.get("sweep_seconds"), "logl": res["logl"], "adapter_says": mode[-2:], **(extra or {})}),
+          flush=True)
+
+
 if "headline" in which:
     block = hbl.codon_model_block(tmpl, pi)
-    for host, binary, env, count in (("adapter (template mode)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals * 4),
-                                      ("adapter, HYPHY_HIP_TEMPLATES=0 (dense mode B)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always", HYPHY_HIP_TEMPLATES="0"), n_evals),
-                                      ("reference 16 threads", None, None, max(8, n_evals // 40))):
-        t0 = time.time()
-        res = hbl.evaluate(model_block=block, globals_=dict(R=0.3, **bench.REV), sweep=dict(param="R", start=0.3, step=0.0001, n=count),
-                           threads=(1 if binary else 16), binary=binary, extra_env=env, **common)
-        emit("mg94_64x10k", host, res, count, t0)
+    for host, binary, env, count, floor in (("adapter (template mode)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals, 50000),
+                                             ("adapter, HYPHY_HIP_TEMPLATES=0 (dense mode B)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always", HYPHY_HIP_TEMPLATES="0"), n_evals // 2, 0),
+                                             ("reference 16 threads", None, None, max(40, n_evals // 100), 0)):
+        measure("mg94_64x10k", host, lambda n: hbl.evaluate(model_block=block, globals_=dict(R=0.3, **bench.REV),
+                                                           sweep=dict(param="R", start=0.3, step=0.00001, n=n), threads=(1 if binary else 16),
+                                                           binary=binary, extra_env=env, **common), count, min_evals=floor)
 
 if "class2" in which:
     # MG94 with two local parameters per branch and branch-specific constraints: foreground / background omega
@@ -70,23 +90,24 @@ if "class2" in which:
     tmp = tempfile.mkdtemp(prefix="hyclass_")
     fasta, outp = os.path.join(tmp, "aln.fasta"), os.path.join(tmp, "out.txt")
     hbl.write_fasta(fasta, syn.flat.leaf_names, syn.seqs)
-    for host, binary, env, count, thr in (("adapter (template mode, one group per branch class)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals * 4, 1),
-                                           ("adapter, HYPHY_HIP_TEMPLATES=0 (dense mode B)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always", HYPHY_HIP_TEMPLATES="0"), n_evals, 1),
-                                           ("reference 16 threads", None, None, max(8, n_evals // 40), 16)):
-        t0 = time.time()
-        txt = hbl.build_script(fasta=fasta, newick=htree.to_newick(syn.tree), unit=3, model_block="\n".join(lines), model_name="MGM",
-                               globals_=dict(R=0.3, R2=0.5, **bench.REV), branch_t=bt, out_path=outp, per_site=False,
-                               sweep=dict(param="R", start=0.3, step=0.0001, n=count), threads=thr)
-        for k, (nm, t) in enumerate(bt.items()):
-            om = "R2" if k % 3 == 0 else "R"
-            txt = txt.replace(f"givenTree.{nm}.t = {hbl._fmt(t)};",
-                              f"givenTree.{nm}.synRate = {hbl._fmt(t)}; givenTree.{nm}.nonSynRate := {om}*givenTree.{nm}.synRate;")
-        assert ".t = " not in txt
-        try:
+    for host, binary, env, count, thr, floor in (("adapter (template mode, one group per branch class)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals, 1, 50000),
+                                                  ("adapter, HYPHY_HIP_TEMPLATES=0 (dense mode B)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always", HYPHY_HIP_TEMPLATES="0"), n_evals // 2, 1, 0),
+                                                  ("reference 16 threads", None, None, max(40, n_evals // 100), 16, 0)):
+        def run_class2(count):
+            txt = hbl.build_script(fasta=fasta, newick=htree.to_newick(syn.tree), unit=3, model_block="\n".join(lines), model_name="MGM",
+                                   globals_=dict(R=0.3, R2=0.5, **bench.REV), branch_t=bt, out_path=outp, per_site=False,
+                                   sweep=dict(param="R", start=0.3, step=0.00001, n=count), threads=thr)
+            for k, (nm, t) in enumerate(bt.items()):
+                om = "R2" if k % 3 == 0 else "R"
+                txt = txt.replace(f"givenTree.{nm}.t = {hbl._fmt(t)};",
+                                  f"givenTree.{nm}.synRate = {hbl._fmt(t)}; givenTree.{nm}.nonSynRate := {om}*givenTree.{nm}.synRate;")
+            assert ".t = " not in txt
             stdout = hbl.run_script(txt, tmp, cpus=thr, timeout=1800.0, binary=binary, extra_env=env)
             res = hbl.parse_output(outp)
             res["stdout"] = stdout
-            emit("mg94_two_omega_classes_64x10k", host, res, count, t0)
+            return res
+        try:
+            measure("mg94_two_omega_classes_64x10k", host, run_class2, count, min_evals=floor)
         except Exception as e:
             print(json.dumps({"case": "class2", "host": host, "error": str(e)[-600:]}), flush=True)
 
@@ -94,29 +115,27 @@ if "cat3" in which:
     block = hbl.codon_model_block(tmpl, pi, omega="R*cc")
     cat = dict(name="cc", weights=[0.7, 0.25, 0.05], values=[0.1 / 0.3, 1.0 / 0.3, 5.0 / 0.3])
     # (LFCompute outside Optimize: device exponentials have to be asked for, as in every other case of this script)
-    for host, binary, env, count in (("adapter", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals),
-                                      ("adapter, HYPHY_HIP_DEVICE_EXPM unset (mode A outside Optimize: host exponentials)", HIP_BIN, ENV, max(100, n_evals // 20)),
-                                      ("reference 16 threads", None, None, max(6, n_evals // 200))):
+    for host, binary, env, count, floor in (("adapter", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals // 2, 20000),
+                                             ("adapter, HYPHY_HIP_DEVICE_EXPM unset (mode A outside Optimize: host exponentials)", HIP_BIN, ENV, max(100, n_evals // 40), 0),
+                                             ("reference 16 threads", None, None, max(12, n_evals // 400), 0)):
         if os.environ.get("ADAPTER_RATE_ROWS") == "first" and host != "adapter":
             continue
-        t0 = time.time()
-        res = hbl.evaluate(model_block=block, globals_=dict(R=0.3, **bench.REV), category=cat,
-                           sweep=dict(param="R", start=0.3, step=0.0001, n=count), threads=(1 if binary else 16), binary=binary, extra_env=env, **common)
-        emit("cat3_64x10k", host, res, count, t0)
+        measure("cat3_64x10k", host, lambda n: hbl.evaluate(model_block=block, globals_=dict(R=0.3, **bench.REV), category=cat,
+                                                           sweep=dict(param="R", start=0.3, step=0.00001, n=n), threads=(1 if binary else 16),
+                                                           binary=binary, extra_env=env, **common), count, min_evals=floor)
 
 if "mix3" in which:
     block = hbl.codon_mixture_model_block(tmpl, pi, ["R1", "R2", "R3"], ["W1", "W2", "(1-W1-W2)"])
     g = dict(R1=0.1, R2=1.0, R3=5.0, W1=0.6, W2=0.3, **bench.REV)
     # three sweeps: a mixture weight (no rate matrix changes: the reference re-mixes cached exponentials), one component's omega
     # (one component of every branch changes), a nucleotide rate (every component of every branch changes)
-    for param, start, step in (("W1", 0.5, 0.00001), ("R2", 1.0, 0.0001), ("AC", 0.5, 0.0001)):
-        for host, binary, env, count in (("adapter", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals),
-                                          ("adapter, HYPHY_HIP_TEMPLATES=0 (dense components)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always", HYPHY_HIP_TEMPLATES="0"), max(200, n_evals // 4)),
-                                          ("reference 16 threads", None, None, max(4, n_evals // 600))):
-            t0 = time.time()
-            res = hbl.evaluate(model_block=block, globals_=g, upper_bounds=dict(W1=1.0, W2=1.0),
-                               sweep=dict(param=param, start=start, step=step, n=count), threads=(1 if binary else 16), binary=binary, extra_env=env, **common)
-            emit(f"mix3_64x10k sweep of {param}", host, res, count, t0)
+    for param, start, step in (("W1", 0.5, 0.000001), ("R2", 1.0, 0.00001), ("AC", 0.5, 0.00001)):
+        for host, binary, env, count, floor in (("adapter", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always"), n_evals // 2, 20000),
+                                                 ("adapter, HYPHY_HIP_TEMPLATES=0 (dense components)", HIP_BIN, dict(ENV, HYPHY_HIP_DEVICE_EXPM="always", HYPHY_HIP_TEMPLATES="0"), max(200, n_evals // 10), 0),
+                                                 ("reference 16 threads", None, None, max(8, n_evals // 500), 0)):
+            measure(f"mix3_64x10k sweep of {param}", host,
+                    lambda n: hbl.evaluate(model_block=block, globals_=g, upper_bounds=dict(W1=1.0, W2=1.0), sweep=dict(param=param, start=start, step=step, n=n),
+                                           threads=(1 if binary else 16), binary=binary, extra_env=env, **common), count, min_evals=floor)
 
 if "manylf" in which:
     # N single-codon likelihood functions, 50 evaluations each (FEL's shape: one LF per site)
