@@ -287,6 +287,10 @@ def measure_traffic(workload, kernels):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         tmp = tempfile.mkdtemp(prefix="hyprof_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp", HYPHY_HIP_TIMING_EVERY="1")
+        if len(kernels) > 1:
+            # a class-compressed pass: keep the counter run on that form — left to itself the library would first time the plain form too
+            # (rep_decide), and those launches of the same pruning kernel move twice the bytes (they were most of an 18-step run's rows)
+            env["HYPHY_HIP_REPEATS"] = "1"
         try:
             subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable,
                             os.path.abspath(__file__), "--workload", workload, "--steps", "12", "--warmup", "6", "--no-cpu-baseline",
@@ -300,7 +304,7 @@ def measure_traffic(workload, kernels):
                             rows.append(float(r["Counter_Value"]))
                 if len(rows) < 4:
                     return None
-                total += float(np.median(rows[len(rows) // 2:]))   # (the first passes persist every node / tune the schedule)
+                total += float(np.median(rows[-8:]))   # (steady state is the END of the run: the first passes persist every node / tune)
             vals[counter] = total
         except Exception:
             return None
@@ -841,7 +845,9 @@ def main():
         if roof.get("traffic"):
             # counter bytes per launch / launch duration: what the memory system really moved (for the 4-state kernel this,
             # not the algorithmic figure, is the number to hold against the ~6.3 TB/s achievable HBM rate)
-            roof["traffic_rate_gbs"] = roof["traffic"] / (roof["kernel_ms_per_launch"] * 1e-3) / 1e9
+            # (a class-compressed pass: `traffic` is the sum over its two launches, so the time is the pass's, not a launch's)
+            t_ms = roof["kernel_ms"] if rep_on and D > 4 else roof["kernel_ms_per_launch"]
+            roof["traffic_rate_gbs"] = roof["traffic"] / (t_ms * 1e-3) / 1e9
             if bound == "hbm":
                 roof["traffic_frac_of_achievable"] = roof["traffic_rate_gbs"] / HBM_ACHIEVABLE_GBS
         out = {

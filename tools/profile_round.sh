@@ -26,9 +26,20 @@ import json, sys
 tag, path = sys.argv[1], sys.argv[2]
 try:
     j = json.loads([l for l in open(path) if l.startswith("{")][-1]); r = j["roofline"]
-    fr = r["frac"] if r.get("frac") is not None else float("nan")
-    extra = f"  VALU {r['valu_tflops']:.2f} TFLOP/s" if r.get("valu_tflops") is not None else ""
-    print(f"{tag:18s} {j['value']:9.1f} evals/s  step {j['ms_per_step']*1e3:8.1f} us  {r['kernel']} {r['kernel_ms']*1e3:8.1f} us  {r['achieved']:8.2f} {r['unit']}  frac {fr:.3f}{extra}  expm {r['expm_ms']}  reduce {r['reduce_ms']}")
+    if r.get("bound") == "hbm":
+        # 4 states: the algorithmic bytes (every conditional vector through HBM) are not what the memory system moves — the kernel keeps
+        # them on chip — so the row reports COUNTER bytes / time against the achievable HBM rate (live PMC passes, else the committed
+        # profiles/pmc_traffic.json entry of this workload and kernel), never an algorithmic figure above the peak
+        if r.get("traffic_rate_gbs") is not None:
+            roof = f"{r['traffic_rate_gbs']:8.1f} GB/s by counters ({r['traffic'] / 1e6:.1f} MB per launch) = {r['traffic_frac_of_achievable']:.3f} of the achievable HBM rate"
+        else:
+            roof = "counter traffic not available"
+        roof += f"  VALU {r['valu_tflops']:.2f} TFLOP/s"
+    else:
+        roof = f"{r['achieved']:8.2f} {r['unit']}  frac {r['frac']:.3f}"
+        if r.get("repeat_ratio") is not None and r["repeat_ratio"] < 1.0:
+            roof += f" (executed flops; repeat ratio {r['repeat_ratio']:.3f}, effective {r['effective_tflops']:.1f} TFLOP/s)"
+    print(f"{tag:18s} {j['value']:9.1f} evals/s  step {j['ms_per_step']*1e3:8.1f} us  {r['kernel']} {r['kernel_ms']*1e3:8.1f} us  {roof}  expm {r['expm_ms']}  reduce {r['reduce_ms']}")
 except Exception as e:
     print(f"{tag:18s} FAILED ({e})")
 PY
