@@ -980,10 +980,7 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     }
   }
   // subtree repeats: classes, compressed set, trunk view and tables (repeats.hip); leaves rep_on false when it would not pay
-  if (rep_setup(p, shard_codes)) {
-    hyphy_hip_destroy(p);
-    return -1;
-  }
+  rep_setup(p, shard_codes);  // (never fails the creation: a partition whose tables cannot be set up evaluates plain)
   *out = p;
   return 0;
 }

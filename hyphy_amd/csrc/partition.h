@@ -137,6 +137,7 @@ struct Shard {
   double *deposits = nullptr; // chain schedules: [C][view's I][ntiles][TILE] edge products of non-last arrivers (allocated on first use: ensure_deposits)
   size_t deposits_cap = 0, deposits_class_stride = 0;  // doubles
   size_t dev_bytes = 0;       // device memory this shard holds
+  size_t rep_bytes = 0;       // ... of which class tables and their maps (repeats.hip)
   int *frag_ctr = nullptr;    // [classes][programs][tiles] arrivals of child fragments (wave-per-tile kernel)
   int32_t *hand_cnt = nullptr;  // [classes][I][tiles][32] 2^64-exponents of fragment roots (own 128-byte line each)
   double *pi = nullptr;       // [DP]

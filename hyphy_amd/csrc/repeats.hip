@@ -549,7 +549,45 @@ std::vector<char> compressed_set(const std::vector<std::vector<int>> &children, 
 // Decide the compressed set, build views[1] and every shard's tables.  `codes[k]`: shard k's leaf table [L][S_pad] in device
 // pattern order (padding patterns included: they are patterns like any other).  Leaves p->rep_on false when compression
 // would not pay (or cannot be used) — nothing else changes then.
+namespace {
+void rep_release(hyphy_hip_partition *p) {  // everything rep_setup_impl may have left behind: the partition runs plain
+  for (Shard &s : p->shards) {
+    if (hipSetDevice(s.device) != hipSuccess) continue;
+    void **bufs[] = {(void **)&s.rep_tab, (void **)&s.rep_cnt, (void **)&s.rep_map, (void **)&s.rep_desc, (void **)&s.rep_sync,
+                     (void **)&s.rep_codes_tile, (void **)&s.rep_leaf};
+    for (void **b : bufs)
+      if (*b) {
+        pool_free_sync(*b);
+        *b = nullptr;
+      }
+    s.dev_bytes -= std::min(s.dev_bytes, s.rep_bytes);
+    s.rep_bytes = 0;
+    s.rep_tabs.clear();
+    s.rep_rows = 0;
+  }
+  p->rep_nodes.clear();
+  p->rep_desc_of.clear();
+  p->views[1] = hyphy_hip_partition::View();
+  p->rep_on = false;
+}
+int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &codes);
+}  // namespace
+
+// Subtree repeats are an optimisation: whatever goes wrong while they are set up (tables that do not fit the device, a failed
+// copy) leaves a partition that evaluates every node at every pattern — hyphy_hip_create never fails because of them.
 int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &codes) {
+  const int rc = rep_setup_impl(p, codes);
+  if (rc != 0 || !p->rep_on) {
+    if (rc != 0 && getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] subtree repeats not set up (%s): plain evaluation\n", g_last_error.c_str());
+    rep_release(p);
+    (void)hipGetLastError();
+    g_last_error.clear();
+  }
+  return 0;
+}
+
+namespace {
+int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &codes) {
   p->rep_on = false;
   const char *env = getenv("HYPHY_HIP_REPEATS");
   if (env && atoi(env) == 0) return 0;
@@ -563,6 +601,15 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
   if (p->variant != 1 && !(env && atoi(env) == 2)) return 0;  // (tiny shards: the workgroup-per-tile kernel keeps the whole tree)
   const int L = (int)p->L, I = (int)p->I, DP = p->DP;
   if (I < 2) return 0;
+  const bool forced = env && atoi(env) == 2;
+  // (before any work: a partition of a few tiles — FEL makes one per site — has nothing to compress, and the class arrays of a
+  //  very large one are host memory this analysis should not take: 4 bytes per internal node and pattern)
+  if (!forced && p->shards[0].ntiles < 8) return 0;
+  {
+    double cells = 0.;
+    for (const Shard &s : p->shards) cells += (double)I * s.S_pad;
+    if (cells * 4. > 4e9) return 0;
+  }
   // theta: the share of the patterns below which a node's classes are worth a table.  0.3-0.4 is the flat optimum of the headline
   // alignment (0.2: 100 us of pruning launches, 0.3: 89, 0.4: 89, 0.5: 101, 0.7: 106): above it the walks of the lower phase get long
   // and few, below it the trunk keeps nodes that repeat heavily
@@ -584,7 +631,7 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
       rep += comp[n] ? (U[0][n] + 15) / 16 * 16 : p->shards[0].S_pad;
     }
     const double need = getenv("HYPHY_HIP_REP_MIN_GAIN") ? atof(getenv("HYPHY_HIP_REP_MIN_GAIN")) : 0.15;
-    if (!(env && atoi(env) == 2) && (rep > (1.0 - need) * full || p->shards[0].ntiles < 8)) return 0;
+    if (!forced && rep > (1.0 - need) * full) return 0;
   }
   // ---- descriptors: leaves with ambiguity codes first (level 0), then the paths, inputs before the paths that read them ----
   // rho: a path goes on into the heaviest compressed child while that child keeps at least rho of the node's classes.  0: paths
@@ -822,9 +869,19 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
       }
     }
     const size_t sync_words = ((size_t)kRepQueues + 1 + (size_t)p->C * ND) * kRepHeadStride;  // (= rep_sync_words(p) words)
+    {  // the tables must leave the device room for everything else the partition allocates later (deposits, mixtures, site fits)
+      size_t free_b = 0, total_b = 0;
+      const size_t need_b = (size_t)p->C * rows * (DP * sizeof(double) + sizeof(int32_t)) + maps.size() * sizeof(int32_t) + ct.size() * sizeof(int16_t);
+      size_t limit = 0;
+      if (const char *e = getenv("HYPHY_HIP_REP_MAX_MB")) limit = (size_t)std::max(0L, atol(e)) << 20;  // (the caller's bound on the tables)
+      else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) limit = free_b / 4;
+      else limit = (size_t)1 << 30;
+      if (need_b > limit) return fail("class tables would take more than a quarter of the free device memory (or than HYPHY_HIP_REP_MAX_MB)");
+    }
 #define R_(ptr, bytes)                                                                  \
   if (pool_malloc((void **)&(ptr), (bytes)) != hipSuccess) return fail("hipMalloc failed (" #ptr ")"); \
-  s.dev_bytes += (size_t)(bytes);
+  s.dev_bytes += (size_t)(bytes);                                                                      \
+  s.rep_bytes += (size_t)(bytes);
     R_(s.rep_tab, (size_t)p->C * rows * DP * sizeof(double));
     R_(s.rep_cnt, (size_t)p->C * rows * sizeof(int32_t));
     R_(s.rep_map, std::max<size_t>(1, maps.size()) * sizeof(int32_t));
@@ -868,6 +925,7 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
   }
   return 0;
 }
+}  // namespace
 
 // The view in use: saves what the tuner decided for the view that is left and restores the other's.
 void switch_mode(hyphy_hip_partition *p, int mode) {

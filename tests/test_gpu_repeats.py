@@ -244,3 +244,27 @@ def test_library_chooses_by_measurement(monkeypatch):
     assert "repeats: lower phase" in info, info
     for k in pts:
         assert abs(got[k] - fx["sweep_logl"][k - 1]) <= RTOL * abs(fx["sweep_logl"][k - 1]), (k, info)
+
+
+def test_tables_that_do_not_fit_leave_a_plain_partition(monkeypatch):
+    """Subtree repeats are an optimisation: when the class tables cannot be set up (here: a bound of 0 MB on them; in the field: a device
+    short of memory) hyphy_hip_create still succeeds, nothing of the attempt stays allocated, and the partition evaluates plain."""
+    monkeypatch.setenv("HYPHY_HIP_REPEATS", "2")
+    monkeypatch.setenv("HYPHY_HIP_REP_THETA", "0.9")
+    monkeypatch.setenv("HYPHY_HIP_REP_MAX_MB", "0")
+    fx = common.load("codon_wide")
+    Q = common.fixture_Q(fx)
+    nodes = common.all_nodes(fx)
+    with _mk(fx) as part:
+        st = part.repeat_stats()
+        assert st["available"] == 0 and st["in_use"] == 0 and st["tables"] == 0, st
+        part.set_repeats(True)   # (asking for them changes nothing when they do not exist)
+        ll = part.evaluate(nodes, nodes, Q, fx["root_freqs"])
+        ch = np.array([3], dtype=np.int64)
+        Q2 = Q.copy()
+        Q2[3] *= 1.5
+        ll2 = part.evaluate(ch, ch, Q2[ch], fx["root_freqs"])
+        full2 = part.evaluate(nodes, nodes, Q2, fx["root_freqs"])
+    ref = float(fx["logl"])
+    assert abs(ll - ref) <= RTOL * abs(ref), (ll, ref)
+    assert abs(ll2 - full2) <= SAME * abs(full2)
