@@ -249,6 +249,10 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       const size_t n_tot = (size_t)mix->n_tot, DD = (size_t)D * D;
       if (mix_built && s.coeff_rows != (int64_t)n_tot)
         return fail("mixture evaluation: hyphy_hip_build_q staged a different number of rows than the components of this evaluation");
+      // (rows are staged without saying what they are: the first evaluation that consumes a staging claims it — one row per (branch,
+      //  component) here — and an evaluation of the other kind that happens to need the same number of rows is refused)
+      if (mix_built && s.coeff_kind == 1) return fail("mixture evaluation: the staged rows were consumed as one row per (class, branch): call hyphy_hip_build_q first");
+      if (mix_built) s.coeff_kind = 2;
       if (s.mix_cap < n_tot || s.mix_nq_cap < (size_t)n_q) {
         HIPCHK(hipStreamSynchronize(s.stream));
         for (void *d : {(void *)s.mix_q, (void *)s.mix_p, (void *)s.mix_w, (void *)s.mix_off})
@@ -307,6 +311,8 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       // (fused construction) or the materialised matrices, with exactly the rows this evaluation consumes
       if (!q_from_templates && !s.qbuf_built) return fail("evaluate from the Q buffer: no rate matrices staged (call hyphy_hip_build_q first)");
       if (s.coeff_rows != n_mat) return fail("evaluate from the Q buffer: hyphy_hip_build_q staged a different number of matrices than this evaluation consumes");
+      if (s.coeff_kind == 2) return fail("evaluate from the Q buffer: the staged rows were consumed as mixture components: call hyphy_hip_build_q first");
+      s.coeff_kind = 1;
     }
     if (!q_on_device) {
       HIPCHK(hipMemcpyAsync(s.qbuf, q, (size_t)n_mat * D * D * sizeof(double), hipMemcpyHostToDevice, s.stream));
@@ -1723,6 +1729,7 @@ int hyphy_hip_set_q_templates(hyphy_hip_partition *p, int64_t K, const double *t
     if (hipHostGetDevicePointer((void **)&s.d_hcoeffs, s.h_coeffs, 0) != hipSuccess) s.d_hcoeffs = nullptr;
     s.coeffs_cur = nullptr;
     s.coeff_rows = 0;
+    s.coeff_kind = 0;
     s.coeff_slot = -1;
     s.qbuf_built = false;
     for (int k = 0; k < 4; k++) {
@@ -1814,6 +1821,7 @@ int hyphy_hip_build_q(hyphy_hip_partition *p, int64_t n, const double *coeffs) {
     memcpy(stage, coeffs, nbytes);
     s.coeff_slot = slot;
     s.coeff_rows = n;
+    s.coeff_kind = 0;  // (unclaimed: the first evaluation that consumes the rows says what they are)
     s.qbuf_built = !fuse;
     if (fuse && s.d_hcoeffs) {
       // the fused expm kernel reads the (few hundred) coefficients straight from the pinned ring slot over

@@ -175,6 +175,7 @@ struct Shard {
   bool coeff_busy[4] = {false, false, false, false};
   int coeff_slot = -1;                 // ring slot of the staged coefficients
   int64_t coeff_rows = 0;              // rows staged by the last hyphy_hip_build_q (0: nothing staged)
+  int coeff_kind = 0;                  // what consumed them first: 0 nobody yet, 1 one row per (class, branch), 2 one row per (branch, mixture component)
   bool qbuf_built = false;             // ... and materialised in qbuf (HYPHY_HIP_MATERIALIZE_Q)
   double *h_small = nullptr;  // pi / weights staging
   size_t h_small_cap = 0;

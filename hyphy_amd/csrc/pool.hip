@@ -24,11 +24,37 @@ Pool &pool() {
 size_t cap_bytes() {
   static const size_t cap = [] {
     const char *e = getenv("HYPHY_HIP_POOL_MB");
-    return (size_t)(e ? atol(e) : 1024) << 20;
+    const long mb = e ? atol(e) : 1024;
+    return (size_t)(mb < 0 ? 0 : mb) << 20;  // (a negative value means "off", not 2^64 bytes)
   }();
   return cap;
 }
 constexpr size_t kMaxCachedBlock = (size_t)64 << 20;
+
+// Give every cached block of one kind back to the driver (the device's, or the pinned host blocks made under it): cached blocks are
+// keyed by exact size, so a new partition of another shape cannot use them — but they still hold the memory it is being refused.
+void release_cached(Pool &P, bool host, int dev) {
+  std::vector<void *> drop;
+  {
+    std::lock_guard<std::mutex> lock(P.m);
+    auto &lists = host ? P.free_host : P.free_dev;
+    size_t &cached = host ? P.cached_host : P.cached_dev;
+    for (auto &kv : lists) {
+      if (kv.first.first != dev) continue;
+      for (void *b : kv.second) {
+        drop.push_back(b);
+        cached -= kv.first.second;
+      }
+      kv.second.clear();
+    }
+  }
+  if (drop.empty()) return;
+  if (!host) hipDeviceSynchronize();
+  for (void *b : drop) {
+    if (host) hipHostFree(b);
+    else hipFree(b);
+  }
+}
 size_t rounded(size_t bytes) { return bytes == 0 ? 256 : (bytes + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -49,7 +75,12 @@ hipError_t pool_malloc(void **out, size_t bytes) {
       return hipSuccess;
     }
   }
-  const hipError_t e = hipMalloc(out, n);
+  hipError_t e = hipMalloc(out, n);
+  if (e != hipSuccess) {  // the blocks this pool keeps for partitions of other shapes may be what is missing: release them, once
+    (void)hipGetLastError();
+    release_cached(P, false, dev);
+    e = hipMalloc(out, n);
+  }
   if (e == hipSuccess) {
     std::lock_guard<std::mutex> lock(P.m);
     P.live_dev[*out] = std::make_pair(dev, n);
@@ -98,7 +129,12 @@ hipError_t pool_host_malloc(void **out, size_t bytes) {
       return hipSuccess;
     }
   }
-  const hipError_t e = hipHostMalloc(out, n);
+  hipError_t e = hipHostMalloc(out, n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    release_cached(P, true, dev);
+    e = hipHostMalloc(out, n);
+  }
   if (e == hipSuccess) {
     std::lock_guard<std::mutex> lock(P.m);
     P.live_host[*out] = std::make_pair(dev, n);

@@ -1478,3 +1478,39 @@ def test_recycled_allocations_carry_nothing_over():
             assert abs(ll2 - ref2) <= RTOL * abs(ref2), (rep, ll2, ref2)
         seen.add(round(ll, 6))
     assert len(seen) >= 3
+
+
+def test_staged_rows_are_claimed_by_their_first_consumer():
+    """hyphy_hip_build_q stages coefficient rows without saying what they are — one row per (class, branch) for hyphy_hip_evaluate_built,
+    one per (branch, mixture component) for hyphy_hip_evaluate_mixture_built.  The first evaluation that consumes a staging claims it; an
+    evaluation of the OTHER kind that happens to need the same number of rows is refused instead of reading rows that mean something
+    else, and a fresh hyphy_hip_build_q makes either kind possible again."""
+    import ctypes as C
+    from hyphy_amd import hip, models
+    fx = common.load("codon_small")
+    rev = dict(zip(common.REV_KEYS, (float(x) for x in fx["rev"])))
+    t = np.asarray(fx["t"], dtype=np.float64)
+    nodes = common.all_nodes(fx)
+    B = len(nodes)
+    T = np.zeros((2, 61, 61))
+    rv = dict(rev, AG=1.0)
+    for (i, j, nm, ns, pf) in models.mg94rev_template(fx["pos_freqs"]):
+        T[1 if ns else 0, i, j] = rv[nm] * pf
+    coeffs = np.ascontiguousarray(np.stack([t, t * float(fx["omega"])], axis=1))   # [B, 2]: one component per branch = the plain model
+    W = np.ones((B, 1))
+    ref = float(fx["logl"])
+    rf = np.ascontiguousarray(fx["root_freqs"], dtype=np.float64)
+    with _mk(fx) as part:
+        part.set_q_templates(T)
+        ll = part.evaluate_mixture_built(nodes, nodes, coeffs[:, None, :], W, rf)       # stages B rows, claims them as components
+        assert abs(ll - ref) <= RTOL * abs(ref)
+        out = C.c_double(0.0)
+        rc = part._lib.hyphy_hip_evaluate_built(part._h, -1, hip._l(nodes), B, hip._l(nodes), B, hip._d(rf), C.byref(out))
+        assert rc != 0 and b"hyphy_hip_build_q first" in part._lib.hyphy_hip_last_error()
+        step = part.prepare_built_step(nodes, nodes, rf, coeffs)                        # stages afresh: now one row per branch
+        assert abs(step() - ref) <= RTOL * abs(ref)
+        cnt = np.ones(B, dtype=np.int64)
+        rc = part._lib.hyphy_hip_evaluate_mixture_built(part._h, -1, hip._l(nodes), B, hip._l(nodes), B, hip._l(cnt), hip._d(W), hip._d(rf),
+                                                        C.byref(out), None, None)
+        assert rc != 0 and b"hyphy_hip_build_q first" in part._lib.hyphy_hip_last_error()
+        assert abs(part.evaluate_mixture_built(nodes, nodes, coeffs[:, None, :], W, rf) - ref) <= RTOL * abs(ref)
