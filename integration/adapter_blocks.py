@@ -251,7 +251,11 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
     const long gen = spmd_generation++;
     {
       const char *base = getenv("HYPHY_HIP_UID_FILE");
-      const std::string path = base ? std::string(base) + "." + std::to_string(gen) : std::string();
+      // HYPHY_HIP_RUN_ID (set by the launcher, the same on every rank, new for every run) goes into the file's name: a rank then
+      // cannot take an earlier run's id for this run's, however far apart the ranks start.  Without it the file is only accepted when
+      // it is not older than this process (minus 2 s) — ranks that start more than that after rank 0 wrote it would wait in vain.
+      const char *run_id = getenv("HYPHY_HIP_RUN_ID");
+      const std::string path = base ? std::string(base) + (run_id ? std::string(".") + run_id : std::string()) + "." + std::to_string(gen) : std::string();
       if (spmd_world == 1) {
         have = hyphy_hip_comm_unique_id(uid) == 0;
       } else if (base && spmd_rank == 0) {
@@ -267,7 +271,7 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
       } else if (base) {
         for (int tries = 0; tries < 6000 && !have; tries++) {  // (up to ~10 minutes: rank 0 may still be parsing its batch file)
           struct stat st;
-          if (stat(path.c_str(), &st) == 0 && st.st_mtime + 2 >= proc_start) {
+          if (stat(path.c_str(), &st) == 0 && (run_id || st.st_mtime + 2 >= proc_start)) {
             FILE *fh = fopen(path.c_str(), "rb");
             if (fh) {
               have = fread(uid, 1, 128, fh) == 128;

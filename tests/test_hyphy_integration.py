@@ -425,7 +425,7 @@ def test_hbl_spmd_site_shard_two_ranks(tmp_path):
     out = {}
 
     def run(rank):
-        env = dict(ENV, HYPHY_HIP_WORLD="2", HYPHY_HIP_RANK=str(rank), HYPHY_HIP_UID_FILE=uid)
+        env = dict(ENV, HYPHY_HIP_WORLD="2", HYPHY_HIP_RANK=str(rank), HYPHY_HIP_UID_FILE=uid, HYPHY_HIP_RUN_ID=str(os.getpid()))
         # (sweep inside an LF_START_COMPUTE bracket, then Optimize: two SetupLFCaches, i.e. two communicators per process —
         #  each is a rendezvous of its own, "<uid file>.<n>")
         out[rank] = hbl.evaluate(binary=HIP_BIN, extra_env=env, per_site=False, optimize=True,
