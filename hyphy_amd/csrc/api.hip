@@ -360,7 +360,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     }
     tr.lap("slots+q");
     bool coeffs_consumed = false;
-    if (p->nuc && prune_nuc_folds_expm((int)p->L, s.S_pad, n_ops_planned) && !(q_from_templates && !ea.coeffs)) {
+    if (p->nuc && p->mode == 0 && prune_nuc_folds_expm((int)p->L, s.S_pad, n_ops_planned) && !(q_from_templates && !ea.coeffs)) {
       folded_expm = ea;  // (4 states, small shard: the pruning launch computes the exponentials itself)
       have_folded = true;
     } else {
@@ -416,10 +416,20 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     na.wg_sum = s.wg_sum;
     na.wg_cnt = s.wg_cnt;
     na.wg_flag = s.wg_flag;
+    if (p->mode == 1) {  // the trunk of a class-compressed partition (repeats.hip): generalised leaves, one leaf per entry
+      const hyphy_hip_partition::View &v = p->vw();
+      na.L = v.L;
+      na.root_inode = v.I - 1;
+      na.codes = s.rep_codes_tile;   // (4 states: row-major [view leaf][pattern])
+      na.PT = nullptr;               // (prune_nuc_kernel)
+      na.leaf_tab = s.rep_leaf;
+      na.gtab = s.rep_tab + (size_t)cat * s.rep_rows * 4;
+      na.gcnt = s.rep_cnt + (size_t)cat * s.rep_rows;
+    }
     n_wg = prune_nuc_grid(na);
     {  // fused final combine (see the codon branch below): the small-shard instantiation of the 4-state kernel carries it
       const char *fuse_env = getenv("HYPHY_HIP_FUSED_REDUCE");
-      if (!(fuse_env && atoi(fuse_env) == 0) && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && prune_nuc_fuses_reduce(na, have_folded)) {
+      if (!(fuse_env && atoi(fuse_env) == 0) && p->mode == 0 && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && prune_nuc_fuses_reduce(na, have_folded)) {
         double *rec = s.d_hout ? s.d_hout : s.out;
         fused_reduce = true;
         na.red_out = d_logl_out ? d_logl_out : rec;
@@ -698,7 +708,7 @@ int hyphy_hip_prune_launches(hyphy_hip_partition *p) { return p ? (int)std::max<
 
 const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p) {
   if (!p) return "";
-  if (p->nuc) return p->nuc_leaf_pairs ? "prune_nuc2_kernel" : "prune_nuc_kernel";
+  if (p->nuc) return (p->nuc_leaf_pairs && p->mode == 0) ? "prune_nuc2_kernel" : "prune_nuc_kernel";
   return p->variant == 1 ? "prune_wave_kernel" : "prune_mfma_kernel";  // (variant 2: the same kernel on a chain schedule)
 }
 

@@ -188,6 +188,10 @@ struct NucArgs {
   const int *red_status = nullptr;
   double red_seq = 0.;
   int *red_done = nullptr;   // arrivals of workgroups (zero between launches)
+  // subtree repeats (repeats.hip; prune_nuc_kernel<PIN, REP>): the schedule's leaves are those of the trunk view
+  const int2 *leaf_tab = nullptr;   // [L] (first row of the leaf's class table or -1: ordinary leaf, matrix slot of an ordinary leaf)
+  const double *gtab = nullptr;     // [rows][4] class tables
+  const int32_t *gcnt = nullptr;    // [rows] their 2^64 exponents
 };
 
 constexpr int kSiteFitParkSlots = 1;  // wave-private LDS parking slots of the per-site fit kernel (8 KiB each at D = 61); nodes

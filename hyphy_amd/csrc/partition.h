@@ -242,7 +242,7 @@ struct hyphy_hip_partition {
   const View &vw() const { return views[mode]; }
   struct ModeState {                         // what the tuner / re-rooting decided, per view
     int variant = 0, wave_variant = 0, n_slots = 0, chain_m_forced = 0;
-    bool rr_use = false, kernel_forced = false;
+    bool rr_use = false, kernel_forced = false, nuc_leaf_pairs = false;
     int64_t tuned_for = 0;
     std::string tune_report;
     std::vector<int> rr_path;

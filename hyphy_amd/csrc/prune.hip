@@ -1426,7 +1426,9 @@ __global__ __launch_bounds__(64) void bc_eval_kernel(BcArgs a) {
 // ---------------------------------------------------------------------------------------------
 // (ops and P are separate __restrict__ kernel arguments: schedule entries and transition matrices then come
 //  through scalar loads; as members of the by-value argument struct they were 30 vector loads per entry)
-template <bool PIN>  // PIN: a node's states are pinned (hyphy_hip_set_pinned_states); compiled apart — the extra
+// REP: the tree is the trunk of a class-compressed partition (repeats.hip): a leaf of the schedule may be a generalised leaf — its
+//      column is a row of a class table (4 doubles, looked up by class id) and carries a 2^64 exponent.
+template <bool PIN, bool REP = false>  // PIN: a node's states are pinned (hyphy_hip_set_pinned_states); compiled apart — the extra
                       // select per leaf entry costs the HBM-bound kernel 30 % (54 vs 41 us at gtr_32x50k)
 __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__ ops, const double *__restrict__ Pm,
                                                         NucArgs a) {
@@ -1440,7 +1442,14 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
   // One entry ahead: the schedule word, the 16 entries of its transition matrix (scalar loads) and, for a leaf,
   // this thread's code — at small shard sizes (< 1 wave per SIMD) the entry-to-entry chain of dependent loads
   // is the whole run time.  Programs are followed by two no-op entries, so oi + 1 is always readable.
-  auto child_of = [](const int4 &o) { return (o.x & 3) == OPK_LEAF ? (o.z & 0xffff) : o.z; };
+  auto child_of = [&](const int4 &o) {  // (matrix slot of the entry's branch)
+    if ((o.x & 3) != OPK_LEAF) return o.z;
+    if constexpr (REP) {
+      const int2 lt = a.leaf_tab[o.z & 0xffff];
+      return lt.x >= 0 ? 0 : lt.y;  // (a generalised leaf needs no matrix: its table rows are edge-applied already)
+    }
+    return o.z & 0xffff;
+  };
   int4 op = ops[0];
   double P[16];
 #pragma unroll
@@ -1463,7 +1472,23 @@ __global__ __launch_bounds__(256) void prune_nuc_kernel(const int4 *__restrict__
     if (!(is_leaf && ((op.x >> 8) & 0x7f) == 0)) {  // (else: padding entry)
     double cv[4];
     bool matvec = true;
-    if (is_leaf) {
+    bool gen = false;
+    if constexpr (REP) {
+      if (is_leaf) {
+        const int2 lt = a.leaf_tab[op.z & 0xffff];
+        if (lt.x >= 0) {  // generalised leaf: the class's row of the subtree root's table
+          gen = true;
+          matvec = false;
+          const double *row = a.gtab + ((size_t)lt.x + (size_t)code) * 4;
+          const f64x2 r0 = *reinterpret_cast<const f64x2 *>(row), r1 = *reinterpret_cast<const f64x2 *>(row + 2);
+          acc[0] *= r0[0], acc[1] *= r0[1], acc[2] *= r1[0], acc[3] *= r1[1];
+          cnt += a.gcnt[lt.x + code];
+        }
+      }
+    }
+    if (gen) {
+      // (done above)
+    } else if (is_leaf) {
       if (code >= 0) {
         matvec = false;
 #pragma unroll
@@ -2130,7 +2155,17 @@ void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
   if (a.variant == 1 && a.T == 1) {  // wave-per-tile kernel: one wave per workgroup
     const dim3 block1(64);
     const size_t lds1 = CLDS ? (size_t)a.L * 16 * sizeof(int16_t) : 0;
-    if (a.leaf_tab) {  // the trunk of a class-compressed partition (production instantiations only)
+    if (a.leaf_tab && a.timeline && NW == 4 && CLDS) {  // tracing build of the trunk (HYPHY_HIP_TIMELINE with HYPHY_HIP_REPEATS=1)
+      if (a.n_slots <= 3) hipLaunchKernelGGL((prune_wave_kernel<4, 1, true, true, false, HYPHY_OCC3, true, false, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      else hipLaunchKernelGGL((prune_wave_kernel<4, 2, true, true, false, HYPHY_OCC3, true, false, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      return;
+    }
+    if (a.leaf_tab && NW == 4 && CLDS && (a.wave_variant == 2 || a.wave_variant == 3) && a.n_slots <= 2) {  // three waves per SIMD, see below
+      if (a.wave_variant == 2) hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 3, false, false, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      else hipLaunchKernelGGL((prune_wave_kernel<4, 0, true, false, true, 3, true, false, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
+      return;
+    }
+    if (a.leaf_tab) {  // the trunk of a class-compressed partition
       if (a.n_slots <= 2) hipLaunchKernelGGL((prune_wave_kernel<NW, 0, CLDS, false, false, HYPHY_OCC3, true, false, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
       else if (a.n_slots == 3) hipLaunchKernelGGL((prune_wave_kernel<NW, 1, CLDS, false, false, HYPHY_OCC3, true, false, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
       else hipLaunchKernelGGL((prune_wave_kernel<NW, 2, CLDS, false, false, HYPHY_OCC3, true, false, false, true>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
@@ -2281,6 +2316,10 @@ void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex) 
   if (a.n_ops <= 0) return;
   const bool pin = a.pin_leaf >= 0 || a.pin_inode >= 0;
   const int np = nuc2_np(a);
+  if (a.leaf_tab) {  // the trunk of a class-compressed partition (no pinned states in that mode)
+    hipLaunchKernelGGL((prune_nuc_kernel<false, true>), dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a.ops, a.P, a);
+    return;
+  }
   if (np == 0) {
     if (pin) hipLaunchKernelGGL(prune_nuc_kernel<true>, dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a.ops, a.P, a);
     else hipLaunchKernelGGL(prune_nuc_kernel<false>, dim3((a.S_pad + 255) / 256), dim3(256), 0, stream, a.ops, a.P, a);

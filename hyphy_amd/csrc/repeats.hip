@@ -449,6 +449,87 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(const int4 *__restri
 
 }  // namespace
 
+// ---- 4 states ----------------------------------------------------------------------------------------------------------
+// A conditional vector is 32 bytes there and an edge product 16 multiply-adds: a compressed subtree is not cut into paths and
+// tables but walked WHOLE, in post-order, by one thread per class of its root — inputs are leaf columns only (by the state the
+// class's representative pattern has at the leaf; an ambiguity code: the product with its resolution vector), a finished
+// child's edge product waits on a small per-thread stack in LDS (children are visited heaviest first: a subtree of n leaves needs
+// at most log2 n + 1 slots) — and only the root's rows are stored.  No table reads another: one launch, no synchronisation.
+constexpr int kNucStack = 8;
+struct RepNucArgs {
+  const int32_t *map;
+  double *tab;        // [rows][4]
+  int32_t *cnt;       // [rows]
+  const double *P;    // [B][16] row-major transition matrices of the class being evaluated
+  const double *ambig;
+};
+
+namespace {
+__global__ __launch_bounds__(128) void class_table_nuc_kernel(const int4 *__restrict__ desc, const int *__restrict__ list, RepNucArgs a) {
+  const int d = list[blockIdx.y];
+  const int4 h0 = desc[2 * d], h1 = desc[2 * d + 1];  // (first row, classes, walked nodes, first node entry), (first index map, rows, -, inputs)
+  const int rows = h1.y, n_nodes = h0.z;
+  if ((int)blockIdx.x * 128 >= rows) return;
+  const int tid = threadIdx.x, u = blockIdx.x * 128 + tid;  // (rows are padded to 16: threads beyond them do nothing but follow)
+  const bool live = u < rows;
+  __shared__ double stk[kNucStack][4][128];
+  __shared__ int stk_cnt[kNucStack][128];
+  int sp = 0, e = 0;
+  double E[4] = {1., 1., 1., 1.};
+  int cnt = 0;
+  for (int k = 0; k < n_nodes; k++) {
+    const int4 ne = desc[h0.w + k];  // (matrix slot of the node's branch, leaf inputs, first input entry, finished children to take off the stack)
+    double acc[4] = {1., 1., 1., 1.};
+    cnt = 0;
+    for (int j = 0; j < ne.y; j++, e++) {
+      const int4 ie = desc[ne.z + j];
+      const int code = live ? a.map[h1.x + (size_t)e * rows + u] : 0;
+      const double *Pl = a.P + (size_t)ie.y * 16;  // uniform
+      if (code >= 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const double p0 = Pl[4 * i], p1 = Pl[4 * i + 1], p2 = Pl[4 * i + 2], p3 = Pl[4 * i + 3];
+          acc[i] *= (code == 0) ? p0 : (code == 1) ? p1 : (code == 2) ? p2 : p3;
+        }
+      } else {
+        const double *av = a.ambig + (size_t)(-code - 1) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] *= fma(Pl[4 * i + 3], av[3], fma(Pl[4 * i + 2], av[2], fma(Pl[4 * i + 1], av[1], Pl[4 * i] * av[0])));
+      }
+    }
+    for (int j = 0; j < ne.w; j++) {
+      sp--;
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[i] *= stk[sp][i][tid];
+      cnt += stk_cnt[sp][tid];
+    }
+    const double tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    double sc;
+    const int m = rescale_decision(tot, sc);
+    if (m != 0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[i] *= sc;
+    }
+    cnt += m;
+    const double *Pn = a.P + (size_t)ne.x * 16;  // uniform
+#pragma unroll
+    for (int i = 0; i < 4; i++) E[i] = fma(Pn[4 * i + 3], acc[3], fma(Pn[4 * i + 2], acc[2], fma(Pn[4 * i + 1], acc[1], Pn[4 * i] * acc[0])));
+    if (k + 1 < n_nodes) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) stk[sp][i][tid] = E[i];
+      stk_cnt[sp][tid] = cnt;
+      sp++;
+    }
+  }
+  if (live) {
+    double *out = a.tab + ((size_t)h0.x + u) * 4;
+    *reinterpret_cast<f64x2 *>(out) = (f64x2){E[0], E[1]};
+    *reinterpret_cast<f64x2 *>(out + 2) = (f64x2){E[2], E[3]};
+    a.cnt[h0.x + u] = cnt;
+  }
+}
+}  // namespace
+
 void launch_class_tables(const RepArgs &a, int NW, hipStream_t stream) {
   const dim3 grid(a.n_waves), block(64);
   if (a.dbg && NW == 4) {
@@ -587,24 +668,227 @@ int rep_setup(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &c
 }
 
 namespace {
+// 4 states (see class_table_nuc_kernel): one descriptor per compressed subtree ROOT, walked whole; theta 0.9 by default (a walk costs
+// 16 multiply-adds per node: everything that repeats at all is worth a table).
+int rep_setup_nuc(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &codes, const std::vector<std::vector<std::vector<int>>> &cls,
+                  const std::vector<std::vector<int>> &U, std::vector<char> &comp, bool forced) {
+  const int L = (int)p->L, I = (int)p->I;
+  const size_t nsh = p->shards.size();
+  // stack slots a subtree's walk needs when every node visits its internal children heaviest first
+  std::vector<int> need(I, 1);
+  std::vector<std::vector<int>> order(I);  // internal children (internal indices) in visiting order
+  for (int n = 0; n < I; n++) {
+    for (int c : p->children[n])
+      if (c >= L) order[n].push_back(c - L);
+    std::stable_sort(order[n].begin(), order[n].end(), [&](int x, int y) { return need[x] > need[y]; });
+    for (size_t j = 0; j < order[n].size(); j++) need[n] = std::max(need[n], (int)j + need[order[n][j]]);
+  }
+  for (int n = I - 1; n >= 0; n--)  // (parents first: a subtree too deep for the stack hands the role of root to its children)
+    if (comp[n] && (p->parents[L + n] < 0 || !comp[p->parents[L + n]]) && need[n] > kNucStack) comp[n] = 0;
+  {
+    double full = 0., repd = 0.;
+    for (int n = 0; n < I - 1; n++) {
+      full += p->shards[0].S_pad;
+      const bool root = comp[n] && !comp[p->parents[L + n]];
+      repd += comp[n] ? (root ? (double)U[0][n] : 0.) : (double)p->shards[0].S_pad;  // (nodes inside a walk cost next to nothing here)
+    }
+    if (!forced && repd > 0.5 * full) return 0;
+  }
+  p->rep_nodes.clear();
+  p->rep_desc_of.assign((size_t)L + I, -1);
+  for (int n = 0; n < I; n++) {
+    if (!comp[n] || comp[p->parents[L + n]]) continue;  // roots only
+    hyphy_hip_partition::RepNode rn;
+    rn.node = L + n;
+    rn.level = 0;
+    // post-order over the subtree, heaviest child first
+    std::vector<std::pair<int, size_t>> stack(1, std::make_pair(n, (size_t)0));
+    while (!stack.empty()) {
+      std::pair<int, size_t> &t = stack.back();
+      if (t.second < order[t.first].size()) {
+        const int c = order[t.first][t.second++];
+        stack.push_back(std::make_pair(c, (size_t)0));
+      } else {
+        const int x = t.first;
+        rn.path.push_back(L + x);
+        rn.flags.push_back((int)order[x].size());  // (4 states: finished children this node takes off the stack)
+        rn.kids.push_back(std::vector<int>());
+        rn.kid_desc.push_back(std::vector<int>());
+        for (int c : p->children[x])
+          if (c < L) {
+            rn.kids.back().push_back(c);
+            rn.kid_desc.back().push_back(-1);
+          }
+        stack.pop_back();
+      }
+    }
+    p->rep_desc_of[L + n] = (int)p->rep_nodes.size();
+    p->rep_nodes.push_back(rn);
+  }
+  const int ND = (int)p->rep_nodes.size();
+  if (ND == 0 || ND > 65535) return 0;
+  // the trunk view: ordinary leaves (ambiguity codes stay with the trunk kernel's own resolution-vector path) and compressed roots
+  hyphy_hip_partition::View &v = p->views[1];
+  v = hyphy_hip_partition::View();
+  std::vector<int> vint(I, -1);
+  for (int n = 0; n < I; n++)
+    if (!comp[n]) vint[n] = v.I++;
+  std::vector<int> leaf_nodes, vleaf((size_t)L + I, -1);
+  for (int n = 0; n < I; n++)
+    if (!comp[n])
+      for (int c : p->children[n])
+        if (c < L || comp[c - L]) {
+          vleaf[c] = (int)leaf_nodes.size();
+          leaf_nodes.push_back(c);
+        }
+  v.L = (int)leaf_nodes.size();
+  if (v.L > 65535 || v.L < 1) return 0;
+  v.parents.assign((size_t)v.L + v.I, -1);
+  v.children.assign(v.I, std::vector<int>());
+  v.slot.assign((size_t)v.L + v.I, 0);
+  v.leaf_has_ambig.assign(v.L, 0);
+  for (int n = 0; n < I; n++) {
+    if (comp[n]) continue;
+    v.slot[v.L + vint[n]] = L + n;
+    const int64_t par = p->parents[L + n];
+    v.parents[v.L + vint[n]] = par < 0 ? -1 : vint[par];
+    for (int c : p->children[n]) {
+      if (c < L || comp[c - L]) {
+        v.children[vint[n]].push_back(vleaf[c]);
+        v.parents[vleaf[c]] = vint[n];
+        v.slot[vleaf[c]] = c;
+        if (c < L) v.leaf_has_ambig[vleaf[c]] = p->leaf_has_ambig[c];
+      } else {
+        v.children[vint[n]].push_back(v.L + vint[c - L]);
+      }
+    }
+    std::sort(v.children[vint[n]].begin(), v.children[vint[n]].end());
+  }
+  for (size_t k = 0; k < nsh; k++) {
+    Shard &s = p->shards[k];
+    if (hipSetDevice(s.device) != hipSuccess) return fail("hipSetDevice failed");
+    const size_t SP = (size_t)s.S_pad;
+    s.rep_tabs.assign(ND, RepTable());
+    std::vector<int32_t> maps;
+    int64_t rows = 0;
+    std::vector<int4> desc((size_t)2 * ND);
+    for (int d = 0; d < ND; d++) {
+      const hyphy_hip_partition::RepNode &rn = p->rep_nodes[d];
+      RepTable &t = s.rep_tabs[d];
+      const std::vector<int> &cl = cls[k][rn.node - L];
+      t.U = U[k][rn.node - L];
+      t.rows = (t.U + 15) / 16 * 16;
+      t.row0 = rows;
+      rows += t.rows;
+      std::vector<int> first_pat(t.rows, -1);
+      for (size_t j = 0; j < SP; j++)
+        if (first_pat[cl[j]] < 0) first_pat[cl[j]] = (int)j;
+      for (int u = t.U; u < t.rows; u++) first_pat[u] = first_pat[0];
+      const int64_t map0 = (int64_t)maps.size();
+      int n_in = 0;
+      for (size_t x = 0; x < rn.path.size(); x++)
+        for (int c : rn.kids[x]) {
+          for (int u = 0; u < t.rows; u++) maps.push_back((int32_t)codes[k][(size_t)c * SP + first_pat[u]]);
+          n_in++;
+        }
+      t.map0.push_back(map0);
+      const int node0 = (int)desc.size();
+      desc[2 * d] = make_int4((int)t.row0, t.U, (int)rn.path.size(), node0);
+      desc[2 * d + 1] = make_int4((int)map0, t.rows, 0, n_in);
+      desc.resize(desc.size() + rn.path.size());
+      for (size_t x = 0; x < rn.path.size(); x++) {
+        desc[node0 + x] = make_int4(rn.path[x], (int)rn.kids[x].size(), (int)desc.size(), rn.flags[x]);
+        for (int c : rn.kids[x]) desc.push_back(make_int4(-1, c, 0, -1));
+      }
+    }
+    s.rep_rows = rows;
+    if (maps.size() > 0x7fffffffull || rows > 0x7fffffffll) return 0;
+    std::vector<int16_t> ct((size_t)v.L * SP, 0);  // the trunk's leaf table, row-major [view leaf][pattern]: state codes / class ids
+    std::vector<int2> lt(v.L);
+    for (int vl = 0; vl < v.L; vl++) {
+      const int c = leaf_nodes[vl], d = p->rep_desc_of[c];
+      lt[vl] = d >= 0 ? make_int2((int)s.rep_tabs[d].row0, (int)s.rep_tabs[d].row0) : make_int2(-1, c);
+      for (size_t j = 0; j < SP; j++) ct[(size_t)vl * SP + j] = (int16_t)(d < 0 ? (int)codes[k][(size_t)c * SP + j] : cls[k][c - L][j]);
+    }
+    {
+      size_t free_b = 0, total_b = 0, limit = (size_t)1 << 30;
+      const size_t need_b = (size_t)p->C * rows * 36 + maps.size() * 4 + ct.size() * 2;
+      if (const char *e = getenv("HYPHY_HIP_REP_MAX_MB")) limit = (size_t)std::max(0L, atol(e)) << 20;
+      else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) limit = free_b / 4;
+      if (need_b > limit) return fail("class tables would take more than a quarter of the free device memory (or than HYPHY_HIP_REP_MAX_MB)");
+    }
+#define R_(ptr, bytes)                                                                  \
+  if (pool_malloc((void **)&(ptr), (bytes)) != hipSuccess) return fail("hipMalloc failed (" #ptr ")"); \
+  s.dev_bytes += (size_t)(bytes);                                                                      \
+  s.rep_bytes += (size_t)(bytes);
+    R_(s.rep_tab, (size_t)p->C * rows * 4 * sizeof(double));
+    R_(s.rep_cnt, (size_t)p->C * rows * sizeof(int32_t));
+    R_(s.rep_map, std::max<size_t>(1, maps.size()) * sizeof(int32_t));
+    R_(s.rep_desc, desc.size() * sizeof(int4));
+    R_(s.rep_codes_tile, ct.size() * sizeof(int16_t));
+    R_(s.rep_leaf, lt.size() * sizeof(int2));
+#undef R_
+    if (getenv("HYPHY_HIP_POISON")) {
+      hipMemset(s.rep_tab, 0xff, (size_t)p->C * rows * 4 * sizeof(double));
+      hipMemset(s.rep_cnt, 0xff, (size_t)p->C * rows * sizeof(int32_t));
+    }
+    hipMemcpy(s.rep_map, maps.data(), maps.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    hipMemcpy(s.rep_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice);
+    hipMemcpy(s.rep_codes_tile, ct.data(), ct.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+    hipMemcpy(s.rep_leaf, lt.data(), lt.size() * sizeof(int2), hipMemcpyHostToDevice);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail("repeats: device initialisation failed");
+  }
+  p->rep_resident.assign(p->C, 0);
+  p->rep_cached_valid = false;
+  hyphy_hip_partition::ModeState &ms = p->saved_mode[1];
+  ms.variant = p->variant;
+  ms.wave_variant = 0;
+  ms.n_slots = p->n_slots;   // (2 + kNucParkSlots)
+  ms.chain_m_forced = 0;
+  ms.rr_use = false;
+  ms.kernel_forced = true;
+  ms.tuned_for = 0;
+  ms.nuc_leaf_pairs = false;  // (the trunk goes through prune_nuc_kernel: one leaf per entry)
+  p->rep_on = true;
+  p->rep_decided = true;       // (4 states: decided here, by the arithmetic above)
+  if (getenv("HYPHY_HIP_VERBOSE")) {
+    long long rows = 0, lower = 0;
+    for (int d = 0; d < ND; d++) {
+      rows += p->shards[0].rep_tabs[d].rows;
+      lower += (long long)p->shards[0].rep_tabs[d].rows * (long long)p->rep_nodes[d].path.size();
+    }
+    fprintf(stderr, "[hyphy_hip] subtree repeats (4 states): %d compressed subtrees walked per class (%lld classes on shard 0, %lld node visits), trunk of %d "
+                    "internal nodes over %d leaves (every pattern at every node: %lld)\n",
+            ND, rows, lower, v.I, v.L, (long long)(I - 1) * p->shards[0].S_pad);
+  }
+  return 0;
+}
+}  // namespace
+
+namespace {
 int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &codes) {
   p->rep_on = false;
   const char *env = getenv("HYPHY_HIP_REPEATS");
   if (env && atoi(env) == 0) return 0;
-  if (p->nuc || p->shards.empty()) return 0;
+  if (p->shards.empty()) return 0;
   if (!env)  // (the diagnostic switches that force a kernel, an instantiation or a cut are about the per-pattern kernels)
     for (const char *sw : {"HYPHY_HIP_KERNEL", "HYPHY_HIP_WAVE_VARIANT", "HYPHY_HIP_CUT", "HYPHY_HIP_CHAIN_M", "HYPHY_HIP_FRAGMENT",
                            "HYPHY_HIP_SLOTS", "HYPHY_HIP_REROOT", "HYPHY_HIP_TILES", "HYPHY_HIP_TIMELINE", "HYPHY_HIP_ABLATE"})
       if (getenv(sw)) return 0;
   for (const Shard &s : p->shards)
     if (s.T != 1) return 0;
-  if (p->variant != 1 && !(env && atoi(env) == 2)) return 0;  // (tiny shards: the workgroup-per-tile kernel keeps the whole tree)
+  if (!p->nuc && p->variant != 1 && !(env && atoi(env) == 2)) return 0;  // (tiny shards: the workgroup-per-tile kernel keeps the whole tree)
+  // 4 states: only on request (HYPHY_HIP_REPEATS=1 / 2).  Measured, it loses: a class row is 36 bytes gathered past the L2 per pattern
+  // and generalised leaf, where prune_nuc2_kernel computes a whole node from registers for 12 multiply-adds — gtr_32x50k 35.0 us plain
+  // against 16.5 (walks) + 26.0 (trunk of 5 nodes) compressed, gtr_32x1m 123.8 against 14.5 + 238.9
+  if (p->nuc && !env) return 0;
   const int L = (int)p->L, I = (int)p->I, DP = p->DP;
   if (I < 2) return 0;
   const bool forced = env && atoi(env) == 2;
   // (before any work: a partition of a few tiles — FEL makes one per site — has nothing to compress, and the class arrays of a
   //  very large one are host memory this analysis should not take: 4 bytes per internal node and pattern)
-  if (!forced && p->shards[0].ntiles < 8) return 0;
+  if (!forced && (p->nuc ? p->shards[0].S_pad < 8192 : p->shards[0].ntiles < 8)) return 0;  // (4 states: a small shard is one launch
+                                                                                              //  with exponentials and combine folded in)
   {
     double cells = 0.;
     for (const Shard &s : p->shards) cells += (double)I * s.S_pad;
@@ -623,7 +907,8 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
   // ---- compressed set: the same on every shard (one schedule serves them all) ----
   std::vector<int> spads;
   for (const Shard &s : p->shards) spads.push_back(s.S_pad);
-  const std::vector<char> comp = compressed_set(p->children, L, I, U, spads, theta);
+  std::vector<char> comp = compressed_set(p->children, L, I, U, spads, p->nuc && !getenv("HYPHY_HIP_REP_THETA") ? 0.9 : theta);
+  if (p->nuc) return rep_setup_nuc(p, codes, cls, U, comp, forced);
   {  // worth it?  compare the edge products of the two forms on the first shard
     double full = 0., rep = 0.;
     for (int n = 0; n < I - 1; n++) {
@@ -912,6 +1197,22 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
   ms.rr_use = false;
   ms.kernel_forced = true;
   ms.tuned_for = 0;
+  ms.rr_path.clear();
+  ms.rr_cands.clear();
+  if (p->C == 1 && !p->nuc) {  // the trunk's own height-minimising roots (the tuner's third stage times the re-rooted schedules)
+    const int mode0 = p->mode;
+    std::vector<int> path0;
+    std::vector<std::vector<int>> cands0;
+    path0.swap(p->rr_path);
+    cands0.swap(p->rr_cands);
+    p->mode = 1;
+    reroot_path(p);
+    ms.rr_path.swap(p->rr_path);
+    ms.rr_cands.swap(p->rr_cands);
+    p->mode = mode0;
+    p->rr_path.swap(path0);
+    p->rr_cands.swap(cands0);
+  }
   p->rep_on = true;
   if (getenv("HYPHY_HIP_VERBOSE")) {
     long long rows = 0, lower = 0;
@@ -937,6 +1238,7 @@ void switch_mode(hyphy_hip_partition *p, int mode) {
   out.chain_m_forced = p->chain_m_forced;
   out.rr_use = p->rr_use;
   out.kernel_forced = p->kernel_forced;
+  out.nuc_leaf_pairs = p->nuc_leaf_pairs;
   out.tuned_for = p->tuned_for;
   out.tune_report = p->tune_report;
   out.rr_path = p->rr_path;
@@ -948,6 +1250,7 @@ void switch_mode(hyphy_hip_partition *p, int mode) {
   p->chain_m_forced = in.chain_m_forced;
   p->rr_use = in.rr_use;
   p->kernel_forced = in.kernel_forced;
+  if (p->nuc) p->nuc_leaf_pairs = in.nuc_leaf_pairs;
   p->tuned_for = in.tuned_for;
   p->tune_report = in.tune_report;
   p->rr_path = in.rr_path;
@@ -955,6 +1258,7 @@ void switch_mode(hyphy_hip_partition *p, int mode) {
   p->mode = mode;
   p->cached_valid = 0;
   p->rr_active = false;
+  for (Shard &sh : p->shards) sh.twins_dirty = true;  // (each view's re-rooted schedules reverse their own edges)
   std::fill(p->last_full.begin(), p->last_full.end(), 0);  // (the first full pass under a view stores every node it keeps)
 }
 
@@ -1054,11 +1358,32 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
   std::vector<int> dirty;
   rep_translate_update(p, update_nodes, n_update, q_nodes, n_q, full, dirty, view_update);
   p->rep_stale_branch = -1;
-  const bool same = p->rep_cached_valid && p->rep_cached_dirty == dirty && p->rep_cached_classes == n_classes * 65536 + cat0;
+  const int pass_key = p->nuc ? n_classes * 65536 : n_classes * 65536 + cat0;  // (4 states: the list of subtrees does not name the class)
+  const bool same = p->rep_cached_valid && p->rep_cached_dirty == dirty && p->rep_cached_classes == pass_key;
   if (same) return 0;
   const int ND = (int)p->rep_nodes.size();
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
+    if (p->nuc) {  // 4 states: the list of subtrees to walk (no items, no queues: one thread per class, no table reads another)
+      const size_t words = std::max<size_t>(1, (dirty.size() + 3) / 4);
+      if (words > s.rep_items_cap) {
+        HIPCHK(hipStreamSynchronize(s.stream));
+        if (s.rep_items) pool_free_sync(s.rep_items);
+        if (s.h_rep_items) pool_host_free(s.h_rep_items);
+        s.rep_items = nullptr;
+        s.h_rep_items = nullptr;
+        const size_t cap = std::max<size_t>(words, ((size_t)ND + 3) / 4);
+        HIPCHK(pool_malloc((void **)&s.rep_items, cap * sizeof(int4)));
+        HIPCHK(pool_host_malloc((void **)&s.h_rep_items, cap * sizeof(int4)));
+        s.rep_items_cap = cap;
+      }
+      HIPCHK(hipStreamSynchronize(s.stream));  // (staging buffer reuse)
+      int *lst = reinterpret_cast<int *>(s.h_rep_items);
+      for (size_t k = 0; k < dirty.size(); k++) lst[k] = dirty[k];
+      if (!dirty.empty()) HIPCHK(hipMemcpyAsync(s.rep_items, s.h_rep_items, words * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+      s.rep_qcap = (int)dirty.size();
+      continue;
+    }
     std::vector<int4> queues;
     int n_static = 0;
     const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues, &n_static);
@@ -1094,7 +1419,7 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
     if (const char *e = getenv("HYPHY_HIP_REP_WAVES")) s.rep_waves = std::max(1, std::min(per_q * kRepQueues, atoi(e)));
   }
   p->rep_cached_dirty = dirty;
-  p->rep_cached_classes = n_classes * 65536 + cat0;
+  p->rep_cached_classes = pass_key;
   p->rep_cached_valid = true;
   return 0;
 }
@@ -1106,6 +1431,19 @@ int rep_sync_stride() { return kRepHeadStride; }
 // the trunk's pruning launch, on the shard's stream).
 int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
   if (s.rep_qcap <= 0) return 0;
+  if (p->nuc) {
+    RepNucArgs a;
+    a.map = s.rep_map;
+    a.tab = s.rep_tab + (size_t)cat0 * s.rep_rows * 4;
+    a.cnt = s.rep_cnt + (size_t)cat0 * s.rep_rows;
+    a.P = s.Prow + (size_t)cat0 * p->B * 16;
+    a.ambig = s.ambig;
+    int max_rows = 16;
+    for (const RepTable &t : s.rep_tabs) max_rows = std::max(max_rows, t.rows);
+    hipLaunchKernelGGL(class_table_nuc_kernel, dim3((max_rows + 127) / 128, s.rep_qcap), dim3(128), 0, s.stream, (const int4 *)s.rep_desc,
+                       (const int *)s.rep_items, a);
+    return 0;
+  }
   (void)cat0;  // (the items name their rate class)
   RepArgs a;
   a.desc = s.rep_desc;

@@ -174,7 +174,7 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   // slot, no register prefetch of deposits) on its three fastest cuts — it wins where waves are plentiful ----
   const double stage1_ms = best_ms;
   int wave_wv = 0;  // instantiation the wave kernel's candidates of the third stage use
-  if (best.kernel == 1 && best.m > 0 && p->NW == 4 && p->mode == 0 && !getenv("HYPHY_HIP_WAVE_VARIANT") && !getenv("HYPHY_HIP_SLOTS"))
+  if (best.kernel == 1 && best.m > 0 && p->NW == 4 && !getenv("HYPHY_HIP_WAVE_VARIANT") && !getenv("HYPHY_HIP_SLOTS"))
     for (size_t k = 0; k < ranked[1].size() && k < 3; k++) {
       const Cand c{1, ranked[1][k].second, 2, -1};
       const double t = time_it(c);

@@ -268,3 +268,41 @@ def test_tables_that_do_not_fit_leave_a_plain_partition(monkeypatch):
     ref = float(fx["logl"])
     assert abs(ll - ref) <= RTOL * abs(ref), (ll, ref)
     assert abs(ll2 - full2) <= SAME * abs(full2)
+
+
+@pytest.mark.parametrize("name", ["nuc_small", "nuc_ambig", "nuc_deep", "nuc_wide", "ref_fluHA"])
+def test_four_states_compressed_equals_plain_and_reference(name, monkeypatch):
+    """4 states: every compressed subtree is walked whole by one thread per class of its root (class_table_nuc_kernel), the trunk goes
+    through prune_nuc_kernel with generalised leaves.  Full passes, partial updates, ambiguity codes (inside walks and at the trunk's
+    own leaves), a 300-taxon ladder that rescales (and whose walks exceed the stack: the roots move down), against plain and reference."""
+    monkeypatch.setenv("HYPHY_HIP_REPEATS", "2")
+    monkeypatch.setenv("HYPHY_HIP_POISON", "1")
+    fx = common.load(name)
+    Q = common.fixture_Q(fx)
+    nodes = common.all_nodes(fx)
+    B = len(nodes)
+    rng = np.random.default_rng(3)
+    with _mk(fx) as part, _mk(fx) as plain:
+        st = part.repeat_stats()
+        assert st["available"] == 1 and st["in_use"] == 1 and st["tables"] > 0, st
+        assert part.prune_kernel_name() in ("prune_nuc_kernel", "prune_nuc2_kernel")
+        plain.set_repeats(False)
+        for _ in range(3):
+            ll, lik, sc = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+        ll0, lik0, sc0 = plain.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+        ref = float(fx["logl"])
+        assert abs(ll - ref) <= RTOL * abs(ref), (ll, ref)
+        site = _site(lik, sc)
+        assert np.max(np.abs(site[fx["site_to_pattern"]] - fx["site_logl"]) / np.abs(fx["site_logl"])) < RTOL
+        assert abs(ll - ll0) <= SAME * abs(ref)
+        assert np.max(np.abs(site - _site(lik0, sc0))) < 1e-11
+        if name.endswith("deep"):
+            assert sc.max() > 0
+        Qc = Q.copy()
+        for trial in range(8):
+            ch = np.sort(rng.choice(B, size=int(rng.integers(1, 4)), replace=False)).astype(np.int64)
+            Qc[ch] *= rng.uniform(0.5, 1.8)
+            a = part.evaluate(ch, ch, Qc[ch], fx["root_freqs"])
+            b = plain.evaluate(ch, ch, Qc[ch], fx["root_freqs"])
+            assert abs(a - b) <= SAME * abs(b), (trial, ch, a, b)
+        assert abs(part.evaluate(nodes, nodes, Qc, fx["root_freqs"]) - a) <= SAME * abs(a)
