@@ -27,10 +27,10 @@ void free_shard(Shard &s) {
                  s.weights, s.templates, s.templates_pad, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.pi_ones, s.codes_tile,
                  s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.mix_q, s.mix_p, s.mix_w, s.mix_off, s.ar_buf, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops, s.rep_tab, s.rep_cnt, s.rep_map, s.rep_desc, s.rep_items, s.rep_sync,
-                 s.rep_codes_tile, s.rep_leaf};
+                 s.rep_codes_tile, s.rep_leaf, s.d_inv};
   for (void *d : dev)
     if (d) pool_free(d);  // (the stream was synchronised above)
-  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn, s.h_tstage, s.h_site, s.h_rep_items};
+  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn, s.h_tstage, s.h_site, s.h_rep_items, s.h_export};
   for (void *h : host)
     if (h) pool_host_free(h);
   for (auto &e : s.ev)
@@ -429,7 +429,8 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     n_wg = prune_nuc_grid(na);
     {  // fused final combine (see the codon branch below): the small-shard instantiation of the 4-state kernel carries it
       const char *fuse_env = getenv("HYPHY_HIP_FUSED_REDUCE");
-      if (!(fuse_env && atoi(fuse_env) == 0) && p->mode == 0 && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && prune_nuc_fuses_reduce(na, have_folded)) {
+      if (!(fuse_env && atoi(fuse_env) == 0) && p->mode == 0 && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && !p->export_sites &&
+          prune_nuc_fuses_reduce(na, have_folded)) {
         double *rec = s.d_hout ? s.d_hout : s.out;
         fused_reduce = true;
         na.red_out = d_logl_out ? d_logl_out : rec;
@@ -478,7 +479,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     // serial tail, so larger shards keep the separate kernel.  HYPHY_HIP_FUSED_REDUCE=0/1 forces either.
     const char *fuse_env = getenv("HYPHY_HIP_FUSED_REDUCE");
     const bool fuse_on = fuse_env ? atoi(fuse_env) != 0 : s.ntiles <= 2 * s.cus;
-    if (fuse_on && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && !pa.timeline && prune_fuses_reduce(pa)) {
+    if (fuse_on && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && !pa.timeline && !p->export_sites && prune_fuses_reduce(pa)) {
       double *rec = s.d_hout ? s.d_hout : s.out;
       fused_reduce = true;
       pa.red_out = d_logl_out ? d_logl_out : rec;
@@ -533,6 +534,14 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     s.ring_count++;
   }
   if (p->all_timings) HIPCHK(hipEventRecord(s.ev[2], s.stream));
+  s.exported = 0;
+  if (p->export_sites && reduce && !floor_log && n_cat_batch <= 1 && s.d_export) {
+    // per-pattern results for the caller, in ITS order, into host-mapped memory — in front of the kernel that publishes the result
+    // record, so that the record's sequence word says they have landed too
+    launch_site_export(site_lik, site_cnt, s.d_inv, (int)s.S, (p->export_sites & 1) ? s.d_export : nullptr,
+                       (p->export_sites & 2) ? reinterpret_cast<long long *>(s.d_export + s.S) : nullptr, s.stream);
+    s.exported = p->export_sites;
+  }
   if (reduce && !fused_reduce) {
     // synchronous entry points: the result record goes straight to host-mapped pinned memory (a
     // posted PCIe write from the kernel) — an SDMA device-to-host copy after the kernels costs far more
@@ -671,6 +680,46 @@ double combine(const std::vector<double> &parts) {
 }
 
 namespace {
+
+// A synchronous evaluation that returns per-pattern results asks for the export in front of its enqueue (single-device partitions;
+// HYPHY_HIP_SITE_EXPORT=0 keeps the copies of gather_sites) ...
+int begin_site_export(hyphy_hip_partition *p, bool want_lik, bool want_cnt) {
+  if (!p) return 0;
+  const char *env = getenv("HYPHY_HIP_SITE_EXPORT");  // (read per call: the tests run both paths in one process)
+  const bool on = !(env && atoi(env) == 0);
+  p->export_sites = 0;
+  if (!on || p->shards.size() != 1 || !(want_lik || want_cnt)) return 0;
+  Shard &s = p->shards[0];
+  if (s.S <= 0 || s.s0 != 0) return 0;
+  HIPCHK(hipSetDevice(s.device));
+  if (!s.h_export) {
+    HIPCHK(pool_host_malloc((void **)&s.h_export, (size_t)s.S * 2 * sizeof(double)));
+    if (hipHostGetDevicePointer((void **)&s.d_export, s.h_export, 0) != hipSuccess) s.d_export = nullptr;
+    if (s.d_export && !p->perm.empty()) {
+      std::vector<int32_t> inv((size_t)s.S, 0);
+      for (int64_t j = 0; j < s.S; j++) inv[(size_t)p->perm[(size_t)j]] = (int32_t)j;
+      HIPCHK(pool_malloc((void **)&s.d_inv, inv.size() * sizeof(int32_t)));
+      HIPCHK(hipMemcpy(s.d_inv, inv.data(), inv.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+  }
+  if (!s.d_export) return 0;
+  p->export_sites = (want_lik ? 1 : 0) | (want_cnt ? 2 : 0);
+  return 0;
+}
+int gather_sites(hyphy_hip_partition *p, int cat, double *site_lik_out, int64_t *site_scaler_out, bool mixed);
+// ... and collects them behind the wait for the result record (whatever was not exported comes through gather_sites)
+int finish_sites(hyphy_hip_partition *p, int cat, double *site_lik_out, int64_t *site_scaler_out) {
+  p->export_sites = 0;
+  if (!site_lik_out && !site_scaler_out) return 0;
+  Shard &s = p->shards[0];
+  const int have = p->shards.size() == 1 ? s.exported : 0;
+  s.exported = 0;
+  const bool lik_ok = !site_lik_out || (have & 1), cnt_ok = !site_scaler_out || (have & 2);
+  if (!(lik_ok && cnt_ok)) return gather_sites(p, cat, site_lik_out, site_scaler_out, false);
+  if (site_lik_out) memcpy(site_lik_out, s.h_export, (size_t)s.S * sizeof(double));
+  if (site_scaler_out) memcpy(site_scaler_out, s.h_export + s.S, (size_t)s.S * sizeof(int64_t));
+  return 0;
+}
 
 int gather_sites(hyphy_hip_partition *p, int cat, double *site_lik_out, int64_t *site_scaler_out, bool mixed) {
   for (Shard &s : p->shards) {
@@ -1168,17 +1217,19 @@ extern "C" {
 int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                        const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
                        const double *root_freqs, double *logl_out, double *site_lik_out, int64_t *site_scaler_out) {
+  if (p && begin_site_export(p, site_lik_out != nullptr, site_scaler_out != nullptr)) return -1;
   if (eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, q_dense, false, q_is_probability, root_freqs, nullptr,
-                  true, false))
+                  true, false)) {
+    if (p) p->export_sites = 0;
     return -1;
+  }
+  p->export_sites = 0;
   std::vector<double> parts;
   if (collect_status(p)) return -1;
   for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
   record_timings(p);
   if (combine_shards(p, logl_out)) return -1;
-  if (site_lik_out || site_scaler_out)
-    return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
-  return 0;
+  return finish_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out);
 }
 
 /* Branch-site mixtures on every branch (the reference's "explicit form" models: BUSTED / BS-REL whole-alignment
@@ -1281,9 +1332,12 @@ int hyphy_hip_collect(hyphy_hip_partition *p, double *logl_out, double *site_lik
 int hyphy_hip_evaluate_built_sites(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                                    const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out,
                                    double *site_lik_out, int64_t *site_scaler_out) {
-  if (hyphy_hip_evaluate_built(p, cat, update_nodes, n_update, q_nodes, n_q, root_freqs, logl_out)) return -1;
-  if (site_lik_out || site_scaler_out) return gather_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out, false);
-  return 0;
+  if (!p) return fail("partition == NULL");
+  if (begin_site_export(p, site_lik_out != nullptr, site_scaler_out != nullptr)) return -1;
+  const int rc = hyphy_hip_evaluate_built(p, cat, update_nodes, n_update, q_nodes, n_q, root_freqs, logl_out);
+  p->export_sites = 0;
+  if (rc) return -1;
+  return finish_sites(p, cat < 0 ? 0 : (int)cat, site_lik_out, site_scaler_out);
 }
 
 int hyphy_hip_evaluate_built(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,

@@ -289,6 +289,8 @@ void launch_prune_mfma(const PruneArgs &a, hipStream_t stream);
 void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex = nullptr);  // ex: matrix exponentials folded into the launch
 bool prune_nuc_folds_expm(int L, int S_pad, int n_ops);
 bool prune_nuc_fuses_reduce(const NucArgs &a, bool folded);  // launch_prune_nuc will run the instantiation that carries the fused final combine
+void launch_site_export(const double *lik, const int32_t *cnt, const int32_t *inv, int S, double *out_lik, long long *out_cnt,
+                        hipStream_t stream);
 void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,
                         double *out_logl, double *out_cnt, const int *status, hipStream_t stream, double seq = 0.);
 void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *wg_flag, int n, double *out_logl,

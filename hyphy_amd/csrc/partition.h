@@ -157,6 +157,10 @@ struct Shard {
   int4 *h_ops = nullptr;
   double *h_out = nullptr;    // pinned, host-mapped: the reduction kernel writes [log-L, scaler sum, status] here
   double *d_hout = nullptr;   // device-side address of h_out
+  double *h_export = nullptr; // per-pattern results in the caller's order (host-mapped pinned: [S] doubles, [S] int64), see site_export_kernel
+  double *d_export = nullptr; // device-side address of h_export
+  int32_t *d_inv = nullptr;   // device pattern of caller pattern i (nullptr: identity)
+  int exported = 0;           // what the last enqueued evaluation exported (1: values, 2: exponents)
   int32_t *h_slots = nullptr;
   double *h_coeffs = nullptr;  // pinned ring (4 x C*B*K) for build_q coefficients
   double *d_hcoeffs = nullptr; // ... as the device sees it (host-mapped): the fused expm kernel reads it directly
@@ -250,6 +254,7 @@ struct hyphy_hip_partition {
   };
   ModeState saved_mode[2];
   // subtree repeats
+  int export_sites = 0;                      // the evaluation being enqueued exports per-pattern results (1: values, 2: exponents)
   bool rep_on = false;                       // views[1] exists
   bool rep_enabled = true;                   // ... and ordinary evaluations use it (hyphy_hip_set_repeats)
   struct RepNode {                           // one class table (descriptor): a path of compressed internal nodes or a leaf with ambiguity codes

@@ -2380,6 +2380,22 @@ void launch_prune_nuc(const NucArgs &a, hipStream_t stream, const ExpmArgs *ex) 
   }
 }
 
+// Per-pattern results in the CALLER's order straight into host-mapped pinned memory (posted writes, 512 contiguous bytes per wave):
+// a host that mixes rate classes itself asks for them once per class and evaluation, and two SDMA copies + a stream wait + a
+// scatter loop on the host cost it more than the evaluation's own host share.  inv[i] = device pattern of caller pattern i.
+__global__ __launch_bounds__(256) void site_export_kernel(const double *__restrict__ lik, const int32_t *__restrict__ cnt,
+                                                          const int32_t *__restrict__ inv, int S, double *out_lik, long long *out_cnt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= S) return;
+  const int j = inv ? inv[i] : i;
+  if (out_lik) out_lik[i] = lik[j];
+  if (out_cnt) out_cnt[i] = (long long)cnt[j];
+}
+void launch_site_export(const double *lik, const int32_t *cnt, const int32_t *inv, int S, double *out_lik, long long *out_cnt,
+                        hipStream_t stream) {
+  hipLaunchKernelGGL(site_export_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, lik, cnt, inv, S, out_lik, out_cnt);
+}
+
 void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const double *freq, int S_pad, int floor_log,
                         double *out, double *out_cnt, const int *status, hipStream_t stream, double seq) {
   hipLaunchKernelGGL(site_reduce_kernel, dim3(1), dim3(1024), 0, stream, site_lik, site_cnt, freq, S_pad, floor_log,

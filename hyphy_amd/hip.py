@@ -96,6 +96,8 @@ def load():
     lib.hyphy_hip_build_q.argtypes = [vp, C.c_int64, dp]
     lib.hyphy_hip_evaluate_built.restype = C.c_int
     lib.hyphy_hip_evaluate_built.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, dp]
+    lib.hyphy_hip_evaluate_built_sites.restype = C.c_int
+    lib.hyphy_hip_evaluate_built_sites.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, dp, dp, lp]
     lib.hyphy_hip_evaluate_categories_built.restype = C.c_int
     lib.hyphy_hip_evaluate_categories_built.argtypes = [vp, lp, C.c_int64, lp, C.c_int64, dp, dp, dp]
     lib.hyphy_hip_site_fits_evaluate.restype = C.c_int
@@ -554,6 +556,18 @@ class HipPartition:
         return step
 
     # -- device-side Q construction -------------------------------------------------------------
+    def evaluate_built(self, update_nodes, q_nodes, root_freqs, cat: int = -1, per_site: bool = False):
+        """Synchronous evaluation over the rate matrices staged by ``build_q`` (one coefficient row per entry of q_nodes);
+        ``per_site``: also the per-pattern values and 2^64 exponents (hyphy_hip_evaluate_built_sites)."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        out = C.c_double(0.0)
+        sl = np.zeros(self.S) if per_site else None
+        sc = np.zeros(self.S, dtype=np.int64) if per_site else None
+        _check(self._lib.hyphy_hip_evaluate_built_sites(self._h, cat, _l(un), len(un), _l(qn), len(qn), _d(rf), C.byref(out), _d(sl), _l(sc)))
+        return (out.value, sl, sc) if per_site else out.value
+
     def set_q_templates(self, templates: np.ndarray):
         t = np.ascontiguousarray(templates, dtype=np.float64)
         _check(self._lib.hyphy_hip_set_q_templates(self._h, t.shape[0], _d(t)))

@@ -97,6 +97,7 @@ struct _HyHipPart {
 static std::map<const void *, std::vector<_HyHipPart>> _hyhip_lfs;
 static std::map<const void *, std::pair<const void *, long>> _hyhip_tree_owner;  // _TheTree* -> (lf, partition index)
 long _hyhip_calls = 0L, _hyhip_cached_calls = 0L, _hyhip_deferred = 0L;
+static double _hyhip_compute_seconds = 0.;  // wall time inside _hyphy_hip_compute (coefficients, library call incl. its wait, downloads)
 // > 0: ExponentiateMatrices hands the queued rate matrices to the adapter instead of exponentiating them on the host.
 // On while Optimize runs (nothing but ComputeBlock reads the transition matrices there; they are brought up to date
 // on the host when it returns); HYPHY_HIP_DEVICE_EXPM=0 keeps mode A, =always forces it (LFCompute benchmarks only:
@@ -142,7 +143,7 @@ static void _hyphy_hip_teardown(const void *lf) {
   _hyhip_lfs.erase(it);
   for (auto o = _hyhip_tree_owner.begin(); o != _hyhip_tree_owner.end();)
     o = o->second.first == lf ? _hyhip_tree_owner.erase(o) : std::next(o);
-  if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %ld ComputeBlock evaluations ran on the device so far (+ %ld through the branch cache); %ld matrix exponentials moved to the device\n", _hyhip_calls, _hyhip_cached_calls, _hyhip_deferred);
+  if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %ld ComputeBlock evaluations ran on the device so far (+ %ld through the branch cache); %ld matrix exponentials moved to the device; adapter mode: %.3f s of wall clock inside the adapter's ComputeBlock calls (coefficients, library call and its wait, per-pattern downloads)\n", _hyhip_calls, _hyhip_cached_calls, _hyhip_deferred, _hyhip_compute_seconds);
 }
 
 static bool _hyphy_hip_defer_handler(_TheTree *t, long catID, _List &nodesToDo, _List &matrixQueue, _SimpleList &parallel,
@@ -1235,8 +1236,19 @@ static void _hyphy_hip_flush_part(_HyHipPart &hp, _TheTree *t) {
 
 // one ComputeBlock evaluation on the device; returns 0 when *result is valid (or, with go_async, when it was enqueued:
 // _hyphy_hip_prepass_result collects it)
+static int _hyphy_hip_compute_impl(const void *lf, long index, _TheTree *t, long catID, _SimpleList &branches,
+                                   _List &matrices, hyFloat *siteRes, long *scc, hyFloat *result, bool go_async);
 static int _hyphy_hip_compute(const void *lf, long index, _TheTree *t, long catID, _SimpleList &branches,
                               _List &matrices, hyFloat *siteRes, long *scc, hyFloat *result, bool go_async = false) {
+  timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  const int rc = _hyphy_hip_compute_impl(lf, index, t, catID, branches, matrices, siteRes, scc, result, go_async);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  _hyhip_compute_seconds += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  return rc;
+}
+static int _hyphy_hip_compute_impl(const void *lf, long index, _TheTree *t, long catID, _SimpleList &branches,
+                                   _List &matrices, hyFloat *siteRes, long *scc, hyFloat *result, bool go_async) {
   _HyHipPart &hp = _hyhip_lfs[lf][index];
   const long D = t->GetCodeBase(), DD = D * D;
   const long B = t->GetLeafCount() + t->GetINodeCount() - 1;

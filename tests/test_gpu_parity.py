@@ -1085,6 +1085,51 @@ def test_sorted_patterns_are_invisible_to_the_caller(monkeypatch):
         assert np.allclose(got[5], ref[5], rtol=1e-12, atol=0), label
 
 
+@pytest.mark.parametrize("sort", ["1", "0"])
+def test_exported_per_pattern_results_equal_the_copied_ones(sort, monkeypatch):
+    """Per-pattern values and exponents reach a synchronous caller through site_export_kernel (caller's order, host-mapped memory,
+    in front of the kernel that publishes the result record); HYPHY_HIP_SITE_EXPORT=0 keeps the two device-to-host copies and the
+    host-side scatter.  Same partition data through both, full passes, a partial update, the template entry point and a pure
+    re-evaluation: identical to the last bit."""
+    from hyphy_amd import data, models, tree
+    rng = np.random.default_rng(5)
+    root = tree.random_tree(20, rng, trifurcating_root=True)
+    flat = tree.flatten(root)
+    S = 1777
+    base = rng.integers(0, 61, size=S)
+    states = np.where(rng.random((flat.L, S)) < 0.25, rng.integers(0, 61, size=(flat.L, S)), base[None, :])
+    pd = data.from_states(states, 61, compress_patterns=False)
+    pf = np.array([[0.3, 0.2, 0.25, 0.25], [0.2, 0.3, 0.3, 0.2], [0.25, 0.25, 0.2, 0.3]])
+    pi = models.f3x4_codon_freqs(pf)
+    B = flat.n_branches
+    nodes = np.arange(B, dtype=np.int64)
+    rev = dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4)
+    tb = rng.uniform(0.02, 0.3, B)
+    Q = models.mg94rev_Q_batch(tb, 0.4, rev, pf)
+    Q2 = models.mg94rev_Q_batch(tb[:3] * 1.5, 0.4, rev, pf)
+    import bench
+    T, pi_b = bench.templates_for(3)
+    coeffs = np.stack([tb, 0.4 * tb], axis=1)
+    hip = _hip()
+    monkeypatch.setenv("HYPHY_HIP_SORT_PATTERNS", sort)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HYPHY_HIP_SITE_EXPORT", mode)
+        got = []
+        with hip.HipPartition(61, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq) as part:
+            got.append(part.evaluate(nodes, nodes, Q, pi, per_site=True))
+            got.append(part.evaluate(nodes[:3], nodes[:3], Q2, pi, per_site=True))
+            got.append(part.evaluate(nodes[:0], nodes[:0], Q[:0], pi, per_site=True))
+            part.set_q_templates(T)
+            part.build_q(coeffs)
+            got.append(part.evaluate_built(nodes, nodes, pi_b, per_site=True))
+        out[mode] = got
+    for a, b in zip(out["1"], out["0"]):
+        assert a[0] == b[0]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.all(out["1"][0][1] > 0)
+
+
 @pytest.mark.parametrize("kernel", ["1", "2"])
 @pytest.mark.parametrize("shape", ["caterpillar", "long caterpillar", "random"])
 def test_rerooted_schedules_match_oracle_without_reversibility(shape, kernel, monkeypatch):

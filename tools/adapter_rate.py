@@ -44,7 +44,7 @@ def emit(tag, host, res, count, t0, extra=None):
     secs = max(res.get("sweep_seconds", 0.0), 1.0)   # (HBL's Time(1) has 1 s resolution)
     mode = [ln for ln in res.get("stdout", "").split("\n") if "mode:" in ln or "template analysis" in ln or "explicit-form" in ln or "template mode" in ln]
     print(json.dumps({"case": tag, "host": host, "evals": count, "sweep_seconds": secs, "evals_per_s": count / secs, "logl": res["logl"],
-                      "wall": time.time() - t0, "adapter_says": mode[-2:], **(extra or {}),
+                      "wall": time.time() - t0, "adapter_says": mode[-3:], **(extra or {}),
                       **({"tuner_says": [ln[:400] for ln in res.get("stdout", "").split("\n") if "schedule tuner" in ln][:3]} if os.environ.get("ADAPTER_RATE_TUNER") else {})}),
           flush=True)
 
@@ -66,7 +66,7 @@ def measure(tag, host, run, n_pilot, target_s=10.0, min_evals=0, extra=None):
     mode = [ln for ln in res.get("stdout", "").split("\n") if "mode:" in ln or "template analysis" in ln or "explicit-form" in ln or "template mode" in ln]
     print(json.dumps({"case": tag, "host": host, "evals": n_long - n_pilot, "seconds": dt, "evals_per_s": (n_long - n_pilot) / dt,
                       "method": f"wall clock of two runs, {n_pilot} and {n_long} evaluations: ({n_long} - {n_pilot}) / ({w1:.2f} s - {w0:.2f} s)",
-                      "hbl_timer_seconds_long_run": res.get("sweep_seconds"), "logl": res["logl"], "adapter_says": mode[-2:], **(extra or {})}),
+                      "hbl_timer_seconds_long_run": res.get("sweep_seconds"), "logl": res["logl"], "adapter_says": mode[-3:], **(extra or {})}),
           flush=True)
 
 
