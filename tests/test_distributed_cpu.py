@@ -229,3 +229,96 @@ def test_bench_line_of_a_multi_gpu_run_carries_every_ranks_numbers():
     assert top["per_rank"] is table and top["collective_ab"] == ab
     cfg, roof, top = bench.multi_gpu_fields(2, "torch", "C-ABI communicator not available", table, None, None)
     assert "torch.distributed" in cfg["collective"] and cfg["collective_note"] and roof == {} and "collective_ab" not in top
+
+
+def _class_form_site_lik(parents, L, codes, ambig, P, pi, comp):
+    """Pruning with per-node pattern classes on the nodes `comp` marks (what class_table_kernel + the trunk kernel do; plain numpy,
+    no rescaling: small trees).  Returns per-pattern likelihoods and the edge products executed (rows of P x vector)."""
+    N, S = len(parents), codes.shape[1]
+    I = N - L
+    kids = [[] for _ in range(I)]
+    for n in range(N - 1):
+        kids[int(parents[n])].append(n)
+    cls = [None] * I      # class id per pattern (compressed nodes)
+    edge = [None] * I     # E_n = P_n x (conditionals of n): [U_n][D] per class (compressed: what a class table holds) or [S][D]
+    work = 0
+    root = None
+
+    def leaf_col(n, c):
+        return P[n][:, c] if c >= 0 else P[n] @ ambig[-c - 1]
+
+    for i in range(I):
+        if comp[i]:       # children are leaves or compressed nodes: classes of the tuples of their class ids / codes
+            key = np.stack([codes[c] if c < L else cls[c - L] for c in kids[i]], axis=1)
+            uniq, inv = np.unique(key, axis=0, return_inverse=True)
+            cls[i] = inv.reshape(-1)
+            v = np.ones((len(uniq), P.shape[1]))
+            for k, c in enumerate(kids[i]):
+                for u in range(len(uniq)):
+                    v[u] *= leaf_col(c, int(uniq[u][k])) if c < L else edge[c - L][int(uniq[u][k])]
+        else:
+            v = np.ones((S, P.shape[1]))
+            for c in kids[i]:
+                if c < L:
+                    for s_ in range(S):
+                        v[s_] *= leaf_col(c, int(codes[c, s_]))
+                else:
+                    v *= edge[c - L][cls[c - L]] if comp[c - L] else edge[c - L]   # a class table is gathered by class id
+        if i == I - 1:
+            root = v
+        else:
+            edge[i] = v @ P[L + i].T   # one edge product per class (compressed) / per pattern
+            work += len(v)
+    return root @ pi, work
+
+
+def _worker_repeats(rank, world, port, name, theta, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    from hyphy_amd import hip
+    fx = common.load(name)
+    L = int(fx["L"])
+    codes, freq, (lo, hi) = hdist.shard_patterns(fx["leaf_codes"], fx["pattern_freq"], rank, world)
+    # every rank plans the classes of ITS patterns (host-only entry point of the C-ABI: no device needed)
+    classes, comp, planned = hip.plan_repeats(fx["flat_parents"], L, codes, theta)
+    P = oracle.expm(common.fixture_Q(fx), str(fx["kind"]) == "codon")
+    lik, work = _class_form_site_lik(np.asarray(fx["flat_parents"]), L, np.asarray(codes), np.asarray(fx["ambig"]), P,
+                                     np.asarray(fx["root_freqs"]), comp)
+    site_ll = np.log(lik)
+    partial = torch.tensor([float((site_ll * freq).sum())], dtype=torch.float64)
+    hdist.allreduce_logl(partial)
+    full = hdist.allgather_sites(torch.from_numpy(site_ll), fx["leaf_codes"].shape[1], rank, world)
+    counts = torch.tensor([float(work), float(planned), float((len(fx["flat_parents"]) - L - 1) * codes.shape[1]), float(comp.sum())],
+                          dtype=torch.float64)
+    dist.all_reduce(counts)
+    if rank == 0:
+        out_q.put((float(partial[0]), full.numpy(), counts.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,theta", [("codon_wide", 0.9), ("codon_small", 1.0), ("nuc_small", 0.5)])
+def test_two_rank_site_sharding_with_subtree_repeats(name, theta):
+    """Subtree repeats under pattern sharding (one process per GPU): each rank plans the classes of ITS shard through the C-ABI's
+    host-only hyphy_hip_plan_repeats, evaluates in class form, and the one all-reduce of the partial log-likelihoods / the
+    all-gather of the per-pattern values give the reference's numbers; the executed edge products the plans announce are the
+    ones the class form performs, and fewer than every-pattern-at-every-node."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_repeats, args=(r, 2, port, name, theta, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    total, sites, counts = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fx = common.load(name)
+    ref = float(fx["logl"])
+    assert abs(total - ref) <= 1e-10 * abs(ref)
+    got = sites[fx["site_to_pattern"]]
+    assert np.max(np.abs(got - fx["site_logl"]) / np.abs(fx["site_logl"])) < 1e-10
+    work, planned, full, n_comp = counts
+    assert work == planned and n_comp > 0 and work < full, counts
