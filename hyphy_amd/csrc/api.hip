@@ -144,9 +144,6 @@ PruneArgs base_prune_args(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
     pa.gcnt = s.rep_cnt + (size_t)cat * s.rep_rows;
     pa.cs_gtab = (size_t)s.rep_rows * DP;
     pa.cs_gcnt = (size_t)s.rep_rows;
-    pa.rep_sync = s.rep_sync;
-    pa.rep_sync_words = (int)rep_sync_words(p);
-    pa.rep_sync_stride = rep_sync_stride();
   }
   pa.pin = s.pin;
   pa.pin_leaf = (p->pin_node >= 0 && p->pin_node < p->L) ? (int)p->pin_node : -1;
@@ -497,7 +494,6 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       pa.red_out = pa.do_root ? red_out : nullptr;
       launch_prune_mfma(pa, s.stream);
     }
-    if (p->mode == 1 && n_ops > 0) s.rep_sync_dirty = false;  // (the trunk's launch has reset the lower phase's counters)
     if (pa.timeline) {  // tracing only: synchronous dump of the per-entry s_memtime stamps
       std::vector<long long> h(tl_n);
       HIPCHK(hipStreamSynchronize(s.stream));

@@ -137,8 +137,6 @@ struct PruneArgs {
   const double *gtab = nullptr;     // [rows][DP] class tables, column-gather layout
   const int32_t *gcnt = nullptr;    // [rows] their 2^64 exponents
   size_t cs_gtab = 0, cs_gcnt = 0;  // class strides
-  int *rep_sync = nullptr;          // the lower phase's queue heads and counters: reset by this launch (rep_sync_words words, rep_sync_stride ints apart)
-  int rep_sync_words = 0, rep_sync_stride = 0;
 };
 constexpr int kTraceWG = 8;
 constexpr int kNucParkSlots = 4;  // LDS parking slots of the 4-state kernel (nodes whose parent is not the next entry)

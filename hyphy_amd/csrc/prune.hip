@@ -799,10 +799,10 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
     if constexpr (REP) {
       a.gtab += cat * a.cs_gtab;
       a.gcnt += cat * a.cs_gcnt;
-      // the lower phase's queue heads and counters (repeats.hip), zero again for its next launch: this launch runs strictly
-      // between two of them on the stream, which spares that kernel an exit count of all its waves on one word
-      if (a.rep_sync && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
-        for (int i = threadIdx.x; i < a.rep_sync_words; i += 64) a.rep_sync[(size_t)i * a.rep_sync_stride] = 0;
+      // (NOT here: resetting the lower phase's queue heads and counters.  r05 had workgroup 0 of this launch store the zeros in
+      //  its prologue; behind that store loop the compiler no longer took the schedule words for unclobbered — every schedule
+      //  entry came through vector loads, every branch on it was a divergent one and each of the 312 buffer loads of the A operands
+      //  sat in a waterfall loop: 7 700 instructions instead of 4 400.  repeats.hip clears the words itself where a launch used them.)
     }
   }
   constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
@@ -858,7 +858,13 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
   auto gather_issue = [&](f64x2 (&dst)[2 * NW], int lf, int c) {
     const double *bl = a.PTg + (size_t)lf * DP * DP;  // uniform; [code][w][g][r]
     if constexpr (REP) {
-      const int2 lt = a.leaf_tab[lf];  // (first row of the leaf's class table or -1, first exponent row / matrix slot)
+      // (first row of the leaf's class table or -1, first exponent row / matrix slot.  The table is a member of the by-value
+      //  argument block: its loads are VECTOR loads, and without the readfirstlane the compiler takes every address derived from
+      //  them — after merging the identical product loops of the call sites, the A operands' buffer resources too — for
+      //  divergent: 312 buffer loads in waterfall loops, 8 500 instructions instead of 4 000)
+      int2 lt = a.leaf_tab[lf];
+      lt.x = __builtin_amdgcn_readfirstlane(lt.x);
+      lt.y = __builtin_amdgcn_readfirstlane(lt.y);
       bl = lt.x >= 0 ? a.gtab + (size_t)lt.x * DP : a.PTg + (size_t)lt.y * DP * DP;
       if (lt.x >= 0) cnt += a.gcnt[lt.y + c];
     }
@@ -997,7 +1003,7 @@ __global__ __launch_bounds__(64, OCC) void prune_wave_kernel(const int4 *__restr
           abl_after_edge = false;
         } else {  // ambiguity codes in this tile: full product with the resolution vector
           const double *av = a.ambig + (size_t)(c < 0 ? -c - 1 : 0) * DP;
-          edge_product(REP ? a.leaf_tab[lf].y : lf, [&](int k2) -> f64x2 {
+          edge_product(REP ? __builtin_amdgcn_readfirstlane(a.leaf_tab[lf].y) : lf, [&](int k2) -> f64x2 {
             f64x2 b;
             b[0] = (c >= 0) ? ((8 * k2 + g == c) ? 1.0 : 0.0) : av[8 * k2 + g];
             b[1] = (c >= 0) ? ((8 * k2 + 4 + g == c) ? 1.0 : 0.0) : av[8 * k2 + 4 + g];

@@ -1150,6 +1150,11 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
         if (d < 0) val = (int)codes[k][(size_t)c * SP + j];
         else if (c < L) val = leaf_cls[c][j];
         else val = cls[k][c - L][j];
+        if (d >= 0 && getenv("HYPHY_HIP_REP_FAKE")) {  // (timing experiment, results invalid: 1 = one row per tile, 2 = 16 consecutive rows)
+          const size_t j0 = j & ~(size_t)15;
+          const int v0 = c < L ? leaf_cls[c][j0] : cls[k][c - L][j0];
+          val = atoi(getenv("HYPHY_HIP_REP_FAKE")) == 1 ? v0 : std::min<int>(v0 + (int)(j & 15), s.rep_tabs[d].rows - 1);
+        }
         ct[((j >> 4) * (size_t)v.L + vl) * 16 + (j & 15)] = (int16_t)val;
       }
     }
@@ -1463,10 +1468,11 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
   a.n_waves = s.rep_waves;
   a.n_static = s.rep_static;
   a.dbg = nullptr;
-  // queue heads and counters are zero between launches: the trunk's pruning launch that follows resets them (PruneArgs::rep_sync);
-  // should a launch not have been followed by one (a failed evaluation), they are cleared here
+  // queue heads and counters are zero between launches.  A launch whose items are dealt by position (n_static) never touches
+  // them; behind any other one they are cleared in front of the next launch (a memset node on the stream: 2-3 us in front of passes
+  // that take hundreds — class tables that read class tables of the same pass, rho > 0 or partial updates)
   if (s.rep_sync_dirty) HIPCHK(hipMemsetAsync(s.rep_sync, 0, rep_sync_words(p) * kRepHeadStride * sizeof(int), s.stream));
-  s.rep_sync_dirty = true;
+  s.rep_sync_dirty = a.n_static == 0;
   const char *tl = getenv("HYPHY_HIP_REP_TIMELINE");
   if (tl && p->NW == 4) {  // diagnostic: synchronous, one file per launch (the last launch survives)
     const size_t n = (size_t)a.n_waves * 16;
