@@ -1317,8 +1317,17 @@ void rep_translate_update(hyphy_hip_partition *p, const int64_t *update_nodes, i
 // tables of the long paths first, then the long paths (they are what the launch waits for at its end), short independent ones last
 // to fill the gaps.  An item's `bound` = the queue index every head must have passed for all its inputs to be sold.
 // Returns items per queue.
+// Waves of a lower-phase launch over n items: one per SIMD while the items fit two rounds of that (a walk is bound by the SIMD's
+// matrix pipe: two walks on one SIMD take twice as long each, and the launch ends with its longest walk), two per SIMD beyond.
+static int rep_wave_count(const Shard &s, size_t n_items) {
+  const int n = (int)((n_items + kRepQueues - 1) / kRepQueues * kRepQueues);
+  int w = n <= 8 * s.cus ? std::min(n, s.cus * 4) : s.cus * 8;
+  if (const char *e = getenv("HYPHY_HIP_REP_WAVES")) w = std::max(1, std::min(n, atoi(e)));
+  return std::max(1, w);
+}
+
 int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vector<int> &dirty, int cat0, int n_classes,
-                    std::vector<int4> &queues /* [kRepQueues][qcap] */, int *n_static = nullptr) {
+                    std::vector<int4> &queues /* [kRepQueues][qcap] */, int *n_static = nullptr, int *n_waves = nullptr) {
   const int ND = (int)p->rep_nodes.size();
   std::vector<char> live(ND, 0);
   for (int d : dirty) live[d] = 1;
@@ -1348,6 +1357,51 @@ int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vec
     *n_static = (int)all.size();
     for (const int4 &it : all)
       if (it.w > 0) *n_static = 0;
+  }
+  const int nw = rep_wave_count(s, all.size());
+  if (n_waves) *n_waves = nw;
+  if (n_static && *n_static > nw && !(getenv("HYPHY_HIP_REP_LPT") && atoi(getenv("HYPHY_HIP_REP_LPT")) == 0)) {
+    // Items dealt by position: wave w takes positions w, 2 nw - 1 - w, 2 nw + w, ... (class_table_kernel).  Which item sits where
+    // decides when the launch ends: 1 519 walks of 8-24 us on 1 024 waves are two rounds at most, and in order of descriptor
+    // priority the waves whose first walk was a 15-us one got a second 15-us one (31.6 us) while 23-us walks sat alone and 16-us
+    // ones too.  Longest-processing-time-first instead: items in descending order of estimated cost (k cycles per walk, fitted to the
+    // kernel's timeline at the headline: 8.5 + 7.0 per walked node — walks of 6 / 4 / 3 nodes took 50.5 / 36.5 / 27.5), each to the
+    // wave with the least so far.
+    std::vector<double> cost(ND, 0.);
+    for (int d : dirty) cost[d] = 8.5 + 7.0 * (double)std::max<size_t>(1, p->rep_nodes[d].path.size());
+    std::vector<int> by_cost(all.size());
+    for (size_t i = 0; i < all.size(); i++) by_cost[i] = (int)i;
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) { return cost[all[x].x] > cost[all[y].x]; });
+    std::vector<std::vector<int>> mine(nw);
+    std::vector<std::pair<double, int>> heap;  // (load so far, wave): min-heap
+    for (int w = 0; w < nw; w++) heap.push_back(std::make_pair(0., w));
+    auto later = [](const std::pair<double, int> &x, const std::pair<double, int> &y) { return x > y; };
+    std::make_heap(heap.begin(), heap.end(), later);
+    for (int i : by_cost) {
+      std::pop_heap(heap.begin(), heap.end(), later);
+      std::pair<double, int> &top = heap.back();
+      mine[top.second].push_back(i);
+      top.first += cost[all[i].x];
+      std::push_heap(heap.begin(), heap.end(), later);
+    }
+    size_t rounds = 0;
+    for (const std::vector<int> &m : mine) rounds = std::max(rounds, m.size());
+    std::vector<int4> placed(rounds * (size_t)nw);
+    for (size_t i = 0; i < placed.size(); i++) placed[i] = make_int4(-1, 0, (int)i, 0);
+    for (int w = 0; w < nw; w++)
+      for (size_t r = 0; r < mine[w].size(); r++) {
+        const size_t pos = r * (size_t)nw + ((r & 1) ? (size_t)(nw - 1 - w) : (size_t)w);
+        placed[pos] = all[mine[w][r]];
+        placed[pos].z = (int)pos;
+      }
+    if (getenv("HYPHY_HIP_VERBOSE") && atoi(getenv("HYPHY_HIP_VERBOSE")) >= 2) {
+      for (int d : dirty) fprintf(stderr, "[hyphy_hip] lower phase: descriptor %d walks %zu nodes, %d tiles, cost %.1f\n", d, p->rep_nodes[d].path.size(), s.rep_tabs[d].rows / 16, cost[d]);
+      double lo = 1e30, hi = 0.;
+      for (const std::pair<double, int> &h : heap) lo = std::min(lo, h.first), hi = std::max(hi, h.first);
+      fprintf(stderr, "[hyphy_hip] lower phase: %zu items on %d waves, %zu rounds, estimated load per wave %.1f .. %.1f k cycles\n", by_cost.size(), nw, rounds, lo, hi);
+    }
+    all.swap(placed);
+    *n_static = (int)all.size();
   }
   while (all.size() % kRepQueues) all.push_back(make_int4(-1, 0, (int)all.size(), 0));
   const int per_q = (int)all.size() / kRepQueues;
@@ -1390,8 +1444,8 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
       continue;
     }
     std::vector<int4> queues;
-    int n_static = 0;
-    const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues, &n_static);
+    int n_static = 0, n_waves = 1;
+    const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues, &n_static, &n_waves);
     s.rep_static = getenv("HYPHY_HIP_REP_STATIC") && atoi(getenv("HYPHY_HIP_REP_STATIC")) == 0 ? 0 : n_static;
     const size_t words = (size_t)kRepQueues * std::max(1, per_q) + (size_t)(ND + 3) / 4;  // queues, then the live flags
     if (words > s.rep_items_cap) {
@@ -1418,10 +1472,7 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
     for (int d : dirty) live[d] = getenv("HYPHY_HIP_REP_NODEPS") ? 0 : 1;  // (diagnostic: nobody waits, results invalid)
     HIPCHK(hipMemcpyAsync(s.rep_items, s.h_rep_items, words * sizeof(int4), hipMemcpyHostToDevice, s.stream));
     s.rep_qcap = per_q;
-    // one wave per SIMD while the items fit two rounds of that (a walk is bound by the SIMD's matrix pipe: two walks on one SIMD take
-    // twice as long each, and the launch ends with its longest walk), two per SIMD beyond
-    s.rep_waves = per_q * kRepQueues <= 8 * s.cus ? std::min(per_q * kRepQueues, s.cus * 4) : s.cus * 8;
-    if (const char *e = getenv("HYPHY_HIP_REP_WAVES")) s.rep_waves = std::max(1, std::min(per_q * kRepQueues, atoi(e)));
+    s.rep_waves = n_waves;  // (rep_wave_count)
   }
   p->rep_cached_dirty = dirty;
   p->rep_cached_classes = pass_key;
