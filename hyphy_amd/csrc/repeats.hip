@@ -89,6 +89,7 @@ struct RepArgs {
   size_t cs_P;
   const double *ambig;
   int n_waves;                // grid size
+  int cat0;                   // first rate class of the pass
   int n_static;               // > 0: no item of this pass reads a table of this pass — the items (this many) are dealt to the waves by
                               // position (wave b: items b, b + n_waves, ..), nobody takes tickets, counts tiles or drains its stores
   long long *dbg;             // diagnostic (HYPHY_HIP_REP_TIMELINE): per wave [wall start, wall end, items, failed polls, shader cycles in
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(const int4 *__restri
     REP_TR(5)
     const int4 h0 = desc[2 * cur.x], h1 = desc[2 * cur.x + 1];
     const int n_nodes = h0.z & 0xffff, kind = h0.z >> 16;
-    const int cat = cur.y >> 20;
+    const int cat = a.cat0 + (cur.y >> 20);  // (items name their class RELATIVE to the pass's first: one list serves every class)
     int *done = a.sync + kRepSyncDone + (size_t)cat * a.n_desc * kRepHeadStride;
     // ---- one tile of 16 classes of the path's top node ----
     const int u0 = (cur.y & 0xfffff) * 16;
@@ -1351,7 +1352,7 @@ int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vec
           if (dd >= 0 && live[dd]) last_dep = std::max(last_dep, pos0[(size_t)dd * n_classes + c] + s.rep_tabs[dd].rows / 16 - 1);
       const int bound = last_dep < 0 ? 0 : (int)(last_dep / kRepQueues) + 1;
       pos0[(size_t)d * n_classes + c] = (long)all.size();
-      for (int t = 0; t < s.rep_tabs[d].rows / 16; t++) all.push_back(make_int4(d, t | ((cat0 + c) << 20), (int)all.size(), bound));
+      for (int t = 0; t < s.rep_tabs[d].rows / 16; t++) all.push_back(make_int4(d, t | (c << 20), (int)all.size(), bound));
     }
   if (n_static) {  // no item waits for another one of this pass?
     *n_static = (int)all.size();
@@ -1417,7 +1418,8 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
   std::vector<int> dirty;
   rep_translate_update(p, update_nodes, n_update, q_nodes, n_q, full, dirty, view_update);
   p->rep_stale_branch = -1;
-  const int pass_key = p->nuc ? n_classes * 65536 : n_classes * 65536 + cat0;  // (4 states: the list of subtrees does not name the class)
+  const int pass_key = n_classes * 65536;  // (the lists do not name the first class: a host that evaluates its rate classes one
+                                           //  ComputeBlock at a time — the reference's category loop — re-uses one list for all of them)
   const bool same = p->rep_cached_valid && p->rep_cached_dirty == dirty && p->rep_cached_classes == pass_key;
   if (same) return 0;
   const int ND = (int)p->rep_nodes.size();
@@ -1500,8 +1502,8 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
                        (const int *)s.rep_items, a);
     return 0;
   }
-  (void)cat0;  // (the items name their rate class)
   RepArgs a;
+  a.cat0 = cat0;
   a.desc = s.rep_desc;
   a.items = s.rep_items;
   a.qcap = s.rep_qcap;

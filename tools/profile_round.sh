@@ -47,7 +47,7 @@ done > $OUT/all_workloads.txt 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp
 if has stats; then
-  HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=12 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > $OUT/stats.log 2>&1
+  HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=8 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > $OUT/stats.log 2>&1
 fi
 pmc() { wl=$1; shift
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
@@ -58,7 +58,7 @@ pmc() { wl=$1; shift
   done
 }
 if has pmc; then
-  pmc mg94_64x10k HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=12
+  pmc mg94_64x10k HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=8
   pmc mg94_128x100k HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=16
 fi
 if has nuc; then
