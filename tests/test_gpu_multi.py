@@ -146,14 +146,17 @@ def test_bench_two_ranks_sharing_one_device_walk_the_multi_rank_code(tmp_path):
     the summed log-L must equal the single-device value of the same sweep point."""
     _hip(1)
     import socket
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
     common = ["--workload", "mg94_64x1250", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-traffic", "--preheat-s", "0", "--cold-s", "0"]
     env = dict(os.environ, HYPHY_BENCH_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
-                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    for attempt in range(4):  # (the port is free when it is picked, not necessarily when the rendezvous binds it: EADDRINUSE -> another one)
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                             env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        if two.returncode == 0 or "address already in use" not in (two.stdout + two.stderr):
+            break
     assert two.returncode == 0, (two.stdout + two.stderr)[-3000:]
     line2 = json.loads([ln for ln in two.stdout.split("\n") if ln.startswith("{")][-1])
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=dict(os.environ),

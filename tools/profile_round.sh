@@ -17,7 +17,7 @@ has() { [ "$PARTS" = all ] || echo "$PARTS" | grep -qw "$1"; }
 cd $GRAFT_REPO_ROOT
 if has line; then timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_line.json 2> $OUT/bench.err; fi
 if has workloads; then
-for wl in mg94_64x10k mg94_32x5k busted3_64x10k mg94_128x100k mg94_64x5000 mg94_64x2500 mg94_64x1250 gtr_32x50k gtr_32x1m hky_8x1k; do
+for wl in mg94_64x10k mg94_32x5k busted3_64x10k mix3_64x10k mg94_128x100k mg94_64x5000 mg94_64x2500 mg94_64x1250 gtr_32x50k gtr_32x1m hky_8x1k; do
   steps=200; [ $wl = mg94_128x100k ] && steps=30
   HYPHY_HIP_VERBOSE=1 timeout 300 python bench.py --workload $wl --steps $steps --warmup 10 --no-cpu-baseline --no-traffic > $OUT/wl_$wl.json 2> $OUT/wl_$wl.err
   grep "schedule tuner" $OUT/wl_$wl.err | tail -1
