@@ -304,7 +304,10 @@ double hyphy_hip_site_fits_kernel_ms(const hyphy_hip_partition *p); /* duration 
 int hyphy_hip_evaluate_built(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                              const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out);
 
-/* hyphy_hip_evaluate_built + the per-pattern outputs of hyphy_hip_evaluate (storageVec / siteCorrections). */
+/* hyphy_hip_evaluate_built + the per-pattern outputs of hyphy_hip_evaluate (storageVec / siteCorrections): what the reference's
+ * category loop (likefunc.cpp:2851-2990) asks for once per rate class.  On a single-device partition the values and exponents are
+ * written in the caller's pattern order into host-mapped memory by a kernel in front of the one that publishes the result record
+ * (r05; HYPHY_HIP_SITE_EXPORT=0: two device-to-host copies and a host-side scatter, as hyphy_hip_evaluate did until r04). */
 int hyphy_hip_evaluate_built_sites(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                                    const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out,
                                    double *site_lik_out, int64_t *site_scaler_out);
@@ -404,7 +407,8 @@ const char *hyphy_hip_schedule_info(const hyphy_hip_partition *p);
  * whose leaves below the node carry the same states into CLASSES; subtrees with few classes are evaluated once per class
  * (class tables, one MFMA product per 16 classes) and enter the rest of the tree as generalised leaves.  Results are the same
  * with and without; partial updates, rate classes, shards and mixtures all run on the compressed form, pinned states and the
- * branch cache on the plain one.
+ * branch cache on the plain one.  49-64 states: on where a measurement on the first steady-state pass says it pays; 4 states: built
+ * and tested but slower than the plain kernel, so only with HYPHY_HIP_REPEATS=1 / 2 in the environment.
  *   hyphy_hip_set_repeats   on = 0: this partition walks every node at every pattern; 1: back on (default where it pays;
  *                           HYPHY_HIP_REPEATS=0 in the environment turns it off for every partition created afterwards).
  *   hyphy_hip_repeat_stats  first shard: out[0] compression available, [1] class tables, [2] table rows (classes padded to
