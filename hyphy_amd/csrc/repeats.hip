@@ -1151,11 +1151,6 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
         if (d < 0) val = (int)codes[k][(size_t)c * SP + j];
         else if (c < L) val = leaf_cls[c][j];
         else val = cls[k][c - L][j];
-        if (d >= 0 && getenv("HYPHY_HIP_REP_FAKE")) {  // (timing experiment, results invalid: 1 = one row per tile, 2 = 16 consecutive rows)
-          const size_t j0 = j & ~(size_t)15;
-          const int v0 = c < L ? leaf_cls[c][j0] : cls[k][c - L][j0];
-          val = atoi(getenv("HYPHY_HIP_REP_FAKE")) == 1 ? v0 : std::min<int>(v0 + (int)(j & 15), s.rep_tabs[d].rows - 1);
-        }
         ct[((j >> 4) * (size_t)v.L + vl) * 16 + (j & 15)] = (int16_t)val;
       }
     }
