@@ -100,6 +100,8 @@ struct RepTable {
   std::vector<int64_t> map0; // per child: offset of its index map in rep_map
 };
 
+struct RepLaunch { size_t off; int qcap, n_static, n_waves; };  // one launch of the lower phase: its items in Shard::rep_items (repeats.hip)
+
 struct Shard {
   int device = 0;
   hipStream_t stream = nullptr;      // stream in use
@@ -216,6 +218,7 @@ struct Shard {
   int2 *rep_leaf = nullptr;          // [view leaves] (table row0 or -1: ordinary leaf, exponent row0 / matrix slot)
   int rep_qcap = 0;                  // items per queue of the pass the device queues hold
   int rep_waves = 0;                 // waves its launch runs
+  std::vector<RepLaunch> rep_launches; // non-empty: the pass runs one launch per level of table-reads-table dependencies
   int rep_static = 0;                // > 0: its items do not depend on one another and are dealt by position (RepArgs::n_static)
   bool rep_sync_dirty = false;       // a lower-phase launch has run and no trunk launch has reset rep_sync behind it yet
 };

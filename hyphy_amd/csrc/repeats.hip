@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(const int4 *__restri
       __syncthreads();
       // is the table behind input entry `ie` complete?  (one look; `block`: sleep until it is)
       auto table_ready = [&](const int4 &ie, bool block) -> bool {
-        if (ie.w < 0 || !live[ie.w & 0xffff]) return true;
+        if (a.n_static > 0 || ie.w < 0 || !live[ie.w & 0xffff]) return true;  // (n_static: the tables below were finished by an earlier launch)
         const int *ctr = done + (size_t)(ie.w & 0xffff) * kRepHeadStride;
         for (;;) {
           int v = 0;
@@ -921,10 +921,13 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
   }
   // ---- descriptors: leaves with ambiguity codes first (level 0), then the paths, inputs before the paths that read them ----
   // rho: a path goes on into the heaviest compressed child while that child keeps at least rho of the node's classes.  0: paths
-  // run to the bottom of the subtree (no table hand-offs on the way up: the lower phase is bound by exactly those, not by its
-  // arithmetic — headline: 82 us of pruning launches against 131 with rho = 0.6, 128 x 100 k: 726 against 785 although the paths
-  // execute 3.4 x the products of the tables); larger values trade products for hand-offs (HYPHY_HIP_REP_RHO)
-  double rho = 0.;
+  // run to the bottom of the subtree — no table reads a table, one launch, more products (3.4 x those of one table per node at
+  // 128 x 100 k).  Larger values trade products for hand-offs; a hand-off is a launch boundary (rep_build_items: one launch per
+  // level).  Where the lower phase is bound by its walks' lengths (a shard of a few hundred tiles: 1.5 walks per wave) rho = 0 wins
+  // (headline pruning launches 74.5 us, 79.0 at 0.3, 77.0 at 0.6, 83.2 at 2); where it is bound by throughput (128 x 100 k: 6 250
+  // tiles, eight rounds of walks) the saved products win: 663.6 us at 0, 584.2 at 0.15, 537.7 at 0.3, 549.6 at 0.45, 552.2 at 2.
+  // (Before the per-level launches, with the ticket protocol: 785 us at 0.6 against 726 at 0.)  HYPHY_HIP_REP_RHO overrides.
+  double rho = p->shards[0].ntiles >= 2048 ? 0.3 : 0.;
   if (const char *e = getenv("HYPHY_HIP_REP_RHO")) rho = atof(e);
   std::vector<int> heavy(I, -1);     // the compressed child a node's path continues into
   std::vector<char> continued(I, 0); // the node is inside its parent's path (no table of its own)
@@ -1323,7 +1326,8 @@ static int rep_wave_count(const Shard &s, size_t n_items) {
 }
 
 int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vector<int> &dirty, int cat0, int n_classes,
-                    std::vector<int4> &queues /* [kRepQueues][qcap] */, int *n_static = nullptr, int *n_waves = nullptr) {
+                    std::vector<int4> &queues /* [kRepQueues][qcap] */, int *n_static = nullptr, int *n_waves = nullptr,
+                    std::vector<RepLaunch> *launches = nullptr) {
   const int ND = (int)p->rep_nodes.size();
   std::vector<char> live(ND, 0);
   for (int d : dirty) live[d] = 1;
@@ -1356,47 +1360,94 @@ int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vec
   }
   const int nw = rep_wave_count(s, all.size());
   if (n_waves) *n_waves = nw;
-  if (n_static && *n_static > nw && !(getenv("HYPHY_HIP_REP_LPT") && atoi(getenv("HYPHY_HIP_REP_LPT")) == 0)) {
-    // Items dealt by position: wave w takes positions w, 2 nw - 1 - w, 2 nw + w, ... (class_table_kernel).  Which item sits where
-    // decides when the launch ends: 1 519 walks of 8-24 us on 1 024 waves are two rounds at most, and in order of descriptor
-    // priority the waves whose first walk was a 15-us one got a second 15-us one (31.6 us) while 23-us walks sat alone and 16-us
-    // ones too.  Longest-processing-time-first instead: items in descending order of estimated cost (k cycles per walk, fitted to the
-    // kernel's timeline at the headline: 8.5 + 7.0 per walked node — walks of 6 / 4 / 3 nodes took 50.5 / 36.5 / 27.5), each to the
-    // wave with the least so far.
-    std::vector<double> cost(ND, 0.);
-    for (int d : dirty) cost[d] = 8.5 + 7.0 * (double)std::max<size_t>(1, p->rep_nodes[d].path.size());
-    std::vector<int> by_cost(all.size());
-    for (size_t i = 0; i < all.size(); i++) by_cost[i] = (int)i;
-    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) { return cost[all[x].x] > cost[all[y].x]; });
-    std::vector<std::vector<int>> mine(nw);
+  const bool lpt_on = !(getenv("HYPHY_HIP_REP_LPT") && atoi(getenv("HYPHY_HIP_REP_LPT")) == 0);
+  // Items dealt by position: wave w takes positions w, 2 w_n - 1 - w, 2 w_n + w, ... (class_table_kernel).  Which item sits where
+  // decides when the launch ends: 1 519 walks of 8-24 us on 1 024 waves are two rounds at most, and in order of descriptor
+  // priority the waves whose first walk was a 15-us one got a second 15-us one (31.6 us) while 23-us walks sat alone and 16-us
+  // ones too.  Longest-processing-time-first instead: items in descending order of estimated cost (k cycles per walk, fitted to the
+  // kernel's timeline at the headline: 8.5 + 7.0 per walked node — walks of 6 / 4 / 3 nodes took 50.5 / 36.5 / 27.5), each to the
+  // wave with the least so far.  Returns the positions (padding items in the gaps).
+  std::vector<double> cost(ND, 0.);
+  for (int d : dirty) cost[d] = 8.5 + 7.0 * (double)std::max<size_t>(1, p->rep_nodes[d].path.size());
+  auto place = [&](std::vector<int4> &its, int w_n, double *longest) {
+    std::vector<int> by_cost(its.size());
+    for (size_t i = 0; i < its.size(); i++) by_cost[i] = (int)i;
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) { return cost[its[x].x] > cost[its[y].x]; });
+    std::vector<std::vector<int>> mine(w_n);
     std::vector<std::pair<double, int>> heap;  // (load so far, wave): min-heap
-    for (int w = 0; w < nw; w++) heap.push_back(std::make_pair(0., w));
+    for (int w = 0; w < w_n; w++) heap.push_back(std::make_pair(0., w));
     auto later = [](const std::pair<double, int> &x, const std::pair<double, int> &y) { return x > y; };
     std::make_heap(heap.begin(), heap.end(), later);
     for (int i : by_cost) {
       std::pop_heap(heap.begin(), heap.end(), later);
       std::pair<double, int> &top = heap.back();
       mine[top.second].push_back(i);
-      top.first += cost[all[i].x];
+      top.first += cost[its[i].x];
       std::push_heap(heap.begin(), heap.end(), later);
     }
     size_t rounds = 0;
     for (const std::vector<int> &m : mine) rounds = std::max(rounds, m.size());
-    std::vector<int4> placed(rounds * (size_t)nw);
+    std::vector<int4> placed(rounds * (size_t)w_n);
     for (size_t i = 0; i < placed.size(); i++) placed[i] = make_int4(-1, 0, (int)i, 0);
-    for (int w = 0; w < nw; w++)
+    for (int w = 0; w < w_n; w++)
       for (size_t r = 0; r < mine[w].size(); r++) {
-        const size_t pos = r * (size_t)nw + ((r & 1) ? (size_t)(nw - 1 - w) : (size_t)w);
-        placed[pos] = all[mine[w][r]];
+        const size_t pos = r * (size_t)w_n + ((r & 1) ? (size_t)(w_n - 1 - w) : (size_t)w);
+        placed[pos] = its[mine[w][r]];
         placed[pos].z = (int)pos;
+        placed[pos].w = 0;
       }
-    if (getenv("HYPHY_HIP_VERBOSE") && atoi(getenv("HYPHY_HIP_VERBOSE")) >= 2) {
-      for (int d : dirty) fprintf(stderr, "[hyphy_hip] lower phase: descriptor %d walks %zu nodes, %d tiles, cost %.1f\n", d, p->rep_nodes[d].path.size(), s.rep_tabs[d].rows / 16, cost[d]);
-      double lo = 1e30, hi = 0.;
-      for (const std::pair<double, int> &h : heap) lo = std::min(lo, h.first), hi = std::max(hi, h.first);
-      fprintf(stderr, "[hyphy_hip] lower phase: %zu items on %d waves, %zu rounds, estimated load per wave %.1f .. %.1f k cycles\n", by_cost.size(), nw, rounds, lo, hi);
+    if (longest) {
+      *longest = 0.;
+      for (const std::pair<double, int> &h : heap) *longest = std::max(*longest, h.first);
     }
-    all.swap(placed);
+    its.swap(placed);
+  };
+  const bool verbose2 = getenv("HYPHY_HIP_VERBOSE") && atoi(getenv("HYPHY_HIP_VERBOSE")) >= 2;
+  if (launches) launches->clear();
+  const bool levels_on = launches && !(getenv("HYPHY_HIP_REP_LEVELS") && atoi(getenv("HYPHY_HIP_REP_LEVELS")) == 0) &&
+                         !(getenv("HYPHY_HIP_REP_STATIC") && atoi(getenv("HYPHY_HIP_REP_STATIC")) == 0);
+  if (n_static && *n_static == 0 && !all.empty() && levels_on) {
+    // Tables that read tables of the same pass: ONE LAUNCH PER LEVEL of that dependency (level 0: no table of this pass among the
+    // inputs), each dealt by position like a pass without dependencies — the launch boundary is the hand-off (2-3 us for everybody at
+    // once) where the ticket protocol paid a drain, a counter and the polling of a thousand waiting waves per table (~6 us each).
+    std::vector<int> lvl(ND, 0);
+    int n_lvl = 1;
+    for (int d = 0; d < ND; d++) {  // (descriptors are stored inputs first)
+      if (!live[d]) continue;
+      for (const std::vector<int> &kk : p->rep_nodes[d].kid_desc)
+        for (int dd : kk)
+          if (dd >= 0 && live[dd]) lvl[d] = std::max(lvl[d], lvl[dd] + 1);
+      n_lvl = std::max(n_lvl, lvl[d] + 1);
+    }
+    queues.clear();
+    for (int lv = 0; lv < n_lvl; lv++) {
+      std::vector<int4> part;
+      for (const int4 &it : all)
+        if (lvl[it.x] == lv) part.push_back(make_int4(it.x, it.y, (int)part.size(), 0));
+      if (part.empty()) continue;
+      const int w_n = rep_wave_count(s, part.size());
+      double longest = 0.;
+      if ((int)part.size() > w_n && lpt_on) place(part, w_n, &longest);
+      const int n_pos = (int)part.size();
+      while (part.size() % kRepQueues) part.push_back(make_int4(-1, 0, (int)part.size(), 0));
+      const int pq = (int)part.size() / kRepQueues;
+      const size_t off = queues.size();
+      queues.resize(off + part.size(), make_int4(-1, 0, 0, 0));
+      for (size_t i = 0; i < part.size(); i++) queues[off + (i % kRepQueues) * (size_t)pq + i / kRepQueues] = part[i];
+      launches->push_back(RepLaunch{off, pq, n_pos, w_n});
+      if (verbose2) fprintf(stderr, "[hyphy_hip] lower phase, level %d: %d positions on %d waves (longest estimated wave %.1f k cycles)\n", lv, n_pos, w_n, longest);
+    }
+    *n_static = launches->empty() ? 0 : (*launches)[0].n_static;
+    if (n_waves && !launches->empty()) *n_waves = (*launches)[0].n_waves;
+    return (int)(queues.size() / kRepQueues);
+  }
+  if (n_static && *n_static > nw && lpt_on) {
+    double longest = 0.;
+    place(all, nw, &longest);
+    if (verbose2) {
+      for (int d : dirty) fprintf(stderr, "[hyphy_hip] lower phase: descriptor %d walks %zu nodes, %d tiles, cost %.1f\n", d, p->rep_nodes[d].path.size(), s.rep_tabs[d].rows / 16, cost[d]);
+      fprintf(stderr, "[hyphy_hip] lower phase: %zu positions on %d waves, longest estimated wave %.1f k cycles\n", all.size(), nw, longest);
+    }
     *n_static = (int)all.size();
   }
   while (all.size() % kRepQueues) all.push_back(make_int4(-1, 0, (int)all.size(), 0));
@@ -1442,7 +1493,8 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
     }
     std::vector<int4> queues;
     int n_static = 0, n_waves = 1;
-    const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues, &n_static, &n_waves);
+    const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues, &n_static, &n_waves, &s.rep_launches);
+    if (dirty.empty()) s.rep_launches.clear();
     s.rep_static = getenv("HYPHY_HIP_REP_STATIC") && atoi(getenv("HYPHY_HIP_REP_STATIC")) == 0 ? 0 : n_static;
     const size_t words = (size_t)kRepQueues * std::max(1, per_q) + (size_t)(ND + 3) / 4;  // queues, then the live flags
     if (words > s.rep_items_cap) {
@@ -1520,7 +1572,7 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
   // them; behind any other one they are cleared in front of the next launch (a memset node on the stream: 2-3 us in front of passes
   // that take hundreds — class tables that read class tables of the same pass, rho > 0 or partial updates)
   if (s.rep_sync_dirty) HIPCHK(hipMemsetAsync(s.rep_sync, 0, rep_sync_words(p) * kRepHeadStride * sizeof(int), s.stream));
-  s.rep_sync_dirty = a.n_static == 0;
+  s.rep_sync_dirty = a.n_static == 0 && s.rep_launches.empty();
   const char *tl = getenv("HYPHY_HIP_REP_TIMELINE");
   if (tl && p->NW == 4) {  // diagnostic: synchronous, one file per launch (the last launch survives)
     const size_t n = (size_t)a.n_waves * 16;
@@ -1538,6 +1590,16 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
         fprintf(f, "%d %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", w, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
       }
       fclose(f);
+    }
+    return 0;
+  }
+  if (!s.rep_launches.empty()) {  // one launch per level of table-reads-table dependencies (rep_build_items), each dealt by position
+    for (const RepLaunch &lv : s.rep_launches) {
+      a.items = s.rep_items + lv.off;
+      a.qcap = lv.qcap;
+      a.n_static = lv.n_static;
+      a.n_waves = lv.n_waves;
+      launch_class_tables(a, p->NW, s.stream);
     }
     return 0;
   }

@@ -30,12 +30,16 @@ def _site(lik, sc):
     return np.log(lik) - sc * LOG_SCALER
 
 
+@pytest.mark.parametrize("levels", ["1", "0"])
 @pytest.mark.parametrize("rho,inline", [("0", "1"), ("0", "0"), ("0.6", "0"), ("0.6", "1"), ("2", "0"), ("2", "1")])
 @pytest.mark.parametrize("name", ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "ref_smallcodon"])
-def test_compressed_equals_plain_and_reference(name, rho, inline, monkeypatch):
+def test_compressed_equals_plain_and_reference(name, rho, inline, levels, monkeypatch):
     """Full passes (first: every node stored; then steady state), per-pattern values and 2^64 exponents: compressed against plain
     against the reference.  rho = 2: one table per node; 0.6: paths while the child keeps 60 % of the classes; 0: longest paths.
-    inline: leaf-only side chains walked inside the item of the path they hang off (the default with rho = 0) or as tables."""
+    inline: leaf-only side chains walked inside the item of the path they hang off (the default with rho = 0) or as tables.
+    levels: tables that read tables of the same pass run as one launch per level of that dependency (1, the default) or in one
+    launch under the ticket protocol (0)."""
+    monkeypatch.setenv("HYPHY_HIP_REP_LEVELS", levels)
     monkeypatch.setenv("HYPHY_HIP_REPEATS", "2")
     monkeypatch.setenv("HYPHY_HIP_REP_INLINE", inline)
     monkeypatch.setenv("HYPHY_HIP_REP_RHO", rho)
@@ -108,10 +112,13 @@ def test_random_trees_and_state_counts_against_the_oracle(seed, taxa, D, monkeyp
     assert np.max(np.abs(_site(lik1, sc1) - _site(lik0, sc0))) < 1e-11
 
 
+@pytest.mark.parametrize("rho", ["0", "0.3", "2"])
 @pytest.mark.parametrize("name", ["codon_deep", "codon_wide", "codon_ambig"])
-def test_partial_updates_on_the_compressed_form(name, monkeypatch):
+def test_partial_updates_on_the_compressed_form(name, rho, monkeypatch):
     """DetermineNodesForUpdate-style dirty lists (a changed branch, its ancestors): the compressed form recomputes the class tables
-    whose path contains a touched node or whose own branch changed, and the trunk above them; against a full pass and against plain."""
+    whose path contains a touched node or whose own branch changed, and the trunk above them; against a full pass and against plain.
+    rho > 0: tables read tables — a partial pass launches the levels of the STALE tables only."""
+    monkeypatch.setenv("HYPHY_HIP_REP_RHO", rho)
     monkeypatch.setenv("HYPHY_HIP_REPEATS", "2")
     monkeypatch.setenv("HYPHY_HIP_REP_THETA", "0.9")
     fx = common.load(name)
