@@ -1638,12 +1638,16 @@ int rep_decide(hyphy_hip_partition *p, int cat, int n_classes) {
   }
   const double plain_ms = p->tuned_ms;
   const double on_ms = trunk_ms + lower_ms;
+  // (the plain form has to win by 7 %: behind the exponential kernel of a real evaluation its launch runs slower than in these
+  //  back-to-back passes, the two launches of the compressed form do not — 32 x 5 k: plain 44.2 us here, 50.3 in production;
+  //  compressed 45.4 here, 44.4 in production — and at parity the measurement flipped from run to run)
+  const bool off = plain_ms > 0. && plain_ms <= 0.93 * on_ms;
   char b[160];
   snprintf(b, sizeof b, "repeats: lower phase %.1fus + trunk %.1fus against %.1fus without -> %s", 1e3 * lower_ms, 1e3 * trunk_ms, 1e3 * plain_ms,
-           (plain_ms > 0. && plain_ms <= on_ms) ? "off" : "on");
+           off ? "off" : "on");
   p->rep_report = b;
   if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %s\n", b);
-  if (plain_ms > 0. && plain_ms <= on_ms) {
+  if (off) {
     p->rep_enabled = false;  // (stays under views[0]; the caller rebuilds the schedule)
   } else {
     switch_mode(p, 1);
