@@ -43,8 +43,17 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    # steady state: the MEDIAN over the dispatches of every kernel (the first evaluations persist everything)
+    # steady state: the MEDIAN over the dispatches of every kernel (the first evaluations persist everything).  A lower phase of
+    # several launches per evaluation (one per level of table dependencies, r05): the MEAN over the later half of its dispatches
+    # times the launches per evaluation, so that every entry of the class kernel is per EVALUATION like the trunk's
     means_all[wl] = {k: {c: med(v) for c, v in dd.items()} for k, dd in acc.items()}
+    n_trunk = max((len(v) for v in acc.get("prune_wave_kernel", {}).values()), default=0)
+    n_class = max((len(v) for v in acc.get("class_table_kernel", {}).values()), default=0)
+    if n_trunk and n_class > 1.2 * n_trunk:
+        per_eval = round(n_class / n_trunk)
+        means_all[wl]["class_table_kernel"] = {c: per_eval * sum(v[len(v) // 2 // per_eval * per_eval:]) / max(1, len(v[len(v) // 2 // per_eval * per_eval:]))
+                                               for c, v in acc["class_table_kernel"].items()}
+        means_all[wl]["class_table_kernel"]["launches_per_evaluation"] = per_eval
     wj = os.path.join(src, f"wl_{wl}.json")
     if os.path.exists(wj):
         b = last_json(wj)
