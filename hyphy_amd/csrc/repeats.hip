@@ -1575,6 +1575,15 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
   s.rep_sync_dirty = a.n_static == 0 && s.rep_launches.empty();
   const char *tl = getenv("HYPHY_HIP_REP_TIMELINE");
   if (tl && p->NW == 4) {  // diagnostic: synchronous, one file per launch (the last launch survives)
+    size_t traced = s.rep_launches.size();  // (several launches per pass: the LAST level is the traced one, the others run plain before it)
+    for (size_t k = 0; k < s.rep_launches.size(); k++) {
+      const RepLaunch &lv = s.rep_launches[k];
+      a.items = s.rep_items + lv.off;
+      a.qcap = lv.qcap;
+      a.n_static = lv.n_static;
+      a.n_waves = lv.n_waves;
+      if (k + 1 < traced) launch_class_tables(a, p->NW, s.stream);
+    }
     const size_t n = (size_t)a.n_waves * 16;
     HIPCHK(pool_malloc((void **)&a.dbg, n * sizeof(long long)));
     HIPCHK(hipMemsetAsync(a.dbg, 0, n * sizeof(long long), s.stream));
