@@ -47,6 +47,8 @@ WORKLOADS = {
     "mg94_64x2500": dict(taxa=64, sites=2500, unit=3, seed=3),    # ... at 4 GPUs
     "mg94_64x5000": dict(taxa=64, sites=5000, unit=3, seed=3),    # ... at 2 GPUs
     "mg94_128x100k": dict(taxa=128, sites=100000, unit=3, seed=4),
+    "mg94_64x20k": dict(taxa=64, sites=20000, unit=3, seed=3),    # mid sizes: where the lower phase's defaults change (repeats.hip: rho)
+    "mg94_64x40k": dict(taxa=64, sites=40000, unit=3, seed=3),
     "hky_8x1k": dict(taxa=8, sites=1000, unit=1, seed=1),
     # configs[2]: BUSTED-style, 3 omega classes (weights .7/.25/.05, omega .1/1/5 scaled by the swept factor),
     # classes batched into one expm launch + one pruning launch, mixed on the device

@@ -926,7 +926,8 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
   // level).  Where the lower phase is bound by its walks' lengths (a shard of a few hundred tiles: 1.5 walks per wave) rho = 0 wins
   // (headline pruning launches 74.5 us, 79.0 at 0.3, 77.0 at 0.6, 83.2 at 2); where it is bound by throughput (128 x 100 k: 6 250
   // tiles, eight rounds of walks) the saved products win: 663.6 us at 0, 584.2 at 0.15, 537.7 at 0.3, 549.6 at 0.45, 552.2 at 2.
-  // (Before the per-level launches, with the ticket protocol: 785 us at 0.6 against 726 at 0.)  HYPHY_HIP_REP_RHO overrides.
+  // In between (64 taxa): 1 250 tiles 110.0 us at 0 against 119.1 at 0.3; 2 500 tiles 173.8 against 169.3 — the default changes at
+  // 2 048.  (Before the per-level launches, with the ticket protocol: 785 us at 0.6 against 726 at 0.)  HYPHY_HIP_REP_RHO overrides.
   double rho = p->shards[0].ntiles >= 2048 ? 0.3 : 0.;
   if (const char *e = getenv("HYPHY_HIP_REP_RHO")) rho = atof(e);
   std::vector<int> heavy(I, -1);     // the compressed child a node's path continues into
