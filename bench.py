@@ -298,7 +298,8 @@ def measure_traffic(workload, kernels):
                             os.path.abspath(__file__), "--workload", workload, "--steps", "12", "--warmup", "6", "--no-cpu-baseline",
                             "--no-traffic"], cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
             total = 0.0
-            for kernel in kernels:   # (a class-compressed pass is two launches: lower phase + trunk; their traffic adds up)
+            per_kernel = {}
+            for kernel in kernels:   # (a class-compressed pass is two launches or more: lower phase + trunk; their traffic adds up)
                 rows = []
                 for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                     for r in csv.DictReader(open(f)):
@@ -306,7 +307,12 @@ def measure_traffic(workload, kernels):
                             rows.append(float(r["Counter_Value"]))
                 if len(rows) < 4:
                     return None
-                total += float(np.median(rows[-8:]))   # (steady state is the END of the run: the first passes persist every node / tune)
+                per_kernel[kernel] = rows
+            n_last = min(len(r) for r in per_kernel.values())   # launches of the kernel that runs once per evaluation
+            for kernel, rows in per_kernel.items():
+                per_eval = max(1, int(round(len(rows) / n_last)))   # (a lower phase of one launch per table level: several per evaluation)
+                tail = rows[-8 * per_eval:]   # (steady state is the END of the run: the first passes persist every node / tune)
+                total += float(np.median(tail)) if per_eval == 1 else per_eval * float(np.mean(tail))
             vals[counter] = total
         except Exception:
             return None
