@@ -220,6 +220,7 @@ struct Shard {
   int rep_waves = 0;                 // waves its launch runs
   std::vector<RepLaunch> rep_launches; // non-empty: the pass runs one launch per level of table-reads-table dependencies
   int rep_static = 0;                // > 0: its items do not depend on one another and are dealt by position (RepArgs::n_static)
+  bool rep_team = false;             // its static launches run the row-split walk (class_table_team_kernel), one workgroup per item
   bool rep_sync_dirty = false;       // a lower-phase launch has run and no trunk launch has reset rep_sync behind it yet
 };
 

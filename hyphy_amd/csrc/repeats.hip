@@ -72,6 +72,7 @@ constexpr int kRepSyncDone = kRepSyncExit + kRepHeadStride;  // per (class, desc
 constexpr int kRepStack = 24;                        // held tickets per wave (tree heights beyond that fall back to waiting)
 constexpr int kRepMaxInputs = 64;                    // inputs of a path whose class indices are staged in LDS (longer paths: cut by the host)
 constexpr int kRepAStages = 3;                       // A-operand chunks in flight ahead of the MFMAs of an edge product
+constexpr int kRepBStages = 2;                       // (row-split walk) B-operand chunks on their way out of LDS ahead of them
 
 struct RepArgs {
   const int4 *desc;
@@ -448,6 +449,212 @@ __global__ __launch_bounds__(64, 2) void class_table_kernel(const int4 *__restri
   // (queue heads and counters are reset by the launch that follows on the stream: the trunk's pruning kernel, prune.hip)
 }
 
+// The ROW-SPLIT walk (r06): the same item — 16 classes of a path's top node, walked bottom-up — by a WORKGROUP of NW waves, wave w
+// owning rows 16 w .. 16 w + 15 of every node on the way: 4 NW matrix instructions per edge product and wave instead of 4 NW^2, its
+// share of every gathered input (two 16-byte loads) instead of the whole row, its row block of the A-operand stream.  What the
+// one-wave walk kept in registers between two nodes — the product's C/D image as the next product's B operand — crosses an LDS tile
+// here: every wave leaves its four k-steps (two 16-byte writes per lane, conflict-free), ONE barrier, every wave reads the whole
+// B image back (2 NW 16-byte reads per lane).  The per-class sum of the rescale test travels the same way (partial row sums of the
+// NW row blocks, added in a fixed order by everybody; the power of 2^64 is applied to B as it leaves LDS — exact, so any wave
+// agreeing on it is all that matters).  Why: the one-wave walk is a chain of 4-6 products of 64 dependent matrix instructions with
+// the gathers in between — 36-50 k cycles — and 1 205 of them on 1 024 SIMDs end with 181 SIMDs running two (30 us of launch for
+// 10 us of matrix-pipe work).  A team's walk is a chain a quarter as long in matrix time, registers drop from 256 to < 128 per wave,
+// so four to five teams share a CU and every SIMD interleaves the products of several walks.  One item per workgroup, workgroups in
+// descending order of estimated cost: the dispatcher hands the next item to whichever CU frees a slot (longest-processing-time-first
+// without a host-side placement).  Static passes only (no item reads a table of its own launch: the production form since the
+// per-level launches of r05); the ticket protocol stays with class_table_kernel.
+template <int NW, bool TRACE = false, int AST = kRepAStages, int BST = kRepBStages, int OCC = 6, int CHAINS = 1>
+__global__ __launch_bounds__(64 * NW, OCC) void class_table_team_kernel(const int4 *__restrict__ desc, const int4 *__restrict__ items, RepArgs a) {
+  [[maybe_unused]] long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] long long tr_last = 0;
+  if constexpr (TRACE) {
+    tr[0] = wall_clock64();
+    tr_last = clock64();
+  }
+  constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64, NS = NKK / 2;
+  constexpr int PF = AST < NS ? AST : NS;
+  // [2][TILE]: the B-operand image of the node being handed over (double-buffered: a wave may write node k + 1 while another still
+  // reads node k); behind the last product the same bytes carry the finished tile on its way out ([16 classes][DP + 2])
+  __shared__ __align__(16) double bx[2 * TILE + 64];
+  __shared__ double psum[2][NW][16];
+  __shared__ __align__(16) int stage_cnt[16];
+  __shared__ int sidx[kRepMaxInputs * 16];
+  static_assert(16 * (DP + 2) <= 2 * TILE + 64, "the outgoing tile fits the exchange buffers");
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, sl = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pos = blockIdx.x;
+  const int4 cur = items[(size_t)(pos % kRepQueues) * a.qcap + pos / kRepQueues];
+  if (cur.x < 0) return;  // padding
+  const int4 h0 = desc[2 * cur.x], h1 = desc[2 * cur.x + 1];
+  const int n_nodes = h0.z & 0xffff, kind = h0.z >> 16;
+  const int cat = a.cat0 + (cur.y >> 20);
+  const int u0 = (cur.y & 0xfffff) * 16;
+  const long long row = (long long)cat * a.rows + h0.x + u0;
+  const f64x4 ones = (f64x4){1., 1., 1., 1.}, zeros = (f64x4){0., 0., 0., 0.};
+  const unsigned lane16 = (unsigned)lane * 16u;
+  f64x4 acc = ones;  // this wave's rows of the node being assembled; behind its edge product: of the next node's first factor
+  int cnt = 0;
+  // this wave's rows of E = P x B for the branch in matrix slot `slot`; B: the whole operand, k2 -> k-steps 2 k2, 2 k2 + 1
+  auto a_rsrc = [&](int slot) { return agent_rsrc(a.Pfrag + (size_t)cat * a.cs_P + ((size_t)slot * NW + w) * TILE); };
+  auto a_first = [&](__amdgpu_buffer_rsrc_t pfr, f64x2 (&A)[PF]) {
+#pragma unroll
+    for (int st = 0; st < PF; st++) A[st] = ld16_buf(pfr, lane16, (unsigned)(st * 128 * 8));
+  };
+  // (B through `bsrc`: the operand leaves LDS a few k-steps ahead of the matrix instructions that read it — kRepBStages chunks in
+  //  flight — instead of standing in 4 NKK registers: 108 -> under 96 registers, five teams per CU instead of four)
+  auto product = [&](__amdgpu_buffer_rsrc_t pfr, f64x2 (&A)[PF], auto bsrc) {
+    constexpr int PB = BST < NS ? BST : NS;
+    f64x4 D0 = zeros, D1 = zeros;  // (two accumulator chains: even / odd k-steps)
+    f64x2 Bq[PB];
+#pragma unroll
+    for (int st = 0; st < PB; st++) Bq[st] = bsrc(st);
+#pragma unroll
+    for (int k2 = 0; k2 < NS; k2++) {
+      const f64x2 Ac = A[k2 % PF], Bc = Bq[k2 % PB];
+      asm volatile("" ::"v"(Ac), "v"(Bc));
+      if (k2 + PF < NS) A[k2 % PF] = ld16_buf(pfr, lane16, (unsigned)((k2 + PF) * 128 * 8));
+      if (k2 + PB < NS) Bq[k2 % PB] = bsrc(k2 + PB);
+      D0 = mfma(Ac[0], Bc[0], D0);
+      if constexpr (CHAINS == 2) D1 = mfma(Ac[1], Bc[1], D1);
+      else D0 = mfma(Ac[1], Bc[1], D0);
+    }
+    if constexpr (CHAINS == 2) acc = D0 + D1;
+    else acc = D0;
+  };
+  if (kind == 0) {
+    const int n_in = h1.w, map0 = h1.x, rows = h1.y * 16;
+    for (int e0 = 0; e0 < n_in; e0 += 4 * NW) {
+      const int e = e0 + (tid >> 4);
+      if (e < n_in) sidx[e * 16 + sl] = a.map[map0 + e * rows + u0 + sl];
+    }
+    __syncthreads();
+    REP_TR(4)
+    // this wave's share of an input's rows (the tables of a static pass were finished by an earlier launch)
+    auto gather = [&](const int4 &ie, int e, f64x2 (&v)[2], int &ec) {
+      const int idx = sidx[e * 16 + sl];
+      const unsigned off = (unsigned)((idx * NW + w) * 16 + g * 4) * 8u;
+      ec = 0;
+      if (ie.x >= 0) {
+        const double *src = a.tab + ((size_t)cat * a.rows + ie.x) * DP;  // uniform
+        v[0] = ld16_agent(src, off), v[1] = ld16_agent(src, off + 16u);
+        ec = __hip_atomic_load(a.cnt + (size_t)cat * a.rows + ie.x + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        const double *src = a.PTg + (size_t)cat * a.cs_P + (size_t)ie.y * DP * DP;  // uniform
+        v[0] = ld16(src, off), v[1] = ld16(src, off + 16u);
+      }
+    };
+    f64x2 pv[2];  // the first input of the NEXT node, requested before this node's edge product
+    int pcnt = 0, park_cnt = 0;
+    f64x4 parked = ones;  // an inline side chain is being walked: the running product waits here
+    bool pf = false;
+    int e_node = 0;
+    for (int k = 0; k < n_nodes; k++) {
+      const int4 ne = desc[h0.w + k];
+      if (ne.w & 1) {
+        parked = acc;
+        park_cnt = cnt;
+        cnt = 0;
+        acc = ones;
+      }
+      for (int j = 0; j < ne.y; j++) {
+        if (j == 0 && pf) {
+          acc *= (f64x4){pv[0][0], pv[0][1], pv[1][0], pv[1][1]};
+          cnt += pcnt;
+          continue;
+        }
+        const int4 ie = desc[ne.z + j];  // uniform
+        f64x2 v[2];
+        int ec;
+        gather(ie, e_node + j, v, ec);
+        acc *= (f64x4){v[0][0], v[0][1], v[1][0], v[1][1]};
+        cnt += ec;
+      }
+      e_node += ne.y;
+      if constexpr (TRACE) asm volatile("" ::"v"(acc[0]));
+      REP_TR(5)
+      // hand the node over: this wave's k-steps 4 w .. 4 w + 3 of the B image and its share of the per-class totals
+      double *bb = bx + (k & 1) * TILE;
+      *reinterpret_cast<f64x2 *>(bb + ((2 * w) * 64 + lane) * 2) = (f64x2){acc[0], acc[1]};
+      *reinterpret_cast<f64x2 *>(bb + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){acc[2], acc[3]};
+      const double ps = row_sum4((acc[0] + acc[1]) + (acc[2] + acc[3]));
+      if (g == 0) psum[k & 1][w][sl] = ps;
+      // in flight across the barrier: the head of this product's A stream and the next node's first input
+      const __amdgpu_buffer_rsrc_t pfr = a_rsrc(ne.x);
+      f64x2 A[PF];
+      a_first(pfr, A);
+      pf = false;
+      if (k + 1 < n_nodes) {
+        const int4 ne2 = desc[h0.w + k + 1];
+        if (ne2.y > 0) {
+          gather(desc[ne2.z], e_node, pv, pcnt);
+          pf = true;
+        }
+      }
+      __syncthreads();
+      double tot = psum[k & 1][0][sl];
+#pragma unroll
+      for (int ww = 1; ww < NW; ww++) tot += psum[k & 1][ww][sl];
+      if constexpr (TRACE) asm volatile("" ::"v"(tot));
+      REP_TR(6)
+      product(pfr, A, [&](int k2) -> f64x2 { return *reinterpret_cast<const f64x2 *>(bb + (k2 * 64 + lane) * 2); });
+      if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) {  // rare: some class needs (or cannot have) a rescale
+        double sc = 1.0;                                            // (behind the product: a power of 2^64 commutes with it exactly)
+        cnt += rescale_decision(tot, sc);
+        acc *= sc;
+      }
+      if (ne.w & 2) {  // the chain's edge product joins the product it was walked for
+        acc *= parked;
+        cnt += park_cnt;
+      }
+      if constexpr (TRACE) asm volatile("" ::"v"(acc[0]));
+      REP_TR(7)
+    }
+  } else {
+    // a leaf with ambiguity codes: E[u] = P_leaf x (resolution vector of the u-th distinct code)
+    const int code = a.map[h1.x + u0 + sl];
+    const double *av = a.ambig + (size_t)(code < 0 ? -code - 1 : 0) * DP;
+    const __amdgpu_buffer_rsrc_t pfr = a_rsrc(h1.w);
+    f64x2 A[PF];
+    a_first(pfr, A);
+    product(pfr, A, [&](int k2) -> f64x2 {
+      f64x2 b;
+      b[0] = (code >= 0) ? ((8 * k2 + g == code) ? 1.0 : 0.0) : av[8 * k2 + g];
+      b[1] = (code >= 0) ? ((8 * k2 + 4 + g == code) ? 1.0 : 0.0) : av[8 * k2 + 4 + g];
+      return b;
+    });
+  }
+  // ---- the rows ([class][w][g][r] = E[16 w + 4 r + g][class]) and their exponents, through the LDS tile: every store
+  //      instruction writes 1 KiB of consecutive bytes ----
+  __syncthreads();  // (nobody reads the exchange buffers any more)
+  double *stage = bx;
+  *reinterpret_cast<f64x2 *>(stage + sl * (DP + 2) + w * 16 + g * 4) = (f64x2){acc[0], acc[1]};
+  *reinterpret_cast<f64x2 *>(stage + sl * (DP + 2) + w * 16 + g * 4 + 2) = (f64x2){acc[2], acc[3]};
+  if (tid < 16) stage_cnt[tid] = cnt;  // (wave 0, g = 0: lane = class)
+  __syncthreads();
+  double *out = a.tab + (size_t)row * DP;  // uniform
+#pragma unroll
+  for (int i2 = 0; i2 < 2; i2++) {
+    const int e = (2 * w + i2) * 128 + lane * 2, r = e / DP, c = e % DP;
+    st16_agent(out, (unsigned)e * 8u, *reinterpret_cast<const f64x2 *>(stage + r * (DP + 2) + c));
+  }
+  if (tid < 4) {
+    const int4 cv = *reinterpret_cast<const int4 *>(stage_cnt + 4 * tid);
+    u32x4_t v;
+    __builtin_memcpy(&v, &cv, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, agent_rsrc(reinterpret_cast<const double *>(a.cnt + row)), (unsigned)tid * 16u, 0, 16);
+  }
+  if constexpr (TRACE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    REP_TR(8)
+    if (a.dbg && tid == 0) {  // one record per workgroup (wave 0): wall start / end, walked nodes, where it ran, cycles per phase
+      tr[1] = wall_clock64();
+      tr[2] = n_nodes;
+      tr[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+      for (int i = 0; i < 16; i++) a.dbg[(size_t)blockIdx.x * 16 + i] = tr[i];
+    }
+  }
+}
+
 }  // namespace
 
 // ---- 4 states ----------------------------------------------------------------------------------------------------------
@@ -531,7 +738,25 @@ __global__ __launch_bounds__(128) void class_table_nuc_kernel(const int4 *__rest
 }
 }  // namespace
 
-void launch_class_tables(const RepArgs &a, int NW, hipStream_t stream) {
+// team != 0: the row-split walk, one workgroup of NW waves per item (static passes only; a.n_static items)
+void launch_class_tables(const RepArgs &a, int NW, hipStream_t stream, int team = 0) {
+  if (team && a.n_static > 0 && NW >= 2) {
+    const dim3 tgrid(a.n_static), tblock(64 * NW);
+    if (a.dbg && NW == 4) {
+      hipLaunchKernelGGL((class_table_team_kernel<4, true>), tgrid, tblock, 0, stream, a.desc, a.items, a);
+      return;
+    }
+    // (measured, r06, headline / 32 x 5 k / 128 x 100 k pruning launches in us — two accumulator chains, 3 + 3 chunks ahead, five teams
+    //  per CU: 67.5 / 37.9 / 564.8; all eight A chunks ahead of the barrier, four teams: 71.2 / 37.5 / 569.0; ONE chain, 3 + 2 chunks,
+    //  SIX teams per CU (80 registers): 65.8 / 37.3 / 550.4 — the form kept: what a team waits for is its partners, and a sixth team on
+    //  the CU fills more of those waits than deeper prefetch does)
+    switch (NW) {
+      case 2: hipLaunchKernelGGL((class_table_team_kernel<2>), tgrid, tblock, 0, stream, a.desc, a.items, a); break;
+      case 3: hipLaunchKernelGGL((class_table_team_kernel<3>), tgrid, tblock, 0, stream, a.desc, a.items, a); break;
+      default: hipLaunchKernelGGL((class_table_team_kernel<4>), tgrid, tblock, 0, stream, a.desc, a.items, a); break;
+    }
+    return;
+  }
   const dim3 grid(a.n_waves), block(64);
   if (a.dbg && NW == 4) {
     hipLaunchKernelGGL((class_table_kernel<4, true>), grid, block, 0, stream, a.desc, a.items, a.live, a);
@@ -1328,7 +1553,7 @@ static int rep_wave_count(const Shard &s, size_t n_items) {
 
 int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vector<int> &dirty, int cat0, int n_classes,
                     std::vector<int4> &queues /* [kRepQueues][qcap] */, int *n_static = nullptr, int *n_waves = nullptr,
-                    std::vector<RepLaunch> *launches = nullptr) {
+                    std::vector<RepLaunch> *launches = nullptr, bool team = false) {
   const int ND = (int)p->rep_nodes.size();
   std::vector<char> live(ND, 0);
   for (int d : dirty) live[d] = 1;
@@ -1403,6 +1628,11 @@ int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vec
     }
     its.swap(placed);
   };
+  // the row-split walk (class_table_team_kernel): one workgroup per item, dispatched in the order of the list — descending cost
+  auto by_cost_desc = [&](std::vector<int4> &its) {
+    std::stable_sort(its.begin(), its.end(), [&](const int4 &x, const int4 &y) { return cost[x.x] > cost[y.x]; });
+    for (size_t i = 0; i < its.size(); i++) its[i].z = (int)i, its[i].w = 0;
+  };
   const bool verbose2 = getenv("HYPHY_HIP_VERBOSE") && atoi(getenv("HYPHY_HIP_VERBOSE")) >= 2;
   if (launches) launches->clear();
   const bool levels_on = launches && !(getenv("HYPHY_HIP_REP_LEVELS") && atoi(getenv("HYPHY_HIP_REP_LEVELS")) == 0) &&
@@ -1428,7 +1658,8 @@ int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vec
       if (part.empty()) continue;
       const int w_n = rep_wave_count(s, part.size());
       double longest = 0.;
-      if ((int)part.size() > w_n && lpt_on) place(part, w_n, &longest);
+      if (team) by_cost_desc(part);
+      else if ((int)part.size() > w_n && lpt_on) place(part, w_n, &longest);
       const int n_pos = (int)part.size();
       while (part.size() % kRepQueues) part.push_back(make_int4(-1, 0, (int)part.size(), 0));
       const int pq = (int)part.size() / kRepQueues;
@@ -1442,7 +1673,9 @@ int rep_build_items(const hyphy_hip_partition *p, const Shard &s, const std::vec
     if (n_waves && !launches->empty()) *n_waves = (*launches)[0].n_waves;
     return (int)(queues.size() / kRepQueues);
   }
-  if (n_static && *n_static > nw && lpt_on) {
+  if (n_static && *n_static > 0 && team) {
+    by_cost_desc(all);
+  } else if (n_static && *n_static > nw && lpt_on) {
     double longest = 0.;
     place(all, nw, &longest);
     if (verbose2) {
@@ -1494,7 +1727,9 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
     }
     std::vector<int4> queues;
     int n_static = 0, n_waves = 1;
-    const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues, &n_static, &n_waves, &s.rep_launches);
+    s.rep_team = p->NW >= 2 && !(getenv("HYPHY_HIP_REP_TEAM") && atoi(getenv("HYPHY_HIP_REP_TEAM")) == 0) &&
+                 !(getenv("HYPHY_HIP_REP_STATIC") && atoi(getenv("HYPHY_HIP_REP_STATIC")) == 0);
+    const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues, &n_static, &n_waves, &s.rep_launches, s.rep_team);
     if (dirty.empty()) s.rep_launches.clear();
     s.rep_static = getenv("HYPHY_HIP_REP_STATIC") && atoi(getenv("HYPHY_HIP_REP_STATIC")) == 0 ? 0 : n_static;
     const size_t words = (size_t)kRepQueues * std::max(1, per_q) + (size_t)(ND + 3) / 4;  // queues, then the live flags
@@ -1583,19 +1818,22 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
       a.qcap = lv.qcap;
       a.n_static = lv.n_static;
       a.n_waves = lv.n_waves;
-      if (k + 1 < traced) launch_class_tables(a, p->NW, s.stream);
+      if (k + 1 < traced) launch_class_tables(a, p->NW, s.stream, s.rep_team);
     }
-    const size_t n = (size_t)a.n_waves * 16;
+    const bool team_tr = s.rep_team && a.n_static > 0;
+    const size_t n_rec = team_tr ? (size_t)a.n_static : (size_t)a.n_waves;
+    const size_t n = n_rec * 16;
     HIPCHK(pool_malloc((void **)&a.dbg, n * sizeof(long long)));
     HIPCHK(hipMemsetAsync(a.dbg, 0, n * sizeof(long long), s.stream));
-    launch_class_tables(a, p->NW, s.stream);
+    launch_class_tables(a, p->NW, s.stream, s.rep_team);
     std::vector<long long> h(n);
     HIPCHK(hipStreamSynchronize(s.stream));
     HIPCHK(hipMemcpy(h.data(), a.dbg, n * sizeof(long long), hipMemcpyDeviceToHost));
     pool_free_sync(a.dbg);
     if (FILE *f = fopen(tl, "w")) {
-      fprintf(f, "# wave wall_start wall_end(100MHz) items failed_polls cycles: tickets waiting gathers product publish\n");
-      for (int w = 0; w < a.n_waves; w++) {
+      if (team_tr) fprintf(f, "# team (one workgroup of NW waves per item, class_table_team_kernel) wall_start wall_end(100MHz) walked_nodes hw_id|xcc<<32 cycles: index-maps gathers exchange product publish\n");
+      else fprintf(f, "# wave wall_start wall_end(100MHz) items failed_polls cycles: tickets waiting gathers product publish\n");
+      for (int w = 0; w < (int)n_rec; w++) {
         const long long *r = &h[(size_t)w * 16];
         fprintf(f, "%d %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", w, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
       }
@@ -1609,11 +1847,11 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
       a.qcap = lv.qcap;
       a.n_static = lv.n_static;
       a.n_waves = lv.n_waves;
-      launch_class_tables(a, p->NW, s.stream);
+      launch_class_tables(a, p->NW, s.stream, s.rep_team);
     }
     return 0;
   }
-  launch_class_tables(a, p->NW, s.stream);
+  launch_class_tables(a, p->NW, s.stream, s.rep_team);
   return 0;
 }
 

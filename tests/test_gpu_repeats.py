@@ -68,6 +68,37 @@ def test_compressed_equals_plain_and_reference(name, rho, inline, levels, monkey
         assert got[0][2].max() > 0   # exponents per class were really exercised
 
 
+@pytest.mark.parametrize("rho,inline", [("0", "1"), ("0.6", "0"), ("2", "1")])
+@pytest.mark.parametrize("name", ["codon_small", "codon_ambig", "codon_deep", "ref_smallcodon"])
+def test_row_split_walk_equals_one_wave_walk(name, rho, inline, monkeypatch):
+    """r06: static lower-phase launches walk a path with a workgroup of NW row-split waves (class_table_team_kernel, the default);
+    HYPHY_HIP_REP_TEAM=0 keeps the one-wave walk of r05 (class_table_kernel).  Same tables, same exponents: per-pattern values of the
+    two forms agree to rounding (the team adds even and odd k-steps in two accumulator chains), both equal the reference's."""
+    monkeypatch.setenv("HYPHY_HIP_REPEATS", "2")
+    monkeypatch.setenv("HYPHY_HIP_REP_INLINE", inline)
+    monkeypatch.setenv("HYPHY_HIP_REP_RHO", rho)
+    monkeypatch.setenv("HYPHY_HIP_REP_THETA", "0.9")
+    monkeypatch.setenv("HYPHY_HIP_POISON", "1")
+    fx = common.load(name)
+    Q = common.fixture_Q(fx)
+    nodes = common.all_nodes(fx)
+    got = {}
+    for team in ("1", "0"):
+        monkeypatch.setenv("HYPHY_HIP_REP_TEAM", team)
+        with _mk(fx) as part:
+            assert part.repeat_stats()["in_use"] == 1
+            for _ in range(3):
+                ll, lik, sc = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+            got[team] = (ll, _site(lik, sc), sc.copy())
+    ref = float(fx["logl"])
+    for ll, site, sc in got.values():
+        assert abs(ll - ref) <= RTOL * abs(ref), (ll, ref)
+        assert np.max(np.abs(site[fx["site_to_pattern"]] - fx["site_logl"]) / np.abs(fx["site_logl"])) < RTOL
+    assert abs(got["1"][0] - got["0"][0]) <= SAME * abs(ref)
+    assert np.max(np.abs(got["1"][1] - got["0"][1]) / np.abs(got["0"][1])) < SAME
+    assert np.array_equal(got["1"][2], got["0"][2]) or name.endswith("deep")   # (exponents may split differently only where a total sits on the threshold)
+
+
 @pytest.mark.parametrize("seed,taxa,D", [(1, 40, 61), (2, 33, 61), (3, 24, 20), (4, 17, 48), (5, 30, 5)])
 def test_random_trees_and_state_counts_against_the_oracle(seed, taxa, D, monkeypatch):
     """Random trees (multifurcating root), random ambiguity codes, 61 / 48 / 20 / 5 states (NW = 4, 3, 2, 1 row blocks), enough
