@@ -625,6 +625,15 @@ def main():
         ar_step = None
         collective = "torch" if multi else "none"
         ll0 = step(0)
+    # 4 states: the library compiles the schedule into straight-line code on a background thread once it has come back a few times
+    # (hyphy_amd/csrc/nucgen.hip) and switches over when the code object is there: reach that steady state before anything is timed
+    # (untimed evaluations, at most 30 s; HYPHY_HIP_NUCGEN=0 keeps the interpreter and skips the wait)
+    nucgen_wait_s = None
+    if D == 4 and os.environ.get("HYPHY_HIP_NUCGEN", "1") != "0" and hasattr(part, "prune_kernel_name"):
+        t_ng = time.perf_counter()
+        while part.prune_kernel_name() != "nucgen_kernel" and time.perf_counter() - t_ng < 30.0:
+            step(1)
+        nucgen_wait_s = time.perf_counter() - t_ng
     # device preheat (clock ramp): the same number of steps on every rank (a step contains a collective when N > 1)
     t_pre = time.perf_counter()
     for _ in range(3):
@@ -807,8 +816,10 @@ def main():
         roof["kernel"] = part.prune_kernel_name()
         kernels = [roof["kernel"]]
         if rep_on and D > 4:   # two launches per pass: the class tables (lower phase), then the trunk through the pruning kernel
-            kernels = ["class_table_kernel", roof["kernel"]]
-            roof["kernel"] = "class_table_kernel + " + roof["kernel"]
+            # (r06: a workgroup of row-split waves walks a path — class_table_team_kernel; HYPHY_HIP_REP_TEAM=0: the one-wave walk)
+            lower = "class_table_team_kernel" if os.environ.get("HYPHY_HIP_REP_TEAM", "1") != "0" else "class_table_kernel"
+            kernels = [lower, roof["kernel"]]
+            roof["kernel"] = lower + " + " + roof["kernel"]
         if bound == "mfma":
             # measured ceiling of the instruction the kernel issues (tools/ubench/mfma4_skew.hip): v_mfma_f64_16x16x4_f64 with VGPR
             # accumulators sustains 73-78 TFLOP/s chip-wide from one operand pair and 66-72 with the kernel's own operand stream

@@ -222,6 +222,22 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
   for (const auto &pr : p->programs) n_ops_planned = std::max(n_ops_planned, pr.n);
   ExpmArgs folded_expm;
   bool have_folded = false;
+  // 4 states: a schedule that keeps coming back runs as straight-line code compiled at run time (nucgen.hip) — requested after
+  // nucgen_after() evaluations under it, used from the evaluation that finds it compiled; the interpreter until then and for
+  // everything the generator does not cover (pinned states, the trunk of a class-compressed partition, one-leaf entries)
+  bool use_gen = false;
+  if (p->nuc && p->mode == 0 && p->nucgen_key != 0 && n_ops_planned > 0 && p->pin_node < 0 && p->nuc_leaf_pairs && p->programs.size() == 1 &&
+      s.S_pad % 256 == 0) {
+    const int gm = nucgen_mode();
+    if (gm != 0) {
+      use_gen = nucgen_ready(p->nucgen_key);
+      if (!use_gen && (gm == 2 || ++p->nucgen_uses >= nucgen_after()) && !p->nucgen_asked) {
+        p->nucgen_asked = true;
+        nucgen_request(p->nucgen_key, p->ops_host.data() + p->programs[0].off, p->programs[0].n, (int)p->L, !p->cached_persist, p->nucgen_small, (int)p->B, gm == 2);
+        use_gen = nucgen_ready(p->nucgen_key);
+      }
+    }
+  }
   if (n_q > 0) {
     // n_cat_batch > 1: the matrices of ALL rate classes in one expm launch, class-major; destination
     // slot of matrix (c, k) is c*B + q_nodes[k] relative to class 0's image arrays
@@ -357,7 +373,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     }
     tr.lap("slots+q");
     bool coeffs_consumed = false;
-    if (p->nuc && p->mode == 0 && prune_nuc_folds_expm((int)p->L, s.S_pad, n_ops_planned) && !(q_from_templates && !ea.coeffs)) {
+    if (p->nuc && p->mode == 0 && (!use_gen || p->nucgen_small) && prune_nuc_folds_expm((int)p->L, s.S_pad, n_ops_planned) && !(q_from_templates && !ea.coeffs)) {
       folded_expm = ea;  // (4 states, small shard: the pruning launch computes the exponentials itself)
       have_folded = true;
     } else {
@@ -427,7 +443,7 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     {  // fused final combine (see the codon branch below): the small-shard instantiation of the 4-state kernel carries it
       const char *fuse_env = getenv("HYPHY_HIP_FUSED_REDUCE");
       if (!(fuse_env && atoi(fuse_env) == 0) && p->mode == 0 && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && !p->export_sites &&
-          prune_nuc_fuses_reduce(na, have_folded)) {
+          (use_gen ? p->nucgen_small : prune_nuc_fuses_reduce(na, have_folded))) {
         double *rec = s.d_hout ? s.d_hout : s.out;
         fused_reduce = true;
         na.red_out = d_logl_out ? d_logl_out : rec;
@@ -437,7 +453,11 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
         na.red_done = s.wg_flag + (size_t)p->C * s.wg_cap + 3;  // (the spare words behind the flags; zeroed at creation)
       }
     }
-    launch_prune_nuc(na, s.stream, have_folded ? &folded_expm : nullptr);
+    if (!(use_gen && nucgen_launch(p->nucgen_key, na, s.stream, p->nucgen_small, (int)p->B, have_folded ? &folded_expm : nullptr))) {
+      if (use_gen) return fail("internal: the generated 4-state kernel could not be launched");
+      launch_prune_nuc(na, s.stream, have_folded ? &folded_expm : nullptr);
+    }
+    s.last_nucgen = use_gen;
     if (have_folded && folded_expm.templates && d_logl_out && s.coeff_slot >= 0) {  // (the ring slot is read by THIS launch)
       HIPCHK(hipEventRecord(s.coeff_ev[s.coeff_slot], s.stream));
       s.coeff_busy[s.coeff_slot] = true;
@@ -593,6 +613,15 @@ int prepare_schedule(hyphy_hip_partition *p, int cat, const int64_t *update_node
   p->cached_persist = persist_all;
   p->cached_valid = 1;
   *changed = true;
+  // (nucgen.hip) the key of this schedule's generated kernel: full passes of a 4-state partition under its own tree
+  // (small-shard form — matrices in LDS, exponentials and final combine inside the launch — for shards of at most two workgroups
+  //  per CU: the interpreter's LP rule; HYPHY_HIP_NUCGEN_SMALL=0/1 forces either)
+  p->nucgen_small = !p->shards.empty() && p->shards[0].S_pad / 256 <= 2 * p->shards[0].cus && p->B <= 1024;
+  if (const char *e = getenv("HYPHY_HIP_NUCGEN_SMALL")) p->nucgen_small = atoi(e) != 0 && p->B <= 1024;
+  p->nucgen_key = (p->nuc && p->mode == 0 && full && p->programs.size() == 1 && p->L <= 256)
+                      ? nucgen_key(p->ops_host.data() + p->programs[0].off, p->programs[0].n, (int)p->L, !persist_all, p->nucgen_small, (int)p->B) : 0;
+  p->nucgen_uses = 0;
+  p->nucgen_asked = false;
   return 0;
 }
 
@@ -753,6 +782,7 @@ int hyphy_hip_prune_launches(hyphy_hip_partition *p) { return p ? (int)std::max<
 
 const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p) {
   if (!p) return "";
+  if (p->nuc && !p->shards.empty() && p->shards[0].last_nucgen) return "nucgen_kernel";  // (run-time generated, nucgen.hip)
   if (p->nuc) return (p->nuc_leaf_pairs && p->mode == 0) ? "prune_nuc2_kernel" : "prune_nuc_kernel";
   return p->variant == 1 ? "prune_wave_kernel" : "prune_mfma_kernel";  // (variant 2: the same kernel on a chain schedule)
 }

@@ -192,6 +192,46 @@ struct NucArgs {
   const int32_t *gcnt = nullptr;    // [rows] their 2^64 exponents
 };
 
+// The argument block of a run-time generated 4-state kernel (nucgen.hip; the generated source carries the same declaration)
+struct NucGenArgs {
+  const double *ambig;
+  double *partials;
+  int32_t *counts;
+  const double *pi;
+  double *site_lik;
+  int32_t *site_cnt;
+  const double *freq;
+  double *wg_sum;
+  long long *wg_cnt;
+  int *wg_flag;
+  long long S_pad;
+  double *red_out;           // fused final combine (small-shard form; see PruneArgs), nullptr: off
+  double *red_rec;
+  const int *red_status;
+  double red_seq;
+  int *red_done;
+};
+struct NucGenExpm {          // what the small-shard form reads of ExpmArgs (declared as hyhip::ExpmArgs in the generated source)
+  const double *Q;
+  const int32_t *slots;
+  int n;
+  int is_prob;
+  double *Prow;
+  double *PTrow;
+  int32_t *status;
+  const double *templates;
+  const double *coeffs;
+  int K;
+  int coef_inline;
+};
+int nucgen_mode();                                     // HYPHY_HIP_NUCGEN: 0 off, 1 background compilation (default), 2 synchronous
+int nucgen_after();                                    // evaluations under one schedule before its kernel is requested
+uint64_t nucgen_key(const int4 *ops, int n_ops, int L, bool lazy, bool small, int n_branches);
+void nucgen_request(uint64_t key, const int4 *ops, int n_ops, int L, bool lazy, bool small, int n_branches, bool sync);
+bool nucgen_ready(uint64_t key);
+bool nucgen_launch(uint64_t key, const NucArgs &a, hipStream_t stream, bool small, int n_branches, const ExpmArgs *ex);
+std::string nucgen_source(const int4 *ops, int n_ops, int L, bool lazy, bool small, int n_branches);
+
 constexpr int kSiteFitParkSlots = 1;  // wave-private LDS parking slots of the per-site fit kernel (8 KiB each at D = 61); nodes
                                       // beyond that go through a scratch copy in HBM (cheap next to the series of an edge)
 

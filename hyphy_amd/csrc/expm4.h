@@ -2,8 +2,12 @@
 // launch of small shards — prune_nuc2_kernel).  Same contract as the MFMA kernels: scaling by a power of two, Taylor polynomial of
 // degree 12 / 9 / 6 by the scaled norm (Paterson-Stockmeyer), diag_populator before and after the squarings, restart with a 2^7 larger scale when a diagonal exceeds 1, early
 // exit from the squarings, sticky status + NaN matrix on failure (matrix.cpp:5537-5951).
+// (also compiled as embedded source by the run-time generated kernels of nucgen.hip — the Makefile turns this file into a string
+//  constant: nothing in it may need more than the names hyhip::ExpmArgs gives it there)
+#ifndef HYPHY_NUCGEN_EMBEDDED
 #pragma once
 #include "common.h"
+#endif
 
 namespace hyhip {
 

@@ -220,6 +220,7 @@ struct Shard {
   int rep_waves = 0;                 // waves its launch runs
   std::vector<RepLaunch> rep_launches; // non-empty: the pass runs one launch per level of table-reads-table dependencies
   int rep_static = 0;                // > 0: its items do not depend on one another and are dealt by position (RepArgs::n_static)
+  bool last_nucgen = false;          // the last 4-state pruning launch ran a generated kernel (hyphy_hip_prune_kernel_name)
   bool rep_team = false;             // its static launches run the row-split walk (class_table_team_kernel), one workgroup per item
   bool rep_sync_dirty = false;       // a lower-phase launch has run and no trunk launch has reset rep_sync behind it yet
 };
@@ -281,6 +282,10 @@ struct hyphy_hip_partition {
   std::vector<char> initialized;             // per class: a full evaluation has populated the caches
   std::vector<char> leaf_has_ambig;          // per leaf: any ambiguity code in its row of the leaf table
   std::vector<int4> ops_host;
+  uint64_t nucgen_key = 0;                   // 4 states: key of the run-time generated kernel of the current schedule (nucgen.hip), 0: none
+  int nucgen_uses = 0;                       // ... evaluations under it so far
+  bool nucgen_small = false;                 // ... in its small-shard form (matrices in LDS, exponentials and combine inside the launch)
+  bool nucgen_asked = false;                 // ... its compilation has been requested
   std::vector<int64_t> cached_update;        // update list the device schedule was built for
   bool cached_full = false;
   int cached_valid = 0;

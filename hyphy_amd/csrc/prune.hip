@@ -21,6 +21,7 @@
 #include "common.h"
 #include "devutil.h"
 #include "expm4.h"
+#include "combine.h"
 
 #ifndef HYPHY_OCC
 #define HYPHY_OCC 3  // waves per SIMD the T = 1 pruning kernel is compiled for
@@ -49,8 +50,6 @@ __device__ __forceinline__ void lds_barrier() {
 // like wg_reduce_kernel does (same flags, same record, same sequence word).  The order of arrival decides only WHO sums.
 // FUSE is a template parameter of the kernels: the combine's registers must not exist in the builds that do not use it (inlined
 // behind a run-time test it cost the production wave kernel 15 scratch instructions and 3 us of 119 at the headline size).
-__device__ __forceinline__ void combine_partials(double *wg_sum, long long *wg_cnt, int *wg_flag, int n, double *red_out,
-                                                 double *red_rec, const int *red_status, double red_seq, int lane);
 template <bool FUSE>
 __device__ __forceinline__ void publish_partial(const PruneArgs &a, int idx, double wsum, long long wcnt, int wflag, int lane) {
   if (!FUSE || a.red_out == nullptr) {
@@ -76,78 +75,6 @@ __device__ __forceinline__ void publish_partial(const PruneArgs &a, int idx, dou
   if (lane == 0) __hip_atomic_store(a.red_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
   combine_partials(a.wg_sum, a.wg_cnt, a.wg_flag, a.red_n, a.red_out, a.red_rec, a.red_status, a.red_seq, lane);
   }  // FUSE
-}
-
-// The last arriver's part of the fused final combine (one full wave): n partial sums read back with sc1 loads, fixed-order
-// compensated sum, result record published like wg_reduce_kernel's.  Shared by the codon kernels' publish_partial and the
-// 4-state kernel's epilogue.
-__device__ __forceinline__ void combine_partials(double *wg_sum, long long *wg_cnt, int *wg_flag, int n, double *red_out,
-                                                 double *red_rec, const int *red_status, double red_seq, int lane) {
-  {
-  // (bounds rounded up to whole 16-byte accesses — the arrays are allocated 4 entries longer than any n —, entries >= n masked below)
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wg_sum, 0, ((n + 1) & ~1) * 8, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(wg_cnt, 0, ((n + 1) & ~1) * 8, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(wg_flag, 0, ((n + 3) & ~3) * 4, 0x00020000);
-  double sum = 0., comp = 0.;
-  long long c = 0;
-  int fl = 0;
-  constexpr int U = 4;
-  for (int base = 0; base < n; base += 128 * U) {
-    u32x4_t vs[U], vc[U];
-    u32x4_t vf[U / 2];
-#pragma unroll
-    for (int j = 0; j < U; j++) {
-      vs[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(base + 128 * j + 2 * lane) * 8u, 0, 16);
-      vc[j] = __builtin_amdgcn_raw_buffer_load_b128(rc, (unsigned)(base + 128 * j + 2 * lane) * 8u, 0, 16);
-    }
-#pragma unroll
-    for (int j = 0; j < U / 2; j++) vf[j] = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)(base + 256 * j + 4 * lane) * 4u, 0, 16);
-#pragma unroll
-    for (int j = 0; j < U; j++) {
-      f64x2 x;
-      long long cc[2];
-      __builtin_memcpy(&x, &vs[j], 16);
-      __builtin_memcpy(cc, &vc[j], 16);
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const bool in = base + 128 * j + 2 * lane + h < n;
-        const double y = (in ? x[h] : 0.) - comp;  // Kahan
-        const double t = sum + y;
-        comp = (t - sum) - y;
-        sum = t;
-        c += in ? cc[h] : 0ll;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < U / 2; j++)
-#pragma unroll
-      for (int h = 0; h < 4; h++)
-        if (base + 256 * j + 4 * lane + h < n) fl |= (int)vf[j][h];
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double b0 = __shfl_down(sum, off), bc = __shfl_down(comp, off);
-    const long long cc = __shfl_down(c, off);
-    fl |= __shfl_down(fl, off);
-    const double t = sum + b0;
-    const double e = (fabs(sum) >= fabs(b0)) ? (sum - t) + b0 : (b0 - t) + sum;  // sum + b0 = t + e exactly
-    comp = comp + bc - e;
-    sum = t;
-    c += cc;
-  }
-  if (lane == 0) {
-    double r = (sum - comp) - kLogScaler * (double)c;
-    if (fl & 2) r = NAN;
-    else if (fl & 1) r = -INFINITY;
-    red_out[0] = r;
-    red_rec[0] = (double)c;
-    red_rec[1] = red_status ? (double)*red_status : 0.;
-    if (red_seq != 0.) {  // host spins on this word instead of waiting for the stream (record complete before it)
-      __threadfence_system();
-      reinterpret_cast<volatile double *>(red_rec)[2] = red_seq;
-    }
-  }
-  }
 }
 
 // Operand bundle fetched one schedule entry ahead: 16 doubles per lane, either the A-operand image

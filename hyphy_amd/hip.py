@@ -24,7 +24,7 @@ EXPORTS = [
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
     "hyphy_hip_set_pinned_states", "hyphy_hip_site_fits_evaluate", "hyphy_hip_site_fits_evaluate_mixture", "hyphy_hip_site_fits_kernel_ms",
-    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_set_repeats", "hyphy_hip_repeat_stats", "hyphy_hip_plan_repeats", "hyphy_hip_last_error",
+    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_set_repeats", "hyphy_hip_repeat_stats", "hyphy_hip_plan_repeats", "hyphy_hip_plan_nucgen", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
 
@@ -142,6 +142,8 @@ def load():
     lib.hyphy_hip_plan_repeats.argtypes = [C.c_int64, C.c_int64, lp, C.c_int64, lp, C.c_double, lp, lp]
     lib.hyphy_hip_repeat_stats.restype = C.c_int
     lib.hyphy_hip_repeat_stats.argtypes = [vp, lp]
+    lib.hyphy_hip_plan_nucgen.restype = C.c_int64
+    lib.hyphy_hip_plan_nucgen.argtypes = [C.c_int64, C.c_int64, lp, lp, C.c_int64, C.c_char_p, C.c_int64, lp]
     lib.hyphy_hip_last_error.restype = C.c_char_p
     lib.hyphy_hip_version.restype = C.c_char_p
     _lib = lib
@@ -207,6 +209,22 @@ def plan_repeats(flat_parents, L: int, leaf_codes, theta: float = 0.0):
     if work < 0:
         raise HipError("plan_repeats: bad arguments")
     return cl, cp.astype(bool), int(work)
+
+
+def plan_nucgen(flat_parents, L: int, leaf_has_ambig=None, compile_it: bool = True, small: bool = False):
+    """Host-only (libhiprtc, no device): (source of the run-time generated 4-state kernel for this tree's steady-state full pass,
+    compiled for gfx950?).  Empty source: the generator does not cover the schedule."""
+    lib = load()
+    fp = np.ascontiguousarray(flat_parents, dtype=np.int64)
+    I = len(fp) - L
+    amb = None if leaf_has_ambig is None else np.ascontiguousarray(leaf_has_ambig, dtype=np.int64)
+    cap = 1 << 22
+    buf = C.create_string_buffer(cap)
+    ok = np.zeros(1, dtype=np.int64)
+    n = lib.hyphy_hip_plan_nucgen(L, I, _l(fp), _l(amb), 1 if small else 0, buf, cap, _l(ok) if compile_it else None)
+    if n < 0:
+        raise HipError("plan_nucgen: bad arguments")
+    return buf.value.decode(), bool(ok[0])
 
 
 def device_count() -> int:

@@ -422,6 +422,20 @@ int64_t hyphy_hip_plan_repeats(int64_t L, int64_t I, const int64_t *flat_parents
                                int64_t *classes_out, int64_t *compressed_out);
 int hyphy_hip_repeat_stats(const hyphy_hip_partition *p, int64_t out[8]);
 
+/* 4 states: schedules as run-time generated straight-line kernels (nucgen.hip; replaces the interpretation of the reference's
+ * 4-state loop, src/core/tree_evaluator.cpp:2253-2273, 3556-4171, entry by entry).  A 4-state partition whose full-pass schedule
+ * keeps coming back (HYPHY_HIP_NUCGEN_AFTER evaluations, default 8) has it compiled by hiprtc on a background thread and runs it
+ * from the evaluation that finds it ready; code objects are shared per process by schedule.  HYPHY_HIP_NUCGEN=0: off (always the
+ * interpreter); =2: compile synchronously at the first full pass.  hyphy_hip_prune_kernel_name() answers "nucgen_kernel" once the
+ * last launch ran one.
+ *   hyphy_hip_plan_nucgen   host-only (needs libhiprtc, no device): the source the library would compile for the steady-state full
+ *                           pass of a 4-state partition over this tree (leaf_has_ambig[L] or NULL: leaves that carry ambiguity
+ *                           codes; small != 0: the form for shards of at most two workgroups per CU — every matrix in LDS, the
+ *                           evaluation's exponentials and the final combine inside the launch); returns its length (src_out, if given, receives at most cap - 1 bytes + NUL), 0 when the
+ *                           generator does not cover the schedule, < 0 on bad arguments; *compiled_out = 1 when it compiled for gfx950. */
+int64_t hyphy_hip_plan_nucgen(int64_t L, int64_t I, const int64_t *flat_parents, const int64_t *leaf_has_ambig, int64_t small, char *src_out,
+                              int64_t cap, int64_t *compiled_out);
+
 const char *hyphy_hip_last_error(void);
 const char *hyphy_hip_version(void);
 

@@ -185,3 +185,34 @@ def test_subtree_repeat_classes_and_compressed_set():
             rows = sorted(below[n])
             runs = 1 + sum(1 for s in range(1, S) if tuple(codes[rows, s]) != tuple(codes[rows, s - 1]))
             assert runs >= classes[n]
+
+
+def test_nucgen_source_covers_every_node_and_compiles_for_gfx950():
+    """hyphy_hip_plan_nucgen (no device; hiprtc cross-compiles): the straight-line kernel the library generates for a 4-state
+    partition's steady-state full pass names every internal node once, reads every leaf's code once, takes the lookup path for
+    plain leaves and the guarded general path for leaves with ambiguity codes, and compiles for gfx950."""
+    import re
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        n = int(rng.integers(4, 70))
+        root = tree.random_tree(n, rng, trifurcating_root=bool(trial % 2))
+        flat = tree.flatten(root)
+        amb = np.zeros(flat.L, dtype=np.int64)
+        if trial >= 3:
+            amb[rng.integers(0, flat.L, size=2)] = 1
+        small = bool(trial % 3 == 0)   # (the small-shard form: matrices in LDS, exponentials and combine inside the launch)
+        src, ok = hip.plan_nucgen(flat.flat_parents, flat.L, amb, compile_it=True, small=small)
+        assert src, "the generator must cover a plain full pass"
+        assert ok, "hiprtc must compile the generated source for gfx950"
+        finals = re.findall(r"double n(\d+)_0 = ", src)
+        assert sorted(int(x) for x in finals) == list(range(flat.I))              # every internal node finalised exactly once
+        codes = re.findall(r"const int k(\d+) = codes\[", src)
+        assert sorted(int(x) for x in codes) == list(range(flat.L))               # every leaf code fetched once, up front
+        assert src.count("leaf_general_(L_") == int(amb.sum())                    # guarded general path only where codes can be < 0
+        assert len(re.findall(r"const double \*P\d+ = (?:L_|PT) \+ ", src)) == flat.I - 1   # one matrix per internal edge
+        assert ("hyhip::expm4_one(" in src) == small and ("hyhip::combine_partials(" in src) == small
+        assert "a.partials[" not in src                                           # lazy steady state: nothing persisted, nothing re-read
+    # a tree beyond the LDS leaf table (L > 256): not covered, the interpreter stays
+    big = tree.flatten(tree.caterpillar_tree(300))
+    src, ok = hip.plan_nucgen(big.flat_parents, big.L, None, compile_it=False)
+    assert src == "" and not ok
