@@ -1182,9 +1182,14 @@ int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes
   bool pi_changed = p->cached_pi.size() != (size_t)p->D || memcmp(p->cached_pi.data(), root_freqs, p->D * sizeof(double));
   if (pi_changed) p->cached_pi.assign(root_freqs, root_freqs + p->D);
   if (p->cached_slots.size() != (size_t)p->C) p->cached_slots.assign(p->C, std::vector<int64_t>());
+  // (a batched evaluation writes its C * n_q slot numbers from the start of the device table, across the regions the classes use one at
+  //  a time: a switch between the two forms invalidates what is known about EVERY class's region, not only this call's — r06: the
+  //  adapter's category hook alternates batched passes with one-class line searches, and class 1 found class 0's batch table in its
+  //  region: exponentials written to slots beyond the last class)
+  if (p->slots_batch_mode != (batch ? 1 : 0))
+    for (auto &v : p->cached_slots) v.assign(1, -1);  // (no list of node codes equals this)
   std::vector<int64_t> &cs = p->cached_slots[cat];
-  bool slots_changed = cs.size() != (size_t)n_q || (n_q > 0 && memcmp(cs.data(), q_nodes, n_q * sizeof(int64_t))) ||
-                       p->slots_batch_mode != (batch ? 1 : 0);
+  bool slots_changed = cs.size() != (size_t)n_q || (n_q > 0 && memcmp(cs.data(), q_nodes, n_q * sizeof(int64_t)));
   if (slots_changed) cs.assign(q_nodes, q_nodes + n_q);
   p->slots_batch_mode = batch ? 1 : 0;
   for (Shard &s : p->shards)
@@ -1439,9 +1444,10 @@ int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_
   return 0;
 }
 
-int hyphy_hip_evaluate_categories_built(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update,
-                                        const int64_t *q_nodes, int64_t n_q, const double *weights,
-                                        const double *root_freqs, double *logl_out) {
+int hyphy_hip_evaluate_categories_built_sites(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update,
+                                              const int64_t *q_nodes, int64_t n_q, const double *weights,
+                                              const double *root_freqs, double *logl_out, double *site_lik_out,
+                                              int64_t *site_scaler_out) {
   if (!p) return fail("partition == NULL");
   if (!p->K) return fail("evaluate_categories_built: templates not set");
   if (p->nuc) return fail("evaluate_categories_built: MFMA partitions only (4-state: hyphy_hip_evaluate_categories)");
@@ -1467,7 +1473,14 @@ int hyphy_hip_evaluate_categories_built(hyphy_hip_partition *p, const int64_t *u
     for (Shard &s : p->shards) parts.push_back(s.h_out[0]);
     *logl_out = combine(parts);
   }
+  if (site_lik_out || site_scaler_out) return gather_sites(p, 0, site_lik_out, site_scaler_out, true);
   return 0;
+}
+
+int hyphy_hip_evaluate_categories_built(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update,
+                                        const int64_t *q_nodes, int64_t n_q, const double *weights,
+                                        const double *root_freqs, double *logl_out) {
+  return hyphy_hip_evaluate_categories_built_sites(p, update_nodes, n_update, q_nodes, n_q, weights, root_freqs, logl_out, nullptr, nullptr);
 }
 
 static int ensure_resident(hyphy_hip_partition *p, int64_t cat);

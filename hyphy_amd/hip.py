@@ -21,7 +21,7 @@ EXPORTS = [
     "hyphy_hip_device_count", "hyphy_hip_create", "hyphy_hip_destroy", "hyphy_hip_evaluate",
     "hyphy_hip_evaluate_device", "hyphy_hip_fetch_device_scalar", "hyphy_hip_plan_reroot", "hyphy_hip_plan_pattern_order", "hyphy_hip_plan_schedule", "hyphy_hip_evaluate_async", "hyphy_hip_collect", "hyphy_hip_evaluate_mixture", "hyphy_hip_evaluate_mixture_built", "hyphy_hip_comm_unique_id", "hyphy_hip_comm_init_rank", "hyphy_hip_comm_init_all", "hyphy_hip_allreduce_device", "hyphy_hip_evaluate_allreduce", "hyphy_hip_evaluate_built_allreduce", "hyphy_hip_last_allreduce_ms", "hyphy_hip_evaluate_categories", "hyphy_hip_download_partials",
     "hyphy_hip_expm_batch", "hyphy_hip_set_q_templates", "hyphy_hip_build_q", "hyphy_hip_q_buffer",
-    "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
+    "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_evaluate_categories_built_sites", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
     "hyphy_hip_set_pinned_states", "hyphy_hip_site_fits_evaluate", "hyphy_hip_site_fits_evaluate_mixture", "hyphy_hip_site_fits_kernel_ms",
     "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_set_repeats", "hyphy_hip_repeat_stats", "hyphy_hip_plan_repeats", "hyphy_hip_plan_nucgen", "hyphy_hip_last_error",
@@ -100,6 +100,8 @@ def load():
     lib.hyphy_hip_evaluate_built_sites.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, dp, dp, lp]
     lib.hyphy_hip_evaluate_categories_built.restype = C.c_int
     lib.hyphy_hip_evaluate_categories_built.argtypes = [vp, lp, C.c_int64, lp, C.c_int64, dp, dp, dp]
+    lib.hyphy_hip_evaluate_categories_built_sites.restype = C.c_int
+    lib.hyphy_hip_evaluate_categories_built_sites.argtypes = [vp, lp, C.c_int64, lp, C.c_int64, dp, dp, dp, dp, lp]
     lib.hyphy_hip_site_fits_evaluate.restype = C.c_int
     lib.hyphy_hip_site_fits_evaluate.argtypes = [vp, C.c_int64, C.c_int64, lp, dp, dp, dp, dp]
     lib.hyphy_hip_site_fits_evaluate_mixture.restype = C.c_int
@@ -514,6 +516,23 @@ class HipPartition:
                 _check(rc)
             return out.value
         return step
+
+    def evaluate_categories_built_sites(self, update_nodes, q_nodes, weights, root_freqs, coeffs: np.ndarray):
+        """``build_q`` (C*n_q coefficient rows, class-major) + ``evaluate_categories_built_sites`` -> (log-L, mixed per-pattern
+        likelihoods, mixed 2^64 exponents) — what the host's weighted-sum category loop leaves in its buffer and scalers."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        wt = np.ascontiguousarray(weights, dtype=np.float64)
+        co = np.ascontiguousarray(coeffs, dtype=np.float64)
+        assert co.shape[0] == self.C * len(qn)
+        out = C.c_double(0.0)
+        sl = np.zeros(self.S)
+        sc = np.zeros(self.S, dtype=np.int64)
+        _check(self._lib.hyphy_hip_build_q(self._h, co.shape[0], _d(co)))
+        _check(self._lib.hyphy_hip_evaluate_categories_built_sites(self._h, _l(un), len(un), _l(qn), len(qn), _d(wt), _d(rf),
+                                                                   C.byref(out), _d(sl), _l(sc)))
+        return out.value, sl, sc
 
     def evaluate_categories(self, update_nodes, q_nodes, q_dense, weights, root_freqs, q_is_probability: bool = False,
                             per_site: bool = False):

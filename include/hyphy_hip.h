@@ -215,6 +215,13 @@ int hyphy_hip_evaluate_categories(hyphy_hip_partition *p, const int64_t *update_
 int hyphy_hip_evaluate_categories_built(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update,
                                         const int64_t *q_nodes, int64_t n_q, const double *weights,
                                         const double *root_freqs, double *logl_out);
+/* ... with the mixed per-pattern values: site_lik_out [S] / site_scaler_out [S] as hyphy_hip_evaluate_categories returns them (what
+ * PopulateConditionalProbabilities' weighted-sum mode leaves in its buffer and scalers, likefunc2.cpp:772-859); either may be NULL.
+ * The adapter's category hook answers the host's whole class loop with this one call ("rate classes"). */
+int hyphy_hip_evaluate_categories_built_sites(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update,
+                                              const int64_t *q_nodes, int64_t n_q, const double *weights,
+                                              const double *root_freqs, double *logl_out, double *site_lik_out,
+                                              int64_t *site_scaler_out);
 
 /*
  * Copies device partials back in the reference's host layout for code that reads the caches

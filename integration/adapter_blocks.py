@@ -95,6 +95,38 @@ struct _HyHipPart {
   long spmd_rank = 0, spmd_world = 1;
 };
 static std::map<const void *, std::vector<_HyHipPart>> _hyhip_lfs;
+// Rate classes batched through the host's category loop (r06; INTEGRATION.md "rate classes").  PopulateConditionalProbabilities'
+// weighted-sum mode (likefunc2.cpp:484-908, :772-859) calls ComputeBlock once per class and mixes after each call; with a batch
+// open (_hyphy_hip_cat_begin) those calls only COLLECT what each class would have sent to the device, the host's mixing of a
+// collected class is skipped (_hyphy_hip_cat_collected), and _hyphy_hip_cat_end answers the whole loop with ONE
+// hyphy_hip_evaluate_categories(_built_sites) call — per-pattern mixed values and exponents into the host's buffer / scalers, or,
+// when _LikelihoodFunction::Compute asked (_hyphy_hip_cat_want), just the summed log-likelihood (SumUpSiteLikelihoods is skipped).
+struct _HyHipCatBatch {
+  bool active = false;
+  const void *lf = nullptr;
+  long index = -1, C = 0, S = 0;
+  _TheTree *tree = nullptr;
+  hyFloat *buffer = nullptr;
+  long *scalers = nullptr;
+  bool mixed_any = false;                 // the adapter has mixed a class into buffer / scalers itself (classes evaluated one by one)
+  std::vector<double> weights;
+  struct ClassCall {
+    bool have = false, taken = false;     // have: inputs stashed; taken: the adapter answers for this class (stashed or mixed already)
+    int kind = 0;                         // 1 coefficient rows (template mode), 2 dense rate matrices, 3 transition matrices of the host, 4 nothing changed
+    long catID = 0;
+    std::vector<int64_t> upd, qn;
+    std::vector<double> data;
+  };
+  std::vector<ClassCall> calls;
+  // what Compute asked for / got
+  const void *want_lf = nullptr;
+  long want_index = -1;
+  bool logl_valid = false;
+  double logl = 0.;
+  long n_batched = 0, n_single = 0;
+};
+static _HyHipCatBatch _hyhip_cb;
+static bool _hyhip_cat_block = false;  // this ComputeBlock call builds / uses a branch cache behind its evaluation: it must really run
 static std::map<const void *, std::pair<const void *, long>> _hyhip_tree_owner;  // _TheTree* -> (lf, partition index)
 long _hyhip_calls = 0L, _hyhip_cached_calls = 0L, _hyhip_deferred = 0L;
 static double _hyhip_compute_seconds = 0.;  // wall time inside _hyphy_hip_compute (coefficients, library call incl. its wait, downloads)
@@ -139,6 +171,12 @@ static void _hyphy_hip_teardown(const void *lf) {
       fprintf(stderr, "[hyphy_hip] template mode: %ld evaluations took their rate matrices as coefficients (K = %ld), %ld RecomputeMatrix calls skipped\n",
               hp.n_template_evals, hp.tmpl_K, hp.n_skipped);
     hyphy_hip_destroy(hp.part);
+  }
+  if (_hyhip_cb.lf == lf) {
+    if (getenv("HYPHY_HIP_VERBOSE") && (_hyhip_cb.n_batched || _hyhip_cb.n_single))
+      fprintf(stderr, "[hyphy_hip] rate classes: %ld category loops answered by ONE device evaluation of all classes, %ld classes evaluated one by one\n",
+              _hyhip_cb.n_batched, _hyhip_cb.n_single);
+    _hyhip_cb = _HyHipCatBatch();
   }
   _hyhip_lfs.erase(it);
   for (auto o = _hyhip_tree_owner.begin(); o != _hyhip_tree_owner.end();)
@@ -1234,6 +1272,9 @@ static void _hyphy_hip_flush_part(_HyHipPart &hp, _TheTree *t) {
   hp.n_stale = 0;
 }
 
+static bool _hyhip_cat_collect(_HyHipPart &hp, _TheTree *t, long cat, long catID, _SimpleList &branches, _List &matrices, long n_q, bool first,
+                               long n_pending, long n_template, long n_mixture);
+static void _hyhip_cat_flush(_HyHipPart &hp);
 // one ComputeBlock evaluation on the device; returns 0 when *result is valid (or, with go_async, when it was enqueued:
 // _hyphy_hip_prepass_result collects it)
 static int _hyphy_hip_compute_impl(const void *lf, long index, _TheTree *t, long catID, _SimpleList &branches,
@@ -1269,6 +1310,14 @@ static int _hyphy_hip_compute_impl(const void *lf, long index, _TheTree *t, long
   double ll = 0.;
   int rc = 0;
   if (hp.spmd && (siteRes || scc || go_async)) return 1;  // (per-pattern outputs live on several ranks: this call stays on the host)
+  if (_hyhip_cb.active && _hyhip_cb.lf == lf && _hyhip_cb.index == index && !go_async) {
+    // the host's category loop is being batched: stash this class's inputs, the device runs once for all classes at the loop's end
+    if (!_hyhip_cat_block && _hyhip_cat_collect(hp, t, cat, catID, branches, matrices, n_q, first, n_pending, n_template, n_mixture)) {
+      *result = 0.;
+      return 0;
+    }
+    _hyhip_cat_flush(hp);  // (a class that cannot be collected: the classes stashed so far run one by one now, this one the ordinary way)
+  }
   if (n_mixture > 0 && (n_mixture < n_q || go_async)) {  // mixed with other kinds (rare): the host's own matrices for everything
     _hyphy_hip_flush_part(hp, t);
     n_pending = n_template = n_mixture = 0;
@@ -1429,6 +1478,242 @@ static int _hyphy_hip_compute_impl(const void *lf, long index, _TheTree *t, long
   return rc;
 }
 
+// ---- rate classes batched through the host's category loop ------------------------------------------------------------------------
+static bool _hyhip_cat_collect(_HyHipPart &hp, _TheTree *t, long cat, long catID, _SimpleList &branches, _List &matrices, long n_q, bool first,
+                               long n_pending, long n_template, long n_mixture) {
+  _HyHipCatBatch &cb = _hyhip_cb;
+  if (first || n_mixture > 0 || cat < 0 || cat >= cb.C || cb.calls[cat].taken) return false;
+  const long D = t->GetCodeBase(), DD = D * D;
+  _HyHipCatBatch::ClassCall &cc = cb.calls[cat];
+  cc.catID = catID;
+  cc.upd.assign((const int64_t *)branches.list_data, (const int64_t *)branches.list_data + branches.lLength);
+  cc.qn.assign(hp.qnodes.begin(), hp.qnodes.begin() + n_q);
+  if (n_q == 0) {
+    cc.kind = 4;
+    cc.data.clear();
+  } else if (n_template == n_q) {
+    const long K = hp.tmpl_K;
+    cc.kind = 1;
+    cc.data.resize((size_t)n_q * K);
+    for (long k = 0; k < n_q; k++)
+      for (long j = 0; j < K; j++) cc.data[(size_t)k * K + j] = hp.tmpl_x[cat][(size_t)hp.qnodes[k] * K + j];
+  } else {
+    if (n_template > 0)  // mixed: template rows become dense rate matrices (as in the ordinary call)
+      for (long k = 0; k < n_q; k++)
+        if (hp.q_pending[cat][hp.qnodes[k]] == 2) {
+          _hyhip_template_dense(hp, cat, hp.qnodes[k], D, hp.qstash[cat].data() + (size_t)hp.qnodes[k] * DD);
+          hp.q_pending[cat][hp.qnodes[k]] = 1;
+          if (hp.host_stale[cat][hp.qnodes[k]]) hp.host_stale[cat][hp.qnodes[k]] = 1;
+        }
+    if (n_pending > 0 && n_pending < n_q) {
+      _hyphy_hip_flush_part(hp, t);
+      n_pending = 0;
+    }
+    const bool rate_matrices = n_pending > 0;
+    cc.kind = rate_matrices ? 2 : 3;
+    cc.data.resize((size_t)n_q * DD);
+    for (long k = 0; k < n_q; k++) {
+      if (rate_matrices) {
+        memcpy(cc.data.data() + (size_t)k * DD, hp.qstash[cat].data() + (size_t)hp.qnodes[k] * DD, sizeof(double) * DD);
+        continue;
+      }
+      _Matrix *P = ((_CalcNode *)matrices(k))->GetCompExp(catID);
+      if (!P || !P->theData) return false;
+      memcpy(cc.data.data() + (size_t)k * DD, P->theData, sizeof(double) * DD);
+    }
+  }
+  cc.have = cc.taken = true;
+  return true;
+}
+
+// what the device did with class `cat`'s stashed matrices: nothing is pending any more
+static void _hyhip_cat_consumed(_HyHipPart &hp, const _HyHipCatBatch::ClassCall &cc, long cat) {
+  if (cc.kind == 1 || cc.kind == 2)
+    for (int64_t code : cc.qn) hp.q_pending[cat][code] = 0;
+  hp.cat_seen[cat] = 1;
+}
+
+// one stashed class through its own device call, mixed into the host's buffer / scalers with the reference's rule
+// (likefunc2.cpp:826-853: the running sum is kept at the smallest exponent seen so far)
+static bool _hyhip_cat_single(_HyHipPart &hp, long cat) {
+  _HyHipCatBatch &cb = _hyhip_cb;
+  _HyHipCatBatch::ClassCall &cc = cb.calls[cat];
+  _TheTree *t = cb.tree;
+  std::vector<double> lik(cb.S);
+  std::vector<int64_t> cnt(cb.S);
+  double ll = 0.;
+  int rc = 0;
+  if (cc.kind == 1) {
+    const long K = hp.tmpl_K;
+    rc = hyphy_hip_update_q_templates(hp.part, K, hp.tmpl_M[cat].data());
+    for (auto &u : hp.tmpl_uploaded) u = 0;
+    hp.tmpl_uploaded[cat] = 1;
+    hp.tmpl_device_cat = cat;
+    if (rc == 0) rc = hyphy_hip_build_q(hp.part, (int64_t)cc.qn.size(), cc.data.data());
+    if (rc == 0)
+      rc = hyphy_hip_evaluate_built_sites(hp.part, cc.catID, cc.upd.data(), (int64_t)cc.upd.size(), cc.qn.data(), (int64_t)cc.qn.size(), t->GetProbs(),
+                                          &ll, lik.data(), cnt.data());
+  } else {
+    rc = hyphy_hip_evaluate(hp.part, cc.catID, cc.upd.data(), (int64_t)cc.upd.size(), cc.qn.data(), (int64_t)cc.qn.size(), cc.data.data(),
+                            cc.kind == 3 ? 1 : 0, t->GetProbs(), &ll, lik.data(), cnt.data());
+  }
+  if (rc != 0) {
+    HandleApplicationError(_String("hyphy_hip (rate classes, one by one): ") & hyphy_hip_last_error());
+    return false;
+  }
+  _hyhip_cat_consumed(hp, cc, cat);
+  _hyhip_calls++;
+  cb.n_single++;
+  const double w = cb.weights[cat];
+  for (long s = 0; s < cb.S; s++) {
+    const long scv = (long)cnt[s];
+    if (!cb.mixed_any) {
+      cb.buffer[s] = w * lik[s];
+      cb.scalers[s] = scv;
+    } else if (scv < cb.scalers[s]) {
+      cb.buffer[s] = w * lik[s] + cb.buffer[s] * acquireScalerMultiplier(cb.scalers[s] - scv);
+      cb.scalers[s] = scv;
+    } else if (scv > cb.scalers[s]) {
+      cb.buffer[s] += w * lik[s] * acquireScalerMultiplier(scv - cb.scalers[s]);
+    } else {
+      cb.buffer[s] += w * lik[s];
+    }
+  }
+  cb.mixed_any = true;
+  cc.have = false;
+  return true;
+}
+
+// the batch cannot go on (a class that is not collectable turned up): the stashed classes run one by one, in class order
+static void _hyhip_cat_flush(_HyHipPart &hp) {
+  _HyHipCatBatch &cb = _hyhip_cb;
+  cb.active = false;
+  for (long c = 0; c < cb.C; c++)
+    if (cb.calls[c].have && !_hyhip_cat_single(hp, c)) return;
+}
+
+// (extern: called from the likefunc2.cpp copy)
+bool _hyphy_hip_cat_begin(const void *lf, long index, long n_classes, const hyFloat *weights, hyFloat *buffer, long *scalers, long block_length) {
+  _HyHipCatBatch &cb = _hyhip_cb;
+  cb.active = false;
+  cb.logl_valid = false;
+  static const bool off = getenv("HYPHY_HIP_CAT_BATCH") && !strcmp(getenv("HYPHY_HIP_CAT_BATCH"), "0");
+  if (off || !_hyphy_hip_enabled() || n_classes < 2 || !weights) return false;
+  auto it = _hyhip_lfs.find(lf);
+  if (it == _hyhip_lfs.end() || index < 0 || index >= (long)it->second.size()) return false;
+  _HyHipPart &hp = it->second[index];
+  if (!hp.part || hp.spmd || hp.pending || (long)hp.cat_seen.size() != n_classes) return false;
+  for (long c = 0; c < n_classes; c++) {
+    if (!hp.cat_seen[c] || !(weights[c] > 0.)) return false;           // (first evaluations and zero weights: the host's own loop)
+    if (c < (long)hp.mix_state.size() && hp.mix_state[c] > 0) return false;  // (explicit-form mixtures have their own entry points)
+  }
+  _TheTree *t = nullptr;
+  for (auto &o : _hyhip_tree_owner)
+    if (o.second.first == lf && o.second.second == index) t = (_TheTree *)o.first;
+  if (!t) return false;
+  cb.active = true;
+  cb.lf = lf;
+  cb.index = index;
+  cb.C = n_classes;
+  cb.S = block_length;
+  cb.tree = t;
+  cb.buffer = buffer;
+  cb.scalers = scalers;
+  cb.mixed_any = false;
+  cb.weights.assign(weights, weights + n_classes);
+  cb.calls.assign(n_classes, _HyHipCatBatch::ClassCall());
+  return true;
+}
+
+// true: the adapter answers for this class — the host must not mix what ComputeBlock left in its buffer
+bool _hyphy_hip_cat_collected(const void *lf, long index, long cls) {
+  const _HyHipCatBatch &cb = _hyhip_cb;
+  return cb.lf == lf && cb.index == index && cls >= 0 && cls < (long)cb.calls.size() && cb.calls[cls].taken;
+}
+
+void _hyphy_hip_cat_want(const void *lf, long index) {
+  _hyhip_cb.want_lf = lf;
+  _hyhip_cb.want_index = index;
+  _hyhip_cb.logl_valid = false;
+}
+
+bool _hyphy_hip_cat_take_logl(const void *lf, long index, hyFloat *value) {
+  _HyHipCatBatch &cb = _hyhip_cb;
+  const bool ok = cb.logl_valid && cb.want_lf == lf && cb.want_index == index;
+  if (ok) *value = cb.logl;
+  cb.logl_valid = false;
+  cb.want_lf = nullptr;
+  cb.want_index = -1;
+  return ok;
+}
+
+bool _hyphy_hip_cat_end(const void *lf, long index) {
+  _HyHipCatBatch &cb = _hyhip_cb;
+  if (cb.lf != lf || cb.index != index) return true;
+  const bool was_active = cb.active;
+  cb.active = false;
+  _HyHipPart &hp = _hyhip_lfs[lf][index];
+  long n_have = 0;
+  for (long c = 0; c < cb.C; c++) n_have += cb.calls[c].have ? 1 : 0;
+  if (n_have == 0) return true;
+  _TheTree *t = cb.tree;
+  const long D = t->GetCodeBase(), DD = D * D;
+  bool batch = was_active && n_have == cb.C && !cb.mixed_any;
+  for (long c = 1; c < cb.C && batch; c++)
+    batch = cb.calls[c].kind == cb.calls[0].kind && cb.calls[c].upd == cb.calls[0].upd && cb.calls[c].qn == cb.calls[0].qn;
+  if (batch) {
+    const _HyHipCatBatch::ClassCall &c0 = cb.calls[0];
+    const int64_t n_q = (int64_t)c0.qn.size();
+    const bool only_logl = cb.want_lf == lf && cb.want_index == index;  // (Compute: the per-pattern values would only be summed up)
+    double ll = 0.;
+    int rc = 0;
+    if (c0.kind == 1) {
+      // template mode: the classes' K templates side by side (C * K of them), class c's row of K locals at its own columns
+      const long K = hp.tmpl_K, KT = cb.C * K;
+      std::vector<double> T((size_t)KT * DD);
+      for (long c = 0; c < cb.C; c++) memcpy(T.data() + (size_t)c * K * DD, hp.tmpl_M[c].data(), sizeof(double) * K * DD);
+      rc = hyphy_hip_update_q_templates(hp.part, KT, T.data());
+      for (auto &u : hp.tmpl_uploaded) u = 0;   // (the one-class template sets are gone from the device)
+      hp.tmpl_device_cat = -2;
+      hp.pbuf.assign((size_t)cb.C * n_q * KT, 0.);
+      for (long c = 0; c < cb.C; c++)
+        for (int64_t k = 0; k < n_q; k++)
+          memcpy(hp.pbuf.data() + ((size_t)c * n_q + k) * KT + (size_t)c * K, cb.calls[c].data.data() + (size_t)k * K, sizeof(double) * K);
+      if (rc == 0) rc = hyphy_hip_build_q(hp.part, cb.C * n_q, hp.pbuf.data());
+      if (rc == 0)
+        rc = hyphy_hip_evaluate_categories_built_sites(hp.part, c0.upd.data(), (int64_t)c0.upd.size(), c0.qn.data(), n_q, cb.weights.data(),
+                                                       t->GetProbs(), &ll, only_logl ? nullptr : cb.buffer, only_logl ? nullptr : (int64_t *)cb.scalers);
+    } else {
+      hp.pbuf.resize((size_t)cb.C * n_q * DD);
+      for (long c = 0; c < cb.C && n_q > 0; c++) memcpy(hp.pbuf.data() + (size_t)c * n_q * DD, cb.calls[c].data.data(), sizeof(double) * n_q * DD);
+      rc = hyphy_hip_evaluate_categories(hp.part, c0.upd.data(), (int64_t)c0.upd.size(), c0.qn.data(), n_q, n_q > 0 ? hp.pbuf.data() : nullptr,
+                                         c0.kind == 3 ? 1 : 0, cb.weights.data(), t->GetProbs(), &ll, only_logl ? nullptr : cb.buffer,
+                                         only_logl ? nullptr : (int64_t *)cb.scalers);
+    }
+    if (rc < 0) {
+      HandleApplicationError(_String("hyphy_hip (rate classes in one evaluation): ") & hyphy_hip_last_error());
+      return false;
+    }
+    if (rc == 0) {
+      for (long c = 0; c < cb.C; c++) {
+        _hyhip_cat_consumed(hp, cb.calls[c], c);
+        cb.calls[c].have = false;
+      }
+      _hyhip_calls++;
+      cb.n_batched++;
+      if (only_logl) {
+        cb.logl = ll;
+        cb.logl_valid = true;
+      }
+      return true;
+    }
+    // (rc > 0: this form is not supported by the library — the classes one by one)
+  }
+  for (long c = 0; c < cb.C; c++)
+    if (cb.calls[c].have && !_hyhip_cat_single(hp, c)) return false;
+  return true;
+}
+
 // pre-pass of _LikelihoodFunction::Compute: every device partition is enqueued before the first result is waited for
 static void _hyphy_hip_note_prepass(const void *lf, long index, hyFloat value) {
   _HyHipPart &hp = _hyhip_lfs[lf][index];
@@ -1579,6 +1864,7 @@ COMPUTE = r'''
           return -INFINITY;  // (the host caches were never filled)
         }
         const bool go_async = _hyhip_async_phase > 0 && !siteRes && doCachedComp == 0;
+        _hyhip_cat_block = doCachedComp != 0;
         if (_hyphy_hip_compute(this, index, t, catID, *branches, *matrices, siteRes, scc, &hip_result, go_async) == 0) {
           if (doCachedComp < 0) {  // the policy asked for a cache of this branch after the normal pass
             const long nd = -doCachedComp - 1;
@@ -1694,3 +1980,50 @@ TREE_HOOK_CALL = r'''
   }
 #endif
 '''
+
+
+# ---- block 7 (r06): rate classes batched through the host's category loop ------------------------------------------------------------
+# likefunc.cpp, Compute(): the category branch asks the batch for the summed log-likelihood and skips SumUpSiteLikelihoods when it got it
+CATWANT_ANCHOR = "#ifdef __HYPHYMPI__\n          if (hy_mpi_node_rank == 0) {\n            ComputeSiteLikelihoodsForABlock(partID, siteResults->theData,"
+CATWANT = r"""#ifdef HYPHY_HIP
+          _hyphy_hip_cat_want(this, partID);
+#endif
+"""
+CATSUM_OLD = "          hyFloat blockResult = SumUpSiteLikelihoods(\n              partID, siteResults->theData, siteScalerBuffer);"
+CATSUM_NEW = r"""          hyFloat blockResult = 0.;
+#ifdef HYPHY_HIP
+          if (!_hyphy_hip_cat_take_logl(this, partID, &blockResult))
+#endif
+          blockResult = SumUpSiteLikelihoods(
+              partID, siteResults->theData, siteScalerBuffer);"""
+# likefunc2.cpp copy, PopulateConditionalProbabilities (weighted-sum mode, one category variable, no HMM)
+CAT_DECL = r"""
+#ifdef HYPHY_HIP
+bool _hyphy_hip_cat_begin(const void *lf, long index, long n_classes, const hyFloat *weights, hyFloat *buffer, long *scalers, long block_length);
+bool _hyphy_hip_cat_collected(const void *lf, long index, long cls);
+bool _hyphy_hip_cat_end(const void *lf, long index);
+#endif
+"""
+CAT_BEGIN_ANCHOR = "  scalers.Populate(arrayDim, 0, 0);\n\n#ifdef __HYPHYMPI__\n  _Vector *computedWeights = nil;"
+CAT_BEGIN = r"""  scalers.Populate(arrayDim, 0, 0);
+
+#ifdef HYPHY_HIP
+  bool hip_cat_batch = false;
+  if (runMode == _hyphyLFConditionProbsWeightedSum && catCount == 0 && hmmCatCount == 0 && !isTrivial && branchIndex < 0 && catWeigths &&
+      catWeigths->lLength >= 1UL && totalSteps == categoryCounts->list_data[0])
+    hip_cat_batch = _hyphy_hip_cat_begin(this, index, totalSteps, ((_Matrix **)catWeigths->list_data)[0]->theData, buffer, scalers.list_data,
+                                         blockLength);
+#endif
+"""
+CAT_SKIP_ANCHOR = "          if (runMode == _hyphyLFConditionProbsWeightedSum ||\n              runMode == _hyphyLFConditionMPIIterate) {\n            long lowerBound = hmmCatCount ? blockLength * currentHMMCat : 0,"
+CAT_SKIP = r"""          if (runMode == _hyphyLFConditionProbsWeightedSum ||
+              runMode == _hyphyLFConditionMPIIterate) {
+#ifdef HYPHY_HIP
+            if (hip_cat_batch && _hyphy_hip_cat_collected(this, index, useThisPartitonIndex)) continue;  // (mixed on the device / by the adapter)
+#endif
+            long lowerBound = hmmCatCount ? blockLength * currentHMMCat : 0,"""
+CAT_END_ANCHOR = "#ifdef __HYPHYMPI__\n  DeleteObject(computedWeights);\n#endif\n  DeleteObject(catWeigths);\n}"
+CAT_END = r"""#ifdef HYPHY_HIP
+  if (hip_cat_batch) _hyphy_hip_cat_end(this, index);
+#endif
+"""

@@ -56,6 +56,9 @@ def main():
     lf = splice(lf, "    for (unsigned long partID = 0; partID < theTrees.lLength; partID++) {\n      if (blockDependancies.list_data[partID]) {\n        // has category variables",
                 AB.PREPASS, before=True)
     lf = replace_once(lf, AB.LOOPCALL_OLD, AB.LOOPCALL_NEW)
+    # r06: the category branch of Compute() takes the summed log-likelihood from the batched rate-class evaluation
+    lf = splice(lf, AB.CATWANT_ANCHOR, AB.CATWANT, before=True)
+    lf = replace_once(lf, AB.CATSUM_OLD, AB.CATSUM_NEW)
     src = os.path.join(OUT, "likefunc_hip.cpp")
     open(src, "w").write(lf)
     # tree.cpp copy: ExponentiateMatrices offers its queue to the adapter before the OpenMP exponentiation loop (mode B)
@@ -65,6 +68,14 @@ def main():
     tr = replace_once(tr, AB.TREE_SKIP_OLD, AB.TREE_SKIP_NEW)
     tsrc = os.path.join(OUT, "tree_hip.cpp")
     open(tsrc, "w").write(tr)
+    # likefunc2.cpp copy (r06): PopulateConditionalProbabilities' weighted-sum loop collects its classes for ONE device evaluation
+    l2 = open(os.path.join(REF, "src/core/likefunc2.cpp")).read()
+    l2 = splice(l2, "using namespace hy_global;\n", AB.CAT_DECL) if "using namespace hy_global;\n" in l2 else splice(l2, '#include "likefunc.h"\n', AB.CAT_DECL)
+    l2 = replace_once(l2, AB.CAT_BEGIN_ANCHOR, AB.CAT_BEGIN + AB.CAT_BEGIN_ANCHOR[len("  scalers.Populate(arrayDim, 0, 0);\n\n"):])
+    l2 = replace_once(l2, AB.CAT_SKIP_ANCHOR, AB.CAT_SKIP)
+    l2 = splice(l2, AB.CAT_END_ANCHOR, AB.CAT_END, before=True)
+    l2src = os.path.join(OUT, "likefunc2_hip.cpp")
+    open(l2src, "w").write(l2)
     # 3. compile that one file with the reference's flags (oracle/Makefile.ref) + -DHYPHY_HIP
     refobj = os.path.join(ROOT, "oracle", "_ref", "obj")
     if not os.path.isdir(refobj):
@@ -75,13 +86,15 @@ def main():
              f"-I{REF}/src/core/include -I{REF}/src/contrib -I{REF}/src/lib/Link -I{REF}/src/new/include").split()
     obj = os.path.join(OUT, "likefunc_hip.o")
     tobj = os.path.join(OUT, "tree_hip.o")
-    procs = [subprocess.Popen(["g++"] + flags + ["-c", src, "-o", obj]), subprocess.Popen(["g++"] + flags + ["-c", tsrc, "-o", tobj])]
+    l2obj = os.path.join(OUT, "likefunc2_hip.o")
+    procs = [subprocess.Popen(["g++"] + flags + ["-c", src, "-o", obj]), subprocess.Popen(["g++"] + flags + ["-c", tsrc, "-o", tobj]),
+             subprocess.Popen(["g++"] + flags + ["-c", l2src, "-o", l2obj])]
     if any(p.wait() != 0 for p in procs):
         raise SystemExit("compilation of the patched copies failed")
-    objs = [tobj]
+    objs = [tobj, l2obj]
     for dp, _, files in os.walk(refobj):
         for f in files:
-            if f.endswith(".o") and not (f in ("likefunc.o", "tree.o") and dp.endswith("core")):
+            if f.endswith(".o") and not (f in ("likefunc.o", "likefunc2.o", "tree.o") and dp.endswith("core")):
                 objs.append(os.path.join(dp, f))
     libdir = os.path.join(ROOT, "hyphy_amd", "lib")
     exe = os.path.join(OUT, "hyphy_hip")
@@ -90,7 +103,7 @@ def main():
                            "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-ldl"])
     if not os.environ.get("HYPHY_HIP_KEEP_PATCHED"):
         # the patched copies are intermediate files: nothing derived from the reference's sources stays in the tree
-        for f in (src, tsrc, obj, tobj):
+        for f in (src, tsrc, l2src, obj, tobj, l2obj):
             os.remove(f)
     print("built", exe)
 

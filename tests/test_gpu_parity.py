@@ -596,6 +596,160 @@ def test_categories_built_on_device_match_host_q():
     assert ll_again == ll
 
 
+def test_categories_built_sites_full_and_partial_passes_with_template_switches():
+    """What the adapter's category hook does (r06, INTEGRATION.md "rate classes"): the classes' templates side by side (C * K of
+    them, class c's coefficients at its own columns), hyphy_hip_evaluate_categories_built_sites for full passes AND for one-branch
+    updates (an optimiser's line search), with one-class calls in between that switch the template set to K and back — mixed
+    per-pattern values and exponents against the dense-matrix entry point at every step."""
+    from hyphy_amd import models, tree
+    fx = common.load("codon_cat3")
+    C = len(fx["cat_weights"])
+    L = int(fx["L"])
+    flat = tree.flat_from_parents(fx["flat_parents"], L)
+    nodes = common.all_nodes(fx)
+    B = len(nodes)
+    tb = np.asarray(fx["t"], dtype=np.float64).copy()
+    omega = float(fx["omega"])
+    rv = dict(zip(common.REV_KEYS, (float(x) for x in fx["rev"])), AG=1.0)
+    T1 = np.zeros((1, 61, 61))            # K = 1 per class: Q_b^(c) = t_b * (class value) * (syn + omega * nonsyn)
+    for (i, j, name, ns, pf) in models.mg94rev_template(fx["pos_freqs"]):
+        T1[0, i, j] = rv[name] * pf * (omega if ns else 1.0)
+    vals = [float(v) for v in fx["cat_values"]]
+    Tst = np.concatenate([T1 * v for v in vals])            # [C][61][61]: class c's template carries its rate
+
+    def dense(tbv):
+        Q = np.zeros((C, B, 61, 61))
+        for c in range(C):
+            for b in range(B):
+                M = Tst[c] * tbv[b]
+                np.fill_diagonal(M, 0.0)
+                np.fill_diagonal(M, -M.sum(1))
+                Q[c, b] = M
+        return Q
+
+    def rows(tbv, which):
+        co = np.zeros((C * len(which), C))
+        for c in range(C):
+            for k, b in enumerate(which):
+                co[c * len(which) + k, c] = tbv[b]
+        return co
+
+    with _mk(fx, C) as a, _mk(fx, C) as b:
+        a.set_q_templates(Tst)
+        ll, lik, sc = a.evaluate_categories_built_sites(nodes, nodes, fx["cat_weights"], fx["root_freqs"], rows(tb, nodes))
+        ll0, lik0, sc0 = b.evaluate_categories(nodes, nodes, dense(tb), fx["cat_weights"], fx["root_freqs"], per_site=True)
+        ref = float(fx["logl"])
+        assert abs(ll - ref) <= RTOL * abs(ref) and abs(ll0 - ref) <= RTOL * abs(ref)
+        rng = np.random.default_rng(3)
+        for it, node in enumerate(rng.choice(B, size=6, replace=False)):
+            tb[node] *= rng.uniform(0.4, 2.5)
+            un = flat.path_update_nodes(int(node))
+            if it % 2 == 1:   # a one-class call with that class's own K = 1 template set in between (then back to the stacked set)
+                a.set_q_templates(Tst[1:2])
+                step = a.prepare_built_step(nodes, nodes, fx["root_freqs"], np.ascontiguousarray(tb[:, None]), cat=1)
+                step()
+                a.set_q_templates(Tst)
+                ll, lik, sc = a.evaluate_categories_built_sites(nodes, nodes, fx["cat_weights"], fx["root_freqs"], rows(tb, nodes))
+                ll0, lik0, sc0 = b.evaluate_categories(nodes, nodes, dense(tb), fx["cat_weights"], fx["root_freqs"], per_site=True)
+            else:
+                ll, lik, sc = a.evaluate_categories_built_sites(un, [node], fx["cat_weights"], fx["root_freqs"], rows(tb, [node]))
+                ll0, lik0, sc0 = b.evaluate_categories(un, [node], dense(tb)[:, [node]], fx["cat_weights"], fx["root_freqs"], per_site=True)
+            assert abs(ll - ll0) <= RTOL * abs(ll0), (it, ll, ll0)
+            va, vb = np.log(lik) - sc * 64 * np.log(2.0), np.log(lik0) - sc0 * 64 * np.log(2.0)
+            assert np.max(np.abs(va - vb) / np.abs(vb)) < RTOL, it
+
+
+@pytest.mark.parametrize("dense_batch", [False, True])
+def test_batched_and_one_class_evaluations_interleaved_with_branch_caches(dense_batch):
+    """The call pattern of the adapter under Optimize with rate classes (r06): full passes of all classes in ONE batched evaluation
+    (template rows or dense matrices), one-branch updates batched or one class at a time, a branch cache per class built behind a
+    one-class pass, line searches through the caches — every step's per-pattern mixture against a partition that only ever
+    evaluates one class at a time.  (Found with this sequence: a batched evaluation writes its C * n_q slot numbers across the regions
+    of the device slot table that the classes use one at a time; a one-class call whose own list had not changed kept the batch's
+    numbers — exponentials landed beyond the last class's images.)"""
+    from hyphy_amd import hip, models, tree
+    fx = common.load("codon_cat3")
+    C = len(fx["cat_weights"])
+    L = int(fx["L"])
+    flat = tree.flat_from_parents(fx["flat_parents"], L)
+    nodes = common.all_nodes(fx)
+    B = len(nodes)
+    tb = np.asarray(fx["t"], dtype=np.float64).copy()
+    omega = float(fx["omega"])
+    rv = dict(zip(common.REV_KEYS, (float(x) for x in fx["rev"])), AG=1.0)
+    T1 = np.zeros((1, 61, 61))
+    for (i, j, name, ns, pf) in models.mg94rev_template(fx["pos_freqs"]):
+        T1[0, i, j] = rv[name] * pf * (omega if ns else 1.0)
+    Tst = np.concatenate([T1 * float(v) for v in fx["cat_values"]])
+    w, pi = np.asarray(fx["cat_weights"]), fx["root_freqs"]
+
+    def dense_c(tbv, c, which):
+        Q = np.zeros((len(which), 61, 61))
+        for k, b in enumerate(which):
+            M = Tst[c] * tbv[b]
+            np.fill_diagonal(M, 0.0)
+            np.fill_diagonal(M, -M.sum(1))
+            Q[k] = M
+        return Q
+
+    def rows(tbv, which):
+        co = np.zeros((C * len(which), C))
+        for c in range(C):
+            for k, b in enumerate(which):
+                co[c * len(which) + k, c] = tbv[b]
+        return co
+
+    def mix(per):
+        m = np.min([p[1] for p in per], axis=0)
+        out = sum(w[c] * lik * np.exp2(-64.0 * (sc - m)) for c, (lik, sc) in enumerate(per))
+        return np.log(out) - m * 64 * np.log(2.0)
+
+    def site(lik, sc):
+        return np.log(lik) - sc * 64 * np.log(2.0)
+
+    with _mk(fx, C) as part, _mk(fx, C) as refp:
+        for c in range(C):   # first evaluations one class at a time, like the adapter's
+            part.evaluate(nodes, nodes, dense_c(tb, c, nodes), pi, cat=c)
+        part.set_q_templates(Tst)
+        rng = np.random.default_rng(5)
+        cached_node = 0
+        for it in range(32):
+            kind = it % 4
+            if kind == 0:      # batched full pass
+                if dense_batch:
+                    _, lik, sc = part.evaluate_categories(nodes, nodes, np.stack([dense_c(tb, c, nodes) for c in range(C)]), w, pi, per_site=True)
+                else:
+                    _, lik, sc = part.evaluate_categories_built_sites(nodes, nodes, w, pi, rows(tb, nodes))
+                got = site(lik, sc)
+            elif kind == 1:    # one-branch update: batched / one class at a time in turn
+                node = int(rng.integers(0, B))
+                tb[node] *= rng.uniform(0.5, 2.0)
+                un = flat.path_update_nodes(node)
+                if it % 8 == 1:
+                    _, lik, sc = part.evaluate_categories_built_sites(un, [node], w, pi, rows(tb, [node]))
+                    got = site(lik, sc)
+                else:
+                    got = mix([part.evaluate(un, [node], dense_c(tb, c, [node]), pi, cat=c, per_site=True)[1:] for c in range(C)])
+            elif kind == 2:    # one class at a time + a branch cache per class (the policy's "build the cache after this pass")
+                node = int(rng.integers(0, B))
+                tb[node] *= rng.uniform(0.5, 2.0)
+                un = flat.path_update_nodes(node)
+                per = []
+                for c in range(C):
+                    per.append(part.evaluate(un, [node], dense_c(tb, c, [node]), pi, cat=c, per_site=True)[1:])
+                    part.branch_cache_build(node, cat=c)
+                got = mix(per)
+                cached_node = node
+            else:              # a line-search step through the caches, then the host's ordinary re-evaluation of that branch
+                tb[cached_node] *= rng.uniform(0.7, 1.4)
+                got = mix([part.branch_cache_evaluate(cached_node, dense_c(tb, c, [cached_node])[0], cat=c, per_site=True)[1:] for c in range(C)])
+                un = flat.path_update_nodes(cached_node)
+                for c in range(C):
+                    part.evaluate(un, [cached_node], dense_c(tb, c, [cached_node]), pi, cat=c)
+            want = mix([refp.evaluate(nodes, nodes, dense_c(tb, c, nodes), pi, cat=c, per_site=True)[1:] for c in range(C)])
+            assert np.max(np.abs(got - want) / np.abs(want)) < RTOL, (it, kind)
+
+
 def test_sharded_partition_equals_single(monkeypatch):
     """device_count > 1 semantics (pattern shards + Neumaier combine) exercised on one GPU by
     mapping every shard to device 0."""

@@ -225,6 +225,52 @@ def test_hbl_optimize_with_rate_categories_through_device():
     assert abs(gpu["logl"] - cpu["logl"]) <= 1e-10 * abs(cpu["logl"])
 
 
+def _cat_batches(stdout):
+    m = re.findall(r"rate classes: (\d+) category loops answered by ONE device evaluation of all classes, (\d+) classes evaluated one by one", stdout)
+    return (max(int(x[0]) for x in m), max(int(x[1]) for x in m)) if m else (0, 0)
+
+
+@pytest.mark.parametrize("expm", ["always", "0"])
+def test_hbl_rate_class_loop_answered_by_one_device_evaluation(expm):
+    """r06: the host's category loop (PopulateConditionalProbabilities, weighted-sum mode, likefunc2.cpp:484-908) calls ComputeBlock
+    once per rate class; the adapter collects the classes and answers the loop with ONE hyphy_hip_evaluate_categories(_built_sites)
+    call (template rows with device exponentials — expm = always — or the host's own transition matrices — 0).  The benchmark's
+    sweep (every matrix of every class changes at every point) against the unmodified binary at every point, and against the
+    adapter with the batching off (HYPHY_HIP_CAT_BATCH=0: one device evaluation per class, mixed by the host)."""
+    _need_binaries()
+    from oracle import hbl
+    cat = dict(name="rc", weights=[0.7, 0.25, 0.05], values=[0.1, 1.0, 5.0])
+    case = _case("codon", 12, 70, 35, category=cat)
+    sweep = dict(param="R", start=0.3, step=0.01, n=20, record=20)
+    env = dict(ENV, HYPHY_HIP_DEVICE_EXPM=expm)
+    cpu = hbl.evaluate(sweep=sweep, per_site=True, **case)
+    gpu = hbl.evaluate(sweep=sweep, per_site=True, binary=HIP_BIN, extra_env=env, **case)
+    off = hbl.evaluate(sweep=sweep, per_site=True, binary=HIP_BIN, extra_env=dict(env, HYPHY_HIP_CAT_BATCH="0"), **case)
+    nb, ns = _cat_batches(gpu["stdout"])
+    assert nb >= 15 and ns == 0, gpu["stdout"][-800:]
+    assert _cat_batches(off["stdout"]) == (0, 0)
+    assert np.max(np.abs(gpu["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10
+    assert np.max(np.abs(off["sweep_values"] - cpu["sweep_values"]) / np.abs(cpu["sweep_values"])) < 1e-10
+    assert abs(gpu["logl"] - cpu["logl"]) <= 1e-10 * abs(cpu["logl"])
+    # per-site values come through the same hook with the mixed per-pattern values (ConstructCategoryMatrix does not ask for the sum)
+    assert np.max(np.abs(gpu["site_logl"] - cpu["site_logl"]) / np.abs(cpu["site_logl"])) < 1e-10
+
+
+def test_hbl_optimize_with_rate_classes_batched_lands_on_the_cpu_optimum():
+    """Optimize of a 3-class model with the class loop batched: full passes go through one device evaluation of all classes, the
+    one-branch line searches through the branch cache (those calls are never collected) — same optimum as the unmodified binary."""
+    _need_binaries()
+    from oracle import hbl
+    cat = dict(name="rc", weights=[0.6, 0.3, 0.1], values=[0.2, 1.0, 4.0])
+    case = _case("codon", 10, 50, 17, category=cat)
+    cpu = hbl.evaluate(optimize=True, per_site=False, **case)
+    gpu = hbl.evaluate(optimize=True, per_site=False, binary=HIP_BIN, extra_env=ENV, **case)
+    nb, _ = _cat_batches(gpu["stdout"])
+    assert nb > 10, gpu["stdout"][-800:]
+    assert abs(gpu["opt_logl"] - cpu["opt_logl"]) <= 2e-3
+    assert abs(gpu["logl"] - cpu["logl"]) <= 1e-10 * abs(cpu["logl"])
+
+
 def test_reference_known_answer_smallcodon_through_device():
     """The reference's own known-answer test SimpleOptimizations/SmallCodon.bf (HIV-1 RT, 8 x 440 codons, MG94x012232,
     expected maximised log L = -3189.516375) fitted through the adapter: every ComputeBlock on the device, exponentials
