@@ -26,13 +26,18 @@ void free_shard(Shard &s) {
                  s.Pfrag, s.PTg,   s.Prow,   s.qbuf,     s.slots,  s.ops,      s.pi,       s.out,       s.status,
                  s.weights, s.templates, s.templates_pad, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.pi_ones, s.codes_tile,
                  s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.mix_q, s.mix_p, s.mix_w, s.mix_off, s.ar_buf, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
-                 s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops, s.rep_tab, s.rep_cnt, s.rep_map, s.rep_desc, s.rep_items, s.rep_sync,
+                 s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops, s.rep_tab, s.rep_cnt, s.rep_map, s.rep_desc, s.rep_sync,
                  s.rep_codes_tile, s.rep_leaf, s.d_inv};
   for (void *d : dev)
     if (d) pool_free(d);  // (the stream was synchronised above)
-  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn, s.h_tstage, s.h_site, s.h_rep_items, s.h_export};
+  void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn, s.h_tstage, s.h_site, s.h_export};
   for (void *h : host)
     if (h) pool_host_free(h);
+  for (RepPassSlot &ps : s.rep_slot) {  // (item queues of the lower phase, repeats.hip)
+    if (ps.items) pool_free(ps.items);
+    if (ps.h_items) pool_host_free(ps.h_items);
+    if (ps.ev) hipEventDestroy(ps.ev);
+  }
   for (auto &e : s.ev)
     if (e) hipEventDestroy(e);
   for (auto &e : s.ev_ar)
@@ -717,17 +722,32 @@ int begin_site_export(hyphy_hip_partition *p, bool want_lik, bool want_cnt) {
   Shard &s = p->shards[0];
   if (s.S <= 0 || s.s0 != 0) return 0;
   HIPCHK(hipSetDevice(s.device));
-  if (!s.h_export) {
-    HIPCHK(pool_host_malloc((void **)&s.h_export, (size_t)s.S * 2 * sizeof(double)));
-    if (hipHostGetDevicePointer((void **)&s.d_export, s.h_export, 0) != hipSuccess) s.d_export = nullptr;
-    if (s.d_export && !p->perm.empty()) {
+  if (!s.h_export && !s.export_failed) {
+    // (the pattern-order map first — a partition whose patterns are sorted must never export without it, and a failed
+    //  allocation must not leave a half-initialised export behind: on any failure this partition keeps the copies of gather_sites)
+    int32_t *d_inv = nullptr;
+    double *h_export = nullptr, *d_export = nullptr;
+    bool ok = true;
+    if (!p->perm.empty()) {
       std::vector<int32_t> inv((size_t)s.S, 0);
       for (int64_t j = 0; j < s.S; j++) inv[(size_t)p->perm[(size_t)j]] = (int32_t)j;
-      HIPCHK(pool_malloc((void **)&s.d_inv, inv.size() * sizeof(int32_t)));
-      HIPCHK(hipMemcpy(s.d_inv, inv.data(), inv.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      ok = pool_malloc((void **)&d_inv, inv.size() * sizeof(int32_t)) == hipSuccess &&
+           hipMemcpy(d_inv, inv.data(), inv.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
     }
+    ok = ok && pool_host_malloc((void **)&h_export, (size_t)s.S * 2 * sizeof(double)) == hipSuccess &&
+         hipHostGetDevicePointer((void **)&d_export, h_export, 0) == hipSuccess && d_export;
+    if (!ok) {
+      (void)hipGetLastError();
+      if (d_inv) pool_free_sync(d_inv);
+      if (h_export) pool_host_free(h_export);
+      s.export_failed = true;
+      return 0;
+    }
+    s.d_inv = d_inv;
+    s.h_export = h_export;
+    s.d_export = d_export;
   }
-  if (!s.d_export) return 0;
+  if (!s.d_export || (!p->perm.empty() && !s.d_inv)) return 0;
   p->export_sites = (want_lik ? 1 : 0) | (want_cnt ? 2 : 0);
   return 0;
 }
@@ -1065,6 +1085,10 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     }
     hipMemcpy(s.freq, fr.data(), fr.size() * sizeof(double), hipMemcpyHostToDevice);
     hipMemcpy(s.ambig, amb.data(), amb.size() * sizeof(double), hipMemcpyHostToDevice);
+    {  // (the host copy is only kept for the class computation of subtree repeats)
+      const char *re = getenv("HYPHY_HIP_REPEATS");
+      if (re && atoi(re) == 0) std::vector<int16_t>().swap(shard_codes.back());
+    }
     if (hipStreamSynchronize(s.stream) != hipSuccess || hipGetLastError() != hipSuccess) {
       hyphy_hip_destroy(p);
       return fail("device initialisation failed");
@@ -1158,6 +1182,13 @@ int eval_common(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes
   }
   // the view this evaluation runs under: the class-compressed one wherever it exists, except with pinned states and for the
   // internal passes that restore the per-pattern copies of every node (branch cache, downloads)
+  if (p->rep_on && p->rep_enabled && !p->rep_decided && !getenv("HYPHY_HIP_REPEATS") && getenv("HYPHY_HIP_TUNE") && atoi(getenv("HYPHY_HIP_TUNE")) == 0) {
+    //  no measurement will ever settle on / off for this partition (the tuner is disabled): the static rule instead
+    p->rep_decided = true;
+    if (!rep_static_decision(p)) p->rep_enabled = false;
+    p->rep_report = std::string("repeats: no measurement (HYPHY_HIP_TUNE=0), static rule -> ") + (p->rep_enabled ? "on" : "off");
+    if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %s\n", p->rep_report.c_str());
+  }
   switch_mode(p, (p->rep_on && p->rep_enabled && p->pin_node < 0 && !force_persist) ? 1 : 0);
   bool changed = false;
   const int64_t bc = batch ? p->C : 1;

@@ -101,6 +101,20 @@ struct RepTable {
 };
 
 struct RepLaunch { size_t off; int qcap, n_static, n_waves; };  // one launch of the lower phase: its items in Shard::rep_items (repeats.hip)
+// The item queues of the last few distinct passes (r06): an optimiser's partial updates move from branch to branch and
+// come back — each dirty set keeps its queues on the device in a slot of its own (device block + pinned staging block + an event
+// recorded behind the launches that read them), so a set that returns costs nothing and a new one overwrites the least recently used
+// slot without waiting for the stream.
+constexpr int kRepPassSlots = 4;
+struct RepPassSlot {
+  int4 *items = nullptr, *h_items = nullptr;
+  size_t cap = 0;
+  int qcap = 0, waves = 0, n_static = 0;
+  bool team = false;
+  std::vector<RepLaunch> launches;
+  hipEvent_t ev = nullptr;
+  bool ev_recorded = false;
+};
 
 struct Shard {
   int device = 0;
@@ -160,6 +174,7 @@ struct Shard {
   double *h_out = nullptr;    // pinned, host-mapped: the reduction kernel writes [log-L, scaler sum, status] here
   double *d_hout = nullptr;   // device-side address of h_out
   double *h_export = nullptr; // per-pattern results in the caller's order (host-mapped pinned: [S] doubles, [S] int64), see site_export_kernel
+  bool export_failed = false;     // the export's buffers could not be set up once: this shard keeps the copies of gather_sites
   double *d_export = nullptr; // device-side address of h_export
   int32_t *d_inv = nullptr;   // device pattern of caller pattern i (nullptr: identity)
   int exported = 0;           // what the last enqueued evaluation exported (1: values, 2: exponents)
@@ -210,10 +225,10 @@ struct Shard {
   int32_t *rep_cnt = nullptr;        // [C][rep_rows]       their 2^64 exponents
   int32_t *rep_map = nullptr;        // per (descriptor, child): [rows of the descriptor] class of the child / leaf code
   int4 *rep_desc = nullptr;          // descriptor headers and child entries (repeats.hip: RepDesc)
-  int4 *rep_items = nullptr;         // work items of the current pass, eight queues
+  RepPassSlot rep_slot[kRepPassSlots];
+  int rep_slot_cur = -1;             // slot the fields below mirror
+  int4 *rep_items = nullptr;         // work items of the current pass, eight queues (= rep_slot[rep_slot_cur].items)
   int *rep_sync = nullptr;           // queue heads, exit counter, per (class, descriptor) finished tiles (zero between launches)
-  int4 *h_rep_items = nullptr;       // pinned staging of the item queues
-  size_t rep_items_cap = 0;          // items per queue the buffers hold
   int16_t *rep_codes_tile = nullptr; // [tile][view leaves][16] leaf table of the trunk: state codes / class ids of generalised leaves
   int2 *rep_leaf = nullptr;          // [view leaves] (table row0 or -1: ordinary leaf, exponent row0 / matrix slot)
   int rep_qcap = 0;                  // items per queue of the pass the device queues hold
@@ -273,9 +288,10 @@ struct hyphy_hip_partition {
   std::vector<RepNode> rep_nodes;            // children before parents
   std::vector<int> rep_desc_of;              // [L+I] descriptor of a node's table, -1: none
   std::vector<char> rep_resident;            // per class: tables and trunk copies are current (mode 1 counterpart of `resident`)
-  std::vector<int> rep_cached_dirty;         // descriptors the item queues on the device were built for
-  int rep_cached_classes = 0;
-  bool rep_cached_valid = false;
+  struct RepPassKey { std::vector<int> dirty; int classes = 0; bool valid = false; uint64_t stamp = 0; };
+  RepPassKey rep_pass[hyhip::kRepPassSlots];  // what each slot of the shards' item-queue rings was built for
+  uint64_t rep_pass_clock = 0;
+  bool rep_cached_valid = false;             // (false: every slot is stale — the tables or the trunk changed)
   int64_t rep_stale_branch = -1;             // a branch whose matrix image was rewritten outside an evaluation (branch cache)
   double rep_kernel_ms = 0.;
   std::vector<hyhip::Shard> shards;
@@ -401,6 +417,7 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
                      int cat0, int n_classes, std::vector<int64_t> &view_update);
 int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0);
 int rep_decide(hyphy_hip_partition *p, int cat, int n_classes);
+bool rep_static_decision(const hyphy_hip_partition *p);  // on / off without a measurement (tuner disabled, forced cut)
 size_t rep_sync_words(const hyphy_hip_partition *p);
 int rep_sync_stride();
 // comm.hip

@@ -2323,6 +2323,10 @@ __global__ __launch_bounds__(256) void site_export_kernel(const double *__restri
   const int j = inv ? inv[i] : i;
   if (out_lik) out_lik[i] = lik[j];
   if (out_cnt) out_cnt[i] = (long long)cnt[j];
+  //  the host reads these rows as soon as it sees the sequence word the NEXT kernel publishes, without waiting for the
+  // stream: every row is pushed out at system scope by the thread that wrote it, so the record's own system-scope fence + store
+  // (behind the kernel boundary) can only be seen after them — not left to the ordering of posted writes of two different kernels
+  __threadfence_system();
 }
 void launch_site_export(const double *lik, const int32_t *cnt, const int32_t *inv, int S, double *out_lik, long long *out_cnt,
                         hipStream_t stream) {

@@ -31,6 +31,9 @@
 // Hand-off of table rows between waves of the launch: 16-byte sc1 (write-through) stores -> asm "s_waitcnt vmcnt(0)" ->
 // relaxed agent-scope RMW on the node's counter; consumer: relaxed agent-scope load that proves the count -> sc1 loads (the
 // same contract as the chain joins of prune.hip).
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <unordered_map>
 
 #include "devutil.h"
@@ -1118,7 +1121,9 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
   {
     double cells = 0.;
     for (const Shard &s : p->shards) cells += (double)I * s.S_pad;
-    if (cells * 4. > 4e9) return 0;
+    // (2.5e8 cells = 1 GB of transient host memory and a few seconds of hashing inside hyphy_hip_create, before it is known
+    //  whether compression pays — 128 taxa x 100 000 codons is 1.3e7; beyond the bound the partition runs plain)
+    if (cells > 2.5e8) return 0;
   }
   // theta: the share of the patterns below which a node's classes are worth a table.  0.3-0.4 is the flat optimum of the headline
   // alignment (0.2: 100 us of pruning launches, 0.3: 89, 0.4: 89, 0.5: 101, 0.7: 106): above it the walks of the lower phase get long
@@ -1134,6 +1139,9 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
   std::vector<int> spads;
   for (const Shard &s : p->shards) spads.push_back(s.S_pad);
   std::vector<char> comp = compressed_set(p->children, L, I, U, spads, p->nuc && !getenv("HYPHY_HIP_REP_THETA") ? 0.9 : theta);
+  for (size_t k = 0; k < nsh; k++)  // (only the classes of compressed nodes are read again: tables, maps, the trunk's leaf table)
+    for (int n = 0; n < I; n++)
+      if (!comp[n]) std::vector<int>().swap(cls[k][n]);
   if (p->nuc) return rep_setup_nuc(p, codes, cls, U, comp, forced);
   {  // worth it?  compare the edge products of the two forms on the first shard
     double full = 0., rep = 0.;
@@ -1700,68 +1708,95 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
   p->rep_stale_branch = -1;
   const int pass_key = n_classes * 65536;  // (the lists do not name the first class: a host that evaluates its rate classes one
                                            //  ComputeBlock at a time — the reference's category loop — re-uses one list for all of them)
-  const bool same = p->rep_cached_valid && p->rep_cached_dirty == dirty && p->rep_cached_classes == pass_key;
-  if (same) return 0;
+  if (!p->rep_cached_valid) {
+    for (auto &k : p->rep_pass) k.valid = false;
+    p->rep_cached_valid = true;
+  }
+  auto activate = [&](int slot) {
+    for (Shard &s : p->shards) {
+      RepPassSlot &ps = s.rep_slot[slot];
+      s.rep_slot_cur = slot;
+      s.rep_items = ps.items;
+      s.rep_qcap = ps.qcap;
+      s.rep_waves = ps.waves;
+      s.rep_static = ps.n_static;
+      s.rep_team = ps.team;
+      s.rep_launches = ps.launches;
+    }
+    p->rep_pass[slot].stamp = ++p->rep_pass_clock;
+  };
+  for (int k = 0; k < kRepPassSlots; k++)
+    if (p->rep_pass[k].valid && p->rep_pass[k].classes == pass_key && p->rep_pass[k].dirty == dirty) {
+      activate(k);  // (a dirty set seen before: its queues are still on the device)
+      return 0;
+    }
+  int slot = 0;  // an unused slot, else the least recently used one
+  for (int k = 1; k < kRepPassSlots; k++)
+    if (!p->rep_pass[k].valid ? p->rep_pass[slot].valid : (p->rep_pass[slot].valid && p->rep_pass[k].stamp < p->rep_pass[slot].stamp)) slot = k;
+  p->rep_pass[slot].valid = false;
   const int ND = (int)p->rep_nodes.size();
   for (Shard &s : p->shards) {
     HIPCHK(hipSetDevice(s.device));
+    RepPassSlot &ps = s.rep_slot[slot];
+    if (!ps.ev) HIPCHK(hipEventCreateWithFlags(&ps.ev, hipEventDisableTiming));
+    if (ps.ev_recorded) {  // (the launches that read this slot last — and the copy that filled its staging block — have they run?)
+      HIPCHK(hipEventSynchronize(ps.ev));
+      ps.ev_recorded = false;
+    }
+    auto ensure = [&](size_t words, size_t cap_wanted) -> int {
+      if (words <= ps.cap) return 0;
+      if (ps.items) pool_free_sync(ps.items);
+      if (ps.h_items) pool_host_free(ps.h_items);
+      ps.items = nullptr;
+      ps.h_items = nullptr;
+      ps.cap = 0;
+      const size_t cap = std::max(words, cap_wanted);
+      HIPCHK(pool_malloc((void **)&ps.items, cap * sizeof(int4)));
+      HIPCHK(pool_host_malloc((void **)&ps.h_items, cap * sizeof(int4)));
+      ps.cap = cap;
+      return 0;
+    };
     if (p->nuc) {  // 4 states: the list of subtrees to walk (no items, no queues: one thread per class, no table reads another)
       const size_t words = std::max<size_t>(1, (dirty.size() + 3) / 4);
-      if (words > s.rep_items_cap) {
-        HIPCHK(hipStreamSynchronize(s.stream));
-        if (s.rep_items) pool_free_sync(s.rep_items);
-        if (s.h_rep_items) pool_host_free(s.h_rep_items);
-        s.rep_items = nullptr;
-        s.h_rep_items = nullptr;
-        const size_t cap = std::max<size_t>(words, ((size_t)ND + 3) / 4);
-        HIPCHK(pool_malloc((void **)&s.rep_items, cap * sizeof(int4)));
-        HIPCHK(pool_host_malloc((void **)&s.h_rep_items, cap * sizeof(int4)));
-        s.rep_items_cap = cap;
-      }
-      HIPCHK(hipStreamSynchronize(s.stream));  // (staging buffer reuse)
-      int *lst = reinterpret_cast<int *>(s.h_rep_items);
+      if (ensure(words, ((size_t)ND + 3) / 4)) return -1;
+      int *lst = reinterpret_cast<int *>(ps.h_items);
       for (size_t k = 0; k < dirty.size(); k++) lst[k] = dirty[k];
-      if (!dirty.empty()) HIPCHK(hipMemcpyAsync(s.rep_items, s.h_rep_items, words * sizeof(int4), hipMemcpyHostToDevice, s.stream));
-      s.rep_qcap = (int)dirty.size();
+      if (!dirty.empty()) HIPCHK(hipMemcpyAsync(ps.items, ps.h_items, words * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+      ps.qcap = (int)dirty.size();
+      ps.waves = 0;
+      ps.n_static = 0;
+      ps.team = false;
+      ps.launches.clear();
       continue;
     }
     std::vector<int4> queues;
     int n_static = 0, n_waves = 1;
-    s.rep_team = p->NW >= 2 && !(getenv("HYPHY_HIP_REP_TEAM") && atoi(getenv("HYPHY_HIP_REP_TEAM")) == 0) &&
-                 !(getenv("HYPHY_HIP_REP_STATIC") && atoi(getenv("HYPHY_HIP_REP_STATIC")) == 0);
-    const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues, &n_static, &n_waves, &s.rep_launches, s.rep_team);
-    if (dirty.empty()) s.rep_launches.clear();
-    s.rep_static = getenv("HYPHY_HIP_REP_STATIC") && atoi(getenv("HYPHY_HIP_REP_STATIC")) == 0 ? 0 : n_static;
+    ps.team = p->NW >= 2 && !(getenv("HYPHY_HIP_REP_TEAM") && atoi(getenv("HYPHY_HIP_REP_TEAM")) == 0) &&
+              !(getenv("HYPHY_HIP_REP_STATIC") && atoi(getenv("HYPHY_HIP_REP_STATIC")) == 0);
+    ps.launches.clear();
+    const int per_q = dirty.empty() ? 0 : rep_build_items(p, s, dirty, cat0, n_classes, queues, &n_static, &n_waves, &ps.launches, ps.team);
+    ps.n_static = getenv("HYPHY_HIP_REP_STATIC") && atoi(getenv("HYPHY_HIP_REP_STATIC")) == 0 ? 0 : n_static;
     const size_t words = (size_t)kRepQueues * std::max(1, per_q) + (size_t)(ND + 3) / 4;  // queues, then the live flags
-    if (words > s.rep_items_cap) {
-      HIPCHK(hipStreamSynchronize(s.stream));
-      if (s.rep_items) pool_free_sync(s.rep_items);
-      if (s.h_rep_items) pool_host_free(s.h_rep_items);
-      s.rep_items = nullptr;
-      s.h_rep_items = nullptr;
+    {
       // (sized for a full pass of every class: partial passes never need more)
-      size_t cap = words;
-      {
-        size_t all = 0;
-        for (const RepTable &t : s.rep_tabs) all += (size_t)t.rows / 16;
-        cap = std::max(cap, (all * (size_t)p->C + (size_t)kRepQueues * (ND + 2)) + (size_t)(ND + 3) / 4 + kRepQueues);
-      }
-      HIPCHK(pool_malloc((void **)&s.rep_items, cap * sizeof(int4)));
-      HIPCHK(pool_host_malloc((void **)&s.h_rep_items, cap * sizeof(int4)));
-      s.rep_items_cap = cap;
+      size_t all = 0;
+      for (const RepTable &t : s.rep_tabs) all += (size_t)t.rows / 16;
+      if (ensure(words, (all * (size_t)p->C + (size_t)kRepQueues * (ND + 2)) + (size_t)(ND + 3) / 4 + kRepQueues)) return -1;
     }
-    HIPCHK(hipStreamSynchronize(s.stream));  // (staging buffer reuse)
-    if (per_q > 0) memcpy(s.h_rep_items, queues.data(), (size_t)kRepQueues * per_q * sizeof(int4));
-    int *live = reinterpret_cast<int *>(s.h_rep_items + (size_t)kRepQueues * std::max(1, per_q));
+    if (per_q > 0) memcpy(ps.h_items, queues.data(), (size_t)kRepQueues * per_q * sizeof(int4));
+    int *live = reinterpret_cast<int *>(ps.h_items + (size_t)kRepQueues * std::max(1, per_q));
     for (int d = 0; d < ND; d++) live[d] = 0;
     for (int d : dirty) live[d] = getenv("HYPHY_HIP_REP_NODEPS") ? 0 : 1;  // (diagnostic: nobody waits, results invalid)
-    HIPCHK(hipMemcpyAsync(s.rep_items, s.h_rep_items, words * sizeof(int4), hipMemcpyHostToDevice, s.stream));
-    s.rep_qcap = per_q;
-    s.rep_waves = n_waves;  // (rep_wave_count)
+    HIPCHK(hipMemcpyAsync(ps.items, ps.h_items, words * sizeof(int4), hipMemcpyHostToDevice, s.stream));
+    HIPCHK(hipEventRecord(ps.ev, s.stream));  // (re-recorded behind every launch that reads the slot: rep_launch)
+    ps.ev_recorded = true;
+    ps.qcap = per_q;
+    ps.waves = n_waves;  // (rep_wave_count)
   }
-  p->rep_cached_dirty = dirty;
-  p->rep_cached_classes = pass_key;
-  p->rep_cached_valid = true;
+  p->rep_pass[slot].dirty = dirty;
+  p->rep_pass[slot].classes = pass_key;
+  p->rep_pass[slot].valid = true;
+  activate(slot);
   return 0;
 }
 
@@ -1770,7 +1805,16 @@ int rep_sync_stride() { return kRepHeadStride; }
 
 // The lower phase of a pass: one launch over the item queues prepared by rep_prepare_pass (behind the exponentials, ahead of
 // the trunk's pruning launch, on the shard's stream).
+static int rep_launch_impl(hyphy_hip_partition *p, Shard &s, int cat0);
 int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
+  const int rc = rep_launch_impl(p, s, cat0);
+  if (rc == 0 && s.rep_qcap > 0 && s.rep_slot_cur >= 0 && s.rep_slot[s.rep_slot_cur].ev) {  // (the slot may be rewritten once these have run)
+    HIPCHK(hipEventRecord(s.rep_slot[s.rep_slot_cur].ev, s.stream));
+    s.rep_slot[s.rep_slot_cur].ev_recorded = true;
+  }
+  return rc;
+}
+static int rep_launch_impl(hyphy_hip_partition *p, Shard &s, int cat0) {
   if (s.rep_qcap <= 0) return 0;
   if (p->nuc) {
     RepNucArgs a;
@@ -1861,10 +1905,52 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
 // of the two stays.  Compression costs a second launch and a chain of table hand-offs; on small shards (a rank's share of an
 // alignment at 4 or 8 GPUs) that outweighs the edge products it saves.  What was decided for the same tree, shard and class
 // batch earlier in this process is taken over without timing anything.
+namespace {
+//  the decision itself is kept per process — keyed like the tuner's choice: states, trunk, shard size, class batch, the
+// tree AND the trunk's leaves (which depend on the alignment) — so that a second partition of the same shape does not time anything
+struct RepDecisionKey {
+  int64_t D, L, I, ntiles, classes;
+  uint64_t topo;
+  bool operator<(const RepDecisionKey &o) const {
+    return std::tie(D, L, I, ntiles, classes, topo) < std::tie(o.D, o.L, o.I, o.ntiles, o.classes, o.topo);
+  }
+};
+std::map<RepDecisionKey, std::pair<bool, std::string>> g_rep_decisions;
+std::mutex g_rep_decisions_mutex;
+RepDecisionKey rep_decision_key(const hyphy_hip_partition *p, int n_classes) {
+  uint64_t topo = 1469598103934665603ull;
+  for (int64_t v : p->views[1].parents) topo = (topo ^ (uint64_t)v) * 1099511628211ull;
+  for (int sl : p->views[1].slot) topo = (topo ^ (uint64_t)sl) * 1099511628211ull;
+  for (int64_t v : p->parents) topo = (topo ^ (uint64_t)v) * 1099511628211ull;
+  return RepDecisionKey{p->D, p->L, p->I, p->shards[0].ntiles, n_classes, topo};
+}
+}  // namespace
+
+// Without a measurement (HYPHY_HIP_TUNE=0, a forced cut): the static rule the measurements of r05 / r06 agree with — compression pays
+// from ~128 tiles per shard upwards (64 x 2 500 and 32 x 5 k: on; 64 x 1 250, 79 tiles: off — a second launch outweighs the products
+// it saves).  Called from hyphy_hip_create's side of things (api.hip) when no measurement will ever run.
+bool rep_static_decision(const hyphy_hip_partition *p) { return !p->shards.empty() && p->shards[0].ntiles >= 128; }
+
 int rep_decide(hyphy_hip_partition *p, int cat, int n_classes) {
   p->rep_decided = true;
   Shard &s = p->shards[0];
   HIPCHK(hipSetDevice(s.device));
+  static const bool cache_on = !(getenv("HYPHY_HIP_TUNE_CACHE") && atoi(getenv("HYPHY_HIP_TUNE_CACHE")) == 0);
+  const RepDecisionKey dkey = rep_decision_key(p, n_classes);
+  if (cache_on) {
+    std::lock_guard<std::mutex> lock(g_rep_decisions_mutex);
+    auto hit = g_rep_decisions.find(dkey);
+    if (hit != g_rep_decisions.end()) {
+      p->rep_report = "(same tree, trunk, shard size and class batch as an earlier partition of this process) " + hit->second.second;
+      if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %s\n", p->rep_report.c_str());
+      if (!hit->second.first) {
+        p->rep_enabled = false;
+        switch_mode(p, 0);
+        p->cached_valid = 0;
+      }
+      return 0;
+    }
+  }
   const double trunk_ms = p->tuned_ms;
   float a_ms = 0.f, b_ms = 0.f;
   if (rep_launch(p, s, cat)) return -1;  // warm-up
@@ -1895,6 +1981,10 @@ int rep_decide(hyphy_hip_partition *p, int cat, int n_classes) {
            off ? "off" : "on");
   p->rep_report = b;
   if (getenv("HYPHY_HIP_VERBOSE")) fprintf(stderr, "[hyphy_hip] %s\n", b);
+  if (cache_on) {
+    std::lock_guard<std::mutex> lock(g_rep_decisions_mutex);
+    g_rep_decisions[dkey] = std::make_pair(!off, std::string(b));
+  }
   if (off) {
     p->rep_enabled = false;  // (stays under views[0]; the caller rebuilds the schedule)
   } else {

@@ -106,26 +106,41 @@ def test_partial_updates_and_pinned_states_stay_with_the_interpreter(monkeypatch
 
 def test_background_compilation_switches_over_without_changing_a_bit(monkeypatch):
     """Default mode: the interpreter runs until the background thread has the code object (requested after HYPHY_HIP_NUCGEN_AFTER
-    evaluations); every evaluation on the way returns the same bits."""
+    evaluations); every evaluation on the way returns the same bits.  A tree no other test of this process uses (code objects are
+    shared per process by schedule), values against the CPU restatement."""
+    from hyphy_amd import data, hip, models
+    from oracle import oracle
     monkeypatch.setenv("HYPHY_HIP_NUCGEN", "1")
     monkeypatch.setenv("HYPHY_HIP_NUCGEN_AFTER", "3")
-    fx = common.load("nuc_wide")
-    Q = common.fixture_Q(fx)
-    nodes = common.all_nodes(fx)
-    with _mk(fx) as part:
-        seen = set()
+    monkeypatch.delenv("HYPHY_HIP_NUCGEN_SMALL", raising=False)
+    syn = data.evolve(23, 700, 1, seed=977, p_change=0.1)
+    pd = data.from_states(syn.states, 4, compress_patterns=True)
+    flat = syn.flat
+    B = flat.n_branches
+    pi = np.array([0.3, 0.2, 0.15, 0.35])
+    rng = np.random.default_rng(9)
+    Q = np.stack([models.nuc_rev_Q(float(rng.uniform(0.02, 0.3)), dict(AC=0.5, AT=0.4, CG=0.4, CT=1.2, GT=0.4), pi) for _ in range(B)])
+    nodes = np.arange(B, dtype=np.int64)
+    op = oracle.OraclePartition(4, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq)
+    op.set_P(nodes, oracle.expm(Q, False))
+    ref = op.compute_block(nodes, pi)
+    with hip.HipPartition(4, flat.flat_parents, flat.L, pd.leaf_codes, None, pd.pattern_freq) as part:
+        seen = []
         first = None
         t0 = time.time()
         while time.time() - t0 < 60.0:
-            ll, lik, sc = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+            ll, lik, sc = part.evaluate(nodes, nodes, Q, pi, per_site=True)
             if first is None:
                 first = (ll, lik.copy(), sc.copy())
             assert ll == first[0] and np.array_equal(lik, first[1]) and np.array_equal(sc, first[2])
-            seen.add(part.prune_kernel_name())
-            if "nucgen_kernel" in seen:
+            k = part.prune_kernel_name()
+            if not seen or seen[-1] != k:
+                seen.append(k)
+            if k == "nucgen_kernel":
                 break
             time.sleep(0.01)
-        assert "nucgen_kernel" in seen and len(seen) == 2, seen
+        assert seen == ["prune_nuc2_kernel", "nucgen_kernel"], seen
+    assert abs(first[0] - ref) <= RTOL * abs(ref), (first[0], ref)
 
 
 def test_full_size_configs_generated_against_reference(monkeypatch):
