@@ -104,6 +104,8 @@ def templates_for(unit):
 
 
 COLLECTIVE_LABEL = {"cabi": "hyphy_hip_evaluate_built_allreduce (in-stream ncclAllReduce of one double, C-ABI communicator)",
+                    "host": "hyphy_hip_evaluate_built_exchange (no device collective: every rank's partial through a shared-memory segment, "
+                            "Neumaier sum in rank order on every rank)",
                     "torch": "torch.distributed.all_reduce on the partition's stream", "none": None}
 PER_RANK_KEYS = ("patterns", "kernel_ms", "expm_ms", "reduce_ms", "allreduce_ms")
 
@@ -442,7 +444,7 @@ def main():
     ap.add_argument("--site-fits", type=int, default=0, metavar="SETS",
                     help="also time per-site batched fits (SURVEY 8f-4): every pattern under its own (alpha, beta), "
                          "SETS candidate parameter vectors per pattern and launch")
-    ap.add_argument("--collective", choices=["auto", "cabi", "torch"], default="auto",
+    ap.add_argument("--collective", choices=["auto", "cabi", "host", "torch"], default="auto",
                     help="N > 1: who sums the ranks' partial log-likelihoods.  cabi (auto for N > 1): the library's own in-stream "
                          "ncclAllReduce (hyphy_hip_evaluate_built_allreduce); torch: torch.distributed.all_reduce on the same stream.  "
                          "With --gpus 1, cabi runs the same entry point on a one-rank communicator (its overhead on one GPU)")
@@ -489,9 +491,13 @@ def main():
     collective = args.collective
     if share:
         collective = "torch"
+    # (N > 1, auto: the C-ABI's RCCL all-reduce AND the host-side exchange are both set up, both are timed on a few untimed steps, the
+    #  faster one runs the timed region — the line says which and carries both timings, `collective_choice`)
+    want_host = multi and args.collective in ("host", "auto")
+    collective_auto = collective == "auto" and multi and not share
     if collective == "auto":
         collective = "cabi" if multi else "none"
-    if single or (N == 1 and collective == "torch"):
+    if single or (N == 1 and collective in ("torch", "host")):
         collective = "none"
 
     wl = WORKLOADS[args.workload]
@@ -554,6 +560,25 @@ def main():
             collective = "torch" if multi else "none"
             collective_note = "C-ABI communicator not available (" + (why or "another rank failed") + "): fell back to torch.distributed.all_reduce"
             sys.stderr.write(f"[bench] rank {rank}: {collective_note}\n")
+    have_host = False
+    if multi and want_host:
+        # the collective-free combine: a shared-memory segment named after this run (rank 0's pid travels over torch.distributed)
+        tag_t = torch.tensor([os.getpid() if rank == 0 else 0], dtype=torch.int64, device=ctl)
+        dist.broadcast(tag_t, src=0)
+        ok = 1
+        try:
+            part.comm_init_host(f"bench_{int(tag_t.item())}_{os.environ.get('MASTER_PORT', '0')}", rank, N)
+        except Exception as e:
+            ok = 0
+            sys.stderr.write(f"[bench] rank {rank}: host exchange not available ({e})\n")
+        flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        have_host = bool(int(flag.item()))
+        if share and have_host:
+            collective = "host"   # (two ranks on one device: no RCCL — the host exchange needs no device collective at all)
+        if not have_host and collective == "host":
+            collective = "cabi"
+            collective_note = "host exchange not available on every rank: the C-ABI's RCCL all-reduce instead"
     coeffs = np.empty((B * n_classes, 2))
     coeffs[:, 0] = np.tile(tb, n_classes)
     class_omega = np.array([0.1, 1.0, 5.0][:n_classes]) / 0.3 if n_classes > 1 else np.array([1.0])
@@ -574,8 +599,11 @@ def main():
         fetch = part.prepare_fetch(d_logl.data_ptr())   # log-L behind the all-reduce -> host (host-mapped record, no D2H copy)
         sync_step = part.prepare_built_step(nodes, nodes, pi, coeffs)   # N == 1: synchronous C-ABI entry point
         ar_step = part.prepare_built_allreduce_step(nodes, nodes, pi, coeffs) if collective == "cabi" else None
+        xch_step = part.prepare_built_exchange_step(nodes, nodes, pi, coeffs) if have_host else None
 
-    def step(k, sync=True, force_torch=False):
+    use_host = [collective == "host" and have_host]   # (a cell: the auto choice below flips it)
+
+    def step(k, sync=True, force_torch=False, force=None):
         if n_mix:
             np.multiply(tb, MIX_OMEGAS[1] + 0.001 * k, out=mix_coeffs[:, 1, 1])   # R2 = 1.0 + 0.001 k on every branch
             v = mix_step()
@@ -600,6 +628,8 @@ def main():
                 hdist.allreduce_logl(d_logl[:1])
                 v = float(d_logl[0].item())
             return v
+        if sync and not force_torch and xch_step is not None and (force == "host" or (force is None and use_host[0])):
+            return xch_step()      # build_q + evaluate_built_exchange: local pass, partials through shared memory, total on every rank
         if sync and ar_step is not None and not force_torch:
             return ar_step()       # build_q + evaluate_built_allreduce: local pass, in-stream ncclAllReduce, value on every rank
         if (not multi) and sync and not os.environ.get("HYPHY_BENCH_DEVICE_STEP"):
@@ -617,7 +647,29 @@ def main():
             return fetch()                                     # log-L back on the host (synchronises)
         return None
 
+    if n_mix or n_classes > 1:
+        xch_step = None
     ll0 = step(0)
+    collective_choice = None
+    if collective_auto and ar_step is not None and xch_step is not None:
+        # which collective for the timed region?  20 untimed steps of each (max over ranks), rank 0's verdict for everybody
+        collective_choice = {}
+        for name in ("cabi", "host", "cabi", "host"):
+            step(1, force=name)
+            dist.barrier()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for k in range(20):
+                step(k + 1, force=name)
+            dist.barrier()
+            torch.cuda.synchronize()
+            ms = 1e3 * max_over_ranks(dist, ctl, time.perf_counter() - ta) / 20
+            collective_choice[name + "_ms_per_step"] = min(ms, collective_choice.get(name + "_ms_per_step", 1e30))
+        pick = torch.tensor([1 if collective_choice["host_ms_per_step"] < collective_choice["cabi_ms_per_step"] else 0], dtype=torch.int32, device=ctl)
+        dist.broadcast(pick, src=0)
+        use_host[0] = bool(int(pick.item()))
+        collective = "host" if use_host[0] else "cabi"
+        collective_choice["chosen"] = collective
     if ar_step is not None and not np.isfinite(ll0):
         # (the all-reduced value is the same on every rank, so every rank takes this branch or none does)
         collective_note = "hyphy_hip_evaluate_built_allreduce returned a non-finite value on the first evaluation: fell back to torch.distributed.all_reduce"
@@ -719,13 +771,14 @@ def main():
             # both collectives in ONE run (which of the two costs less per step on this node?): 8 + 8 more steps
             # behind the timed region, the library's in-stream all-reduce and torch.distributed's on the same stream
             collective_ab = {}
-            for name, ft in (("cabi", False), ("torch", True), ("cabi_again", False)):
-                step(1, force_torch=ft)
+            for name, ft in (("cabi", False), ("torch", True), ("cabi_again", False)) + ((("host", False),) if xch_step is not None else ()):
+                fc = "host" if name == "host" else ("cabi" if not ft else None)
+                step(1, force_torch=ft, force=fc)
                 dist.barrier()
                 torch.cuda.synchronize()
                 ta = time.perf_counter()
                 for k in range(8):
-                    step(k + 1, force_torch=ft)
+                    step(k + 1, force_torch=ft, force=fc)
                 dist.barrier()
                 torch.cuda.synchronize()
                 collective_ab[name + "_ms_per_step"] = 1e3 * max_over_ranks(dist, ctl, time.perf_counter() - ta) / 8
@@ -887,7 +940,8 @@ def main():
                        **({"mixture_components": n_mix, "mixture_weights": list(MIX_WEIGHTS[:n_mix]), "mixture_omegas": list(MIX_OMEGAS[:n_mix])} if n_mix else {}),
                        "step": ("device build + expm of every component of every branch + mixing into the branches' matrices + full pruning pass + reduction" if n_mix else
                                 "device Q build + expm of all branches + full pruning pass + reduction") +
-                               (" + RCCL all-reduce" if (multi or collective == "cabi") else "") + ", log-L returned to host every step"},
+                               (" + host-side exchange of the ranks' partials (shared memory)" if collective == "host" else
+                                (" + RCCL all-reduce" if (multi or collective == "cabi") else "")) + ", log-L returned to host every step"},
             "logl_first": ll0, "logl_last": last,
             "roofline": roof,
             **({"branch_cache": branch_cache} if branch_cache else {}),
@@ -898,6 +952,8 @@ def main():
             out["config"].update(cfg_m)
             roof.update(roof_m)
             out.update(top_m)
+            if collective_choice:   # (auto: both collectives timed on untimed steps, the faster one ran the timed region)
+                out["collective_choice"] = collective_choice
         if pipelined:
             out["value_pipelined_no_host_sync"] = pipelined
         if not args.no_cpu_baseline and N == 1 and n_mix:

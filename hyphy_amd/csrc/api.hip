@@ -834,6 +834,7 @@ void hyphy_hip_destroy(hyphy_hip_partition *p) {
   if (!p) return;
   for (Shard &s : p->shards) free_shard(s);
   if (p->h_qstage) { hipDeviceSynchronize(); pool_host_free(p->h_qstage); }
+  if (p->xch) hyphy_hip_xch_close(p->xch);
   delete p;
 }
 

@@ -1,6 +1,11 @@
 // RCCL over xGMI for libhyphy_hip.so: librccl is loaded on first use (a host that never all-reduces does not need it),
 // plus the C-ABI entry points that sum the partition log-likelihood over ranks / devices.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "partition.h"
 
@@ -67,6 +72,132 @@ int combine_shards(hyphy_hip_partition *p, double *logl_out) {
     HIPCHK(hipStreamSynchronize(s.stream));
   }
   *logl_out = tot;
+  return 0;
+}
+
+// ---- the collective-free combine of one-process-per-GPU runs (r06) ------------------------------------------------------------------
+// What the single-process form has had since r02 — shard partials back over PCIe into host-mapped records, Neumaier on the host
+// (likefunc.cpp:11046-11093) — for ranks that are separate PROCESSES of one node: every rank finishes its local evaluation exactly as a
+// one-GPU run does (the reduction kernel posts the record to host-mapped memory, the host spins on its sequence word), then posts
+// (value, epoch) into its slot of a POSIX shared-memory segment and reads everybody else's — a release store and N - 1 acquire loads
+// between cores of one host, no device work, no launch, no stream dependency.  The in-stream ncclAllReduce costs a collective launch
+// + the ring's latency (~25 us measured on one device with a one-rank communicator + the fetch kernel behind it); this costs the skew
+// between the ranks' kernels and a cache-line transfer.  RCCL stays the default collective of the C-ABI (north_star) and of the
+// adapter; bench.py --gpus N times both behind its timed region (collective_ab) and says which one the timed steps used.
+// Slots are double-buffered by epoch parity: a rank can only be one exchange ahead of the slowest reader of its previous value.
+struct XchSlot {
+  double value;
+  uint64_t epoch;
+  uint64_t ready;
+  char pad[40];
+};
+static_assert(sizeof(XchSlot) == 64, "one cache line per slot");
+struct HostExchange {
+  XchSlot *slots = nullptr;  // [2][n]
+  size_t bytes = 0;
+  int rank = 0, n = 1;
+  uint64_t epoch = 0;
+  std::string name;
+};
+
+static double xch_now() {
+  timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+static double xch_timeout_s() {
+  const char *e = getenv("HYPHY_HIP_EXCHANGE_TIMEOUT_S");
+  return e ? atof(e) : 120.;
+}
+
+HostExchange *xch_open(const char *name, int rank, int n_ranks) {
+  if (!name || !*name || n_ranks < 1 || rank < 0 || rank >= n_ranks) {
+    fail("host exchange: bad arguments");
+    return nullptr;
+  }
+  std::string nm = std::string("/hyphy_hip_") + name;
+  for (char &c : nm)
+    if (&c != &nm[0] && c == '/') c = '_';
+  const int fd = shm_open(nm.c_str(), O_CREAT | O_RDWR, 0600);
+  if (fd < 0) {
+    fail("host exchange: shm_open(" + nm + ") failed");
+    return nullptr;
+  }
+  const size_t bytes = (size_t)2 * n_ranks * sizeof(XchSlot);
+  if (ftruncate(fd, (off_t)bytes) != 0) {  // (idempotent: every rank sets the same size; a new segment reads as zeros)
+    close(fd);
+    fail("host exchange: ftruncate failed");
+    return nullptr;
+  }
+  void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) {
+    fail("host exchange: mmap failed");
+    return nullptr;
+  }
+  HostExchange *x = new HostExchange;
+  x->slots = static_cast<XchSlot *>(m);
+  x->bytes = bytes;
+  x->rank = rank;
+  x->n = n_ranks;
+  x->name = nm;
+  // handshake: every rank marks its slots, then waits for everybody's mark (the name is unique per run: no stale marks)
+  uint64_t nonce = 1469598103934665603ull;
+  for (unsigned char c : nm) nonce = (nonce ^ c) * 1099511628211ull;
+  nonce ^= (uint64_t)n_ranks << 48;
+  if (nonce == 0) nonce = 1;
+  for (int b = 0; b < 2; b++) {
+    XchSlot &mine = x->slots[(size_t)b * n_ranks + rank];
+    mine.value = 0.;
+    __atomic_store_n(&mine.epoch, (uint64_t)0, __ATOMIC_RELAXED);
+    __atomic_store_n(&mine.ready, nonce, __ATOMIC_RELEASE);
+  }
+  const double t0 = xch_now(), limit = xch_timeout_s();
+  for (int r = 0; r < n_ranks; r++)
+    for (int b = 0; b < 2; b++)
+      while (__atomic_load_n(&x->slots[(size_t)b * n_ranks + r].ready, __ATOMIC_ACQUIRE) != nonce) {
+        if (xch_now() - t0 > limit) {
+          munmap(m, bytes);
+          delete x;
+          fail("host exchange: the other ranks did not attach to " + nm);
+          return nullptr;
+        }
+        usleep(200);
+      }
+  return x;
+}
+
+void xch_close(HostExchange *x) {
+  if (!x) return;
+  if (x->rank == 0) shm_unlink(x->name.c_str());  // (the mappings keep the segment alive until the last rank has gone)
+  munmap(x->slots, x->bytes);
+  delete x;
+}
+
+// one exchange: post this rank's value (NaN when its local evaluation failed), wait for everybody's, sum in rank order with the
+// reference's compensated combine — every rank computes the same bits
+int xch_sum(HostExchange *x, double local, bool local_failed, double *sum_out) {
+  if (!x) return fail("host exchange: not initialised");
+  const uint64_t e = ++x->epoch;
+  XchSlot *row = x->slots + (size_t)(e & 1) * x->n;
+  row[x->rank].value = local_failed ? NAN : local;
+  __atomic_store_n(&row[x->rank].epoch, e, __ATOMIC_RELEASE);
+  std::vector<double> parts((size_t)x->n);
+  const double limit = xch_timeout_s();
+  double t0 = 0.;
+  for (int r = 0; r < x->n; r++) {
+    for (long spins = 1; __atomic_load_n(&row[r].epoch, __ATOMIC_ACQUIRE) != e; spins++) {
+      if ((spins & 0xfffff) == 0) {
+        if (t0 == 0.) t0 = xch_now();
+        else if (xch_now() - t0 > limit) return fail("host exchange: a rank did not arrive (HYPHY_HIP_EXCHANGE_TIMEOUT_S)");
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    parts[(size_t)r] = row[r].value;
+  }
+  if (sum_out) *sum_out = combine(parts);
   return 0;
 }
 
@@ -215,5 +346,75 @@ int hyphy_hip_comm_init_all(hyphy_hip_partition *p) {
   }
   return 0;
 }
+
+/* ---- collective-free combine for one process per GPU on ONE node (see HostExchange above) --------------------------------------
+ *   hyphy_hip_comm_init_host   attach this rank's partition to the run's shared-memory exchange (`name`: the same string on every rank,
+ *                              unique per run); returns when every rank has attached.
+ *   hyphy_hip_evaluate(_built)_exchange   the local evaluation of hyphy_hip_evaluate(_built) + ONE host-side exchange: every rank
+ *                              returns the log-likelihood of the whole alignment (same bits on every rank).  A rank whose local
+ *                              evaluation fails still posts (NaN) and then returns its error: nobody is left waiting.
+ *   hyphy_hip_xch_open / _sum / _close   the exchange alone, without a partition or a device (CPU tests; hosts that sum something else). */
+int hyphy_hip_comm_init_host(hyphy_hip_partition *p, const char *name, int rank, int n_ranks) {
+  if (!p) return fail("partition == NULL");
+  if (p->shards.size() != 1) return fail("comm_init_host: one device per rank (device_count = 1)");
+  HostExchange *x = xch_open(name, rank, n_ranks);
+  if (!x) return -1;
+  if (p->xch) xch_close(static_cast<HostExchange *>(p->xch));
+  p->xch = x;
+  return 0;
+}
+
+static int exchange_after(hyphy_hip_partition *p, int local_rc, double *logl_out) {
+  const std::string local_error = g_last_error;
+  double local = 0., total = 0.;
+  bool failed = local_rc != 0;
+  if (!failed) {
+    if (collect_status(p)) failed = true;
+    else local = p->shards[0].h_out[0];
+  }
+  const std::string err2 = g_last_error;
+  const int xrc = xch_sum(static_cast<HostExchange *>(p->xch), local, failed, &total);
+  if (local_rc) {
+    g_last_error = local_error;
+    return -1;
+  }
+  if (failed) {
+    g_last_error = err2;
+    return -1;
+  }
+  if (xrc) return -1;
+  record_timings(p);
+  if (logl_out) *logl_out = total;
+  return 0;
+}
+
+int hyphy_hip_evaluate_exchange(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update, const int64_t *q_nodes,
+                                int64_t n_q, const double *q_dense, int q_is_probability, const double *root_freqs, double *logl_out) {
+  if (!p) return fail("partition == NULL");
+  if (p->shards.size() != 1 || !p->xch) return fail("evaluate_exchange: hyphy_hip_comm_init_host first");
+  const int rc = eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, q_dense, false, q_is_probability, root_freqs, nullptr, true, false);
+  return exchange_after(p, rc, logl_out);
+}
+
+int hyphy_hip_evaluate_built_exchange(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                                      const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out) {
+  if (!p) return fail("partition == NULL");
+  if (!p->K) return fail("evaluate_built_exchange: templates not set");
+  if (p->shards.size() != 1 || !p->xch) return fail("evaluate_built_exchange: hyphy_hip_comm_init_host first");
+  const int rc = eval_common(p, cat, update_nodes, n_update, q_nodes, n_q, &kOwnQBuffer, true, 0, root_freqs, nullptr, true, false);
+  return exchange_after(p, rc, logl_out);
+}
+
+int hyphy_hip_xch_open(const char *name, int rank, int n_ranks, void **handle_out) {
+  if (!handle_out) return fail("host exchange: null handle pointer");
+  HostExchange *x = xch_open(name, rank, n_ranks);
+  if (!x) return -1;
+  *handle_out = x;
+  return 0;
+}
+int hyphy_hip_xch_sum(void *handle, double local, int local_failed, double *sum_out) {
+  return xch_sum(static_cast<HostExchange *>(handle), local, local_failed != 0, sum_out);
+}
+void hyphy_hip_xch_close(void *handle) { xch_close(static_cast<HostExchange *>(handle)); }
 
 }  // extern "C"

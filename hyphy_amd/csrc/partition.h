@@ -295,6 +295,7 @@ struct hyphy_hip_partition {
   int64_t rep_stale_branch = -1;             // a branch whose matrix image was rewritten outside an evaluation (branch cache)
   double rep_kernel_ms = 0.;
   std::vector<hyhip::Shard> shards;
+  void *xch = nullptr;                       // host-side exchange of one-process-per-GPU runs (comm.hip: HostExchange), or nullptr
   std::vector<char> initialized;             // per class: a full evaluation has populated the caches
   std::vector<char> leaf_has_ambig;          // per leaf: any ambiguity code in its row of the leaf table
   std::vector<int4> ops_host;

@@ -24,7 +24,8 @@ EXPORTS = [
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_evaluate_categories_built_sites", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
     "hyphy_hip_set_pinned_states", "hyphy_hip_site_fits_evaluate", "hyphy_hip_site_fits_evaluate_mixture", "hyphy_hip_site_fits_kernel_ms",
-    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_set_repeats", "hyphy_hip_repeat_stats", "hyphy_hip_plan_repeats", "hyphy_hip_plan_nucgen", "hyphy_hip_last_error",
+    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_set_repeats", "hyphy_hip_repeat_stats", "hyphy_hip_plan_repeats", "hyphy_hip_plan_nucgen", "hyphy_hip_comm_init_host", "hyphy_hip_evaluate_exchange", "hyphy_hip_evaluate_built_exchange",
+    "hyphy_hip_xch_open", "hyphy_hip_xch_sum", "hyphy_hip_xch_close", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
 
@@ -144,6 +145,18 @@ def load():
     lib.hyphy_hip_plan_repeats.argtypes = [C.c_int64, C.c_int64, lp, C.c_int64, lp, C.c_double, lp, lp]
     lib.hyphy_hip_repeat_stats.restype = C.c_int
     lib.hyphy_hip_repeat_stats.argtypes = [vp, lp]
+    lib.hyphy_hip_comm_init_host.restype = C.c_int
+    lib.hyphy_hip_comm_init_host.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    lib.hyphy_hip_evaluate_exchange.restype = C.c_int
+    lib.hyphy_hip_evaluate_exchange.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, C.c_int, dp, dp]
+    lib.hyphy_hip_evaluate_built_exchange.restype = C.c_int
+    lib.hyphy_hip_evaluate_built_exchange.argtypes = [vp, C.c_int64, lp, C.c_int64, lp, C.c_int64, dp, dp]
+    lib.hyphy_hip_xch_open.restype = C.c_int
+    lib.hyphy_hip_xch_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.hyphy_hip_xch_sum.restype = C.c_int
+    lib.hyphy_hip_xch_sum.argtypes = [C.c_void_p, C.c_double, C.c_int, dp]
+    lib.hyphy_hip_xch_close.restype = None
+    lib.hyphy_hip_xch_close.argtypes = [C.c_void_p]
     lib.hyphy_hip_plan_nucgen.restype = C.c_int64
     lib.hyphy_hip_plan_nucgen.argtypes = [C.c_int64, C.c_int64, lp, lp, C.c_int64, C.c_char_p, C.c_int64, lp]
     lib.hyphy_hip_last_error.restype = C.c_char_p
@@ -227,6 +240,27 @@ def plan_nucgen(flat_parents, L: int, leaf_has_ambig=None, compile_it: bool = Tr
     if n < 0:
         raise HipError("plan_nucgen: bad arguments")
     return buf.value.decode(), bool(ok[0])
+
+
+class HostExchange:
+    """The collective-free combine of one-process-per-GPU runs on one node (hyphy_hip_xch_*): every rank posts its partial
+    log-likelihood into a shared-memory segment and reads the others'; ``sum`` returns the total (same bits on every rank)."""
+
+    def __init__(self, name: str, rank: int, n_ranks: int):
+        self._lib = load()
+        h = C.c_void_p()
+        _check(self._lib.hyphy_hip_xch_open(name.encode(), int(rank), int(n_ranks), C.byref(h)))
+        self._h = h
+
+    def sum(self, local: float, failed: bool = False) -> float:
+        out = C.c_double(0.0)
+        _check(self._lib.hyphy_hip_xch_sum(self._h, float(local), 1 if failed else 0, C.byref(out)))
+        return out.value
+
+    def close(self):
+        if self._h:
+            self._lib.hyphy_hip_xch_close(self._h)
+            self._h = None
 
 
 def device_count() -> int:
@@ -485,6 +519,33 @@ class HipPartition:
             rc = lib.hyphy_hip_build_q(h, nco, pco)
             if rc == 0:
                 rc = lib.hyphy_hip_evaluate_built_allreduce(h, cat, pun, nun, pqn, nqn, prf, pout)
+            if rc:
+                _check(rc)
+            return out.value
+        return step
+
+    def comm_init_host(self, name: str, rank: int, n_ranks: int):
+        """Attach this rank's partition to the run's shared-memory exchange (collective-free combine, one node)."""
+        _check(self._lib.hyphy_hip_comm_init_host(self._h, name.encode(), int(rank), int(n_ranks)))
+
+    def prepare_built_exchange_step(self, update_nodes, q_nodes, root_freqs, coeffs: np.ndarray, cat: int = -1):
+        """``build_q`` + ``evaluate_built_exchange``: the local evaluation, then ONE host-side exchange of the partial log-likelihoods
+        through shared memory (no collective on the device); the total on every rank.  Needs ``comm_init_host`` first."""
+        un = np.ascontiguousarray(update_nodes, dtype=np.int64)
+        qn = np.ascontiguousarray(q_nodes, dtype=np.int64)
+        rf = np.ascontiguousarray(root_freqs, dtype=np.float64)
+        assert coeffs.flags.c_contiguous and coeffs.dtype == np.float64
+        keep = (un, qn, rf, coeffs)
+        lib, h = self._lib, self._h
+        pun, pqn, prf, pco = _l(un), _l(qn), _d(rf), _d(coeffs)
+        nun, nqn, nco = len(un), len(qn), coeffs.shape[0]
+        out = C.c_double(0.0)
+        pout = C.byref(out)
+
+        def step(_keep=keep):
+            rc = lib.hyphy_hip_build_q(h, nco, pco)
+            if rc == 0:
+                rc = lib.hyphy_hip_evaluate_built_exchange(h, cat, pun, nun, pqn, nqn, prf, pout)
             if rc:
                 _check(rc)
             return out.value

@@ -183,6 +183,24 @@ int hyphy_hip_evaluate_built_allreduce(hyphy_hip_partition *p, int64_t cat, cons
                                        const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out);
 double hyphy_hip_last_allreduce_ms(const hyphy_hip_partition *p);
 
+/* The collective-free combine of one process per GPU on ONE node (r06): what the single-process form does with its shards — partials
+ * back over PCIe into host-mapped records, the reference's Neumaier combine on the host (likefunc.cpp:11046-11093) — between processes,
+ * through a POSIX shared-memory segment: each rank finishes its local evaluation like a one-GPU run, posts (value, epoch) into its slot and
+ * reads the others' (one release store, N - 1 acquire loads; no device work).  Same bits on every rank (summed in rank order).
+ *   hyphy_hip_comm_init_host            `name`: the same string on every rank, unique per run; returns when every rank has attached
+ *   hyphy_hip_evaluate(_built)_exchange hyphy_hip_evaluate(_built) + one exchange; a rank whose local evaluation fails still posts (NaN)
+ *                                       and then returns its own error: nobody is left waiting (HYPHY_HIP_EXCHANGE_TIMEOUT_S, default 120)
+ *   hyphy_hip_xch_open / _sum / _close  the exchange alone (no partition, no device).
+ * RCCL (above) stays the C-ABI's and the adapter's default collective; bench.py --gpus N times both and uses the faster (collective_ab). */
+int hyphy_hip_comm_init_host(hyphy_hip_partition *p, const char *name, int rank, int n_ranks);
+int hyphy_hip_evaluate_exchange(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update, const int64_t *q_nodes,
+                                int64_t n_q, const double *q_dense, int q_is_probability, const double *root_freqs, double *logl_out);
+int hyphy_hip_evaluate_built_exchange(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
+                                      const int64_t *q_nodes, int64_t n_q, const double *root_freqs, double *logl_out);
+int hyphy_hip_xch_open(const char *name, int rank, int n_ranks, void **handle_out);
+int hyphy_hip_xch_sum(void *handle, double local, int local_failed, double *sum_out);
+void hyphy_hip_xch_close(void *handle);
+
 /*
  * Same evaluation with device-resident inputs/outputs, enqueued asynchronously on the
  * partition's stream (device_count must be 1): d_q is a DEVICE pointer [n_q*D*D];

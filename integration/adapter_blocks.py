@@ -93,6 +93,7 @@ struct _HyHipPart {
   // and every evaluation ends in ONE ncclAllReduce of the partition log-likelihood (hyphy_hip_evaluate*_allreduce)
   bool spmd = false;
   long spmd_rank = 0, spmd_world = 1;
+  bool spmd_host = false;   // HYPHY_HIP_COLLECTIVE=host: the ranks' partials through shared memory (hyphy_hip_comm_init_host), no RCCL
 };
 static std::map<const void *, std::vector<_HyHipPart>> _hyhip_lfs;
 // Rate classes batched through the host's category loop (r06; INTEGRATION.md "rate classes").  PopulateConditionalProbabilities'
@@ -276,7 +277,21 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   }
   int rc = hyphy_hip_create(&hp.part, D, S_dev, L, I, cT->categoryCount, parents.data(), codes.data(),
                             n_amb ? ambigs->theData : nullptr, n_amb, freq.data(), my_first, my_count);
-  if (rc == 0 && spmd) {
+  const bool spmd_host = spmd && getenv("HYPHY_HIP_COLLECTIVE") && !strcmp(getenv("HYPHY_HIP_COLLECTIVE"), "host");
+  if (rc == 0 && spmd_host) {
+    // r06: the collective-free combine of one node — every rank attaches to a shared-memory segment named after the run
+    // (HYPHY_HIP_RUN_ID, the same on every rank, new for every run) and the n-th SPMD set-up of this process
+    static long host_generation = 0;
+    const char *run_id = getenv("HYPHY_HIP_RUN_ID");
+    const std::string name = std::string(run_id ? run_id : "run") + "_" + std::to_string(host_generation++);
+    if (hyphy_hip_comm_init_host(hp.part, name.c_str(), (int)spmd_rank, (int)spmd_world) != 0) {
+      ReportWarning(_String("hyphy_hip: SPMD site sharding could not attach to the host exchange (") & hyphy_hip_last_error() & "); host path");
+      hyphy_hip_destroy(hp.part);
+      hp.part = nullptr;
+      return;
+    }
+  }
+  if (rc == 0 && spmd && !spmd_host) {
     // the RCCL unique id: made by rank 0, handed to the other ranks through a file
     // (HYPHY_HIP_UID_FILE) that rank 0 writes and the others wait for
     // One rendezvous PER COMMUNICATOR: every process runs the same batch file, so the n-th SPMD set-up of this process pairs
@@ -330,7 +345,7 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   }
   if (rc == 0 && getenv("HYPHY_HIP_VERBOSE"))
     fprintf(stderr, "[hyphy_hip] partition %lu of %lu -> device %d%s (%ld states, %ld patterns, %ld leaves)%s\n", i, n_parts, my_first,
-            my_count > 1 ? " (+ site shards on the following devices)" : "", D, S_dev, L, spmd ? " [SPMD site shard, RCCL all-reduce per evaluation]" : "");
+            my_count > 1 ? " (+ site shards on the following devices)" : "", D, S_dev, L, spmd ? (spmd_host ? " [SPMD site shard, host-side exchange per evaluation]" : " [SPMD site shard, RCCL all-reduce per evaluation]") : "");
   if (rc != 0) {  // > 0: unsupported here -> the CPU path keeps working; < 0: report and use the CPU path
     hp.part = nullptr;
     ReportWarning(_String("hyphy_hip_create: ") & hyphy_hip_last_error());
@@ -347,6 +362,7 @@ static void _hyphy_hip_setup(const void *lf, unsigned long i, unsigned long n_pa
   hp.n_stale = 0;
   hp.pending = hp.pre_done = false;
   hp.spmd = spmd;
+  hp.spmd_host = spmd_host;
   hp.spmd_rank = spmd_rank;
   hp.spmd_world = spmd_world;
   hp.tmpl_state.assign(n_cat, getenv("HYPHY_HIP_TEMPLATES") && !strcmp(getenv("HYPHY_HIP_TEMPLATES"), "0") ? -1 : 0);
@@ -1410,7 +1426,10 @@ static int _hyphy_hip_compute_impl(const void *lf, long index, _TheTree *t, long
     for (long k = 0; k < n_q; k++)
       for (long j = 0; j < K; j++) hp.pbuf[(size_t)k * K + j] = hp.tmpl_x[cat][(size_t)hp.qnodes[k] * K + j];
     if (rc == 0) rc = hyphy_hip_build_q(hp.part, n_q, hp.pbuf.data());
-    if (rc == 0 && hp.spmd)
+    if (rc == 0 && hp.spmd && hp.spmd_host)
+      rc = hyphy_hip_evaluate_built_exchange(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(),
+                                             n_q, t->GetProbs(), &ll);
+    else if (rc == 0 && hp.spmd)
       rc = hyphy_hip_evaluate_built_allreduce(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(),
                                               n_q, t->GetProbs(), &ll);
     else if (rc == 0)
@@ -1456,6 +1475,9 @@ static int _hyphy_hip_compute_impl(const void *lf, long index, _TheTree *t, long
     rc = hyphy_hip_evaluate_async(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(), n_q,
                                   hp.pbuf.data(), rate_matrices ? 0 : 1, t->GetProbs());
     if (rc == 0) hp.pending = true;
+  } else if (hp.spmd && hp.spmd_host) {
+    rc = hyphy_hip_evaluate_exchange(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(), n_q,
+                                     hp.pbuf.data(), /* q_is_probability = */ rate_matrices ? 0 : 1, t->GetProbs(), &ll);
   } else if (hp.spmd) {
     rc = hyphy_hip_evaluate_allreduce(hp.part, catID, (const int64_t *)branches.list_data, branches.lLength, hp.qnodes.data(), n_q,
                                       hp.pbuf.data(), /* q_is_probability = */ rate_matrices ? 0 : 1, t->GetProbs(), &ll);

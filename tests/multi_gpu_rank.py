@@ -41,7 +41,11 @@ if __name__ == "__main__":
     codes, freq, _ = hdist.shard_patterns(pd.leaf_codes, pd.pattern_freq, rank, world)
     flat = syn.flat
     nodes = np.arange(flat.n_branches, dtype=np.int64)
-    if rank == 0:
+    exchange = os.environ.get("HOST_EXCHANGE") is not None   # the collective-free combine (hyphy_hip_comm_init_host): no RCCL, and
+                                                             # the ranks may share a device (HOST_EXCHANGE=share: all on device 0)
+    if exchange:
+        uid = None
+    elif rank == 0:
         uid = hip.HipPartition.comm_unique_id()
         with open(uid_file + ".tmp", "wb") as fh:
             fh.write(uid)
@@ -53,11 +57,17 @@ if __name__ == "__main__":
                 raise SystemExit("no unique id")
             time.sleep(0.05)
         uid = open(uid_file, "rb").read()
-    with hip.HipPartition(61, flat.flat_parents, flat.L, codes, None, freq, device_first=rank) as part:
+    dev = 0 if os.environ.get("HOST_EXCHANGE") == "share" else rank
+    with hip.HipPartition(61, flat.flat_parents, flat.L, codes, None, freq, device_first=dev) as part:
         part.set_q_templates(T)
-        part.comm_init_rank(uid, rank, world)
+        if exchange:
+            part.comm_init_host("t_" + os.path.basename(os.path.dirname(uid_file)) + "_" + os.path.basename(uid_file), rank, world)
+            prepare = part.prepare_built_exchange_step
+        else:
+            part.comm_init_rank(uid, rank, world)
+            prepare = part.prepare_built_allreduce_step
         co = coeffs_for(tb, OMEGAS[0])
-        step = part.prepare_built_allreduce_step(nodes, nodes, pi, co)
+        step = prepare(nodes, nodes, pi, co)
         vals = []
         for om in OMEGAS:
             co[:] = coeffs_for(tb, om)
@@ -70,7 +80,7 @@ if __name__ == "__main__":
             if rank == int(os.environ["FAIL_RANK"]):
                 bad_nodes[1] = bad_nodes[0]
             try:
-                v = part.prepare_built_allreduce_step(nodes, bad_nodes, pi, co)()
+                v = prepare(nodes, bad_nodes, pi, co)()
                 err = "nan" if v != v else f"value {v!r}"
             except hip.HipError as e:
                 err = f"error: {e}"

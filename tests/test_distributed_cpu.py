@@ -322,3 +322,57 @@ def test_two_rank_site_sharding_with_subtree_repeats(name, theta):
     assert np.max(np.abs(got - fx["site_logl"]) / np.abs(fx["site_logl"])) < 1e-10
     work, planned, full, n_comp = counts
     assert work == planned and n_comp > 0 and work < full, counts
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# r06: the collective-free combine of one-process-per-GPU runs (hyphy_hip_xch_*, comm.hip: HostExchange) — host-only code
+# (POSIX shared memory), so the REAL library runs it here: world 2 and 3, against gloo's all-reduce of the same partials.
+# ---------------------------------------------------------------------------------------------------------------------
+def _xch_worker(rank, world, port, name, tag, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hyphy_amd import hip
+    from oracle import oracle
+    fx = common.load(name)
+    codes, freq, (lo, hi) = hdist.shard_patterns(fx["leaf_codes"], fx["pattern_freq"], rank, world)
+    part = oracle.OraclePartition(int(fx["D"]), fx["flat_parents"], int(fx["L"]), codes, fx["ambig"], freq)
+    nodes = common.all_nodes(fx)
+    part.set_P(nodes, oracle.expm(common.fixture_Q(fx), str(fx["kind"]) == "codon"))
+    x = hip.HostExchange(tag, rank, world)          # returns when every rank has attached
+    got, want = [], []
+    for it in range(40):                            # many exchanges back to back: the slots are reused every other one
+        local = part.compute_block(nodes, fx["root_freqs"]) * (1.0 + 0.01 * it) + rank * 1e-3
+        got.append(x.sum(local))
+        t = torch.tensor([local], dtype=torch.float64)
+        dist.all_reduce(t)
+        want.append(float(t[0]))
+    # a rank whose local evaluation failed posts NaN: every rank sees NaN, nobody waits
+    nan_seen = x.sum(1.0, failed=(rank == world - 1))
+    after = x.sum(float(rank + 1))                  # ... and the exchange goes on
+    x.close()
+    everyone = [None] * world
+    dist.all_gather_object(everyone, got)           # same bits on every rank?
+    if rank == 0:
+        out_q.put((got, want, nan_seen, after, everyone))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_exchange_sums_like_an_allreduce(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    tag = f"test_{os.getpid()}_{port}"
+    procs = [ctx.Process(target=_xch_worker, args=(r, world, port, "nuc_small", tag, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, want, nan_seen, after, everyone = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.allclose(got, want, rtol=1e-14, atol=0.0)
+    assert all(e == got for e in everyone)          # bit-identical on every rank (summed in rank order)
+    assert np.isnan(nan_seen)
+    assert after == sum(range(1, world + 1))

@@ -82,6 +82,41 @@ def test_a_failing_rank_does_not_leave_the_others_in_the_collective(tmp_path):
     assert by_rank[0] == "nan", by_rank     # rank 0's own evaluation was fine; the sum carries rank 1's NaN
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_exchange_between_processes_sharing_one_device(world, tmp_path):
+    """r06: the collective-free combine (hyphy_hip_comm_init_host + hyphy_hip_evaluate_built_exchange) needs no device collective, so
+    a one-GPU box runs it for real: `world` PROCESSES, each with its own partition over its pattern shard (all on device 0), every
+    evaluation ends in one shared-memory exchange — the whole alignment's log-likelihood on every rank, same bits."""
+    hip = _hip(1)
+    want = _single_device_values(hip)
+    res = _run_ranks(world, tmp_path, extra_env={"HOST_EXCHANGE": "share"})
+    for r in res:
+        got = np.array(r["values"]).reshape(len(want), 2)
+        for k, w in enumerate(want):
+            assert abs(got[k, 0] - w) <= 1e-12 * abs(w) and abs(got[k, 1] - w) <= 1e-12 * abs(w), (r["rank"], k, got[k], w)
+    assert all(res[0]["values"] == r["values"] for r in res[1:])
+
+
+def test_host_exchange_a_failing_rank_does_not_leave_the_others_waiting(tmp_path):
+    _hip(1)
+    res = _run_ranks(2, tmp_path, extra_env={"HOST_EXCHANGE": "share", "FAIL_RANK": "1"})
+    by_rank = {r["rank"]: r["failure_case"] for r in res}
+    assert by_rank[1].startswith("error:") and "twice" in by_rank[1], by_rank
+    assert by_rank[0] == "nan", by_rank     # rank 0's own evaluation was fine; the sum carries rank 1's NaN
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_one_process_per_gpu_host_exchange(world, tmp_path):
+    hip = _hip(world)
+    want = _single_device_values(hip)
+    res = _run_ranks(world, tmp_path, extra_env={"HOST_EXCHANGE": "1"})
+    for r in res:
+        got = np.array(r["values"]).reshape(len(want), 2)
+        for k, w in enumerate(want):
+            assert abs(got[k, 0] - w) <= 1e-12 * abs(w) and abs(got[k, 1] - w) <= 1e-12 * abs(w), (r["rank"], k, got[k], w)
+    assert all(res[0]["values"] == r["values"] for r in res[1:])
+
+
 @pytest.mark.parametrize("combine", ["host", "rccl"])
 @pytest.mark.parametrize("n_dev", [2, 8])
 def test_single_process_multi_device_combine(n_dev, combine, monkeypatch):

@@ -489,6 +489,39 @@ def test_hbl_spmd_site_shard_two_ranks(tmp_path):
     assert out[0]["opt_logl"] == out[1]["opt_logl"]
 
 
+def test_hbl_spmd_two_host_processes_with_the_host_side_exchange(tmp_path):
+    """r06: SPMD site sharding with HYPHY_HIP_COLLECTIVE=host — two REAL host processes run the same batch file, each holds half of
+    the patterns in a partition of its own, every evaluation ends in ONE shared-memory exchange of the two partial log-likelihoods
+    (hyphy_hip_evaluate(_built)_exchange; no RCCL, so both processes may share device 0 and a one-GPU box runs it): LFCompute, an
+    R sweep and a full Optimize report the whole alignment's values, identical on both ranks."""
+    _need_binaries()
+    from oracle import hbl
+    import threading
+    fx = common.load("codon_wide")
+    case = _case("codon", 64, 60, 15)
+    out = {}
+
+    def run(rank):
+        env = dict(ENV, HYPHY_HIP_WORLD="2", HYPHY_HIP_RANK=str(rank), HYPHY_HIP_LOCAL_RANK="0", HYPHY_HIP_COLLECTIVE="host",
+                   HYPHY_HIP_RUN_ID=f"it{os.getpid()}_{id(tmp_path) & 0xffff}")
+        out[rank] = hbl.evaluate(binary=HIP_BIN, extra_env=env, per_site=False, optimize=True,
+                                 sweep=dict(param="R", start=0.3, step=0.01, n=8, record=8), **case)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    ref = float(fx["logl"])
+    for r in (0, 1):
+        assert "host-side exchange per evaluation" in out[r]["stdout"], out[r]["stdout"][-600:]
+        assert abs(out[r]["logl"] - ref) <= 1e-10 * abs(ref), (r, out[r]["logl"], ref)
+    assert np.array_equal(out[0]["sweep_values"], out[1]["sweep_values"])
+    assert out[0]["opt_logl"] == out[1]["opt_logl"]
+    cpu = hbl.evaluate(per_site=False, optimize=True, **case)
+    assert abs(out[0]["opt_logl"] - cpu["opt_logl"]) <= 2e-3
+
+
 def _run_constrained_local_model(binary=None, env=None, optimize=False, sweep=None, branch_specific=False):
     """MG94 written the way HyPhy's own codon models carry a global omega: two LOCAL parameters per branch (synRate,
     nonSynRate) and the constraint `givenTree.N.nonSynRate := R*givenTree.N.synRate` on every branch — nonSynRate is a
