@@ -649,6 +649,16 @@ def main():
 
     if n_mix or n_classes > 1:
         xch_step = None
+    if os.environ.get("HYPHY_BENCH_STEP_TIMES") == "all":   # (diagnostic: wall clock of EVERY step of the run, from the first)
+        _step0, _marks = step, []
+
+        def step(k, **kw):   # noqa: F811
+            t_ = time.perf_counter()
+            v_ = _step0(k, **kw)
+            _marks.append((time.perf_counter() - t_) * 1e6)
+            if len(_marks) in (40, 120):
+                sys.stderr.write("[bench] every step so far, us: " + " ".join(f"{x:.0f}" for x in _marks) + "\n")
+            return v_
     ll0 = step(0)
     collective_choice = None
     if collective_auto and ar_step is not None and xch_step is not None:
@@ -691,6 +701,13 @@ def main():
     for _ in range(3):
         step(1)
     per = (time.perf_counter() - t_pre) / 3.0
+    # Python's cyclic garbage collector is kept out of the timed windows (r06): a generation-2 collection of a process that has torch
+    # loaded takes 30-40 ms and fires at an allocation COUNT — two more ctypes prototypes in hyphy_amd/hip.py moved it from the untimed
+    # part of this script into the 2 ms timed window of the driver's protocol (value 10 000 -> 490 evals/s, `git log` of this file).
+    # Collected once here, then disabled until the measurements are done.
+    import gc
+    gc.collect()
+    gc.disable()
     # value_cold: the driver's exact protocol (W warm-up steps, K timed steps) on a chip that has just idled — no preheat
     value_cold = None
     if args.cold_s > 0:
@@ -701,12 +718,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         tc0 = time.perf_counter()
+        cold_marks = [] if os.environ.get("HYPHY_BENCH_STEP_TIMES") else None
         for k in range(args.steps):
             step(k + 1)
+            if cold_marks is not None:
+                cold_marks.append(time.perf_counter())
         if multi:
             dist.barrier()
+        t_sync = time.perf_counter()
         torch.cuda.synchronize()
         dtc = time.perf_counter() - tc0
+        if cold_marks is not None and rank == 0:
+            sys.stderr.write(f"[bench] un-preheated window: torch.cuda.synchronize() behind the last step took {1e6 * (time.perf_counter() - t_sync):.0f} us\n")
+        if cold_marks and rank == 0:
+            sys.stderr.write("[bench] un-preheated window, per-step us: " + " ".join(f"{x:.0f}" for x in np.diff(np.array([tc0] + cold_marks)) * 1e6) + "\n")
         if multi:
             tcm = torch.tensor([dtc], dtype=torch.float64, device=ctl)
             dist.all_reduce(tcm, op=dist.ReduceOp.MAX)
@@ -738,6 +763,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     if step_marks is not None and rank == 0:
         marks = np.diff(np.array([t0] + step_marks)) * 1e6
         sys.stderr.write("[bench] per-step us: " + " ".join(f"{x:.0f}" for x in marks) + "\n")

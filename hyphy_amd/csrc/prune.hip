@@ -81,6 +81,7 @@ __device__ __forceinline__ void publish_partial(const PruneArgs &a, int idx, dou
 // of the next internal edge's transition matrix or the gathered columns of the next leaf group.
 struct Payload {
   f64x2 v[8];
+  int c0 = 0, c1 = 0;  // (REP builds) 2^64 exponents of the class-table rows gathered for the entry's leaves
 };
 
 // Root epilogue shared by the pruning kernels: L_s = sum_k root[s][k] pi[k]; this workgroup's share of
@@ -150,10 +151,15 @@ __device__ __forceinline__ void root_epilogue(const PruneArgs &a, const double *
 // instead of 64 from one wave), the waves agree on every arrival through one LDS word, and each wave deposits / fetches only
 // its own 16 rows.  A tile's critical path is then (height of the tree) x (a quarter of the wave kernel's edge latency):
 // what small shards — a rank's share of an alignment at 4 or 8 GPUs — are bound by.
-template <int NW, int T, bool CLDS, bool TRACE, int ABL = 0, bool CHAIN = false, bool FUSE = false>
+// REP (r06): the tree is the TRUNK of a class-compressed partition (repeats.hip) — a leaf of the schedule may be a generalised leaf: its
+// columns are rows of a class table, gathered by class id, and carry a 2^64 exponent (what prune_wave_kernel<.., REP> does with one wave
+// per tile).  The trunk is a handful of nodes: a tile's critical path, not the chip's arithmetic, bounds the launch, and a team's edge
+// product is a quarter of a wave's.  T = 1, leaf table of the view staged in LDS.
+template <int NW, int T, bool CLDS, bool TRACE, int ABL = 0, bool CHAIN = false, bool FUSE = false, bool REP = false>
 __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_kernel(const int4 *__restrict__ ops,
                                                                                PruneArgs a) {
   static_assert(!CHAIN || T == 1, "chain schedules: one tile per workgroup");
+  static_assert(!REP || (T == 1 && CLDS), "class-compressed trunk: one tile per workgroup, leaf table in LDS");
   // forest scheduling: grid.z = subtree fragment of this level, each with its own program
   const int4 prg = a.prog[blockIdx.z];
   const int4 *const ops0 = ops;
@@ -174,6 +180,10 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
     a.wg_sum += cat * a.cs_wg;
     a.wg_cnt += cat * a.cs_wg;
     a.wg_flag += cat * a.cs_wg;
+    if constexpr (REP) {
+      a.gtab += cat * a.cs_gtab;
+      a.gcnt += cat * a.cs_gcnt;
+    }
   }
   constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64;
   constexpr int G = (T <= 2) ? 2 : 1;  // leaves per leaf-group entry (T*G*4 doubles <= 16)
@@ -202,8 +212,12 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
     const int n = a.L * T * 16;
     for (int i = threadIdx.x; i < n; i += 64 * NW) {
       const int leaf = i / (T * 16), off = i - leaf * (T * 16);
-      codes_lds[i] = (leaf == a.pin_leaf) ? a.pin[tile0 * 16 + off]  // pinned leaf: its states replace the data
-                                          : a.codes[(size_t)leaf * S_pad + tile0 * 16 + off];
+      if constexpr (REP) {  // (the view's leaf table is tile-major [tile][view leaves][16]: state codes / class ids)
+        codes_lds[i] = a.codes_tile[((size_t)tile0 * a.L + leaf) * 16 + off];
+      } else {
+        codes_lds[i] = (leaf == a.pin_leaf) ? a.pin[tile0 * 16 + off]  // pinned leaf: its states replace the data
+                                            : a.codes[(size_t)leaf * S_pad + tile0 * 16 + off];
+      }
     }
     __syncthreads();
   }
@@ -231,6 +245,17 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
     }
     const double *bl0 = a.PTg + ((size_t)leaf0 * DP * NW + w) * 16;     // uniform
     const double *bl1 = a.PTg + ((size_t)leaf1 * DP * NW + w) * 16;     // uniform
+    if constexpr (REP) {
+      // (first row of the leaf's class table or -1, first exponent row / matrix slot; the table is a member of the by-value argument
+      //  block — vector loads: back into scalar registers, or every address derived from them counts as divergent)
+      int2 lt0 = a.leaf_tab[leaf0], lt1 = a.leaf_tab[leaf1];
+      lt0.x = __builtin_amdgcn_readfirstlane(lt0.x), lt0.y = __builtin_amdgcn_readfirstlane(lt0.y);
+      lt1.x = __builtin_amdgcn_readfirstlane(lt1.x), lt1.y = __builtin_amdgcn_readfirstlane(lt1.y);
+      bl0 = (lt0.x >= 0 ? a.gtab + (size_t)lt0.x * DP : a.PTg + (size_t)lt0.y * DP * DP) + (size_t)w * 16;
+      bl1 = (lt1.x >= 0 ? a.gtab + (size_t)lt1.x * DP : a.PTg + (size_t)lt1.y * DP * DP) + (size_t)w * 16;
+      pay.c0 = (is_leaf && lt0.x >= 0) ? a.gcnt[lt0.y + code[0][0]] : 0;
+      pay.c1 = (is_leaf && lt1.x >= 0) ? a.gcnt[lt1.y + code[1][0]] : 0;
+    }
     const double *bfr = a.Pfrag + ((size_t)op.z * NW + w) * TILE;       // uniform (internal entries)
     constexpr int NLOADS = G * T * 2;  // gather loads of a leaf group (<= 8)
 #pragma unroll
@@ -252,6 +277,7 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
   auto arrive = [](const Payload &q) {
     asm volatile("" ::"v"(q.v[0]), "v"(q.v[1]), "v"(q.v[2]), "v"(q.v[3]), "v"(q.v[4]), "v"(q.v[5]), "v"(q.v[6]),
                  "v"(q.v[7]));
+    if constexpr (REP) asm volatile("" ::"v"(q.c0), "v"(q.c1));
   };
 
   f64x4 acc[T];  // this wave's 16 parent states x 16 sites running product
@@ -354,6 +380,7 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
             acc[t] *= two ? m : (f64x4){1., 1., 1., 1.};
           }
         }
+        if constexpr (REP) cnt[0] += (nl > 0 ? pay.c0 : 0) + (nl > 1 ? pay.c1 : 0);
       } else {
         // slow path: some leaf of the group carries ambiguity codes.  Tiles containing one take the
         // full product with the resolution vector as B operand (operands streamed, not staged).
@@ -501,6 +528,18 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
       const double *dep = a.deposits + ((size_t)child * a.ntiles + tile) * TILE + (size_t)w * 256;             // uniform
       const double *b0 = is_leaf ? a.PTg + ((size_t)leaf0 * DP * NW + w) * 16 : dep;                         // uniform
       const double *b1 = is_leaf ? a.PTg + ((size_t)leaf1 * DP * NW + w) * 16 : dep;                         // uniform
+      [[maybe_unused]] int gc = 0;  // (REP) exponents of the class-table rows of the entry's generalised leaves
+      if constexpr (REP) {
+        if (is_leaf) {
+          int2 lt0 = a.leaf_tab[leaf0], lt1 = a.leaf_tab[leaf1];
+          lt0.x = __builtin_amdgcn_readfirstlane(lt0.x), lt0.y = __builtin_amdgcn_readfirstlane(lt0.y);
+          lt1.x = __builtin_amdgcn_readfirstlane(lt1.x), lt1.y = __builtin_amdgcn_readfirstlane(lt1.y);
+          b0 = (lt0.x >= 0 ? a.gtab + (size_t)lt0.x * DP : a.PTg + (size_t)lt0.y * DP * DP) + (size_t)w * 16;
+          b1 = (lt1.x >= 0 ? a.gtab + (size_t)lt1.x * DP : a.PTg + (size_t)lt1.y * DP * DP) + (size_t)w * 16;
+          if (lt0.x >= 0 && nl > 0) gc += a.gcnt[lt0.y + (c0 < 0 ? 0 : c0)];
+          if (lt1.x >= 0 && nl > 1) gc += a.gcnt[lt1.y + (c1 < 0 ? 0 : c1)];
+        }
+      }
       const unsigned g0 = (unsigned)((c0 < 0 ? 0 : c0) * NW * 16 + g * 4) * 8u, g1 = (unsigned)((c1 < 0 ? 0 : c1) * NW * 16 + g * 4) * 8u;
       const unsigned o0 = is_leaf ? g0 : (unsigned)lane * 16u, o0b = is_leaf ? g0 + 16u : (unsigned)(64 + lane) * 16u;
       const unsigned o1 = is_leaf ? g1 : (unsigned)lane * 16u, o1b = is_leaf ? g1 + 16u : (unsigned)(64 + lane) * 16u;
@@ -509,6 +548,7 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
       it.v[2] = ld16_agent(b1, o1);
       it.v[3] = ld16_agent(b1, o1b);
       it.cnt = __hip_atomic_load(a.hand_cnt + ((size_t)child * a.ntiles + tile) * 32 + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (REP) it.cnt = is_leaf ? gc : it.cnt;
     };
     Payload pimg;
 #ifdef HYPHY_TRUNK_PRIO
@@ -596,6 +636,7 @@ __global__ __launch_bounds__(64 * NW, (T == 1 ? HYPHY_OCC : 1)) void prune_mfma_
           if (!slow) {
             if (nl > 0) acc[0] *= (f64x4){it.v[0][0], it.v[0][1], it.v[1][0], it.v[1][1]};
             if (nl > 1) acc[0] *= (f64x4){it.v[2][0], it.v[2][1], it.v[3][0], it.v[3][1]};
+            if constexpr (REP) cnt[0] += it.cnt;
           } else {  // ambiguity codes in this tile: product with the resolution vectors
             const int leaf = o.z & 0xffff;
             const int cd = leaf_code(leaf, 0);
@@ -2125,6 +2166,19 @@ void launch_prune_T(const PruneArgs &a, hipStream_t stream) {
     else hipLaunchKernelGGL((prune_wave_kernel<NW, 2, CLDS>), gridw, block1, lds1, stream, a.ops, a.prog, a.jn, a);
     return;
   }
+  if (a.leaf_tab && a.variant != 1) {  // the trunk of a class-compressed partition under the row-split workgroup kernel (r06)
+    if constexpr (NW == 4 && CLDS) {
+      if (a.T == 1 && a.chain) {
+        hipLaunchKernelGGL((prune_mfma_kernel<4, 1, true, false, 0, true, false, true>), grid, block, lds, stream, a.ops, a);
+        return;
+      }
+      if (a.T == 1) {
+        hipLaunchKernelGGL((prune_mfma_kernel<4, 1, true, false, 0, false, false, true>), grid, block, lds, stream, a.ops, a);
+        return;
+      }
+    }
+    return;  // (no other form of this mode exists: the tuner only offers the two above)
+  }
   if (a.variant == 2 && a.chain && a.T == 1) {  // row-split workgroups on a chain schedule: grid = (tiles, classes, sources)
     if constexpr (NW == 4 && CLDS) {
       if (a.red_out) {
@@ -2357,6 +2411,7 @@ bool prune_fuses_reduce(const PruneArgs &a) {
   // (not the wave-per-tile kernel: at 231 VGPRs the combine's registers push 15 spill instructions into its main loop —
   //  what the fusion saves on a small shard, the spills cost)
   if (a.NW != 4 || !a.codes_in_lds || a.T != 1 || a.timeline || a.ablate) return false;
+  if (a.leaf_tab) return false;  // (the trunk of a class-compressed partition: its instantiations carry no fused combine)
   return a.variant == 0 || (a.variant == 2 && a.chain);
 }
 

@@ -1437,6 +1437,16 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
   ms.tuned_for = 0;
   ms.rr_path.clear();
   ms.rr_cands.clear();
+  // (r06: the trunk under the row-split workgroup kernel, prune_mfma_kernel<.., REP> — the tuner offers it on shards below eight tiles
+  //  per CU; HYPHY_HIP_TRUNK_KERNEL=0 / 2 forces it — whole trunk per workgroup / on chain schedules — for tests and A/B runs)
+  if (const char *tk = getenv("HYPHY_HIP_TRUNK_KERNEL")) {
+    const int kv = atoi(tk);
+    const hyphy_hip_partition::View &tv = p->views[1];
+    if ((kv == 0 || kv == 2) && p->NW == 4 && !p->nuc && (size_t)tv.L * 32 + (size_t)(tv.L + tv.I) * 16 <= 24576) {
+      ms.variant = kv;
+      ms.n_slots = lds_slots(1);
+    }
+  }
   if (p->C == 1 && !p->nuc) {  // the trunk's own height-minimising roots (the tuner's third stage times the re-rooted schedules)
     const int mode0 = p->mode;
     std::vector<int> path0;

@@ -158,6 +158,15 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   if (((forced < 0 && medium && team_on) || forced == 2) && T0 == 1)
     for (int m : {3, 5, 8, 12, 16, 24})
       if (m < I) stage1.push_back({2, m, 0, -1});
+  // r06: the trunk of a class-compressed partition under row-split workgroups (prune_mfma_kernel<.., REP>): a trunk is a handful of
+  // nodes, its launch is bound by a tile's critical path — a team's edge product is a quarter of a wave's
+  const bool rep_team_on = !(getenv("HYPHY_HIP_TRUNK_TEAM") && atoi(getenv("HYPHY_HIP_TRUNK_TEAM")) == 0);  // (per call: tests run both)
+  if (p->mode == 1 && forced == 1 && rep_team_on && T0 == 1 && p->NW == 4 && s.ntiles < 8 * s.cus &&
+      (size_t)p->vw().L * 32 + (size_t)(p->vw().L + p->vw().I) * 16 <= 24576) {
+    stage1.push_back({0, 0, 0, -1});
+    for (int m : {1, 2, 3, 5, 8})
+      if (m < I) stage1.push_back({2, m, 0, -1});
+  }
   std::vector<std::pair<double, int>> ranked[3];  // per kernel: (time, cut) of the chain schedules
   for (const Cand &c : stage1) {
     const double t = time_it(c);

@@ -99,6 +99,48 @@ def test_row_split_walk_equals_one_wave_walk(name, rho, inline, monkeypatch):
     assert np.array_equal(got["1"][2], got["0"][2]) or name.endswith("deep")   # (exponents may split differently only where a total sits on the threshold)
 
 
+@pytest.mark.parametrize("kernel,m", [("2", "3"), ("2", "1"), ("0", None)])
+@pytest.mark.parametrize("name", ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "ref_smallcodon"])
+def test_trunk_under_row_split_workgroups(name, kernel, m, monkeypatch):
+    """r06: the trunk of a class-compressed partition under prune_mfma_kernel<.., REP> (generalised leaves gathered by class id, their
+    exponents added) — on chain schedules (kernel 2) and one workgroup per tile (kernel 0) — against the wave-per-tile trunk, the
+    plain form and the reference; first (persisting) pass and lazy steady state."""
+    monkeypatch.setenv("HYPHY_HIP_REPEATS", "2")
+    monkeypatch.setenv("HYPHY_HIP_REP_THETA", "0.9")
+    monkeypatch.setenv("HYPHY_HIP_POISON", "1")
+    fx = common.load(name)
+    Q = common.fixture_Q(fx)
+    nodes = common.all_nodes(fx)
+    got = {}
+    for form in ("team", "wave"):
+        if form == "team":
+            monkeypatch.setenv("HYPHY_HIP_TRUNK_KERNEL", kernel)
+            if m:
+                monkeypatch.setenv("HYPHY_HIP_CHAIN_M", m)
+            else:
+                monkeypatch.setenv("HYPHY_HIP_TUNE", "0")
+        else:
+            monkeypatch.delenv("HYPHY_HIP_TRUNK_KERNEL")
+            monkeypatch.delenv("HYPHY_HIP_CHAIN_M", raising=False)
+            monkeypatch.setenv("HYPHY_HIP_TUNE", "0")   # (the tuner would offer — and on shards this small pick, or take from its cache — the
+                                                        #  row-split form: without it the trunk stays with the wave-per-tile kernel)
+        with _mk(fx) as part:
+            assert part.repeat_stats()["in_use"] == 1
+            for _ in range(3):
+                ll, lik, sc = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+            got[form] = (ll, _site(lik, sc), part.prune_kernel_name())
+            part.set_repeats(False)
+            ll0, lik0, sc0 = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+            got[form + "_plain"] = (ll0, _site(lik0, sc0))
+    assert got["team"][2] == "prune_mfma_kernel" and got["wave"][2] == "prune_wave_kernel", (got["team"][2], got["wave"][2])
+    ref = float(fx["logl"])
+    for k in ("team", "wave"):
+        assert abs(got[k][0] - ref) <= RTOL * abs(ref), (k, got[k][0], ref)
+        assert np.max(np.abs(got[k][1][fx["site_to_pattern"]] - fx["site_logl"]) / np.abs(fx["site_logl"])) < RTOL
+    assert np.max(np.abs(got["team"][1] - got["wave"][1]) / np.abs(got["wave"][1])) < SAME
+    assert np.max(np.abs(got["team"][1] - got["team_plain"][1]) / np.abs(got["team_plain"][1])) < SAME
+
+
 @pytest.mark.parametrize("seed,taxa,D", [(1, 40, 61), (2, 33, 61), (3, 24, 20), (4, 17, 48), (5, 30, 5)])
 def test_random_trees_and_state_counts_against_the_oracle(seed, taxa, D, monkeypatch):
     """Random trees (multifurcating root), random ambiguity codes, 61 / 48 / 20 / 5 states (NW = 4, 3, 2, 1 row blocks), enough
