@@ -41,6 +41,27 @@ extern "C" {
 
 typedef struct hyphy_hip_partition hyphy_hip_partition; /* device-side state of ONE (filter, tree) partition */
 
+/*
+ * Environment switches.  A host integrator needs at most these TEN; the library works without any of them:
+ *   HYPHY_HIP_VERBOSE=1           what was decided and why (schedule tuner, subtree repeats on / off, generated kernels) on stderr
+ *   HYPHY_HIP_POOL_MB=n           device / pinned blocks of destroyed partitions kept for the next one of the same shape (MiB per kind,
+ *                                 default 1024; 0: nothing is kept)
+ *   HYPHY_HIP_CACHE=always        every pass stores every node's conditionals (default: lazy persistence, see hyphy_hip_download_partials)
+ *   HYPHY_HIP_TUNE=0              no run-time schedule measurement (with HYPHY_HIP_CUT=levels: bit-identical repeats, see below)
+ *   HYPHY_HIP_CUT=levels          fixed multiplication order, no arrival-order joins
+ *   HYPHY_HIP_REPEATS=0|1         subtree repeats (the reference's `tcc`) never / always, instead of decided by measurement
+ *   HYPHY_HIP_NUCGEN=0|2          4 states: never generate straight-line kernels / compile them synchronously at the first full pass
+ *   HYPHY_HIP_NUCGEN_AFTER=n      ... evaluations under one schedule before its kernel is compiled in the background (default 8)
+ *   HYPHY_HIP_COMBINE=rccl        one process, several devices: sum the shard partials by one RCCL group all-reduce instead of on the host
+ *   HYPHY_HIP_EXCHANGE_TIMEOUT_S  one process per GPU, host-side exchange: how long a rank waits for the others (default 120)
+ * Everything else that starts with HYPHY_HIP_ (about forty names: HYPHY_HIP_KERNEL, _CHAIN_M, _WAVE_VARIANT, _SLOTS, _REROOT, _FRAGMENT,
+ * _TILES, _REP_*, _TRUNK_*, _NUC*, _EXPM*, _FUSED_REDUCE, _SITE_EXPORT, _SPIN, _XCD_PAD, _TIMELINE, _ABLATE, _POISON, _TRACE, ...) is a
+ * DIAGNOSTIC of the kernels' authors: it forces one of the forms the tuner chooses between, turns a mechanism off for an A/B run or
+ * writes a trace.  The tests use them to reach every form; a host should not.  (The adapter of INTEGRATION.md has a handful of its own:
+ * HYPHY_HIP=1 turns it on, HYPHY_HIP_DEVICE(S), HYPHY_HIP_WORLD / _RANK / _LOCAL_RANK / _RUN_ID / _UID_FILE / _COLLECTIVE for one
+ * process per GPU, HYPHY_HIP_DEVICE_EXPM, HYPHY_HIP_TEMPLATES, HYPHY_HIP_MIXTURES, HYPHY_HIP_CAT_BATCH.)
+ */
+
 /* Number of usable gfx950 devices (0 if none / no HIP runtime). */
 int hyphy_hip_device_count(void);
 

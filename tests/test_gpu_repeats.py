@@ -73,7 +73,7 @@ def test_compressed_equals_plain_and_reference(name, rho, inline, levels, monkey
 def test_row_split_walk_equals_one_wave_walk(name, rho, inline, monkeypatch):
     """r06: static lower-phase launches walk a path with a workgroup of NW row-split waves (class_table_team_kernel, the default);
     HYPHY_HIP_REP_TEAM=0 keeps the one-wave walk of r05 (class_table_kernel).  Same tables, same exponents: per-pattern values of the
-    two forms agree to rounding (the team adds even and odd k-steps in two accumulator chains), both equal the reference's."""
+    two forms agree to rounding (the rescale is applied on the other side of the product), both equal the reference's."""
     monkeypatch.setenv("HYPHY_HIP_REPEATS", "2")
     monkeypatch.setenv("HYPHY_HIP_REP_INLINE", inline)
     monkeypatch.setenv("HYPHY_HIP_REP_RHO", rho)

@@ -10,7 +10,7 @@
 #   adapter_rate.jsonl       evaluations per second through the real host (tools/adapter_rate.py)
 #   phases_*.txt             where a wave's cycles go (trace build of the wave kernel, tools/timeline_waves.py)
 #   ubench_*.txt             instruction / edge-product / edge+leaf microbenchmarks (tools/ubench)
-R=${1:-r05}; PARTS=${2:-all}
+R=${1:-r06}; PARTS=${2:-all}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
 has() { [ "$PARTS" = all ] || echo "$PARTS" | grep -qw "$1"; }
@@ -48,6 +48,10 @@ fi
 cd /tmp && export TMPDIR=/tmp
 if has stats; then
   HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=8 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > $OUT/stats.log 2>&1
+  # 4 states (r06): the run-time generated kernel (nucgen_kernel) in steady state; bench.py waits for it before anything is timed
+  for wl in gtr_32x1m gtr_32x50k; do
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > $OUT/stats_$wl.log 2>&1
+  done
 fi
 pmc() { wl=$1; shift
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
@@ -68,14 +72,26 @@ fi
 cd $GRAFT_REPO_ROOT
 if has adapter; then timeout 1500 python tools/adapter_rate.py headline,class2,cat3,mix3,manylf 10000 400 2>/dev/null > $OUT/adapter_rate.jsonl; fi
 if has phases; then
-  for spec in "mg94_64x10k 12 624" "mg94_128x100k 40 6250" "mg94_64x2500 8 157"; do
+  # r06: the kernels the headline RUNS — the trunk of the class-compressed form (prune_wave_kernel<.., REP>, trace build) and the lower
+  # phase (class_table_team_kernel, trace build: one record per workgroup) — then the plain form for reference
+  for spec in "mg94_64x10k 8 624" "mg94_128x100k 16 6250"; do
     set -- $spec
-    HYPHY_HIP_CHAIN_M=$2 HYPHY_HIP_TIMELINE=$OUT/tl_$1.txt timeout 300 python bench.py --workload $1 --steps 3 --warmup 3 --no-cpu-baseline --no-traffic > /dev/null 2>&1
-    (echo "# $1, chain cut m = $2, trace build of prune_wave_kernel (HYPHY_HIP_TIMELINE; every stamp is an s_memtime + lgkmcnt(0): ~25 % slower than production)"; python tools/timeline_waves.py $OUT/tl_$1.txt $3) > $OUT/phases_$1.txt
+    HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=$2 HYPHY_HIP_TIMELINE=$OUT/tl_$1.txt timeout 300 python bench.py --workload $1 --steps 3 --warmup 3 --no-cpu-baseline --no-traffic > /dev/null 2>&1
+    (echo "# $1, TRUNK of the class-compressed form (HYPHY_HIP_REPEATS=1), chain cut m = $2, trace build of prune_wave_kernel<.., REP> (HYPHY_HIP_TIMELINE; every stamp is an s_memtime + lgkmcnt(0): ~10-25 % slower than production)"; python tools/timeline_waves.py $OUT/tl_$1.txt $3) > $OUT/phases_a_trunk_$1.txt
     rm -f $OUT/tl_$1.txt
+    HYPHY_HIP_REPEATS=1 HYPHY_HIP_REP_TIMELINE=$OUT/tlr_$1.txt timeout 300 python bench.py --workload $1 --steps 3 --warmup 3 --no-cpu-baseline --no-traffic > /dev/null 2>&1
+    (echo "# $1, LOWER PHASE of the class-compressed form: class_table_team_kernel, trace build (HYPHY_HIP_REP_TIMELINE; the last level's launch when the pass has several)"; python tools/rep_team_timeline.py $OUT/tlr_$1.txt) > $OUT/phases_b_lower_$1.txt
+    rm -f $OUT/tlr_$1.txt
   done
+  HYPHY_HIP_CHAIN_M=12 HYPHY_HIP_TIMELINE=$OUT/tl_plain.txt timeout 300 python bench.py --workload mg94_64x10k --steps 3 --warmup 3 --no-cpu-baseline --no-traffic > /dev/null 2>&1
+  (echo "# mg94_64x10k, PLAIN form (every node at every pattern; what r04 ran), chain cut m = 12, trace build of prune_wave_kernel"; python tools/timeline_waves.py $OUT/tl_plain.txt 624) > $OUT/phases_c_plain_mg94_64x10k.txt
+  rm -f $OUT/tl_plain.txt
 fi
 if has ubench; then
   (cd tools/ubench && OLD_ONLY=1 ./mfma4_skew > $OUT/ubench_agpr_vs_vgpr.txt 2>&1; ./mfma4_skew > $OUT/ubench_edge_product.txt 2>&1; ./overlap_probe > $OUT/ubench_edge_plus_leaf.txt 2>&1)
 fi
 find $OUT -name "*.csv" | wc -l
+# the raw counter / trace files are tens of MiB: summarise HERE and keep the summaries only (gpurun_out/ travels back up to 64 MiB)
+python tools/summarize_profiles.py $OUT $R $OUT/summary > $OUT/summary.log 2>&1
+rm -rf $OUT/pmc_* $OUT/stats $OUT/stats_gtr_32x1m $OUT/stats_gtr_32x50k
+cat $OUT/summary.log | tail -12

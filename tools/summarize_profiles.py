@@ -1,12 +1,14 @@
 """Turn a tools/profile_round.sh output directory (gpurun_out/<tag>) into the committed summaries under profiles/: the driver's
 bench line, the per-workload table, rocprofv3 kernel stats, per-workload / per-kernel PMC medians, HBM traffic of the dominant kernel
 ((2*FETCH_SIZE + WRITE_SIZE) KB, MI355X_MICROARCH.md HBM section), MFMA-pipe utilisation and instruction mix of the pruning kernel,
-the wave-cycle breakdown of the 4-state kernel, adapter rates, phase budgets.  Usage: python tools/summarize_profiles.py gpurun_out/r04 r04"""
+the wave-cycle breakdown of the 4-state kernel, adapter rates, phase budgets.  Usage: python tools/summarize_profiles.py gpurun_out/r06 r06 [out dir]
+(tools/profile_round.sh runs it on the GPU box into gpurun_out/<tag>/summary and deletes the raw counter files: they exceed what travels back)"""
 import collections, csv, glob, json, os, re, shutil, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = os.path.join(ROOT, "profiles")
+out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")   # (on the GPU box: a directory under gpurun_out/, copied to profiles/ here)
+os.makedirs(out, exist_ok=True)
 
 
 def kname(full):
@@ -30,6 +32,10 @@ for f, dst in (("bench_driver_line.json", f"{tag}_bench_driver_line.json"), ("al
 st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if st:
     shutil.copy(st[0], os.path.join(out, f"{tag}_rocprofv3_kernel_stats.csv"))
+for wl in ("gtr_32x1m", "gtr_32x50k"):
+    st = glob.glob(os.path.join(src, f"stats_{wl}", "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        shutil.copy(st[0], os.path.join(out, f"{tag}_rocprofv3_kernel_stats_{wl}.csv"))
 ph = sorted(glob.glob(os.path.join(src, "phases_*.txt")))
 if ph:
     with open(os.path.join(out, f"{tag}_wave_phase_budget.txt"), "w") as fh:
@@ -48,12 +54,14 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     # times the launches per evaluation, so that every entry of the class kernel is per EVALUATION like the trunk's
     means_all[wl] = {k: {c: med(v) for c, v in dd.items()} for k, dd in acc.items()}
     n_trunk = max((len(v) for v in acc.get("prune_wave_kernel", {}).values()), default=0)
-    n_class = max((len(v) for v in acc.get("class_table_kernel", {}).values()), default=0)
+    # (r06: the lower phase is class_table_team_kernel — a workgroup of row-split waves per item — unless HYPHY_HIP_REP_TEAM=0)
+    lower = "class_table_team_kernel" if "class_table_team_kernel" in acc else "class_table_kernel"
+    n_class = max((len(v) for v in acc.get(lower, {}).values()), default=0)
     if n_trunk and n_class > 1.2 * n_trunk:
         per_eval = round(n_class / n_trunk)
-        means_all[wl]["class_table_kernel"] = {c: per_eval * sum(v[len(v) // 2 // per_eval * per_eval:]) / max(1, len(v[len(v) // 2 // per_eval * per_eval:]))
-                                               for c, v in acc["class_table_kernel"].items()}
-        means_all[wl]["class_table_kernel"]["launches_per_evaluation"] = per_eval
+        means_all[wl][lower] = {c: per_eval * sum(v[len(v) // 2 // per_eval * per_eval:]) / max(1, len(v[len(v) // 2 // per_eval * per_eval:]))
+                                for c, v in acc[lower].items()}
+        means_all[wl][lower]["launches_per_evaluation"] = per_eval
     wj = os.path.join(src, f"wl_{wl}.json")
     if os.path.exists(wj):
         b = last_json(wj)
@@ -76,7 +84,7 @@ if means_all:
 if traffic:
     old = {}
     try:
-        old = json.load(open(os.path.join(out, "pmc_traffic.json")))
+        old = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
         pass
     old.update(traffic)
@@ -113,13 +121,16 @@ for wl in ("mg94_64x10k", "mg94_128x100k"):
                   "mfma_pipe_busy_fraction (counter: 64 cycles per v_mfma_f64_16x16x4_f64)": pm["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles),
                   "mfma_instruction": "v_mfma_f64_16x16x4_f64 only (VGPR accumulators; tools/ubench/mfma4_skew.hip: 66-72 TFLOP/s with the kernel's operand stream)",
                   "LDS_bank_conflict_cycles": pm.get("SQ_LDS_BANK_CONFLICT")})
-        pc = means_all.get(wl, {}).get("class_table_kernel", {})
+        lower = "class_table_team_kernel" if "class_table_team_kernel" in means_all.get(wl, {}) else "class_table_kernel"
+        pc = means_all.get(wl, {}).get(lower, {})
         if "SQ_INSTS_MFMA" in pc:   # subtree repeats: the lower phase is a launch of its own
             uc = wave_cycle_table(pc)
             cyc = pc["GRBM_GUI_ACTIVE"] / 8.0
             uc.update({"SQ_INSTS_MFMA": pc["SQ_INSTS_MFMA"], "SQ_VALU_MFMA_BUSY_CYCLES": pc.get("SQ_VALU_MFMA_BUSY_CYCLES"),
                        "mfma_pipe_busy_fraction (counter: 64 cycles per v_mfma_f64_16x16x4_f64)": pc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cyc) if cyc else None})
-            u = {"prune_wave_kernel (trunk)": u, "class_table_kernel (lower phase)": uc,
+            u = {"method": "counters only: SQ_VALU_MFMA_BUSY_CYCLES / (1 024 SIMDs x GRBM_GUI_ACTIVE / 8), collected in passes of their own "
+                           "(profiled launches run a few per cent slower than production: compare fractions, not microseconds)",
+                 "prune_wave_kernel (trunk)": u, lower + " (lower phase)": uc,
                  "SQ_INSTS_MFMA_per_evaluation": pm.get("SQ_INSTS_MFMA", 0.0) + pc["SQ_INSTS_MFMA"],
                  "SQ_INSTS_MFMA_per_evaluation_without_repeats (r04, every internal edge at every pattern)": 2436096 if wl == "mg94_64x10k" else None,
                  "mfma_pipe_busy_fraction (counter: 64 cycles per v_mfma_f64_16x16x4_f64)":
@@ -132,12 +143,13 @@ if util:
     json.dump(util, open(os.path.join(out, f"{tag}_mfma_utilisation.json"), "w"), indent=1, sort_keys=True)
 nuc = {}
 for wl in ("gtr_32x1m", "gtr_32x50k"):
-    pm = means_all.get(wl, {}).get("prune_nuc2_kernel", {})
-    if "SQ_WAVE_CYCLES" in pm:
-        nuc[wl] = wave_cycle_table(pm)
-        if wl in traffic:
-            nuc[wl]["hbm_traffic"] = traffic[wl]
+    for kern in ("nucgen_kernel", "prune_nuc2_kernel"):   # (r06: the run-time generated kernel once it is compiled, the interpreter before)
+        pm = means_all.get(wl, {}).get(kern, {})
+        if "SQ_WAVE_CYCLES" in pm:
+            nuc.setdefault(wl, {})[kern] = wave_cycle_table(pm)
+    if wl in traffic and wl in nuc:
+        nuc[wl]["hbm_traffic"] = traffic[wl]
 if nuc:
-    json.dump(nuc, open(os.path.join(out, f"{tag}_nuc2_wave_cycles.json"), "w"), indent=1, sort_keys=True)
+    json.dump(nuc, open(os.path.join(out, f"{tag}_nuc_wave_cycles.json"), "w"), indent=1, sort_keys=True)
 for f, dst in (("ubench_agpr_vs_vgpr.txt", None), ("ubench_edge_product.txt", None), ("ubench_edge_plus_leaf.txt", None)):
     pass  # (the microbenchmark outputs are committed by hand with their headers: profiles/r04_ubench_*.txt)
