@@ -27,7 +27,7 @@ void free_shard(Shard &s) {
                  s.weights, s.templates, s.templates_pad, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.pi_ones, s.codes_tile,
                  s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.mix_q, s.mix_p, s.mix_w, s.mix_off, s.ar_buf, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops, s.rep_tab, s.rep_cnt, s.rep_map, s.rep_desc, s.rep_sync,
-                 s.rep_codes_tile, s.rep_leaf, s.d_inv};
+                 s.rep_codes_tile, s.rep_leaf, s.rep_walk, s.d_inv};
   for (void *d : dev)
     if (d) pool_free(d);  // (the stream was synchronised above)
   void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn, s.h_tstage, s.h_site, s.h_export};
@@ -512,12 +512,19 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       pa.red_n = n_wg;
     }
     double *const red_out = pa.red_out;
+    if (trunk_walk_applies(p, s) && !pa.timeline && n_ops > 0) {
+      // (repeats.hip) the trunk of a class-compressed partition, lazy full pass: one row-split walk per tile instead of the schedule
+      if (launch_trunk_walk(p, s, cat, n_cat_batch, true)) return -1;
+      s.last_walk = true;
+    } else {
+    s.last_walk = false;
     for (size_t lv = 0; lv < p->levels.size(); lv++) {  // one launch per level of subtree fragments
       pa.prog = s.prog + p->levels[lv].first;
       pa.n_prog = p->levels[lv].count;
       pa.do_root = (lv + 1 == p->levels.size()) ? 1 : 0;
       pa.red_out = pa.do_root ? red_out : nullptr;
       launch_prune_mfma(pa, s.stream);
+    }
     }
     if (pa.timeline) {  // tracing only: synchronous dump of the per-entry s_memtime stamps
       std::vector<long long> h(tl_n);
@@ -804,6 +811,7 @@ const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p) {
   if (!p) return "";
   if (p->nuc && !p->shards.empty() && p->shards[0].last_nucgen) return "nucgen_kernel";  // (run-time generated, nucgen.hip)
   if (p->nuc) return (p->nuc_leaf_pairs && p->mode == 0) ? "prune_nuc2_kernel" : "prune_nuc_kernel";
+  if (p->mode == 1 && !p->shards.empty() && p->shards[0].last_walk) return "trunk_walk_kernel";  // (repeats.hip)
   return p->variant == 1 ? "prune_wave_kernel" : "prune_mfma_kernel";  // (variant 2: the same kernel on a chain schedule)
 }
 

@@ -11,6 +11,16 @@ __device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (vmcnt(0)), i.e. it would stall every node on the operand prefetch issued for the next
+// schedule entry and on the fire-and-forget persist stores; nothing exchanged between the waves of
+// a workgroup inside the walks goes through global memory (except OP_GSYNC entries of the pruning kernels).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // Decide the power-of-2^64 rescale for a site whose conditional vector sums to `tot`
 // (__ll_loop_handle_scaling tree_evaluator.cpp:410-525, _computeBoostScaler /
 // _computeReductionScaler tree.cpp:160-202).  Returns the exponent change m (true value =

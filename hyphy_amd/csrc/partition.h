@@ -231,10 +231,13 @@ struct Shard {
   int *rep_sync = nullptr;           // queue heads, exit counter, per (class, descriptor) finished tiles (zero between launches)
   int16_t *rep_codes_tile = nullptr; // [tile][view leaves][16] leaf table of the trunk: state codes / class ids of generalised leaves
   int2 *rep_leaf = nullptr;          // [view leaves] (table row0 or -1: ordinary leaf, exponent row0 / matrix slot)
+  int4 *rep_walk = nullptr;          // the trunk as ONE post-order walk per tile (repeats.hip: trunk_walk_kernel), or nullptr
+  std::vector<int2> rep_leaf_host;   // host copy of rep_leaf (the walk's program carries it)
   int rep_qcap = 0;                  // items per queue of the pass the device queues hold
   int rep_waves = 0;                 // waves its launch runs
   std::vector<RepLaunch> rep_launches; // non-empty: the pass runs one launch per level of table-reads-table dependencies
   int rep_static = 0;                // > 0: its items do not depend on one another and are dealt by position (RepArgs::n_static)
+  bool last_walk = false;            // the last trunk pass ran trunk_walk_kernel (hyphy_hip_prune_kernel_name)
   bool last_nucgen = false;          // the last 4-state pruning launch ran a generated kernel (hyphy_hip_prune_kernel_name)
   bool rep_team = false;             // its static launches run the row-split walk (class_table_team_kernel), one workgroup per item
   bool rep_sync_dirty = false;       // a lower-phase launch has run and no trunk launch has reset rep_sync behind it yet
@@ -266,7 +269,7 @@ struct hyphy_hip_partition {
   const View &vw() const { return views[mode]; }
   struct ModeState {                         // what the tuner / re-rooting decided, per view
     int variant = 0, wave_variant = 0, n_slots = 0, chain_m_forced = 0;
-    bool rr_use = false, kernel_forced = false, nuc_leaf_pairs = false;
+    bool rr_use = false, kernel_forced = false, nuc_leaf_pairs = false, trunk_walk = false;
     int64_t tuned_for = 0;
     std::string tune_report;
     std::vector<int> rr_path;
@@ -333,6 +336,8 @@ struct hyphy_hip_partition {
   std::vector<int64_t> bc_node;              // per rate class: branch whose outside vector is resident (-1: none)
   std::vector<int> bc_use_pi;                // ... hangs off the root (frequencies applied at evaluation)
   int variant = 0;                           // pruning kernel variant (common.h PruneArgs::variant)
+  bool trunk_walk = false;                   // (views[1]) lazy full passes of the trunk run trunk_walk_kernel; `variant` (0) serves the rest
+  std::vector<int4> rep_walk_host;           // its program (empty: the trunk is deeper than the walk's stack, or has too many leaves)
   int n_slots = 0;                           // LDS slots the schedules are compiled for (0: lds_slots(T))
   struct Prog { int off, n, parent = -1, need = 0; };
   bool chain = false;                        // the current schedule is a chain schedule (common.h PruneArgs::chain)
@@ -417,6 +422,10 @@ void switch_mode(hyphy_hip_partition *p, int mode);
 int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_t n_update, const int64_t *q_nodes, int64_t n_q, bool full,
                      int cat0, int n_classes, std::vector<int64_t> &view_update);
 int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0);
+// the trunk's lazy full pass as one row-split walk per tile (trunk_walk_kernel); false: not applicable to this pass — the caller runs the
+// pruning kernels.  `timeline`: HYPHY_HIP_WALK_TIMELINE diagnostics allowed (evaluations, not the tuner's passes)
+bool trunk_walk_applies(const hyphy_hip_partition *p, const Shard &s);
+int launch_trunk_walk(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, bool timeline);
 int rep_decide(hyphy_hip_partition *p, int cat, int n_classes);
 bool rep_static_decision(const hyphy_hip_partition *p);  // on / off without a measurement (tuner disabled, forced cut)
 size_t rep_sync_words(const hyphy_hip_partition *p);

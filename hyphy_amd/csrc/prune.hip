@@ -31,16 +31,6 @@ namespace hyhip {
 
 namespace {
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
-// counter (vmcnt(0)), i.e. it would stall every node on the operand prefetch issued for the next
-// schedule entry and on the fire-and-forget persist stores; nothing exchanged between the waves of
-// a workgroup inside this kernel goes through global memory (except OP_GSYNC entries).
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
 // A root-finalising wave's share of the log-likelihood sum (all 64 lanes active, values wave-uniform): entry `idx` of the
 // per-tile partial sums.  PruneArgs::red_out == nullptr: plain stores, wg_reduce_kernel combines them behind the launch.
 // Otherwise (r03, fused final combine) the partials go out with agent-scope stores, the wave arrives at red_done, and the

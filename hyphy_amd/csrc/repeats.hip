@@ -31,6 +31,7 @@
 // Hand-off of table rows between waves of the launch: 16-byte sc1 (write-through) stores -> asm "s_waitcnt vmcnt(0)" ->
 // relaxed agent-scope RMW on the node's counter; consumer: relaxed agent-scope load that proves the count -> sc1 loads (the
 // same contract as the chain joins of prune.hip).
+#include <functional>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void class_table_team_kernel(const in
           pf = true;
         }
       }
-      __syncthreads();
+      lds_barrier();  // (not __syncthreads(): that would also wait for the A chunks and the gather just requested; measured: no difference)
       double tot = psum[k & 1][0][sl];
 #pragma unroll
       for (int ww = 1; ww < NW; ww++) tot += psum[k & 1][ww][sl];
@@ -654,6 +655,274 @@ __global__ __launch_bounds__(64 * NW, OCC) void class_table_team_kernel(const in
       tr[2] = n_nodes;
       tr[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
       for (int i = 0; i < 16; i++) a.dbg[(size_t)blockIdx.x * 16 + i] = tr[i];
+    }
+  }
+}
+
+
+// The TRUNK under the row-split walk (r06): the rest of the tree — every node above the class tables, one value per PATTERN — walked by
+// the same workgroup of NW waves, one tile of 16 patterns each.  The wave-per-tile trunk (prune_wave_kernel<.., REP>) gives a tile three
+// waves that each issue 64 matrix instructions per edge product from one SIMD; here a product is split over the CU's four SIMDs and
+// crosses the LDS tile, exactly as in the class tables' walk.  A trunk is a tree, not a path: a node's second internal child starts a
+// new chain while the product walked so far waits — the inline side chains of the class tables (flags 1 / 2) nested, the waiting
+// products on a small register stack (kWalkDepth; deeper trunks keep the pruning kernels).  Generalised leaves are gathered exactly as
+// the pruning kernels' REP builds do (class id of the pattern -> row of the leaf's table, or the pattern's state -> column of the
+// leaf's matrix).  The root has no edge product: its conditionals meet the root frequencies, and wave 0 leaves the tile's per-pattern
+// values and its share of sum f log L (tree_evaluator.cpp:4046-4128, likefunc.cpp:11123) where the reduction kernel expects them.
+// TWO CHAINS per tile (grid.z) where tiles are scarce (the headline: 624 tiles on 256 CUs): the subtrees below the root are dealt to
+// two workgroups; each ends with the product of its subtrees' edge products, leaves it in memory (16-byte sc1 stores -> s_waitcnt
+// vmcnt(0) -> relaxed agent RMW on the tile's counter: the protocol of the pruning kernels' joins), and the one that arrives LAST
+// multiplies the other's in and finishes the root (two factors: the order of arrival does not change a bit).  Nobody waits.
+// Nothing is persisted: the launch serves full passes under lazy persistence (api.hip); everything else runs the pruning kernels on
+// the same view.
+// Program (int4 words, per shard; absolute word indices): [0] = (first word of the one-chain form, of the two-chain form or 0, 0, 0).
+// A form: (chains, 0, 0, 0), then per chain (first node word, nodes, 0, 0); node = (matrix slot of the node's branch or -1: the chain's
+// end at the root, leaf children, first input word, flags); input = (view leaf, first row of its table or -1: ordinary leaf, first
+// exponent row / matrix slot, 0).
+struct TrunkWalkArgs {
+  const double *Pfrag, *PTg;  // class 0 (blockIdx.y = rate class)
+  size_t cs_P;
+  const double *gtab;         // class tables, class 0
+  const int32_t *gcnt;
+  size_t cs_gtab, cs_gcnt;
+  const int16_t *codes_tile;  // [tile][view leaves][16]
+  int L;                      // view leaves
+  int form;                   // first word of the form in use
+  const double *pi;           // [DP]
+  double *site_lik;
+  int32_t *site_cnt;
+  size_t cs_site;
+  const double *freq;
+  double *wg_sum;
+  long long *wg_cnt;
+  int *wg_flag;
+  size_t cs_wg;
+  // two chains: products handed over at the root
+  double *deposits;           // [class][chain][tile][TILE]
+  size_t cs_deposits;
+  int32_t *hand_cnt;          // [class][chain][tile][16]
+  int *arrivals;              // [class][tile], zero between launches
+  int ntiles;
+  long long *dbg;             // diagnostic (HYPHY_HIP_WALK_TIMELINE): the lower phase's record per workgroup, or nullptr
+};
+constexpr int kWalkDepth = 3;
+
+template <int NW, bool TRACE = false, int AST = kRepAStages, int BST = kRepBStages>
+__global__ __launch_bounds__(64 * NW, 5) void trunk_walk_kernel(const int4 *__restrict__ walk, TrunkWalkArgs a) {
+  [[maybe_unused]] long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] long long tr_last = 0;
+  if constexpr (TRACE) {
+    tr[0] = wall_clock64();
+    tr_last = clock64();
+  }
+  constexpr int NKK = 4 * NW, DP = 16 * NW, TILE = NKK * 64, NS = NKK / 2;
+  constexpr int PF = AST < NS ? AST : NS;
+  __shared__ __align__(16) double bx[2 * TILE];
+  __shared__ double psum[2][NW][16];
+  __shared__ double epi[NW][16];
+  __shared__ int arrived;
+  extern __shared__ __align__(16) int16_t walk_codes[];  // [view leaves][16]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, sl = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x, chain = blockIdx.z;
+  const size_t cat = blockIdx.y;
+  {
+    const int *src = reinterpret_cast<const int *>(a.codes_tile + (size_t)tile * a.L * 16);
+    int *dst = reinterpret_cast<int *>(walk_codes);
+    for (int i = tid; i < a.L * 8; i += 64 * NW) dst[i] = src[i];
+  }
+  const int n_chains = walk[a.form].x;
+  const int4 ch = walk[a.form + 1 + chain];
+  const int node0 = ch.x, n_nodes = ch.y;
+  const f64x4 ones = (f64x4){1., 1., 1., 1.}, zeros = (f64x4){0., 0., 0., 0.};
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const double *const Pfrag = a.Pfrag + cat * a.cs_P, *const PTg = a.PTg + cat * a.cs_P, *const gtab = a.gtab + cat * a.cs_gtab;
+  const int32_t *const gcnt = a.gcnt + cat * a.cs_gcnt;
+  f64x4 acc = ones;
+  int cnt = 0;
+  auto a_rsrc = [&](int slot) { return agent_rsrc(Pfrag + ((size_t)slot * NW + w) * TILE); };
+  auto a_first = [&](__amdgpu_buffer_rsrc_t pfr, f64x2 (&A)[PF]) {
+#pragma unroll
+    for (int st = 0; st < PF; st++) A[st] = ld16_buf(pfr, lane16, (unsigned)(st * 128 * 8));
+  };
+  auto product = [&](__amdgpu_buffer_rsrc_t pfr, f64x2 (&A)[PF], const double *bb) {
+    constexpr int PB = BST < NS ? BST : NS;
+    f64x4 D0 = zeros;
+    f64x2 Bq[PB];
+#pragma unroll
+    for (int st = 0; st < PB; st++) Bq[st] = *reinterpret_cast<const f64x2 *>(bb + (st * 64 + lane) * 2);
+#pragma unroll
+    for (int k2 = 0; k2 < NS; k2++) {
+      const f64x2 Ac = A[k2 % PF], Bc = Bq[k2 % PB];
+      asm volatile("" ::"v"(Ac), "v"(Bc));
+      if (k2 + PF < NS) A[k2 % PF] = ld16_buf(pfr, lane16, (unsigned)((k2 + PF) * 128 * 8));
+      if (k2 + PB < NS) Bq[k2 % PB] = *reinterpret_cast<const f64x2 *>(bb + ((k2 + PB) * 64 + lane) * 2);
+      D0 = mfma(Ac[0], Bc[0], D0);
+      D0 = mfma(Ac[1], Bc[1], D0);
+    }
+    acc = D0;
+  };
+  __syncthreads();
+  REP_TR(4)
+  // this wave's share of a generalised leaf's columns for the tile's patterns, and their 2^64 exponents
+  auto gather = [&](const int4 &in, f64x2 (&v)[2], int &ec) {
+    const int idx = (int)walk_codes[in.x * 16 + sl];
+    const unsigned off = (unsigned)((idx * NW + w) * 16 + g * 4) * 8u;
+    ec = 0;
+    if (in.y >= 0) {
+      const double *src = gtab + (size_t)in.y * DP;  // uniform
+      v[0] = ld16(src, off), v[1] = ld16(src, off + 16u);
+      ec = gcnt[in.z + idx];
+    } else {
+      const double *src = PTg + (size_t)in.z * DP * DP;  // uniform
+      v[0] = ld16(src, off), v[1] = ld16(src, off + 16u);
+    }
+  };
+  f64x2 pv[2];  // the first input of the NEXT node, requested before this node's edge product
+  int pcnt = 0;
+  bool pf = false;
+  f64x4 pk0 = ones, pk1 = ones, pk2 = ones;  // products waiting for the chain walked for them
+  int pc0 = 0, pc1 = 0, pc2 = 0, depth = 0;
+  for (int k = 0; k < n_nodes; k++) {
+    const int4 ne = walk[node0 + k];
+    if (ne.w & 1) {
+      if (depth == 0) pk0 = acc, pc0 = cnt;
+      else if (depth == 1) pk1 = acc, pc1 = cnt;
+      else pk2 = acc, pc2 = cnt;
+      depth++;
+      cnt = 0;
+      acc = ones;
+    }
+    for (int j = 0; j < ne.y; j++) {
+      if (j == 0 && pf) {
+        acc *= (f64x4){pv[0][0], pv[0][1], pv[1][0], pv[1][1]};
+        cnt += pcnt;
+        continue;
+      }
+      f64x2 v[2];
+      int ec;
+      gather(walk[ne.z + j], v, ec);
+      acc *= (f64x4){v[0][0], v[0][1], v[1][0], v[1][1]};
+      cnt += ec;
+    }
+    if constexpr (TRACE) asm volatile("" ::"v"(acc[0]));
+    REP_TR(5)
+    if (ne.x < 0) break;  // the root: this chain's share of its conditionals is complete
+    double *bb = bx + (k & 1) * TILE;
+    *reinterpret_cast<f64x2 *>(bb + ((2 * w) * 64 + lane) * 2) = (f64x2){acc[0], acc[1]};
+    *reinterpret_cast<f64x2 *>(bb + ((2 * w + 1) * 64 + lane) * 2) = (f64x2){acc[2], acc[3]};
+    const double ps = row_sum4((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if (g == 0) psum[k & 1][w][sl] = ps;
+    const __amdgpu_buffer_rsrc_t pfr = a_rsrc(ne.x);
+    f64x2 A[PF];
+    a_first(pfr, A);
+    pf = false;
+    {
+      const int4 ne2 = walk[node0 + k + 1];  // (the chain's end at the root follows every other node)
+      if (ne2.y > 0) {
+        gather(walk[ne2.z], pv, pcnt);
+        pf = true;
+      }
+    }
+    lds_barrier();  // (not __syncthreads(): that would also wait for the A chunks and the columns just requested)
+    double tot = psum[k & 1][0][sl];
+#pragma unroll
+    for (int ww = 1; ww < NW; ww++) tot += psum[k & 1][ww][sl];
+    if constexpr (TRACE) asm volatile("" ::"v"(tot));
+    REP_TR(6)
+    product(pfr, A, bb);
+    if (__any(!(tot >= kScalerThreshold && tot <= kScalerUp))) {  // rare: some pattern needs (or cannot have) a rescale
+      double sc = 1.0;                                            // (behind the product: a power of 2^64 commutes with it exactly)
+      cnt += rescale_decision(tot, sc);
+      acc *= sc;
+    }
+    if (ne.w & 2) {  // the chain's edge product joins the product it was walked for
+      depth--;
+      if (depth == 0) acc *= pk0, cnt += pc0;
+      else if (depth == 1) acc *= pk1, cnt += pc1;
+      else acc *= pk2, cnt += pc2;
+    }
+    if constexpr (TRACE) asm volatile("" ::"v"(acc[0]));
+    REP_TR(7)
+  }
+  if (n_chains > 1) {
+    // ---- two chains: leave this chain's product, arrive; the last arriver takes the other's and goes on to the root ----
+    const size_t slot = (cat * 2 + chain) * (size_t)a.ntiles + tile, other = (cat * 2 + (1 - chain)) * (size_t)a.ntiles + tile;
+    double *dst = a.deposits + slot * TILE;
+    st16_agent(dst, (unsigned)((2 * w) * 64 + lane) * 16u, (f64x2){acc[0], acc[1]});
+    st16_agent(dst, (unsigned)((2 * w + 1) * 64 + lane) * 16u, (f64x2){acc[2], acc[3]});
+    if (w == 0 && g == 0) __hip_atomic_store(a.hand_cnt + slot * 16 + sl, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) arrived = __hip_atomic_fetch_add(a.arrivals + cat * a.ntiles + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (arrived == 0) {
+      if constexpr (TRACE) {
+        if (a.dbg && tid == 0) {
+          tr[1] = wall_clock64();
+          tr[2] = n_nodes;
+          tr[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+          for (int i = 0; i < 16; i++) a.dbg[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + i] = tr[i];
+        }
+      }
+      return;
+    }
+    if (tid == 0) __hip_atomic_store(a.arrivals + cat * a.ntiles + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+    const double *src = a.deposits + other * TILE;
+    const f64x2 o0 = ld16_agent(src, (unsigned)((2 * w) * 64 + lane) * 16u), o1 = ld16_agent(src, (unsigned)((2 * w + 1) * 64 + lane) * 16u);
+    cnt += __hip_atomic_load(a.hand_cnt + other * 16 + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc *= (f64x4){o0[0], o0[1], o1[0], o1[1]};
+  }
+  // ---- root: L_s = sum_k root[k][s] pi[k] over the NW row blocks (fixed order), then the tile's share of the log-likelihood ----
+  {
+    double pr = 0.;
+#pragma unroll
+    for (int r = 0; r < 4; r++) pr = fma(acc[r], a.pi[16 * w + 4 * r + g], pr);
+    pr = row_sum4(pr);
+    if (g == 0) epi[w][sl] = pr;
+  }
+  __syncthreads();
+  if (w == 0) {
+    double s = epi[0][sl];
+#pragma unroll
+    for (int ww = 1; ww < NW; ww++) s += epi[ww][sl];
+    double wsum = 0.;
+    long long wcnt = 0;
+    int wflag = 0;
+    if (g == 0) {
+      const size_t site = (size_t)tile * 16 + sl;
+      a.site_lik[cat * a.cs_site + site] = s;
+      a.site_cnt[cat * a.cs_site + site] = cnt;
+      const double f = a.freq[site];
+      if (f != 0.) {
+        if (s != s || isinf(s)) wflag |= 2;
+        else if (s <= 0.) wflag |= 1;
+        else {
+          wsum = log(s) * f;
+          wcnt = (long long)cnt * (long long)f;
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {  // fixed-order butterfly over the 16 pattern lanes (lanes >= 16 hold zeros)
+      wsum += __shfl_xor(wsum, off);
+      wcnt += __shfl_xor(wcnt, off);
+      wflag |= __shfl_xor(wflag, off);
+    }
+    if (lane == 0) {
+      a.wg_sum[cat * a.cs_wg + tile] = wsum;
+      a.wg_cnt[cat * a.cs_wg + tile] = wcnt;
+      a.wg_flag[cat * a.cs_wg + tile] = wflag;
+    }
+  }
+  if constexpr (TRACE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    REP_TR(8)
+    if (a.dbg && tid == 0) {
+      tr[1] = wall_clock64();
+      tr[2] = n_nodes;
+      tr[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+      for (int i = 0; i < 16; i++) a.dbg[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + i] = tr[i];
     }
   }
 }
@@ -864,7 +1133,7 @@ void rep_release(hyphy_hip_partition *p) {  // everything rep_setup_impl may hav
   for (Shard &s : p->shards) {
     if (hipSetDevice(s.device) != hipSuccess) continue;
     void **bufs[] = {(void **)&s.rep_tab, (void **)&s.rep_cnt, (void **)&s.rep_map, (void **)&s.rep_desc, (void **)&s.rep_sync,
-                     (void **)&s.rep_codes_tile, (void **)&s.rep_leaf};
+                     (void **)&s.rep_codes_tile, (void **)&s.rep_leaf, (void **)&s.rep_walk};
     for (void **b : bufs)
       if (*b) {
         pool_free_sync(*b);
@@ -1422,7 +1691,110 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
     hipMemcpy(s.rep_desc, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice);
     hipMemcpy(s.rep_codes_tile, ct.data(), ct.size() * sizeof(int16_t), hipMemcpyHostToDevice);
     hipMemcpy(s.rep_leaf, lt.data(), lt.size() * sizeof(int2), hipMemcpyHostToDevice);
+    s.rep_leaf_host = lt;
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail("repeats: device initialisation failed");
+  }
+  // the trunk as one post-order walk per tile (trunk_walk_kernel): heaviest internal child first — its chain stays in the running
+  // product —, every other internal child a chain of its own behind a push (flag 1 on its first walked node, 2 on the child itself).
+  // Two forms: ONE workgroup per tile walks everything; TWO split the subtrees below the root (longest-processing-time-first).
+  p->rep_walk_host.clear();
+  if (!p->nuc && p->NW >= 2 && v.L <= 1024) {
+    std::vector<int> weight(v.I, 1);
+    for (int i = 0; i < v.I; i++)  // (children before parents)
+      for (int c : v.children[i])
+        if (c >= v.L) weight[i] += weight[c - v.L];
+    struct WalkNode { int node, n_in, in0, flags; };  // node: view-internal index, -1: the chain's end at the root
+    std::vector<WalkNode> nodes;
+    std::vector<int> inputs;
+    int depth = 0, max_depth = 0;
+    auto leaf_inputs = [&](int i, int &n_in, int &in0) {
+      n_in = 0, in0 = (int)inputs.size();
+      for (int c : v.children[i])
+        if (c < v.L) inputs.push_back(c), n_in++;
+    };
+    std::function<void(int)> emit = [&](int i) {
+      std::vector<int> kids;
+      for (int c : v.children[i])
+        if (c >= v.L) kids.push_back(c - v.L);
+      std::stable_sort(kids.begin(), kids.end(), [&](int x, int y) { return weight[x] > weight[y]; });
+      for (size_t j = 0; j < kids.size(); j++) {
+        const size_t first = nodes.size();
+        if (j > 0) max_depth = std::max(max_depth, ++depth);
+        emit(kids[j]);
+        if (j > 0) {
+          nodes[first].flags |= 1;
+          nodes.back().flags |= 2;
+          depth--;
+        }
+      }
+      int n_in, in0;
+      leaf_inputs(i, n_in, in0);
+      nodes.push_back(WalkNode{i, n_in, in0, 0});
+    };
+    // a chain: the given subtrees below the root one after the other (the second and later ones behind a push), then the chain's end:
+    // the root's own leaf children (first chain only)
+    auto emit_chain = [&](const std::vector<int> &subs, bool root_leaves, std::vector<int> &range) {
+      range.push_back((int)nodes.size());
+      for (size_t j = 0; j < subs.size(); j++) {
+        const size_t first = nodes.size();
+        if (j > 0) max_depth = std::max(max_depth, ++depth);
+        emit(subs[j]);
+        if (j > 0) {
+          nodes[first].flags |= 1;
+          nodes.back().flags |= 2;
+          depth--;
+        }
+      }
+      int n_in = 0, in0 = (int)inputs.size();
+      if (root_leaves) leaf_inputs(v.I - 1, n_in, in0);
+      nodes.push_back(WalkNode{-1, n_in, in0, 0});
+      range.push_back((int)nodes.size());
+    };
+    std::vector<int> subs;
+    for (int c : v.children[v.I - 1])
+      if (c >= v.L) subs.push_back(c - v.L);
+    std::stable_sort(subs.begin(), subs.end(), [&](int x, int y) { return weight[x] > weight[y]; });
+    std::vector<int> one_range, two_range;
+    emit_chain(subs, true, one_range);
+    bool two = false;
+    if (subs.size() >= 2) {
+      std::vector<int> c0, c1;
+      int w0 = 0, w1 = 0;
+      for (int sb : subs)
+        if (w0 <= w1) c0.push_back(sb), w0 += weight[sb];
+        else c1.push_back(sb), w1 += weight[sb];
+      if (std::min(w0, w1) >= 2 && 4 * std::min(w0, w1) >= std::max(w0, w1)) {  // (a second chain of a node or two is not worth its workgroup)
+        emit_chain(c0, true, two_range);
+        emit_chain(c1, false, two_range);
+        two = true;
+      }
+    }
+    if (max_depth <= kWalkDepth && nodes.size() < 4096 && !inputs.empty()) {
+      for (Shard &s : p->shards) {
+        const std::vector<int2> &lt = s.rep_leaf_host;
+        // [0] header, one-chain form (1 + 1 words), two-chain form (1 + 2 words), node words, input words
+        const int form1 = 1, form2 = two ? 3 : 0, node_base = two ? 6 : 3, in_base = node_base + (int)nodes.size();
+        std::vector<int4> prog((size_t)in_base + inputs.size());
+        prog[0] = make_int4(form1, form2, max_depth, (int)prog.size());
+        prog[form1] = make_int4(1, 0, 0, 0);
+        prog[form1 + 1] = make_int4(node_base + one_range[0], one_range[1] - one_range[0], 0, 0);
+        if (two) {
+          prog[form2] = make_int4(2, 0, 0, 0);
+          prog[form2 + 1] = make_int4(node_base + two_range[0], two_range[1] - two_range[0], 0, 0);
+          prog[form2 + 2] = make_int4(node_base + two_range[2], two_range[3] - two_range[2], 0, 0);
+        }
+        for (size_t k = 0; k < nodes.size(); k++)
+          prog[node_base + k] = make_int4(nodes[k].node < 0 ? -1 : v.slot[v.L + nodes[k].node], nodes[k].n_in, in_base + nodes[k].in0, nodes[k].flags);
+        for (size_t k = 0; k < inputs.size(); k++) prog[in_base + k] = make_int4(inputs[k], lt[inputs[k]].x, lt[inputs[k]].y, 0);
+        if (&s == &p->shards[0]) p->rep_walk_host = prog;
+        if (hipSetDevice(s.device) != hipSuccess) return fail("hipSetDevice failed");
+        const size_t bytes = prog.size() * sizeof(int4);
+        if (pool_malloc((void **)&s.rep_walk, bytes) != hipSuccess) return fail("hipMalloc failed (s.rep_walk)");
+        s.dev_bytes += bytes;
+        s.rep_bytes += bytes;
+        hipMemcpy(s.rep_walk, prog.data(), bytes, hipMemcpyHostToDevice);
+      }
+    }
   }
   p->rep_resident.assign(p->C, 0);
   p->rep_cached_valid = false;
@@ -1444,6 +1816,15 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
     const hyphy_hip_partition::View &tv = p->views[1];
     if ((kv == 0 || kv == 2) && p->NW == 4 && !p->nuc && (size_t)tv.L * 32 + (size_t)(tv.L + tv.I) * 16 <= 24576) {
       ms.variant = kv;
+      ms.n_slots = lds_slots(1);
+    }
+  }
+  ms.trunk_walk = false;
+  if (const char *tw = getenv("HYPHY_HIP_TRUNK_WALK")) {  // = 1: the walk without asking the tuner (tests, A/B runs, HYPHY_HIP_TUNE=0)
+    const hyphy_hip_partition::View &tv = p->views[1];
+    if (atoi(tw) == 1 && !p->rep_walk_host.empty() && (size_t)tv.L * 32 + (size_t)(tv.L + tv.I) * 16 <= 24576) {
+      ms.trunk_walk = true;
+      ms.variant = 0;
       ms.n_slots = lds_slots(1);
     }
   }
@@ -1487,6 +1868,7 @@ void switch_mode(hyphy_hip_partition *p, int mode) {
   out.rr_use = p->rr_use;
   out.kernel_forced = p->kernel_forced;
   out.nuc_leaf_pairs = p->nuc_leaf_pairs;
+  out.trunk_walk = p->trunk_walk;
   out.tuned_for = p->tuned_for;
   out.tune_report = p->tune_report;
   out.rr_path = p->rr_path;
@@ -1499,6 +1881,7 @@ void switch_mode(hyphy_hip_partition *p, int mode) {
   p->rr_use = in.rr_use;
   p->kernel_forced = in.kernel_forced;
   if (p->nuc) p->nuc_leaf_pairs = in.nuc_leaf_pairs;
+  p->trunk_walk = in.trunk_walk;
   p->tuned_for = in.tuned_for;
   p->tune_report = in.tune_report;
   p->rr_path = in.rr_path;
@@ -1906,6 +2289,81 @@ static int rep_launch_impl(hyphy_hip_partition *p, Shard &s, int cat0) {
     return 0;
   }
   launch_class_tables(a, p->NW, s.stream, s.rep_team);
+  return 0;
+}
+
+// ---- the trunk's lazy full pass as one row-split walk per tile (trunk_walk_kernel) ----
+static bool trunk_walk_allowed() {  // (per call: tests and A/B runs switch it)
+  const char *e = getenv("HYPHY_HIP_TRUNK_WALK");
+  return !(e && atoi(e) == 0);
+}
+bool trunk_walk_applies(const hyphy_hip_partition *p, const Shard &s) {
+  return p->mode == 1 && p->trunk_walk && !p->nuc && s.rep_walk && s.T == 1 && p->sched_full && !p->sched_persist && p->pin_node < 0 &&
+         (size_t)p->views[1].L * 32 <= 32768 && trunk_walk_allowed();
+}
+int launch_trunk_walk(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, bool timeline) {
+  const int DP = p->DP, n_cat = std::max(1, n_cat_batch);
+  // two workgroups per tile where that still fits the chip in one round (five workgroups per CU); HYPHY_HIP_WALK_CHAINS=1/2 forces
+  int chains = (p->rep_walk_host[0].y > 0 && (size_t)2 * s.ntiles * n_cat <= (size_t)5 * s.cus) ? 2 : 1;
+  if (const char *e = getenv("HYPHY_HIP_WALK_CHAINS")) chains = (atoi(e) == 2 && p->rep_walk_host[0].y > 0) ? 2 : 1;
+  TrunkWalkArgs a;
+  a.Pfrag = s.Pfrag + (size_t)cat * p->B * DP * DP;
+  a.PTg = s.PTg + (size_t)cat * p->B * DP * DP;
+  a.cs_P = (size_t)p->B * DP * DP;
+  a.gtab = s.rep_tab + (size_t)cat * s.rep_rows * DP;
+  a.gcnt = s.rep_cnt + (size_t)cat * s.rep_rows;
+  a.cs_gtab = (size_t)s.rep_rows * DP;
+  a.cs_gcnt = (size_t)s.rep_rows;
+  a.codes_tile = s.rep_codes_tile;
+  a.L = p->views[1].L;
+  a.form = chains == 2 ? p->rep_walk_host[0].y : p->rep_walk_host[0].x;
+  a.pi = s.pi;
+  a.site_lik = s.site_lik + (size_t)cat * s.S_pad;
+  a.site_cnt = s.site_cnt + (size_t)cat * s.S_pad;
+  a.cs_site = (size_t)s.S_pad;
+  a.freq = s.freq;
+  a.wg_sum = s.wg_sum;
+  a.wg_cnt = s.wg_cnt;
+  a.wg_flag = s.wg_flag;
+  a.cs_wg = (size_t)s.ntiles;
+  a.deposits = nullptr;
+  a.cs_deposits = 0;
+  a.hand_cnt = s.hand_cnt;
+  a.arrivals = s.frag_ctr;
+  a.ntiles = s.ntiles;
+  a.dbg = nullptr;
+  if (chains == 2) {  // (the buffers of the pruning kernels' chain schedules: [class][node][tile] tiles, exponents, arrival counters)
+    if (ensure_deposits(p, s)) return -1;
+    if (s.deposits_cap < (size_t)p->C * 2 * s.ntiles * 16 * DP) return fail("internal: trunk walk: deposits too small");
+    a.deposits = s.deposits;
+  }
+  const dim3 grid(s.ntiles, n_cat, chains), block(64 * p->NW);
+  const size_t lds = (size_t)a.L * 32;
+  const char *tl = timeline ? getenv("HYPHY_HIP_WALK_TIMELINE") : nullptr;
+  if (tl && p->NW == 4) {  // diagnostic: synchronous, one record per workgroup (the lower phase's format: tools/rep_team_timeline.py)
+    const size_t n = (size_t)grid.x * grid.y * grid.z * 16;
+    HIPCHK(pool_malloc((void **)&a.dbg, n * sizeof(long long)));
+    HIPCHK(hipMemsetAsync(a.dbg, 0, n * sizeof(long long), s.stream));
+    hipLaunchKernelGGL((trunk_walk_kernel<4, true>), grid, block, lds, s.stream, (const int4 *)s.rep_walk, a);
+    std::vector<long long> h(n);
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipMemcpy(h.data(), a.dbg, n * sizeof(long long), hipMemcpyDeviceToHost));
+    pool_free_sync(a.dbg);
+    if (FILE *f = fopen(tl, "w")) {
+      fprintf(f, "# team (one workgroup of NW waves per tile and chain, trunk_walk_kernel) wall_start wall_end(100MHz) walked_nodes hw_id|xcc<<32 cycles: leaf-table gathers exchange product epilogue\n");
+      for (size_t w = 0; w < n / 16; w++) {
+        const long long *r = &h[w * 16];
+        fprintf(f, "%zu %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", w, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+      }
+      fclose(f);
+    }
+    return 0;
+  }
+  switch (p->NW) {
+    case 2: hipLaunchKernelGGL((trunk_walk_kernel<2>), grid, block, lds, s.stream, (const int4 *)s.rep_walk, a); break;
+    case 3: hipLaunchKernelGGL((trunk_walk_kernel<3>), grid, block, lds, s.stream, (const int4 *)s.rep_walk, a); break;
+    default: hipLaunchKernelGGL((trunk_walk_kernel<4>), grid, block, lds, s.stream, (const int4 *)s.rep_walk, a); break;
+  }
   return 0;
 }
 

@@ -40,6 +40,10 @@ void launch_prune_current(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_b
   pa.deposits = s.deposits;
   pa.cs_deposits = s.deposits_class_stride;
   if (const char *ab = getenv("HYPHY_HIP_ABLATE")) pa.ablate = atoi(ab);
+  if (trunk_walk_applies(p, s)) {  // (the trunk of a class-compressed partition as one row-split walk per tile, repeats.hip)
+    launch_trunk_walk(p, s, cat, n_cat_batch, false);
+    return;
+  }
   for (size_t lv = 0; lv < p->levels.size(); lv++) {
     pa.prog = s.prog + p->levels[lv].first;
     pa.n_prog = p->levels[lv].count;
@@ -59,18 +63,20 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   const int I = p->vw().I;  // (the tree the schedules are cut from: the trunk when the partition is class-compressed)
   Shard &s = p->shards[0];
   const int T0 = s.T;
-  // a candidate: kernel (0 row-split workgroups / 1 wave per tile / 2 row-split workgroups on a chain schedule), cut
+  // a candidate: kernel (0 row-split workgroups / 1 wave per tile / 2 row-split workgroups on a chain schedule / 3 (trunks) the
+  // row-split walk, trunk_walk_kernel, with kernel 0 behind it for the passes it does not serve), cut
   // (m > 0: chain schedule with sources of at most m nodes, -1: level-peeled fragments, 0: the kernel's own heuristic),
   // instantiation of the wave kernel (0 / 2: three waves per SIMD), re-rooting candidate (-1: the given root)
   struct Cand { int kernel, m, wv, rr; };
   auto label = [](const Cand &c) {
     char b[48];
     snprintf(b, sizeof b, "%s%s%s%d", c.rr >= 0 ? (c.rr ? "rr1/" : "rr0/") : "", c.wv == 2 ? "occ3/" : "",
-             c.kernel == 0 ? "wg-kernel" : (c.kernel == 2 ? "team/m" : (c.m < 0 ? "levels" : "m")), c.m < 0 ? 0 : c.m);
+             c.kernel == 3 ? "walk" : c.kernel == 0 ? "wg-kernel" : (c.kernel == 2 ? "team/m" : (c.m < 0 ? "levels" : "m")), c.m < 0 ? 0 : c.m);
     return std::string(b);
   };
   auto apply = [&](const Cand &c) -> bool {  // build the candidate's schedule; false: not applicable
-    p->variant = c.kernel;
+    p->variant = c.kernel == 3 ? 0 : c.kernel;
+    p->trunk_walk = c.kernel == 3;
     p->wave_variant = c.kernel == 1 ? c.wv : 0;
     p->n_slots = c.kernel == 1 ? (c.wv == 2 ? 2 : p->n_slots_wave) : lds_slots(T0);
     p->chain_m_forced = c.m;
@@ -83,6 +89,7 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
     if (p->ops_host.size() > ops_capacity(p)) return false;
     if (c.m > 0 && !p->chain) return false;  // (m >= I, or a tree the join table cannot describe: the same as no cut)
     if (c.rr >= 0 && !p->rr_active) return false;
+    if (c.kernel == 3 && !trunk_walk_applies(p, s)) return false;
     return true;
   };
   int err = 0;
@@ -132,7 +139,7 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
   for (int64_t v : p->vw().parents) topo = (topo ^ (uint64_t)v) * 1099511628211ull;
   if (p->mode == 1)  // (the trunk depends on the alignment: leaves that are class tables gather differently from plain ones)
     for (int sl : p->vw().slot) topo = (topo ^ (uint64_t)sl) * 1099511628211ull;
-  const Key key{p->D, p->vw().L, p->vw().I, s.ntiles, n_cat_batch, p->kernel_forced ? p->variant : -1, p->mode, topo};
+  const Key key{p->D, p->vw().L, p->vw().I, s.ntiles, n_cat_batch, p->kernel_forced ? p->variant + (p->trunk_walk ? 8 : 0) : -1, p->mode, topo};
   if (cache_on) {
     std::lock_guard<std::mutex> lock(cache_mutex);
     auto hit = cache.find(key);
@@ -167,7 +174,12 @@ int tune_schedule(hyphy_hip_partition *p, int cat, int n_cat_batch) {
     for (int m : {1, 2, 3, 5, 8})
       if (m < I) stage1.push_back({2, m, 0, -1});
   }
-  std::vector<std::pair<double, int>> ranked[3];  // per kernel: (time, cut) of the chain schedules
+  // r06: ... and as ONE row-split walk per tile (trunk_walk_kernel: six-team occupancy class, A ring, B from LDS — the lower phase's kernel
+  // shape); any shard size
+  if (p->mode == 1 && (forced == 1 || forced == 0) && T0 == 1 && p->NW >= 2 && !p->rep_walk_host.empty() &&
+      (size_t)p->vw().L * 32 + (size_t)(p->vw().L + p->vw().I) * 16 <= 24576)
+    stage1.push_back({3, 0, 0, -1});
+  std::vector<std::pair<double, int>> ranked[4];  // per kernel: (time, cut) of the chain schedules
   for (const Cand &c : stage1) {
     const double t = time_it(c);
     if (err) return -1;

@@ -141,6 +141,51 @@ def test_trunk_under_row_split_workgroups(name, kernel, m, monkeypatch):
     assert np.max(np.abs(got["team"][1] - got["team_plain"][1]) / np.abs(got["team_plain"][1])) < SAME
 
 
+@pytest.mark.parametrize("chains", ["1", "2"])
+@pytest.mark.parametrize("theta", ["0.9", "0.3", "0.05"])
+@pytest.mark.parametrize("name", ["codon_small", "codon_ambig", "codon_deep", "codon_wide", "ref_smallcodon"])
+def test_trunk_as_one_row_split_walk_per_tile(name, theta, chains, monkeypatch):
+    """r06: lazy full passes of the trunk under trunk_walk_kernel (repeats.hip) — one post-order walk per tile by a workgroup of NW
+    row-split waves, internal side chains behind a push / pop of the running product, the root's conditionals straight into the
+    per-pattern values — against the wave-per-tile trunk, the plain form and the reference.  theta moves the cut: a trunk of one or
+    two nodes (0.9), a bushy one (0.05: most of the tree, nested side chains).  chains = 2: the subtrees below the root dealt to two
+    workgroups per tile that meet at the root through memory (where the trunk has two of a size worth it; else one walk)."""
+    monkeypatch.setenv("HYPHY_HIP_WALK_CHAINS", chains)
+    monkeypatch.setenv("HYPHY_HIP_REPEATS", "2")
+    monkeypatch.setenv("HYPHY_HIP_REP_THETA", theta)
+    monkeypatch.setenv("HYPHY_HIP_POISON", "1")
+    monkeypatch.setenv("HYPHY_HIP_TUNE", "0")
+    fx = common.load(name)
+    Q = common.fixture_Q(fx)
+    nodes = common.all_nodes(fx)
+    got = {}
+    for form in ("walk", "wave"):
+        monkeypatch.setenv("HYPHY_HIP_TRUNK_WALK", "1" if form == "walk" else "0")
+        with _mk(fx) as part:
+            if part.repeat_stats()["in_use"] != 1:
+                pytest.skip("nothing to compress at this threshold")
+            names = []
+            for _ in range(3):   # (first pass persists: the pruning kernel; from the second on: the walk)
+                ll, lik, sc = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+                names.append(part.prune_kernel_name())
+            got[form] = (ll, _site(lik, sc), names, sc.copy())
+            # a partial update behind lazy passes (the walk persists nothing: the library restores the copies first), then lazy again
+            some = nodes[: max(1, len(nodes) // 3)]
+            ll_p, lik_p, sc_p = part.evaluate(some, some, Q[: len(some)], fx["root_freqs"], per_site=True)
+            got[form + "_partial"] = (ll_p, _site(lik_p, sc_p))
+            ll_b, lik_b, sc_b = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+            ll_b, lik_b, sc_b = part.evaluate(nodes, nodes, Q, fx["root_freqs"], per_site=True)
+            got[form + "_back"] = (ll_b, _site(lik_b, sc_b), part.prune_kernel_name())
+    assert got["walk"][2][0] != "trunk_walk_kernel" and got["walk"][2][-1] == "trunk_walk_kernel", got["walk"][2]
+    assert got["walk_back"][2] == "trunk_walk_kernel"
+    assert "trunk_walk_kernel" not in got["wave"][2]
+    ref = float(fx["logl"])
+    for k in ("walk", "wave", "walk_partial", "walk_back"):
+        assert abs(got[k][0] - ref) <= RTOL * abs(ref), (k, got[k][0], ref)
+        assert np.max(np.abs(got[k][1][fx["site_to_pattern"]] - fx["site_logl"]) / np.abs(fx["site_logl"])) < RTOL, k
+    assert np.max(np.abs(got["walk"][1] - got["wave"][1]) / np.abs(got["wave"][1])) < SAME
+
+
 @pytest.mark.parametrize("seed,taxa,D", [(1, 40, 61), (2, 33, 61), (3, 24, 20), (4, 17, 48), (5, 30, 5)])
 def test_random_trees_and_state_counts_against_the_oracle(seed, taxa, D, monkeypatch):
     """Random trees (multifurcating root), random ambiguity codes, 61 / 48 / 20 / 5 states (NW = 4, 3, 2, 1 row blocks), enough
