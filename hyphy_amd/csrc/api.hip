@@ -500,8 +500,10 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
     // 77.0); at the headline size the gain shrinks to ~1 us while the pruning kernel's own duration grows by the 3-4 us of the
     // serial tail, so larger shards keep the separate kernel.  HYPHY_HIP_FUSED_REDUCE=0/1 forces either.
     const char *fuse_env = getenv("HYPHY_HIP_FUSED_REDUCE");
-    const bool fuse_on = fuse_env ? atoi(fuse_env) != 0 : s.ntiles <= 2 * s.cus;
-    if (fuse_on && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && !pa.timeline && !p->export_sites && prune_fuses_reduce(pa)) {
+    const bool walk = trunk_walk_applies(p, s) && !pa.timeline && n_ops > 0;  // (repeats.hip: the trunk as one row-split walk per tile)
+    const bool fuse_on = fuse_env ? atoi(fuse_env) != 0 : s.ntiles <= 2 * s.cus;  // (the walk at the headline: 90.0 / 89.8 us fused, 88.3 / 89.5 not)
+    if (fuse_on && reduce && n_ops > 0 && !floor_log && n_cat_batch <= 1 && !pa.timeline && !p->export_sites &&
+        (walk ? (trunk_walk_fuses_reduce(p) && !getenv("HYPHY_HIP_WALK_TIMELINE")) : prune_fuses_reduce(pa))) {
       double *rec = s.d_hout ? s.d_hout : s.out;
       fused_reduce = true;
       pa.red_out = d_logl_out ? d_logl_out : rec;
@@ -512,9 +514,10 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       pa.red_n = n_wg;
     }
     double *const red_out = pa.red_out;
-    if (trunk_walk_applies(p, s) && !pa.timeline && n_ops > 0) {
-      // (repeats.hip) the trunk of a class-compressed partition, lazy full pass: one row-split walk per tile instead of the schedule
-      if (launch_trunk_walk(p, s, cat, n_cat_batch, true)) return -1;
+    if (walk) {
+      // the trunk of a class-compressed partition, lazy full pass: one row-split walk per tile instead of the schedule
+      pa.red_out = red_out;
+      if (launch_trunk_walk(p, s, cat, n_cat_batch, true, &pa)) return -1;
       s.last_walk = true;
     } else {
     s.last_walk = false;

@@ -425,7 +425,8 @@ int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0);
 // the trunk's lazy full pass as one row-split walk per tile (trunk_walk_kernel); false: not applicable to this pass — the caller runs the
 // pruning kernels.  `timeline`: HYPHY_HIP_WALK_TIMELINE diagnostics allowed (evaluations, not the tuner's passes)
 bool trunk_walk_applies(const hyphy_hip_partition *p, const Shard &s);
-int launch_trunk_walk(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, bool timeline);
+bool trunk_walk_fuses_reduce(const hyphy_hip_partition *p);  // its launch can carry the fused final combine (PruneArgs::red_*)
+int launch_trunk_walk(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, bool timeline, const hyhip::PruneArgs *red = nullptr);
 int rep_decide(hyphy_hip_partition *p, int cat, int n_classes);
 bool rep_static_decision(const hyphy_hip_partition *p);  // on / off without a measurement (tuner disabled, forced cut)
 size_t rep_sync_words(const hyphy_hip_partition *p);

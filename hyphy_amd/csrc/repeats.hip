@@ -38,6 +38,7 @@
 #include <unordered_map>
 
 #include "devutil.h"
+#include "combine.h"
 #include "partition.h"
 
 namespace hyhip {
@@ -703,12 +704,19 @@ struct TrunkWalkArgs {
   int32_t *hand_cnt;          // [class][chain][tile][16]
   int *arrivals;              // [class][tile], zero between launches
   int ntiles;
+  // fused final combine (FUSE builds, red_out != nullptr): the workgroup that finishes the launch's LAST root sums the per-tile
+  // partial sums and publishes the result record (prune.hip: publish_partial) — no reduction kernel behind the launch
+  double *red_out, *red_rec;
+  const int *red_status;
+  double red_seq;
+  int *red_done;
+  int red_n;
   long long *dbg;             // diagnostic (HYPHY_HIP_WALK_TIMELINE): the lower phase's record per workgroup, or nullptr
 };
 constexpr int kWalkDepth = 3;
 
-template <int NW, bool TRACE = false, int AST = kRepAStages, int BST = kRepBStages>
-__global__ __launch_bounds__(64 * NW, 5) void trunk_walk_kernel(const int4 *__restrict__ walk, TrunkWalkArgs a) {
+template <int NW, bool TRACE = false, bool FUSE = false, int AST = kRepAStages, int DEPTH = kWalkDepth, int OCC = 5, int BST = kRepBStages>
+__global__ __launch_bounds__(64 * NW, OCC) void trunk_walk_kernel(const int4 *__restrict__ walk, TrunkWalkArgs a) {
   [[maybe_unused]] long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   [[maybe_unused]] long long tr_last = 0;
   if constexpr (TRACE) {
@@ -786,8 +794,8 @@ __global__ __launch_bounds__(64 * NW, 5) void trunk_walk_kernel(const int4 *__re
   for (int k = 0; k < n_nodes; k++) {
     const int4 ne = walk[node0 + k];
     if (ne.w & 1) {
-      if (depth == 0) pk0 = acc, pc0 = cnt;
-      else if (depth == 1) pk1 = acc, pc1 = cnt;
+      if (DEPTH == 1 || depth == 0) pk0 = acc, pc0 = cnt;
+      else if (DEPTH == 2 || depth == 1) pk1 = acc, pc1 = cnt;
       else pk2 = acc, pc2 = cnt;
       depth++;
       cnt = 0;
@@ -838,8 +846,8 @@ __global__ __launch_bounds__(64 * NW, 5) void trunk_walk_kernel(const int4 *__re
     }
     if (ne.w & 2) {  // the chain's edge product joins the product it was walked for
       depth--;
-      if (depth == 0) acc *= pk0, cnt += pc0;
-      else if (depth == 1) acc *= pk1, cnt += pc1;
+      if (DEPTH == 1 || depth == 0) acc *= pk0, cnt += pc0;
+      else if (DEPTH == 2 || depth == 1) acc *= pk1, cnt += pc1;
       else acc *= pk2, cnt += pc2;
     }
     if constexpr (TRACE) asm volatile("" ::"v"(acc[0]));
@@ -909,7 +917,22 @@ __global__ __launch_bounds__(64 * NW, 5) void trunk_walk_kernel(const int4 *__re
       wcnt += __shfl_xor(wcnt, off);
       wflag |= __shfl_xor(wflag, off);
     }
-    if (lane == 0) {
+    if (FUSE && a.red_out != nullptr) {
+      if (lane == 0) {
+        __hip_atomic_store(a.wg_sum + tile, wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.wg_cnt + tile, wcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.wg_flag + tile, wflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (payload written through before the arrival: the protocol of the joins)
+      int old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(a.red_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      asm volatile("" ::: "memory");
+      if (old + 1 == a.red_n) {
+        if (lane == 0) __hip_atomic_store(a.red_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+        combine_partials(a.wg_sum, a.wg_cnt, a.wg_flag, a.red_n, a.red_out, a.red_rec, a.red_status, a.red_seq, lane);
+      }
+    } else if (lane == 0) {
       a.wg_sum[cat * a.cs_wg + tile] = wsum;
       a.wg_cnt[cat * a.cs_wg + tile] = wcnt;
       a.wg_flag[cat * a.cs_wg + tile] = wflag;
@@ -1430,7 +1453,9 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
   // tiles, eight rounds of walks) the saved products win: 663.6 us at 0, 584.2 at 0.15, 537.7 at 0.3, 549.6 at 0.45, 552.2 at 2.
   // In between (64 taxa): 1 250 tiles 110.0 us at 0 against 119.1 at 0.3; 2 500 tiles 173.8 against 169.3 — the default changes at
   // 2 048.  (Before the per-level launches, with the ticket protocol: 785 us at 0.6 against 726 at 0.)  HYPHY_HIP_REP_RHO overrides.
-  double rho = p->shards[0].ntiles >= 2048 ? 0.3 : 0.;
+  // (r06, row-split walks in both phases, pruning launches at 128 x 100 k: 625 us at 0, 537 at 0.15, 501 at 0.3, 489 at 0.5, 485 at 0.6,
+  //  504 at 0.7, 508 at 1 and 2: the default there moved from 0.3 to 0.5)
+  double rho = p->shards[0].ntiles >= 2048 ? 0.5 : 0.;
   if (const char *e = getenv("HYPHY_HIP_REP_RHO")) rho = atof(e);
   std::vector<int> heavy(I, -1);     // the compressed child a node's path continues into
   std::vector<char> continued(I, 0); // the node is inside its parent's path (no table of its own)
@@ -1786,7 +1811,14 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
         for (size_t k = 0; k < nodes.size(); k++)
           prog[node_base + k] = make_int4(nodes[k].node < 0 ? -1 : v.slot[v.L + nodes[k].node], nodes[k].n_in, in_base + nodes[k].in0, nodes[k].flags);
         for (size_t k = 0; k < inputs.size(); k++) prog[in_base + k] = make_int4(inputs[k], lt[inputs[k]].x, lt[inputs[k]].y, 0);
-        if (&s == &p->shards[0]) p->rep_walk_host = prog;
+        if (&s == &p->shards[0]) {
+          p->rep_walk_host = prog;
+          if (getenv("HYPHY_HIP_VERBOSE")) {
+            fprintf(stderr, "[hyphy_hip] trunk walk: %d nodes, waiting products at most %d deep", one_range[1] - one_range[0], max_depth);
+            if (two) fprintf(stderr, "; two chains per tile: %d + %d nodes", two_range[1] - two_range[0], two_range[3] - two_range[2]);
+            fprintf(stderr, "\n");
+          }
+        }
         if (hipSetDevice(s.device) != hipSuccess) return fail("hipSetDevice failed");
         const size_t bytes = prog.size() * sizeof(int4);
         if (pool_malloc((void **)&s.rep_walk, bytes) != hipSuccess) return fail("hipMalloc failed (s.rep_walk)");
@@ -2301,7 +2333,8 @@ bool trunk_walk_applies(const hyphy_hip_partition *p, const Shard &s) {
   return p->mode == 1 && p->trunk_walk && !p->nuc && s.rep_walk && s.T == 1 && p->sched_full && !p->sched_persist && p->pin_node < 0 &&
          (size_t)p->views[1].L * 32 <= 32768 && trunk_walk_allowed();
 }
-int launch_trunk_walk(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, bool timeline) {
+bool trunk_walk_fuses_reduce(const hyphy_hip_partition *p) { return p->NW == 4; }
+int launch_trunk_walk(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, bool timeline, const PruneArgs *red) {
   const int DP = p->DP, n_cat = std::max(1, n_cat_batch);
   // two workgroups per tile where that still fits the chip in one round (five workgroups per CU); HYPHY_HIP_WALK_CHAINS=1/2 forces
   int chains = (p->rep_walk_host[0].y > 0 && (size_t)2 * s.ntiles * n_cat <= (size_t)5 * s.cus) ? 2 : 1;
@@ -2331,6 +2364,11 @@ int launch_trunk_walk(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch
   a.hand_cnt = s.hand_cnt;
   a.arrivals = s.frag_ctr;
   a.ntiles = s.ntiles;
+  a.red_out = nullptr, a.red_rec = nullptr, a.red_status = nullptr, a.red_seq = 0., a.red_done = nullptr, a.red_n = 0;
+  if (red && red->red_out && n_cat == 1) {
+    a.red_out = red->red_out, a.red_rec = red->red_rec, a.red_status = red->red_status, a.red_seq = red->red_seq;
+    a.red_done = red->red_done, a.red_n = s.ntiles;
+  }
   a.dbg = nullptr;
   if (chains == 2) {  // (the buffers of the pruning kernels' chain schedules: [class][node][tile] tiles, exponents, arrival counters)
     if (ensure_deposits(p, s)) return -1;
@@ -2359,11 +2397,19 @@ int launch_trunk_walk(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch
     }
     return 0;
   }
-  switch (p->NW) {
-    case 2: hipLaunchKernelGGL((trunk_walk_kernel<2>), grid, block, lds, s.stream, (const int4 *)s.rep_walk, a); break;
-    case 3: hipLaunchKernelGGL((trunk_walk_kernel<3>), grid, block, lds, s.stream, (const int4 *)s.rep_walk, a); break;
-    default: hipLaunchKernelGGL((trunk_walk_kernel<4>), grid, block, lds, s.stream, (const int4 *)s.rep_walk, a); break;
+  // (measured, r06: an instantiation with ONE waiting product — 76 registers, six workgroups per CU — is not faster anywhere: 61.9 against
+  //  60.5 us at the headline, 148 / 145 with three classes; two waiting products + two A chunks ahead, six per CU: 510 against 499 us at
+  //  128 x 100 k.  One form.)
+#define WALK_(nw, fuse) hipLaunchKernelGGL((trunk_walk_kernel<nw, false, fuse>), grid, block, lds, s.stream, (const int4 *)s.rep_walk, a)
+  if (p->NW == 4) {
+    if (a.red_out) WALK_(4, true);
+    else WALK_(4, false);
+  } else if (p->NW == 3) {
+    WALK_(3, false);
+  } else {
+    WALK_(2, false);
   }
+#undef WALK_
   return 0;
 }
 
