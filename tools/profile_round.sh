@@ -72,19 +72,23 @@ fi
 cd $GRAFT_REPO_ROOT
 if has adapter; then timeout 1500 python tools/adapter_rate.py headline,class2,cat3,mix3,manylf 10000 400 2>/dev/null > $OUT/adapter_rate.jsonl; fi
 if has phases; then
-  # r06: the kernels the headline RUNS — the trunk of the class-compressed form (prune_wave_kernel<.., REP>, trace build) and the lower
-  # phase (class_table_team_kernel, trace build: one record per workgroup) — then the plain form for reference
+  # r06: the kernels the headline RUNS — the trunk of the class-compressed form as a row-split walk per tile (trunk_walk_kernel, trace
+  # build: one record per workgroup), the lower phase (class_table_team_kernel, the same record) — then the wave-per-tile trunk it
+  # replaced (prune_wave_kernel<.., REP>) and the plain form for reference
   for spec in "mg94_64x10k 8 624" "mg94_128x100k 16 6250"; do
     set -- $spec
-    HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=$2 HYPHY_HIP_TIMELINE=$OUT/tl_$1.txt timeout 300 python bench.py --workload $1 --steps 3 --warmup 3 --no-cpu-baseline --no-traffic > /dev/null 2>&1
-    (echo "# $1, TRUNK of the class-compressed form (HYPHY_HIP_REPEATS=1), chain cut m = $2, trace build of prune_wave_kernel<.., REP> (HYPHY_HIP_TIMELINE; every stamp is an s_memtime + lgkmcnt(0): ~10-25 % slower than production)"; python tools/timeline_waves.py $OUT/tl_$1.txt $3) > $OUT/phases_a_trunk_$1.txt
-    rm -f $OUT/tl_$1.txt
+    HYPHY_HIP_REPEATS=1 HYPHY_HIP_TRUNK_WALK=1 HYPHY_HIP_WALK_TIMELINE=$OUT/tlw_$1.txt timeout 300 python bench.py --workload $1 --steps 3 --warmup 3 --no-cpu-baseline --no-traffic > /dev/null 2>&1
+    (echo "# $1, TRUNK of the class-compressed form: trunk_walk_kernel, trace build (HYPHY_HIP_WALK_TIMELINE; one record per workgroup = (tile, chain); 'index maps' = the tile's leaf table into LDS, 'publish' = the hand-over at the root and the root epilogue)"; python tools/rep_team_timeline.py $OUT/tlw_$1.txt) > $OUT/phases_a_trunk_walk_$1.txt
+    rm -f $OUT/tlw_$1.txt
     HYPHY_HIP_REPEATS=1 HYPHY_HIP_REP_TIMELINE=$OUT/tlr_$1.txt timeout 300 python bench.py --workload $1 --steps 3 --warmup 3 --no-cpu-baseline --no-traffic > /dev/null 2>&1
     (echo "# $1, LOWER PHASE of the class-compressed form: class_table_team_kernel, trace build (HYPHY_HIP_REP_TIMELINE; the last level's launch when the pass has several)"; python tools/rep_team_timeline.py $OUT/tlr_$1.txt) > $OUT/phases_b_lower_$1.txt
     rm -f $OUT/tlr_$1.txt
+    HYPHY_HIP_REPEATS=1 HYPHY_HIP_TRUNK_WALK=0 HYPHY_HIP_CHAIN_M=$2 HYPHY_HIP_TIMELINE=$OUT/tl_$1.txt timeout 300 python bench.py --workload $1 --steps 3 --warmup 3 --no-cpu-baseline --no-traffic > /dev/null 2>&1
+    (echo "# $1, the trunk under the wave-per-tile kernel it replaced (HYPHY_HIP_TRUNK_WALK=0), chain cut m = $2, trace build of prune_wave_kernel<.., REP> (HYPHY_HIP_TIMELINE; every stamp is an s_memtime + lgkmcnt(0): ~10-25 % slower than production)"; python tools/timeline_waves.py $OUT/tl_$1.txt $3) > $OUT/phases_c_trunk_wave_$1.txt
+    rm -f $OUT/tl_$1.txt
   done
   HYPHY_HIP_CHAIN_M=12 HYPHY_HIP_TIMELINE=$OUT/tl_plain.txt timeout 300 python bench.py --workload mg94_64x10k --steps 3 --warmup 3 --no-cpu-baseline --no-traffic > /dev/null 2>&1
-  (echo "# mg94_64x10k, PLAIN form (every node at every pattern; what r04 ran), chain cut m = 12, trace build of prune_wave_kernel"; python tools/timeline_waves.py $OUT/tl_plain.txt 624) > $OUT/phases_c_plain_mg94_64x10k.txt
+  (echo "# mg94_64x10k, PLAIN form (every node at every pattern; what r04 ran), chain cut m = 12, trace build of prune_wave_kernel"; python tools/timeline_waves.py $OUT/tl_plain.txt 624) > $OUT/phases_d_plain_mg94_64x10k.txt
   rm -f $OUT/tl_plain.txt
 fi
 if has ubench; then

@@ -53,7 +53,8 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     # several launches per evaluation (one per level of table dependencies, r05): the MEAN over the later half of its dispatches
     # times the launches per evaluation, so that every entry of the class kernel is per EVALUATION like the trunk's
     means_all[wl] = {k: {c: med(v) for c, v in dd.items()} for k, dd in acc.items()}
-    n_trunk = max((len(v) for v in acc.get("prune_wave_kernel", {}).values()), default=0)
+    trunk = "trunk_walk_kernel" if "trunk_walk_kernel" in acc else "prune_wave_kernel"   # (r06: the trunk as a row-split walk per tile)
+    n_trunk = max((len(v) for v in acc.get(trunk, {}).values()), default=0)
     # (r06: the lower phase is class_table_team_kernel — a workgroup of row-split waves per item — unless HYPHY_HIP_REP_TEAM=0)
     lower = "class_table_team_kernel" if "class_table_team_kernel" in acc else "class_table_kernel"
     n_class = max((len(v) for v in acc.get(lower, {}).values()), default=0)
@@ -113,7 +114,8 @@ def wave_cycle_table(pm, n_simd=1024):
 
 util = {}
 for wl in ("mg94_64x10k", "mg94_128x100k"):
-    pm = means_all.get(wl, {}).get("prune_wave_kernel", {})
+    trunk = "trunk_walk_kernel" if "trunk_walk_kernel" in means_all.get(wl, {}) else "prune_wave_kernel"
+    pm = means_all.get(wl, {}).get(trunk, {})
     if "SQ_VALU_MFMA_BUSY_CYCLES" in pm and "GRBM_GUI_ACTIVE" in pm:
         cycles = pm["GRBM_GUI_ACTIVE"] / 8.0
         u = wave_cycle_table(pm)
@@ -130,7 +132,7 @@ for wl in ("mg94_64x10k", "mg94_128x100k"):
                        "mfma_pipe_busy_fraction (counter: 64 cycles per v_mfma_f64_16x16x4_f64)": pc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cyc) if cyc else None})
             u = {"method": "counters only: SQ_VALU_MFMA_BUSY_CYCLES / (1 024 SIMDs x GRBM_GUI_ACTIVE / 8), collected in passes of their own "
                            "(profiled launches run a few per cent slower than production: compare fractions, not microseconds)",
-                 "prune_wave_kernel (trunk)": u, lower + " (lower phase)": uc,
+                 trunk + " (trunk)": u, lower + " (lower phase)": uc,
                  "SQ_INSTS_MFMA_per_evaluation": pm.get("SQ_INSTS_MFMA", 0.0) + pc["SQ_INSTS_MFMA"],
                  "SQ_INSTS_MFMA_per_evaluation_without_repeats (r04, every internal edge at every pattern)": 2436096 if wl == "mg94_64x10k" else None,
                  "mfma_pipe_busy_fraction (counter: 64 cycles per v_mfma_f64_16x16x4_f64)":
