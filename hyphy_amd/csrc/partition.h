@@ -114,6 +114,7 @@ struct RepPassSlot {
   std::vector<RepLaunch> launches;
   hipEvent_t ev = nullptr;
   bool ev_recorded = false;
+  bool used = false;                 // launches have read the slot since `ev` was recorded last (recorded when the pass moves to another slot)
 };
 
 struct Shard {

@@ -2141,8 +2141,21 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
     for (auto &k : p->rep_pass) k.valid = false;
     p->rep_cached_valid = true;
   }
+  // (a slot's event says "everything that read these queues has run".  It used to be recorded behind every lower-phase launch: a marker
+  //  between the class tables' kernel and the trunk's — 5.6 us of every evaluation by the kernel trace.  Now: when the pass leaves the
+  //  slot, or when the slot is about to be rewritten — steady-state evaluations record nothing.)
+  auto leave = [&](Shard &s, RepPassSlot &ps) -> int {
+    if (ps.used && ps.ev) {
+      HIPCHK(hipSetDevice(s.device));
+      HIPCHK(hipEventRecord(ps.ev, s.stream));
+      ps.ev_recorded = true;
+    }
+    ps.used = false;
+    return 0;
+  };
   auto activate = [&](int slot) {
     for (Shard &s : p->shards) {
+      if (s.rep_slot_cur >= 0 && s.rep_slot_cur != slot) leave(s, s.rep_slot[s.rep_slot_cur]);
       RepPassSlot &ps = s.rep_slot[slot];
       s.rep_slot_cur = slot;
       s.rep_items = ps.items;
@@ -2168,6 +2181,7 @@ int rep_prepare_pass(hyphy_hip_partition *p, const int64_t *update_nodes, int64_
     HIPCHK(hipSetDevice(s.device));
     RepPassSlot &ps = s.rep_slot[slot];
     if (!ps.ev) HIPCHK(hipEventCreateWithFlags(&ps.ev, hipEventDisableTiming));
+    if (leave(s, ps)) return -1;
     if (ps.ev_recorded) {  // (the launches that read this slot last — and the copy that filled its staging block — have they run?)
       HIPCHK(hipEventSynchronize(ps.ev));
       ps.ev_recorded = false;
@@ -2237,10 +2251,7 @@ int rep_sync_stride() { return kRepHeadStride; }
 static int rep_launch_impl(hyphy_hip_partition *p, Shard &s, int cat0);
 int rep_launch(hyphy_hip_partition *p, Shard &s, int cat0) {
   const int rc = rep_launch_impl(p, s, cat0);
-  if (rc == 0 && s.rep_qcap > 0 && s.rep_slot_cur >= 0 && s.rep_slot[s.rep_slot_cur].ev) {  // (the slot may be rewritten once these have run)
-    HIPCHK(hipEventRecord(s.rep_slot[s.rep_slot_cur].ev, s.stream));
-    s.rep_slot[s.rep_slot_cur].ev_recorded = true;
-  }
+  if (rc == 0 && s.rep_qcap > 0 && s.rep_slot_cur >= 0) s.rep_slot[s.rep_slot_cur].used = true;  // (rep_prepare_pass: the slot's event)
   return rc;
 }
 static int rep_launch_impl(hyphy_hip_partition *p, Shard &s, int cat0) {
