@@ -47,7 +47,7 @@ done > $OUT/all_workloads.txt 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp
 if has stats; then
-  HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=8 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > $OUT/stats.log 2>&1
+  HYPHY_HIP_REPEATS=1 HYPHY_HIP_TRUNK_WALK=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > $OUT/stats.log 2>&1
   # 4 states (r06): the run-time generated kernel (nucgen_kernel) in steady state; bench.py waits for it before anything is timed
   for wl in gtr_32x1m gtr_32x50k; do
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > $OUT/stats_$wl.log 2>&1
@@ -62,8 +62,9 @@ pmc() { wl=$1; shift
   done
 }
 if has pmc; then
-  pmc mg94_64x10k HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=8
-  pmc mg94_128x100k HYPHY_HIP_REPEATS=1 HYPHY_HIP_CHAIN_M=16
+  # (the forms the production runs settle on, forced so that the tuner's choice cannot differ between the counter passes)
+  pmc mg94_64x10k HYPHY_HIP_REPEATS=1 HYPHY_HIP_TRUNK_WALK=1
+  pmc mg94_128x100k HYPHY_HIP_REPEATS=1 HYPHY_HIP_TRUNK_WALK=1
 fi
 if has nuc; then
   pmc gtr_32x1m X=1
