@@ -715,6 +715,7 @@ struct TrunkWalkArgs {
 };
 constexpr int kWalkDepth = 3;
 
+// (AST: A chunks ahead of a product, DEPTH: waiting products, OCC: workgroups per CU the build allows — one production form: 3 / 3 / 5)
 template <int NW, bool TRACE = false, bool FUSE = false, int AST = kRepAStages, int DEPTH = kWalkDepth, int OCC = 5, int BST = kRepBStages>
 __global__ __launch_bounds__(64 * NW, OCC) void trunk_walk_kernel(const int4 *__restrict__ walk, TrunkWalkArgs a) {
   [[maybe_unused]] long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1387,6 +1388,88 @@ int rep_setup_nuc(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>
 }
 }  // namespace
 
+// The trunk as one post-order walk per tile (trunk_walk_kernel): heaviest internal child first — its chain stays in the running
+// product —, every other internal child a chain of its own behind a push (flag 1 on its first walked node, 2 on the child itself).
+// Two forms: ONE workgroup per tile walks everything; TWO split the subtrees below the root (longest-processing-time-first); each
+// chain ends with a node -1: the root's own leaf children (first chain only) and the hand-over / epilogue.
+struct WalkPlan {
+  struct Node { int node, n_in, in0, flags; };  // node: view-internal index (-1: the chain's end at the root); in0: first entry of `inputs`
+  std::vector<Node> nodes;
+  std::vector<int> inputs;                      // view leaves
+  std::vector<int> one_range, two_range;        // [first, end) node ranges: the one-chain form; the two chains
+  int max_depth = 0;
+  bool two = false;
+};
+static WalkPlan plan_trunk_walk(const hyphy_hip_partition::View &v) {
+  WalkPlan wp;
+  std::vector<int> weight(v.I, 1);
+  for (int i = 0; i < v.I; i++)  // (children before parents)
+    for (int c : v.children[i])
+      if (c >= v.L) weight[i] += weight[c - v.L];
+  std::vector<WalkPlan::Node> &nodes = wp.nodes;
+  std::vector<int> &inputs = wp.inputs;
+  int depth = 0;
+  auto leaf_inputs = [&](int i, int &n_in, int &in0) {
+    n_in = 0, in0 = (int)inputs.size();
+    for (int c : v.children[i])
+      if (c < v.L) inputs.push_back(c), n_in++;
+  };
+  std::function<void(int)> emit = [&](int i) {
+    std::vector<int> kids;
+    for (int c : v.children[i])
+      if (c >= v.L) kids.push_back(c - v.L);
+    std::stable_sort(kids.begin(), kids.end(), [&](int x, int y) { return weight[x] > weight[y]; });
+    for (size_t j = 0; j < kids.size(); j++) {
+      const size_t first = nodes.size();
+      if (j > 0) wp.max_depth = std::max(wp.max_depth, ++depth);
+      emit(kids[j]);
+      if (j > 0) {
+        nodes[first].flags |= 1;
+        nodes.back().flags |= 2;
+        depth--;
+      }
+    }
+    int n_in, in0;
+    leaf_inputs(i, n_in, in0);
+    nodes.push_back(WalkPlan::Node{i, n_in, in0, 0});
+  };
+  auto emit_chain = [&](const std::vector<int> &subs, bool root_leaves, std::vector<int> &range) {
+    range.push_back((int)nodes.size());
+    for (size_t j = 0; j < subs.size(); j++) {
+      const size_t first = nodes.size();
+      if (j > 0) wp.max_depth = std::max(wp.max_depth, ++depth);
+      emit(subs[j]);
+      if (j > 0) {
+        nodes[first].flags |= 1;
+        nodes.back().flags |= 2;
+        depth--;
+      }
+    }
+    int n_in = 0, in0 = (int)inputs.size();
+    if (root_leaves) leaf_inputs(v.I - 1, n_in, in0);
+    nodes.push_back(WalkPlan::Node{-1, n_in, in0, 0});
+    range.push_back((int)nodes.size());
+  };
+  std::vector<int> subs;
+  for (int c : v.children[v.I - 1])
+    if (c >= v.L) subs.push_back(c - v.L);
+  std::stable_sort(subs.begin(), subs.end(), [&](int x, int y) { return weight[x] > weight[y]; });
+  emit_chain(subs, true, wp.one_range);
+  if (subs.size() >= 2) {
+    std::vector<int> c0, c1;
+    int w0 = 0, w1 = 0;
+    for (int sb : subs)
+      if (w0 <= w1) c0.push_back(sb), w0 += weight[sb];
+      else c1.push_back(sb), w1 += weight[sb];
+    if (std::min(w0, w1) >= 2 && 4 * std::min(w0, w1) >= std::max(w0, w1)) {  // (a second chain of a node or two is not worth its workgroup)
+      emit_chain(c0, true, wp.two_range);
+      emit_chain(c1, false, wp.two_range);
+      wp.two = true;
+    }
+  }
+  return wp;
+}
+
 namespace {
 int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t>> &codes) {
   p->rep_on = false;
@@ -1720,81 +1803,15 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
     s.rep_leaf_host = lt;
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail("repeats: device initialisation failed");
   }
-  // the trunk as one post-order walk per tile (trunk_walk_kernel): heaviest internal child first — its chain stays in the running
-  // product —, every other internal child a chain of its own behind a push (flag 1 on its first walked node, 2 on the child itself).
-  // Two forms: ONE workgroup per tile walks everything; TWO split the subtrees below the root (longest-processing-time-first).
+  // the trunk as one post-order walk per tile (trunk_walk_kernel): plan_trunk_walk below
   p->rep_walk_host.clear();
   if (!p->nuc && p->NW >= 2 && v.L <= 1024) {
-    std::vector<int> weight(v.I, 1);
-    for (int i = 0; i < v.I; i++)  // (children before parents)
-      for (int c : v.children[i])
-        if (c >= v.L) weight[i] += weight[c - v.L];
-    struct WalkNode { int node, n_in, in0, flags; };  // node: view-internal index, -1: the chain's end at the root
-    std::vector<WalkNode> nodes;
-    std::vector<int> inputs;
-    int depth = 0, max_depth = 0;
-    auto leaf_inputs = [&](int i, int &n_in, int &in0) {
-      n_in = 0, in0 = (int)inputs.size();
-      for (int c : v.children[i])
-        if (c < v.L) inputs.push_back(c), n_in++;
-    };
-    std::function<void(int)> emit = [&](int i) {
-      std::vector<int> kids;
-      for (int c : v.children[i])
-        if (c >= v.L) kids.push_back(c - v.L);
-      std::stable_sort(kids.begin(), kids.end(), [&](int x, int y) { return weight[x] > weight[y]; });
-      for (size_t j = 0; j < kids.size(); j++) {
-        const size_t first = nodes.size();
-        if (j > 0) max_depth = std::max(max_depth, ++depth);
-        emit(kids[j]);
-        if (j > 0) {
-          nodes[first].flags |= 1;
-          nodes.back().flags |= 2;
-          depth--;
-        }
-      }
-      int n_in, in0;
-      leaf_inputs(i, n_in, in0);
-      nodes.push_back(WalkNode{i, n_in, in0, 0});
-    };
-    // a chain: the given subtrees below the root one after the other (the second and later ones behind a push), then the chain's end:
-    // the root's own leaf children (first chain only)
-    auto emit_chain = [&](const std::vector<int> &subs, bool root_leaves, std::vector<int> &range) {
-      range.push_back((int)nodes.size());
-      for (size_t j = 0; j < subs.size(); j++) {
-        const size_t first = nodes.size();
-        if (j > 0) max_depth = std::max(max_depth, ++depth);
-        emit(subs[j]);
-        if (j > 0) {
-          nodes[first].flags |= 1;
-          nodes.back().flags |= 2;
-          depth--;
-        }
-      }
-      int n_in = 0, in0 = (int)inputs.size();
-      if (root_leaves) leaf_inputs(v.I - 1, n_in, in0);
-      nodes.push_back(WalkNode{-1, n_in, in0, 0});
-      range.push_back((int)nodes.size());
-    };
-    std::vector<int> subs;
-    for (int c : v.children[v.I - 1])
-      if (c >= v.L) subs.push_back(c - v.L);
-    std::stable_sort(subs.begin(), subs.end(), [&](int x, int y) { return weight[x] > weight[y]; });
-    std::vector<int> one_range, two_range;
-    emit_chain(subs, true, one_range);
-    bool two = false;
-    if (subs.size() >= 2) {
-      std::vector<int> c0, c1;
-      int w0 = 0, w1 = 0;
-      for (int sb : subs)
-        if (w0 <= w1) c0.push_back(sb), w0 += weight[sb];
-        else c1.push_back(sb), w1 += weight[sb];
-      if (std::min(w0, w1) >= 2 && 4 * std::min(w0, w1) >= std::max(w0, w1)) {  // (a second chain of a node or two is not worth its workgroup)
-        emit_chain(c0, true, two_range);
-        emit_chain(c1, false, two_range);
-        two = true;
-      }
-    }
+    const WalkPlan wp = plan_trunk_walk(v);
+    const std::vector<WalkPlan::Node> &nodes = wp.nodes;
+    const std::vector<int> &inputs = wp.inputs;
+    const std::vector<int> &one_range = wp.one_range, &two_range = wp.two_range;
+    const int max_depth = wp.max_depth;
+    const bool two = wp.two;
     if (max_depth <= kWalkDepth && nodes.size() < 4096 && !inputs.empty()) {
       for (Shard &s : p->shards) {
         const std::vector<int2> &lt = s.rep_leaf_host;
@@ -2541,6 +2558,31 @@ extern "C" {
  * classes_out[I]: classes of every internal node over the S patterns as given (no padding, one shard); compressed_out[I]: 1 where
  * the node's subtree is evaluated per class (theta <= 0: the library's default).  Returns the edge products a full pass executes
  * with one table per compressed node (sum of their classes + S per trunk edge), < 0 on bad arguments. */
+/* Host-only: the walk program of a trunk given as a tree over generalised leaves (node codes 0 .. L - 1: leaves, L + i: internal node
+ * i, children before parents, the root last; parents[c] = node code of c's parent, the root's entry is ignored).
+ * out: [nodes, inputs, stack depth, two chains?, first / end node of the one-chain form, of chain 0, of chain 1], then per node
+ * (internal index or -1, leaf children, first input, flags), then the inputs (leaf codes).  Returns the words written, < 0: cap too small. */
+int64_t hyphy_hip_plan_trunk_walk(int64_t L, int64_t I, const int64_t *parents, int64_t *out, int64_t cap) {
+  if (L < 1 || I < 1 || !parents || !out) return -1;
+  hyphy_hip_partition::View v;
+  v.L = (int)L, v.I = (int)I;
+  v.children.assign((size_t)I, std::vector<int>());
+  for (int64_t c = 0; c < L + I - 1; c++) {
+    if (parents[c] < L || parents[c] >= L + I) return -1;
+    v.children[(size_t)(parents[c] - L)].push_back((int)c);
+  }
+  const hyhip::WalkPlan wp = hyhip::plan_trunk_walk(v);
+  const int64_t need = 10 + 4 * (int64_t)wp.nodes.size() + (int64_t)wp.inputs.size();
+  if (need > cap) return -need;
+  int64_t *o = out;
+  *o++ = (int64_t)wp.nodes.size(), *o++ = (int64_t)wp.inputs.size(), *o++ = wp.max_depth, *o++ = wp.two ? 1 : 0;
+  *o++ = wp.one_range[0], *o++ = wp.one_range[1];
+  for (int k = 0; k < 4; k++) *o++ = wp.two ? wp.two_range[(size_t)k] : 0;
+  for (const auto &n : wp.nodes) *o++ = n.node, *o++ = n.n_in, *o++ = n.in0, *o++ = n.flags;
+  for (int x : wp.inputs) *o++ = x;
+  return need;
+}
+
 int64_t hyphy_hip_plan_repeats(int64_t L, int64_t I, const int64_t *flat_parents, int64_t S, const int64_t *leaf_codes, double theta,
                                int64_t *classes_out, int64_t *compressed_out) {
   if (L < 2 || I < 1 || S < 1 || !flat_parents || !leaf_codes) return -1;

@@ -24,7 +24,7 @@ EXPORTS = [
     "hyphy_hip_evaluate_built", "hyphy_hip_evaluate_built_sites", "hyphy_hip_update_q_templates", "hyphy_hip_evaluate_categories_built", "hyphy_hip_evaluate_categories_built_sites", "hyphy_hip_prune_timings", "hyphy_hip_prune_launches",
     "hyphy_hip_prune_kernel_name", "hyphy_hip_branch_cache_build", "hyphy_hip_branch_cache_evaluate",
     "hyphy_hip_set_pinned_states", "hyphy_hip_site_fits_evaluate", "hyphy_hip_site_fits_evaluate_mixture", "hyphy_hip_site_fits_kernel_ms",
-    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_set_repeats", "hyphy_hip_repeat_stats", "hyphy_hip_plan_repeats", "hyphy_hip_plan_nucgen", "hyphy_hip_comm_init_host", "hyphy_hip_evaluate_exchange", "hyphy_hip_evaluate_built_exchange",
+    "hyphy_hip_synchronize", "hyphy_hip_stream", "hyphy_hip_set_stream", "hyphy_hip_last_timings", "hyphy_hip_set_timing_detail", "hyphy_hip_schedule_info", "hyphy_hip_set_repeats", "hyphy_hip_repeat_stats", "hyphy_hip_plan_repeats", "hyphy_hip_plan_trunk_walk", "hyphy_hip_plan_nucgen", "hyphy_hip_comm_init_host", "hyphy_hip_evaluate_exchange", "hyphy_hip_evaluate_built_exchange",
     "hyphy_hip_xch_open", "hyphy_hip_xch_sum", "hyphy_hip_xch_close", "hyphy_hip_last_error",
     "hyphy_hip_version",
 ]
@@ -141,6 +141,8 @@ def load():
     lib.hyphy_hip_prune_kernel_name.argtypes = [vp]
     lib.hyphy_hip_set_repeats.restype = C.c_int
     lib.hyphy_hip_set_repeats.argtypes = [vp, C.c_int]
+    lib.hyphy_hip_plan_trunk_walk.restype = C.c_int64
+    lib.hyphy_hip_plan_trunk_walk.argtypes = [C.c_int64, C.c_int64, lp, lp, C.c_int64]
     lib.hyphy_hip_plan_repeats.restype = C.c_int64
     lib.hyphy_hip_plan_repeats.argtypes = [C.c_int64, C.c_int64, lp, C.c_int64, lp, C.c_double, lp, lp]
     lib.hyphy_hip_repeat_stats.restype = C.c_int
@@ -224,6 +226,26 @@ def plan_repeats(flat_parents, L: int, leaf_codes, theta: float = 0.0):
     if work < 0:
         raise HipError("plan_repeats: bad arguments")
     return cl, cp.astype(bool), int(work)
+
+
+def plan_trunk_walk(parents, L: int):
+    """Host-only: the program trunk_walk_kernel runs for a trunk over ``L`` generalised leaves (``parents[c]`` = node code of c's
+    parent; internal node i has code L + i, children before parents, the root last).  Returns a dict: ``nodes`` [(internal index or
+    -1, leaf children, first input, flags)], ``inputs`` (leaf codes), ``depth``, ``one`` = (first, end) node range of the one-chain
+    form, ``two`` = ((first, end), (first, end)) of the two chains or None."""
+    lib = load()
+    par = np.ascontiguousarray(parents, dtype=np.int64)
+    I = len(par) + 1 - L
+    cap = 16 + 8 * (L + I) + 4 * L
+    out = np.zeros(cap, dtype=np.int64)
+    n = lib.hyphy_hip_plan_trunk_walk(L, I, _l(par), _l(out), cap)
+    if n < 0:
+        raise HipError("plan_trunk_walk: bad arguments")
+    nn, ni, depth, two = (int(x) for x in out[:4])
+    nodes = [tuple(int(x) for x in out[10 + 4 * k: 14 + 4 * k]) for k in range(nn)]
+    inputs = [int(x) for x in out[10 + 4 * nn: 10 + 4 * nn + ni]]
+    return {"nodes": nodes, "inputs": inputs, "depth": depth, "one": (int(out[4]), int(out[5])),
+            "two": ((int(out[6]), int(out[7])), (int(out[8]), int(out[9]))) if two else None}
 
 
 def plan_nucgen(flat_parents, L: int, leaf_has_ambig=None, compile_it: bool = True, small: bool = False):

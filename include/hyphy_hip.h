@@ -419,7 +419,9 @@ int64_t hyphy_hip_prune_timings(hyphy_hip_partition *p, double *out_ms, int64_t 
  * evaluation into levels of subtree fragments, one launch per level; partial updates use one). */
 int hyphy_hip_prune_launches(hyphy_hip_partition *p);
 /* Name of the pruning kernel this partition's evaluations launch (chosen by shard size and state count;
- * as it appears in a rocprofv3 kernel trace).  Static string. */
+ * as it appears in a rocprofv3 kernel trace).  Static string.  Class-compressed partitions (subtree repeats, below) run
+ * "class_table_team_kernel" in front of it, and answer "trunk_walk_kernel" once their full passes run the trunk as one
+ * row-split walk per tile (r06; first passes, partial updates and pinned states keep the pruning kernels). */
 const char *hyphy_hip_prune_kernel_name(const hyphy_hip_partition *p);
 
 /* What the schedule tuner measured for this partition ("" before it ran): on the first steady-state full pass the
@@ -467,6 +469,14 @@ int hyphy_hip_set_repeats(hyphy_hip_partition *p, int on);
 int64_t hyphy_hip_plan_repeats(int64_t L, int64_t I, const int64_t *flat_parents, int64_t S, const int64_t *leaf_codes, double theta,
                                int64_t *classes_out, int64_t *compressed_out);
 int hyphy_hip_repeat_stats(const hyphy_hip_partition *p, int64_t out[8]);
+/* Host-only (no device): the program trunk_walk_kernel would run for a trunk given as a tree over generalised leaves — node codes
+ * 0 .. L - 1 leaves, L + i internal node i (children before parents, the root last), parents[c] = node code of c's parent.
+ * out: [nodes, inputs, stack depth, two chains?, first / end node of the one-chain form, of chain 0, of chain 1], then per walked node
+ * (internal index, or -1: the chain's end at the root; leaf children; first input; flags 1: push the running product and start from
+ * ones, 2: multiply the waiting product back in behind the edge product), then the inputs (leaf codes).  Returns the words written
+ * (< 0: -words needed).  Restates nothing of the reference: it is the order in which src/core/tree_evaluator.cpp:3556-4171 visits the
+ * nodes above the class tables, cut for one or two workgroups per tile. */
+int64_t hyphy_hip_plan_trunk_walk(int64_t L, int64_t I, const int64_t *parents, int64_t *out, int64_t cap);
 
 /* 4 states: schedules as run-time generated straight-line kernels (nucgen.hip; replaces the interpretation of the reference's
  * 4-state loop, src/core/tree_evaluator.cpp:2253-2273, 3556-4171, entry by entry).  A 4-state partition whose full-pass schedule

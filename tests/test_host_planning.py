@@ -4,6 +4,7 @@ table of chain schedules as the kernels decode it."""
 import collections
 
 import numpy as np
+import pytest
 
 from hyphy_amd import hip, tree
 
@@ -216,3 +217,93 @@ def test_nucgen_source_covers_every_node_and_compiles_for_gfx950():
     big = tree.flatten(tree.caterpillar_tree(300))
     src, ok = hip.plan_nucgen(big.flat_parents, big.L, None, compile_it=False)
     assert src == "" and not ok
+
+
+def _random_trunk(rng, n_internal):
+    """A random tree over generalised leaves in the layout of a trunk view: leaves 0 .. L - 1, internal nodes L + i with children
+    before parents, the root last, every internal node with at least two children."""
+    kids = []                       # per internal node: children as ("leaf",) placeholders or internal indices
+    roots = []                      # internal nodes without a parent yet
+    for i in range(n_internal):
+        k = []
+        n_int = int(rng.integers(0, min(3, len(roots)) + 1)) if i + 1 < n_internal else len(roots)
+        for _ in range(n_int):
+            k.append(roots.pop(int(rng.integers(len(roots)))))
+        n_leaf = max(0, 2 - len(k)) + int(rng.integers(0, 3))
+        k += [None] * n_leaf
+        kids.append(k)
+        roots.append(i)
+    L = sum(c is None for k in kids for c in k)
+    parents = np.full(L + n_internal - 1, -1, dtype=np.int64)
+    leaf = 0
+    children = [[] for _ in range(n_internal)]
+    for i, k in enumerate(kids):
+        for c in k:
+            if c is None:
+                parents[leaf] = L + i
+                children[i].append(leaf)
+                leaf += 1
+            else:
+                parents[L + c] = L + i
+                children[i].append(L + c)
+    return L, parents, children
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_trunk_walk_program_computes_the_root_conditionals(seed):
+    """hyphy_hip_plan_trunk_walk (repeats.hip: plan_trunk_walk, what trunk_walk_kernel interprets): random trunks, the program run by
+    a small stack machine in numpy — inputs multiplied in, the edge product, a push in front of every second internal child's chain
+    and its pop behind that child's product — against the plain recursion; one chain, and two chains whose products meet at the root."""
+    from hyphy_amd import hip
+    rng = np.random.default_rng(100 + seed)
+    n_int = int(rng.integers(1, 14))
+    L, parents, children = _random_trunk(rng, n_int)
+    D = 3
+    P = rng.uniform(0.1, 1.0, (n_int, D, D))          # one matrix per internal node's branch
+    E_leaf = rng.uniform(0.1, 1.0, (L, D))            # what a generalised leaf contributes to its parent
+
+    def cond(i):
+        v = np.ones(D)
+        for c in children[i]:
+            v = v * (E_leaf[c] if c < L else P[c - L] @ cond(c - L))
+        return v
+
+    want = cond(n_int - 1)
+    plan = hip.plan_trunk_walk(parents, L)
+    assert plan["depth"] <= max(1, n_int)
+
+    def run(first, end):
+        acc, stack, seen = np.ones(D), [], 0
+        for k in range(first, end):
+            node, n_in, in0, flags = plan["nodes"][k]
+            if flags & 1:
+                stack.append(acc)
+                acc = np.ones(D)
+            for j in range(n_in):
+                acc = acc * E_leaf[plan["inputs"][in0 + j]]
+            if node < 0:
+                assert k == end - 1 and not stack
+                return acc
+            seen += 1
+            acc = P[node] @ acc
+            if flags & 2:
+                acc = acc * stack.pop()
+        raise AssertionError("a chain must end at the root")
+
+    one = run(*plan["one"])
+    assert np.allclose(one, want, rtol=1e-12)
+    if plan["two"] is not None:
+        a, b = run(*plan["two"][0]), run(*plan["two"][1])
+        assert np.allclose(a * b, want, rtol=1e-12)
+        n0, n1 = (e - f - 1 for f, e in plan["two"])          # real nodes per chain
+        assert n0 + n1 == n_int - 1 and min(n0, n1) >= 2 and 4 * min(n0, n1) >= max(n0, n1)
+    # every internal node but the root is walked exactly once per form; the stack never goes deeper than reported
+    first, end = plan["one"]
+    walked = sorted(n for n, _, _, _ in plan["nodes"][first:end] if n >= 0)
+    assert walked == list(range(n_int - 1))
+    depth = d = 0
+    for _, _, _, flags in plan["nodes"][first:end]:
+        d += 1 if flags & 1 else 0
+        depth = max(depth, d)
+        d -= 1 if flags & 2 else 0
+    assert depth <= plan["depth"]
