@@ -307,3 +307,36 @@ def test_trunk_walk_program_computes_the_root_conditionals(seed):
         depth = max(depth, d)
         d -= 1 if flags & 2 else 0
     assert depth <= plan["depth"]
+
+
+def test_trunk_walk_program_of_a_balanced_trunk_nests_its_waiting_products():
+    """A complete binary trunk of 15 internal nodes: the walk keeps the heavier (here: first) child's chain running and parks it
+    while the sibling subtree is walked — three levels deep at the bottom; the two-chain form splits the root's two subtrees 7 + 7."""
+    from hyphy_amd import hip
+    depth_levels = 4
+    n_int = 2 ** depth_levels - 1
+    L = 2 ** depth_levels
+    # internal nodes in post-order: build recursively
+    parents = {}
+    counter = {"leaf": 0, "int": 0}
+
+    def build(level):
+        if level == depth_levels:
+            c = counter["leaf"]
+            counter["leaf"] += 1
+            return c
+        a, b = build(level + 1), build(level + 1)
+        me = L + counter["int"]
+        counter["int"] += 1
+        parents[a] = me
+        parents[b] = me
+        return me
+
+    root = build(0)
+    assert root == L + n_int - 1
+    par = np.array([parents[c] for c in range(L + n_int - 1)], dtype=np.int64)
+    plan = hip.plan_trunk_walk(par, L)
+    assert plan["depth"] == 3 and plan["two"] is not None
+    assert [e - f - 1 for f, e in plan["two"]] == [7, 7]
+    first, end = plan["one"]
+    assert sum(1 for _, _, _, fl in plan["nodes"][first:end] if fl & 1) == sum(1 for _, _, _, fl in plan["nodes"][first:end] if fl & 2) == 7
