@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Per evaluation of the last steady-state steps: every kernel of the step with its duration and the gap in front of it, from a
+rocprofv3 --kernel-trace CSV (one line per evaluation; lower phases of several level launches show each level).
+usage: tools/level_trace.py <dir with *_kernel_trace.csv>"""
 import csv,glob,re,sys
 rows=[]
 for f in glob.glob(sys.argv[1]+"/**/*kernel_trace.csv",recursive=True):
