@@ -1873,9 +1873,14 @@ int rep_setup_impl(hyphy_hip_partition *p, const std::vector<std::vector<int16_t
     }
   }
   ms.trunk_walk = false;
-  if (const char *tw = getenv("HYPHY_HIP_TRUNK_WALK")) {  // = 1: the walk without asking the tuner (tests, A/B runs, HYPHY_HIP_TUNE=0)
+  {
+    // HYPHY_HIP_TRUNK_WALK=1: the walk without asking the tuner (tests, A/B runs).  No tuner at all (HYPHY_HIP_TUNE=0): the walk too —
+    // it is the faster form wherever the static rule turns compression on, and with the one-workgroup-per-tile kernel behind it for
+    // the other passes nothing in this mode depends on an order of arrival: the same bits on every run (tested)
+    const char *tw = getenv("HYPHY_HIP_TRUNK_WALK");
+    const bool tune_off = getenv("HYPHY_HIP_TUNE") && atoi(getenv("HYPHY_HIP_TUNE")) == 0;
     const hyphy_hip_partition::View &tv = p->views[1];
-    if (atoi(tw) == 1 && !p->rep_walk_host.empty() && (size_t)tv.L * 32 + (size_t)(tv.L + tv.I) * 16 <= 24576) {
+    if ((tw ? atoi(tw) == 1 : tune_off) && p->NW == 4 && !p->rep_walk_host.empty() && (size_t)tv.L * 32 + (size_t)(tv.L + tv.I) * 16 <= 24576) {
       ms.trunk_walk = true;
       ms.variant = 0;
       ms.n_slots = lds_slots(1);

@@ -125,7 +125,11 @@ void hyphy_hip_destroy(hyphy_hip_partition *p);
  * order in which their workgroups arrive, and the schedule itself is chosen by timing (HYPHY_HIP_TUNE): the same inputs can
  * give log-likelihoods that differ in the last bits (<= a few 1e-16 relative) between runs and between ranks.  The reference's
  * CPU path is deterministic for a fixed thread count; a host that needs bit-identical repeats sets
- * HYPHY_HIP_TUNE=0 HYPHY_HIP_CUT=levels (fixed order, no joins; ~25 % slower at the headline size).
+ * HYPHY_HIP_TUNE=0 HYPHY_HIP_CUT=levels (fixed order, no joins; ~25 % slower at the headline size on the plain form).  r06: with
+ * HYPHY_HIP_TUNE=0 alone a partition that runs class-compressed (subtree repeats; 49-64 states from ~128 tiles of 16 patterns per
+ * shard) is bit-identical from run to run too, at the speed of the tuned form — its two walks have no join whose result depends on who
+ * arrives first (tests/test_gpu_fullsize.py::test_class_compressed_form_without_tuner_is_bit_reproducible); smaller partitions
+ * of that mode still run chain schedules: add HYPHY_HIP_CUT=levels there.
  */
 int hyphy_hip_evaluate(hyphy_hip_partition *p, int64_t cat, const int64_t *update_nodes, int64_t n_update,
                        const int64_t *q_nodes, int64_t n_q, const double *q_dense, int q_is_probability,
