@@ -108,6 +108,7 @@ def test_trunk_under_row_split_workgroups(name, kernel, m, monkeypatch):
     monkeypatch.setenv("HYPHY_HIP_REPEATS", "2")
     monkeypatch.setenv("HYPHY_HIP_REP_THETA", "0.9")
     monkeypatch.setenv("HYPHY_HIP_POISON", "1")
+    monkeypatch.setenv("HYPHY_HIP_TRUNK_WALK", "0")   # (the pruning kernels on the trunk are the subject: without the tuner the walk would take the lazy passes)
     fx = common.load(name)
     Q = common.fixture_Q(fx)
     nodes = common.all_nodes(fx)
