@@ -27,7 +27,7 @@ void free_shard(Shard &s) {
                  s.weights, s.templates, s.templates_pad, s.coeffs, s.wg_sum, s.wg_cnt, s.wg_flag, s.prog, s.frag_ctr, s.hand_cnt, s.pi_ones, s.codes_tile,
                  s.bc_ops, s.bc_prog, s.bc_slot, s.bc_q, s.pin, s.jn, s.deposits, s.mix_q, s.mix_p, s.mix_w, s.mix_off, s.ar_buf, s.fit_Timg, s.fit_bcoef, s.fit_smult, s.fit_smix, s.fit_out, s.fit_scratch,
                  s.fit_pi, s.fit_bgroup, s.fit_scratch_cnt, s.fit_ops, s.rep_tab, s.rep_cnt, s.rep_map, s.rep_desc, s.rep_sync,
-                 s.rep_codes_tile, s.rep_leaf, s.rep_walk, s.d_inv};
+                 s.rep_codes_tile, s.rep_leaf, s.rep_walk, s.d_inv, s.expm_need};
   for (void *d : dev)
     if (d) pool_free(d);  // (the stream was synchronised above)
   void *host[] = {s.h_ops, s.h_out, s.h_slots, s.h_small, s.h_coeffs, s.h_prog, s.h_jn, s.h_tstage, s.h_site, s.h_export};
@@ -363,6 +363,11 @@ int enqueue_eval(hyphy_hip_partition *p, Shard &s, int cat, int n_cat_batch, boo
       ea.Prow = nullptr;
       ea.Pfrag = s.Pfrag + (size_t)cat * B * DP * DP;
       ea.PTg = s.PTg + (size_t)cat * B * DP * DP;
+      static const bool mask_on = !(getenv("HYPHY_HIP_EXPM_MASK") && atoi(getenv("HYPHY_HIP_EXPM_MASK")) == 0);
+      if (mask_on && s.expm_need) {
+        ea.need = s.expm_need;
+        ea.need_B = (int)B;
+      }
     }
     if (!p->rr_path.empty() && !p->nuc && n_cat_batch <= 1) {  // keep the transposed twins in step with the matrices they mirror
       const size_t k = p->rr_path.size() - 1;
@@ -1010,6 +1015,14 @@ int hyphy_hip_create(hyphy_hip_partition **out, int64_t D, int64_t S, int64_t L,
     A_(s.codes, (size_t)L * s.S_pad * sizeof(int16_t));
     if (!p->nuc) {
       A_(s.codes_tile, (size_t)L * s.S_pad * sizeof(int16_t));
+      {  // which matrix images a branch's consumers read (ExpmArgs::need): leaves are gathered from by state — the column-gather
+         // image —, internal branches are A operands of edge products; a leaf with ambiguity codes is both
+        std::vector<unsigned char> need((size_t)B, 3);
+        for (int64_t c = 0; c < L && c < B; c++) need[(size_t)c] = p->leaf_has_ambig[(size_t)c] ? 3 : 2;
+        for (int64_t c = L; c < L + I - 1 && c < B; c++) need[(size_t)c] = 1;
+        A_(s.expm_need, (size_t)B);
+        hipMemcpy(s.expm_need, need.data(), (size_t)B, hipMemcpyHostToDevice);
+      }
       A_(s.bc_ops, ops_capacity(p) * sizeof(int4));
       A_(s.bc_prog, sizeof(int4));
       A_(s.bc_slot, (size_t)C * sizeof(int32_t));

@@ -279,6 +279,8 @@ struct ExpmArgs {
   const double *coeffs;      // [n][K]
   int K;
   int prof;                  // diagnostic: workgroup 0 stamps its phases (HYPHY_HIP_EXPM_PROF)
+  const unsigned char *need = nullptr;  // (expm64_kernel, r06) per branch [need_B]: bit 0 its consumers read the A-operand image, bit 1 the
+  int need_B = 0;                       // column-gather image; nullptr: both are written.  Slot s belongs to branch s % need_B
   int fixed_degree = 0;      // expm64_kernel: 1 = always degree 12 (HYPHY_HIP_EXPM_DEGREE=12); 0 = degree from the scaled norm
   // re-rooted schedules (api.hip: reroot_path): matrix j of twin_src (a slot number) also leaves the TRANSPOSED image
   // M[r][c] = P[c][r] (times twin_pi[c] for j == 0, the edge that leaves the old root) in slot twin_dst0 + j of Pfrag

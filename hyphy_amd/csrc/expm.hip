@@ -841,7 +841,10 @@ __global__ __launch_bounds__(512) void expm64_kernel(ExpmArgs a, CoefInline ci) 
         if (r < D && c < D) out[r * D + c] = Xs[r * LD + c];
       }
     }
-    if (a.Pfrag) {
+    // (r06) only the images this branch's consumers read: internal branches the A-operand image, leaf branches the column-gather
+    // image (+ the A-operand image when the leaf carries ambiguity codes) — half of the launch's 8-16 MB of stores
+    const int need = a.need ? (int)a.need[slot % a.need_B] : 3;
+    if (a.Pfrag && (need & 1)) {
       // wave wb, k-step kk, lane l  <-  P[16 wb + (l & 15)][4 kk + (l >> 4)]; a row block is one contiguous 8 KiB run
       double *out = a.Pfrag + (size_t)slot * DP * DP + (size_t)row0 * DP;
       for (int idx = tid; idx < nrows * DP; idx += NTHR) {
@@ -866,7 +869,7 @@ __global__ __launch_bounds__(512) void expm64_kernel(ExpmArgs a, CoefInline ci) 
           }
         }
     }
-    if (a.PTg) {
+    if (a.PTg && (need & 2)) {
       // [code][wb][gg][r]  <-  P[16 wb + 4 r + gg][code]: lane (g, sl) of the wave that owns tile (rb, ct) holds the four
       // consecutive entries r = 0..3 of code = 16 ct + sl  ->  32 contiguous bytes per lane, straight from the registers
       double *out = a.PTg + (size_t)slot * DP * DP;

@@ -137,6 +137,7 @@ struct Shard {
   int32_t *slots = nullptr;                                 // [C*B]
   int4 *ops = nullptr;
   int16_t *codes_tile = nullptr;  // [tile][L][16] copy of the leaf table (wave-per-tile kernels)
+  unsigned char *expm_need = nullptr;  // [B] which matrix images a branch's consumers read (ExpmArgs::need), or nullptr
   int16_t *pin = nullptr;         // [S_pad] pinned states (hyphy_hip_set_pinned_states)
   int4 *bc_ops = nullptr;         // branch cache: schedule of the re-rooted chain, its one-entry program table,
   int4 *bc_prog = nullptr;        //   the slot word and the rate matrix of the cached branch
