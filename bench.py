@@ -649,6 +649,16 @@ def main():
 
     if n_mix or n_classes > 1:
         xch_step = None
+    if not multi and not n_mix and n_classes == 1 and not os.environ.get("HYPHY_BENCH_DEVICE_STEP"):
+        # (one GPU, one rate class: the same work as the general step above — new coefficients, build_q + evaluate_built, log-L back —
+        #  without its case analysis: what a C host's loop does, and ≈ 1 us of interpreter per step less)
+        _general, _col = step, coeffs[:, 1]
+
+        def step(k, sync=True, force_torch=False, force=None):   # noqa: F811
+            if not sync or force_torch or force is not None:
+                return _general(k, sync=sync, force_torch=force_torch, force=force)
+            np.multiply(tb, omega0 + 0.001 * k, out=_col)
+            return sync_step()
     if os.environ.get("HYPHY_BENCH_STEP_TIMES") == "all":   # (diagnostic: wall clock of EVERY step of the run, from the first)
         _step0, _marks = step, []
 
