@@ -2058,6 +2058,37 @@ __global__ __launch_bounds__(64) void wave_reduce_kernel(double *wg_sum, long lo
   combine_partials(wg_sum, wg_cnt, wg_flag, n, out, out_cnt, status, seq, (int)threadIdx.x);
 }
 
+// Thousands of partials (128 x 100 k: 6 250 tiles; 10^6 nucleotide sites: 3 907 workgroups): NWV waves take a contiguous range each —
+// the one-wave kernel's sum over that range — and wave 0 adds the NWV results in wave order with the same compensated step.  A
+// different (fixed) order of summation than one wave's: used from 2 048 partials upwards, where no fused launch exists to disagree with
+// (one wave: 10.5 us for 6 250 partials, 8.6 for 3 907).
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void multi_wave_reduce_kernel(double *wg_sum, long long *wg_cnt, int *wg_flag, int n, double *out,
+                                                                     double *out_cnt, const int *status, double seq) {
+  __shared__ double ssum[NWV], scomp[NWV];
+  __shared__ long long sc[NWV];
+  __shared__ int sfl[NWV];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int chunk = ((n + NWV - 1) / NWV + 511) / 512 * 512;
+  double sum, comp;
+  long long c;
+  int fl;
+  combine_range(wg_sum, wg_cnt, wg_flag, n, min(n, w * chunk), min(n, (w + 1) * chunk), lane, sum, comp, c, fl);
+  if (lane == 0) ssum[w] = sum, scomp[w] = comp, sc[w] = c, sfl[w] = fl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < NWV; k++) {
+      const double b0 = ssum[k], t = sum + b0;
+      const double e = (fabs(sum) >= fabs(b0)) ? (sum - t) + b0 : (b0 - t) + sum;  // sum + b0 = t + e exactly
+      comp = comp + scomp[k] - e;
+      sum = t;
+      c += sc[k];
+      fl |= sfl[k];
+    }
+    combine_publish(sum, comp, c, fl, out, out_cnt, status, seq);
+  }
+}
+
 // Category mixing on the device: PopulateConditionalProbabilities weighted-sum mode
 // (likefunc2.cpp:820-853): buf[s] = sum_c w_c L_c[s] 2^(-64 (c_c[s] - min_c c_c[s])).
 __global__ void mix_categories_kernel(const double *__restrict__ site_lik, const int32_t *__restrict__ site_cnt,
@@ -2386,8 +2417,12 @@ void launch_site_reduce(const double *site_lik, const int32_t *site_cnt, const d
 void launch_wg_reduce(const double *wg_sum, const long long *wg_cnt, const int *wg_flag, int n, double *out_logl,
                       double *out_cnt, const int *status, hipStream_t stream, double seq) {
   static const bool block_form = getenv("HYPHY_HIP_REDUCE") && !strcmp(getenv("HYPHY_HIP_REDUCE"), "block");
+  static const bool multi_off = getenv("HYPHY_HIP_REDUCE") && !strcmp(getenv("HYPHY_HIP_REDUCE"), "wave");
   if (block_form)
     hipLaunchKernelGGL(wg_reduce_kernel, dim3(1), dim3(256), 0, stream, wg_sum, wg_cnt, wg_flag, n, out_logl, out_cnt, status, seq);
+  else if (n >= 2048 && !multi_off)
+    hipLaunchKernelGGL(multi_wave_reduce_kernel<8>, dim3(1), dim3(512), 0, stream, const_cast<double *>(wg_sum), const_cast<long long *>(wg_cnt),
+                       const_cast<int *>(wg_flag), n, out_logl, out_cnt, status, seq);
   else
     hipLaunchKernelGGL(wave_reduce_kernel, dim3(1), dim3(64), 0, stream, const_cast<double *>(wg_sum), const_cast<long long *>(wg_cnt),
                        const_cast<int *>(wg_flag), n, out_logl, out_cnt, status, seq);
